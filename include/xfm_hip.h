@@ -1,0 +1,162 @@
+/* libxfm_hip.so -- C ABI of the MI355X-native XFM transformer forward/backward hot path.
+ *
+ * Every entry point returns 0 on success or a negative XFM_E_* code; the message is available from
+ * xfm_last_error() (thread local).  No entry point allocates, synchronises the device or throws: the caller owns
+ * all device memory (PyTorch's caching allocator in the shipped binding), passes plain device pointers, element
+ * strides and a hipStream_t (as void*), and every kernel is enqueued on that stream only, so calls are re-entrant
+ * per stream and hipGraph-capturable.  There is no global mutable state.
+ *
+ * The reference has no FFI for this path (it bottoms out in stock ATen ops); each symbol below
+ * cites the Python code whose arithmetic it replaces.  bf16 tensors are row-major uint16 payloads.
+ */
+#ifndef XFM_HIP_H
+#define XFM_HIP_H
+#include <stdint.h>
+
+#ifdef XFM_INTERNAL_BF16
+typedef __bf16 xfm_bf16;
+#else
+typedef uint16_t xfm_bf16;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XFM_OK 0
+#define XFM_E_ARG (-1)
+#define XFM_E_LAUNCH (-2)
+#define XFM_E_UNSUPPORTED (-3)
+
+#define XFM_ABI_VERSION 1
+
+const char* xfm_last_error(void);
+int xfm_abi_version(void);
+
+/* ---- Linear layers (torch.nn.Linear / F.linear call sites: beit2.py:131,162,64-68,229; xroberta.py:211,224-234,
+ * 301,368,382,1326,1331; xfm.py:117-120,617-620) ------------------------------------------------------------------ */
+enum { XFM_EPI_BF16 = 0, XFM_EPI_F32 = 1, XFM_EPI_GELU = 2, XFM_EPI_DGELU = 3, XFM_EPI_F32_ACC = 4 };
+
+/* C[M,N] = A[M,K] . B[N,K]^T + bias.  A, B bf16 (K contiguous).  Epilogues: bf16 out | fp32 out |
+ * aux = pre-activation (bf16), C = gelu(aux)  | C = acc * gelu'(aux) | fp32 C += acc.  K % 64 == 0; lda, ldb % 8 == 0.
+ * tile_hint: 0 = auto, 1 = 128x128, 2 = 64x128, 3 = 64x64. */
+int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* C, long ldc, const float* bias,
+                xfm_bf16* aux, long ldaux, int M, int N, int K, int epilogue, int tile_hint, void* stream);
+
+/* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]   (weight gradient; split over M, atomically accumulated). */
+int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float* dW, long ldw, int M, int N, int K,
+                int splits_hint, void* stream);
+
+/* fp32 master weight [N,K] -> bf16 copy wb[N,ldb] and/or transposed bf16 copy wt[K,ldt] (zero padded). */
+int xfm_cast_transpose(const float* w, int N, int K, xfm_bf16* wb, long ldb, xfm_bf16* wt, long ldt, void* stream);
+
+/* out[n] += sum_m Y[m,n]  (bias gradients).  workspace >= xfm_colsum_workspace(M,N) bytes. */
+long xfm_colsum_workspace(int M, int N);
+int xfm_colsum(const xfm_bf16* Y, long ldy, int M, int N, float* out, float* workspace, long workspace_bytes,
+               void* stream);
+
+/* ---- LayerNorm family (nn.LayerNorm call sites: beit2.py:191-206,460; xroberta.py:300-304,381-385,1329;
+ * xfm.py:118).  Width D in {256,512,768,1024,1536}. ---------------------------------------------------------------- */
+enum { XFM_LN_PLAIN = 0, XFM_LN_POST = 1, XFM_LN_LS = 2 };
+
+typedef struct {
+  const float* x32;        /* PLAIN: fp32 input | LS: residual stream in */
+  const xfm_bf16* x16;     /* PLAIN: bf16 input */
+  const xfm_bf16* h;       /* POST / LS: output of the producing GEMM (bias included) */
+  const xfm_bf16* res;     /* POST: residual */
+  const float* ls_gamma;   /* LS: layer-scale gamma_1 / gamma_2 */
+  const float* row_scale;  /* LS: per-sample drop-path scale [rows / rows_per_sample] or NULL */
+  const float* w; const float* b;
+  float* x_out;            /* LS: residual stream out (may alias x32) */
+  xfm_bf16* z_out;         /* POST: pre-norm sum saved for backward */
+  xfm_bf16* y;             /* normalised output */
+  float* y32;              /* optional fp32 copy of y */
+  float* mean; float* rstd;
+  int rows, rows_per_sample;
+  float eps;
+  uint32_t drop_thresh; float drop_scale; uint32_t seed_lo, seed_hi;  /* POST: dropout on h (thresh = p * 2^32) */
+} xfm_ln_fwd_args;
+
+typedef struct {
+  const xfm_bf16* dy1; const xfm_bf16* dy2; const float* dy32;  /* gradients w.r.t. y, summed on load (NULL ok) */
+  const float* x32; const xfm_bf16* x16;                        /* the tensor that was normalised */
+  const float* mean; const float* rstd; const float* w;
+  float* dx32; xfm_bf16* dx16; int dx_accum;                     /* PLAIN: gradient w.r.t. the input */
+  xfm_bf16* dh; xfm_bf16* dres;                                  /* POST / LS: to the producing GEMM / residual */
+  float* dstream;                                                /* LS: in/out fp32 residual-stream gradient */
+  const xfm_bf16* h; const float* ls_gamma; const float* row_scale;
+  float* partial;                                                /* set by the library (workspace) */
+  int rows, rows_per_sample;
+  uint32_t drop_thresh; float drop_scale; uint32_t seed_lo, seed_hi;
+} xfm_ln_bwd_args;
+
+int xfm_layernorm_fwd(const xfm_ln_fwd_args* a, int D, int mode, void* stream);
+long xfm_layernorm_bwd_workspace(int rows, int D, int mode);
+/* dgamma/dbeta (LN affine), dbias (column sums of dh: bias grad of the producing Linear), dls (layer-scale grad):
+ * fp32 [D], accumulated (+=); NULL skips. */
+int xfm_layernorm_bwd(const xfm_ln_bwd_args* a, int D, int mode, float* dgamma, float* dbeta, float* dbias, float* dls,
+                      float* workspace, long workspace_bytes, void* stream);
+
+/* ---- Attention, head_dim 64 (beit2.py:126-166; xroberta.py:201-289; causal mask xroberta.py:772-792) ------------- */
+typedef struct {
+  const xfm_bf16* q; long q_rs;   /* element (b,s,h,d) at ptr[(b*S + s)*rs + h*64 + d] */
+  const xfm_bf16* k; long k_rs;
+  const xfm_bf16* v; long v_rs;
+  xfm_bf16* o; long o_rs;
+  float* lse;                     /* [B,H,Sq] log-sum-exp of the final scores */
+  const float* bias; long bias_ld;/* dense additive bias [H,Sq,bias_ld] or NULL */
+  const int* key_keep;            /* [B,Sk] 1 attend / 0 padded (adds -10000) or NULL */
+  int B, H, Sq, Sk;
+  float scale; int causal;
+  uint32_t drop_thresh; float drop_scale; uint32_t seed_lo, seed_hi;
+  const xfm_bf16* dout; long do_rs;
+  xfm_bf16* dq; long dq_rs; xfm_bf16* dk; long dk_rs; xfm_bf16* dv; long dv_rs;
+  float* delta;                   /* [B,H,Sq] scratch */
+  float* dbias;                   /* [H,Sq,bias_ld] fp32, += over the batch, or NULL */
+} xfm_attn_args;
+
+int xfm_attn_fwd(const xfm_attn_args* a, void* stream);
+int xfm_attn_bwd(const xfm_attn_args* a, void* stream);
+/* dense[h,i,j] = table[index[i*N+j]*H + h] (beit2.py:139-145), rows padded to ld; and its scatter-add gradient. */
+int xfm_relpos_gather(const float* table, const int* index, int H, int N, long ld, float* dense, void* stream);
+int xfm_relpos_scatter(const float* ddense, const int* index, int H, int N, long ld, float* dtable, void* stream);
+
+/* ---- Patch gather for the patch-embed GEMM (beit2.py:224-230) --------------------------------------------------- */
+int xfm_patchify(const float* image, int B, int C, int H, int W, int P, xfm_bf16* out, void* stream);
+
+/* ---- RoBERTa embeddings + LayerNorm + dropout (xroberta.py:104-137, 1747-1757) ----------------------------------- */
+typedef struct {
+  const int64_t* ids;
+  const float* word; const float* pos; const float* type;
+  const float* w; const float* b;
+  xfm_bf16* y; float* mean; float* rstd; int* pos_ids;
+  int B, T, pad_id; float eps;
+  uint32_t drop_thresh; float drop_scale; uint32_t seed_lo, seed_hi;
+  const xfm_bf16* dy; float* dword; float* dpos; float* partial;
+} xfm_embed_args;
+int xfm_embed_ln_fwd(const xfm_embed_args* a, int D, void* stream);
+long xfm_embed_ln_bwd_workspace(int rows, int D);
+int xfm_embed_ln_bwd(const xfm_embed_args* a, int D, float* dgamma, float* dbeta, float* dtype, float* workspace,
+                     long workspace_bytes, void* stream);
+
+/* ---- Vocabulary cross-entropy, ignore_index -100 (xroberta.py:1296-1297, 1107-1114) ------------------------------ */
+int xfm_ce_fwd(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, void* stream);
+int xfm_ce_bwd(const float* logits, long ld, int R, int V, const int64_t* labels, const float* lse, const float* scale,
+               xfm_bf16* dlogits, long ldd, void* stream);
+
+/* ---- Flat-arena optimiser step (optim.py:4-50 + clip, apex_ddp_accelerator.py:100-110) --------------------------- */
+typedef struct {
+  float* p; const float* g; float* m; float* v;
+  const uint8_t* group;       /* group id per 256-element block */
+  float lr[4]; float wd[4];
+  float beta1, beta2, eps, bc1, bc2;
+  const float* clip_coef;     /* device scalar or NULL */
+  long n;
+} xfm_adamw_args;
+int xfm_adamw(const xfm_adamw_args* a, void* stream);
+int xfm_sumsq(const float* x, long n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XFM_HIP_H */

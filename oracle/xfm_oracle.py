@@ -1,0 +1,353 @@
+"""CPU oracle for the XFM transformer forward/backward hot path.
+
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+bench.py's `cpu_baseline` leg may import this module; xfm_amd/ never does.
+
+This is a plain-PyTorch fp32 *restatement* (functional style, weights passed as a
+`state_dict`-shaped mapping `P`) of the arithmetic the reference performs on its hot
+path.  Each function cites the reference file:line it follows.  Stochastic pieces of
+the reference (dropout, drop-path, hard-negative sampling, MIM block masks) are NOT
+drawn here: the oracle runs the eval-mode arithmetic and takes the sampled indices /
+masks / per-sample drop-path scales as explicit inputs, so that both sides of a parity
+test consume identical draws.
+
+Parity pin: tests/golden/*.npz hold outputs of the real reference (imported in the build
+container by tools/oracle/gen_golden.py behind tools/oracle/ref_shim.py) on
+formula-generated weights and inputs (oracle/formula.py); tests/test_oracle_golden.py
+checks every function here against them (<= 1e-5 abs, fp32).  Third-party arithmetic not
+under /root/reference: torch.nn.functional (torch 2.10) and the exact-erf GELU that
+transformers' ACT2FN["gelu"] names (reference pins transformers==4.12.5; call sites
+xroberta.py:363,1327) -- pinned only through those fixtures.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+MASK_NEG = -10000.0  # xroberta.py:805-806 (and transformers 4.12.5 invert_attention_mask)
+
+
+# --------------------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------------------
+def _lin(P, key, x):
+    return F.linear(x, P[key + ".weight"], P.get(key + ".bias"))
+
+
+def _ln(P, key, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), P[key + ".weight"], P[key + ".bias"], eps)
+
+
+def gelu_erf(x):
+    """transformers.activations.gelu == x * 0.5 * (1 + erf(x / sqrt(2)))  (xroberta.py:363,1327)."""
+    return F.gelu(x)
+
+
+# --------------------------------------------------------------------------------------
+# BEiT-v2 vision tower  (models/beit2.py)
+# --------------------------------------------------------------------------------------
+def beit_relative_position_index(gh, gw):
+    """beit2.py:92-116: [gh*gw+1, gh*gw+1] int64 index into the [(2gh-1)(2gw-1)+3, H] bias table."""
+    nrd = (2 * gh - 1) * (2 * gw - 1) + 3
+    ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    ys, xs = ys.reshape(-1), xs.reshape(-1)
+    dy = ys[:, None] - ys[None, :] + (gh - 1)
+    dx = xs[:, None] - xs[None, :] + (gw - 1)
+    n = gh * gw
+    idx = torch.zeros(n + 1, n + 1, dtype=torch.int64)
+    idx[1:, 1:] = dy * (2 * gw - 1) + dx
+    idx[0, :] = nrd - 3
+    idx[:, 0] = nrd - 2
+    idx[0, 0] = nrd - 1
+    return idx
+
+
+def beit_patch_embed(P, pre, image, patch=16):
+    """beit2.py:224-230: Conv2d(3,D,k=16,s=16) == per-patch GEMM over (c,ky,kx); -> [B, gh*gw, D]."""
+    B, C, H, W = image.shape
+    gh, gw = H // patch, W // patch
+    w = P[pre + "patch_embed.proj.weight"]  # [D, C, p, p]
+    cols = image.reshape(B, C, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * patch * patch)
+    return cols @ w.reshape(w.shape[0], -1).t() + P[pre + "patch_embed.proj.bias"]
+
+
+def beit_attention(P, pre, x, heads, image_atts=None):
+    """beit2.py:126-166.  q is scaled BEFORE q@k^T (:136); bias = cat(q_bias, 0, v_bias) (:128-132)."""
+    B, N, C = x.shape
+    d = C // heads
+    qb, vb = P[pre + "q_bias"], P[pre + "v_bias"]
+    bias = torch.cat([qb, torch.zeros_like(vb), vb])
+    qkv = F.linear(x, P[pre + "qkv.weight"], bias).reshape(B, N, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (d ** -0.5), qkv[1], qkv[2]
+    s = q @ k.transpose(-2, -1)
+    table = P[pre + "relative_position_bias_table"]  # [(2g-1)^2+3, heads]
+    index = P[pre + "relative_position_index"]       # [N, N] int64
+    s = s + table[index.reshape(-1)].reshape(N, N, heads).permute(2, 0, 1).unsqueeze(0)
+    if image_atts is not None:
+        s = s + image_atts
+    p = s.softmax(dim=-1)
+    ctx = (p @ v).transpose(1, 2).reshape(B, N, C)
+    return _lin(P, pre + "proj", ctx)
+
+
+def beit_block(P, pre, x, heads, eps=1e-6, dp1=None, dp2=None):
+    """beit2.py:191-206 (gamma branch) + Mlp :62-69.  dp1/dp2: optional per-sample drop-path scales [B]
+    (= bernoulli(keep)/keep, beit2.py:38-49 / timm drop_path); None == eval mode."""
+    y = P[pre + "gamma_1"] * beit_attention(P, pre + "attn.", _ln(P, pre + "norm1", x, eps), heads)
+    if dp1 is not None:
+        y = y * dp1.view(-1, 1, 1)
+    x = x + y
+    h = _lin(P, pre + "mlp.fc2", F.gelu(_lin(P, pre + "mlp.fc1", _ln(P, pre + "norm2", x, eps))))
+    y = P[pre + "gamma_2"] * h
+    if dp2 is not None:
+        y = y * dp2.view(-1, 1, 1)
+    return x + y
+
+
+def beit_pool_tail(P, pre, x, eps=1e-6):
+    """beit2.py:456-466: drop cls, fc_norm over patch tokens, mean over patches as pseudo-cls, concat."""
+    patches = _ln(P, pre + "fc_norm", x[:, 1:], eps)
+    return torch.cat([patches.mean(dim=1, keepdim=True), patches], dim=1)
+
+
+def beit_forward(P, pre, image, depth=12, heads=12, ids_mask=None, drop_path=None, eps=1e-6):
+    """beit2.py:423-466 forward_avgpool (use_abs_pos_emb=False, per-block rel-pos bias).
+    ids_mask: optional bool [B, gh*gw] (the MaskingGenerator draws, :430-441);
+    drop_path: optional list of (dp1, dp2) per block."""
+    x = beit_patch_embed(P, pre, image)
+    B = x.shape[0]
+    if ids_mask is not None:
+        w = ids_mask.unsqueeze(-1).to(x.dtype)
+        x = x * (1 - w) + P[pre + "mask_token"].expand(B, x.shape[1], -1) * w
+    x = torch.cat([P[pre + "cls_token"].expand(B, -1, -1), x], dim=1)
+    for i in range(depth):
+        dp1, dp2 = (None, None) if drop_path is None else drop_path[i]
+        x = beit_block(P, f"{pre}blocks.{i}.", x, heads, eps, dp1, dp2)
+    return beit_pool_tail(P, pre, x, eps)
+
+
+# --------------------------------------------------------------------------------------
+# RoBERTa text / fusion tower  (models/xroberta.py; xbert.py differs where flagged)
+# --------------------------------------------------------------------------------------
+def roberta_position_ids(input_ids, padding_idx=1):
+    """xroberta.py:1747-1757."""
+    m = input_ids.ne(padding_idx).int()
+    return (torch.cumsum(m, dim=1).type_as(m) * m).long() + padding_idx
+
+
+def roberta_embeddings(P, pre, input_ids, eps=1e-5, padding_idx=1):
+    """xroberta.py:104-137 (token_type_ids all zero; dropout is eval-mode identity here)."""
+    pos = roberta_position_ids(input_ids, padding_idx)
+    e = P[pre + "word_embeddings.weight"][input_ids] + P[pre + "token_type_embeddings.weight"][0] \
+        + P[pre + "position_embeddings.weight"][pos]
+    return _ln(P, pre + "LayerNorm", e, eps)
+
+
+def extended_attention_mask(att, causal=False):
+    """xroberta.py:751-807.  att [B,S] (1 keep / 0 pad) -> additive [B,1,1,S] (or [B,1,S,S] causal)."""
+    att = att.to(torch.float32)
+    if causal:
+        S = att.shape[1]
+        ids = torch.arange(S, device=att.device)
+        cm = (ids[None, None, :] <= ids[None, :, None]).to(att.dtype)  # [1,S,S]
+        ext = cm[:, None, :, :] * att[:, None, None, :]
+    else:
+        ext = att[:, None, None, :]
+    return (1.0 - ext) * MASK_NEG
+
+
+def roberta_attention(P, pre, x, add_mask, kv_src=None, heads=12, eps=1e-5, scale_after=False):
+    """RobertaSelfAttention.forward xroberta.py:201-289 + RobertaSelfOutput :300-304.
+    kv_src: encoder_hidden_states for cross-attention (K,V projected from it, :224-226).
+    scale_after=True gives xbert.py:329-330 (scores / sqrt(d) after QK^T, non-fp16 branch)."""
+    B, T, C = x.shape
+    d = C // heads
+    src = x if kv_src is None else kv_src
+    S = src.shape[1]
+    q = _lin(P, pre + "self.query", x).view(B, T, heads, d).permute(0, 2, 1, 3)
+    k = _lin(P, pre + "self.key", src).view(B, S, heads, d).permute(0, 2, 1, 3)
+    v = _lin(P, pre + "self.value", src).view(B, S, heads, d).permute(0, 2, 1, 3)
+    if scale_after:
+        s = (q @ k.transpose(-1, -2)) / math.sqrt(d)
+    else:
+        s = (q / math.sqrt(d)) @ k.transpose(-1, -2)
+    if add_mask is not None:
+        s = s + add_mask
+    p = s.softmax(dim=-1)
+    ctx = (p @ v).permute(0, 2, 1, 3).reshape(B, T, C)
+    return _ln(P, pre + "output.LayerNorm", _lin(P, pre + "output.dense", ctx) + x, eps)
+
+
+def roberta_layer(P, pre, x, add_mask, enc=None, enc_mask=None, has_cross=False, heads=12, eps=1e-5,
+                  scale_after=False):
+    """RobertaLayer.forward xroberta.py:405-473."""
+    y = roberta_attention(P, pre + "attention.", x, add_mask, None, heads, eps, scale_after)
+    if has_cross and enc is not None:
+        y = roberta_attention(P, pre + "crossattention.", y, enc_mask, enc, heads, eps, scale_after)
+    h = gelu_erf(_lin(P, pre + "intermediate.dense", y))
+    return _ln(P, pre + "output.LayerNorm", _lin(P, pre + "output.dense", h) + y, eps)
+
+
+def roberta_encoder(P, pre, x, att, enc=None, enc_att=None, num_layers=12, fusion_layer=12, heads=12,
+                    eps=1e-5, causal=False, scale_after=False):
+    """RobertaModel.forward xroberta.py:817-957 after the embedding step, mode='multi_modal' (:504-516).
+    `pre` is the '...roberta.' prefix; x is the embedding output or `encoder_embeds` (:920-929)."""
+    add_mask = extended_attention_mask(att, causal)
+    enc_mask = None
+    if enc is not None:
+        if enc_att is None:
+            enc_att = torch.ones(enc.shape[:2], device=enc.device)
+        enc_mask = (1.0 - enc_att.to(torch.float32))[:, None, None, :] * MASK_NEG
+    for i in range(num_layers):
+        x = roberta_layer(P, f"{pre}encoder.layer.{i}.", x, add_mask, enc, enc_mask, i >= fusion_layer, heads, eps,
+                          scale_after)
+    return x
+
+
+def roberta_model(P, pre, input_ids=None, att=None, encoder_embeds=None, enc=None, enc_att=None, **kw):
+    """RobertaForMaskedLM.bert / RobertaModel.forward: embeddings (unless encoder_embeds) + encoder."""
+    x = encoder_embeds if encoder_embeds is not None else roberta_embeddings(P, pre + "embeddings.", input_ids)
+    return roberta_encoder(P, pre, x, att, enc, enc_att, **kw)
+
+
+def roberta_lm_head(P, pre, x, eps=1e-5):
+    """RobertaLMHead.forward xroberta.py:1325-1333 (decoder.bias is tied to `bias`)."""
+    h = _ln(P, pre + "layer_norm", gelu_erf(_lin(P, pre + "dense", x)), eps)
+    return F.linear(h, P[pre + "decoder.weight"], P[pre + "bias"])
+
+
+def gather_by_pos(seq, pos):
+    """xroberta.py:1215-1216."""
+    return torch.gather(seq, 1, pos.unsqueeze(2).expand(-1, -1, seq.size(-1)))
+
+
+def masked_lm_loss(P, model_pre, seq_out, masked_pos, labels, head="lm_head", causal_shift=False, reduction="mean"):
+    """RobertaForMaskedLM.forward tail xroberta.py:1273-1299."""
+    if masked_pos is not None:
+        seq_out = gather_by_pos(seq_out, masked_pos)
+    logits = roberta_lm_head(P, f"{model_pre}{head}.", seq_out)
+    if causal_shift:
+        logits, labels = logits[:, :-1, :], labels[:, 1:]
+    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1), reduction=reduction), logits
+
+
+# --------------------------------------------------------------------------------------
+# XFMBase glue and losses  (models/xfm.py, models/model_pretrain.py)
+# --------------------------------------------------------------------------------------
+def build_mlp_forward(P, pre, x, eps=1e-5):
+    """xfm.py:115-121: Linear(D,2D) -> LayerNorm -> GELU -> Linear(2D,out)."""
+    return _lin(P, pre + "3", F.gelu(_ln(P, pre + "1", _lin(P, pre + "0", x), eps)))
+
+
+def get_features(P, image_embeds=None, text_embeds=None):
+    """xfm.py:614-621."""
+    out = []
+    if image_embeds is not None:
+        out.append(F.normalize(_lin(P, "vision_proj", image_embeds[:, 0, :]), dim=-1))
+    if text_embeds is not None:
+        out.append(F.normalize(_lin(P, "text_proj", text_embeds[:, 0, :]), dim=-1))
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def contrastive_loss(image_feat_all, text_feat_all, temp, idx_all=None):
+    """xfm.py:683-715 after the all-gather (feats are the gathered [B*W, E] matrices)."""
+    logits = image_feat_all @ text_feat_all.t() / temp
+    n = logits.shape[0]
+    if idx_all is None:
+        labels = torch.arange(n, device=logits.device)
+        return (F.cross_entropy(logits, labels) + F.cross_entropy(logits.t(), labels)) / 2
+    idx_all = idx_all.view(-1, 1)
+    pos = torch.eq(idx_all, idx_all.t()).float()
+    labels = pos / pos.sum(1, keepdim=True)
+    l_i2t = -torch.sum(F.log_softmax(logits, dim=1) * labels, dim=1).mean()
+    l_t2i = -torch.sum(F.log_softmax(logits.t(), dim=1) * labels, dim=1).mean()
+    return (l_i2t + l_t2i) / 2
+
+
+def hard_negative_weights(image_feat, text_feat, temp, idx=None):
+    """xfm.py:717-734: the multinomial sampling weights (the draw itself is an input to the oracle)."""
+    with torch.no_grad():
+        w_i2t = F.softmax(image_feat @ text_feat.t() / temp, dim=1) + 1e-5
+        w_t2i = F.softmax(text_feat @ image_feat.t() / temp, dim=1) + 1e-5
+        if idx is None:
+            w_i2t.fill_diagonal_(0)
+            w_t2i.fill_diagonal_(0)
+        else:
+            m = torch.eq(idx.view(-1, 1), idx.view(1, -1))
+            w_i2t.masked_fill_(m, 0)
+            w_t2i.masked_fill_(m, 0)
+    return w_i2t, w_t2i
+
+
+def matching_loss(P, cfg, image_embeds, image_atts, text_embeds, text_atts, image_neg_idx, text_neg_idx,
+                  is_pretrain=True):
+    """xfm.py:749-802 given the sampled negatives (image_neg_idx / text_neg_idx: sequences of B ints)."""
+    bs = image_embeds.shape[0]
+    ini = torch.as_tensor(image_neg_idx, dtype=torch.long)
+    tni = torch.as_tensor(text_neg_idx, dtype=torch.long)
+    text_embeds_all = torch.cat([text_embeds, text_embeds[tni]], 0)
+    text_atts_all = torch.cat([text_atts, text_atts[tni]], 0)
+    image_embeds_all = torch.cat([image_embeds[ini], image_embeds], 0)
+    image_atts_all = torch.cat([image_atts[ini], image_atts], 0)
+
+    def cross(img, iatt, temb, tatt):  # xfm.py:659-680, text_embeds branch
+        temb = temb.detach() if is_pretrain else temb
+        return roberta_model(P, "fusion_encoder.roberta.", att=tatt, encoder_embeds=temb, enc=img, enc_att=iatt,
+                             num_layers=cfg["fusion_layers"], fusion_layer=cfg["fusion_start"])[:, 0, :]
+
+    pos = cross(image_embeds, image_atts, text_embeds, text_atts)
+    neg = cross(image_embeds_all, image_atts_all, text_embeds_all, text_atts_all)
+    out = build_mlp_forward(P, "itm_head.", torch.cat([pos, neg], 0))
+    labels = torch.cat([torch.ones(bs, dtype=torch.long), torch.zeros(2 * bs, dtype=torch.long)])
+    return F.cross_entropy(out, labels)
+
+
+def fuse_mlm_loss(P, cfg, text_ids_masked, text_atts, image_embeds, image_atts, masked_pos, masked_ids):
+    """xfm.py:638-656 (detach_text_forMLM=True default)."""
+    emb = roberta_model(P, "text_encoder.roberta.", input_ids=text_ids_masked, att=text_atts,
+                        num_layers=cfg["text_layers"], fusion_layer=cfg["text_layers"]).detach()
+    seq = roberta_model(P, "fusion_encoder.roberta.", att=text_atts, encoder_embeds=emb, enc=image_embeds,
+                        enc_att=image_atts, num_layers=cfg["fusion_layers"], fusion_layer=cfg["fusion_start"])
+    return masked_lm_loss(P, "fusion_encoder.", seq, masked_pos, masked_ids)[0]
+
+
+def mim_loss(image_embeds_masked, targets, ids_mask):
+    """xfm.py:624-635 (mim_cls_only=False): MSE on masked patches + MSE on the pooled cls."""
+    t = targets.detach()
+    return F.mse_loss(image_embeds_masked[:, 1:, :][ids_mask], t[:, 1:, :][ids_mask]) \
+        + F.mse_loss(image_embeds_masked[:, 0, :], t[:, 0, :])
+
+
+def default_cfg(text_layers=12, fusion_layers=12, vit_depth=12):
+    return {"text_layers": text_layers, "fusion_layers": fusion_layers, "fusion_start": 0, "vit_depth": vit_depth,
+            "min_temp": 0.001, "max_temp": 0.5}
+
+
+def pretrain_forward(P, cfg, batch, image_neg_idx=None, text_neg_idx=None, ids_mask=None, sampler=None):
+    """model_pretrain.py:30-91 forward_multimodal, data_source='image', all four losses, world_size 1.
+    If the negative indices are not given they are drawn with `sampler(weights_row)->int`
+    (default torch.multinomial, xfm.py:736-744)."""
+    with torch.no_grad():
+        P["temp"].clamp_(cfg["min_temp"], cfg["max_temp"])
+    image, text_ids, text_atts = batch["image"], batch["text_ids"], batch["text_atts"]
+    image_embeds = beit_forward(P, "vision_encoder.", image, depth=cfg["vit_depth"])
+    image_atts = torch.ones(image_embeds.shape[:2], dtype=torch.long)
+    text_embeds = roberta_model(P, "text_encoder.roberta.", input_ids=text_ids, att=text_atts,
+                                num_layers=cfg["text_layers"], fusion_layer=cfg["text_layers"])
+    image_feat, text_feat = get_features(P, image_embeds, text_embeds)
+    loss_itc = contrastive_loss(image_feat, text_feat, P["temp"])
+    if image_neg_idx is None:
+        w_i2t, w_t2i = hard_negative_weights(image_feat, text_feat, P["temp"])
+        draw = sampler or (lambda w: torch.multinomial(w, 1).item())
+        image_neg_idx = [draw(w_t2i[b]) for b in range(image.shape[0])]
+        text_neg_idx = [draw(w_i2t[b]) for b in range(image.shape[0])]
+    loss_itm = matching_loss(P, cfg, image_embeds, image_atts, text_embeds, text_atts, image_neg_idx, text_neg_idx)
+    loss_mlm = fuse_mlm_loss(P, cfg, batch["text_ids_masked"], text_atts, image_embeds, image_atts,
+                             batch["masked_pos"], batch["masked_ids"])
+    loss_mim = torch.zeros(())
+    if ids_mask is not None:
+        masked = beit_forward(P, "vision_encoder.", image, depth=cfg["vit_depth"], ids_mask=ids_mask)
+        loss_mim = mim_loss(masked, image_embeds, ids_mask)
+    return {"loss_itc": loss_itc, "loss_itm": loss_itm, "loss_mlm": loss_mlm, "loss_mim": loss_mim,
+            "image_embeds": image_embeds, "text_embeds": text_embeds,
+            "image_neg_idx": list(image_neg_idx), "text_neg_idx": list(text_neg_idx)}

@@ -1,0 +1,120 @@
+"""ctypes binding of libxfm_hip.so (include/xfm_hip.h).
+
+The product path has no CPU or PyTorch-eager fallback: if the library is missing or was built for another ABI,
+loading fails loudly, and every op refuses non-CUDA(HIP) tensors.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxfm_hip.so")
+ABI_VERSION = 1
+
+c_void_p, c_int, c_long, c_float, c_u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint32
+
+
+class LnFwdArgs(ctypes.Structure):
+    _fields_ = [("x32", c_void_p), ("x16", c_void_p), ("h", c_void_p), ("res", c_void_p), ("ls_gamma", c_void_p),
+                ("row_scale", c_void_p), ("w", c_void_p), ("b", c_void_p), ("x_out", c_void_p), ("z_out", c_void_p),
+                ("y", c_void_p), ("y32", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
+                ("rows", c_int), ("rows_per_sample", c_int), ("eps", c_float),
+                ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32)]
+
+
+class LnBwdArgs(ctypes.Structure):
+    _fields_ = [("dy1", c_void_p), ("dy2", c_void_p), ("dy32", c_void_p), ("x32", c_void_p), ("x16", c_void_p),
+                ("mean", c_void_p), ("rstd", c_void_p), ("w", c_void_p),
+                ("dx32", c_void_p), ("dx16", c_void_p), ("dx_accum", c_int),
+                ("dh", c_void_p), ("dres", c_void_p), ("dstream", c_void_p),
+                ("h", c_void_p), ("ls_gamma", c_void_p), ("row_scale", c_void_p), ("partial", c_void_p),
+                ("rows", c_int), ("rows_per_sample", c_int),
+                ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32)]
+
+
+class AttnArgs(ctypes.Structure):
+    _fields_ = [("q", c_void_p), ("q_rs", c_long), ("k", c_void_p), ("k_rs", c_long), ("v", c_void_p), ("v_rs", c_long),
+                ("o", c_void_p), ("o_rs", c_long), ("lse", c_void_p), ("bias", c_void_p), ("bias_ld", c_long),
+                ("key_keep", c_void_p), ("B", c_int), ("H", c_int), ("Sq", c_int), ("Sk", c_int),
+                ("scale", c_float), ("causal", c_int),
+                ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32),
+                ("dout", c_void_p), ("do_rs", c_long), ("dq", c_void_p), ("dq_rs", c_long), ("dk", c_void_p),
+                ("dk_rs", c_long), ("dv", c_void_p), ("dv_rs", c_long), ("delta", c_void_p), ("dbias", c_void_p)]
+
+
+class EmbedArgs(ctypes.Structure):
+    _fields_ = [("ids", c_void_p), ("word", c_void_p), ("pos", c_void_p), ("type", c_void_p), ("w", c_void_p),
+                ("b", c_void_p), ("y", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("pos_ids", c_void_p),
+                ("B", c_int), ("T", c_int), ("pad_id", c_int), ("eps", c_float),
+                ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32),
+                ("dy", c_void_p), ("dword", c_void_p), ("dpos", c_void_p), ("partial", c_void_p)]
+
+
+class AdamWArgs(ctypes.Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("group", c_void_p),
+                ("lr", c_float * 4), ("wd", c_float * 4),
+                ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("bc1", c_float), ("bc2", c_float),
+                ("clip_coef", c_void_p), ("n", c_long)]
+
+
+# name -> (restype, argtypes); mirrors include/xfm_hip.h one to one
+SIGNATURES = {
+    "xfm_last_error": (ctypes.c_char_p, []),
+    "xfm_abi_version": (c_int, []),
+    "xfm_gemm_nt": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long,
+                            c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "xfm_gemm_tn": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p]),
+    "xfm_cast_transpose": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
+    "xfm_colsum_workspace": (c_long, [c_int, c_int]),
+    "xfm_colsum": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_long, c_void_p]),
+    "xfm_layernorm_fwd": (c_int, [ctypes.POINTER(LnFwdArgs), c_int, c_int, c_void_p]),
+    "xfm_layernorm_bwd_workspace": (c_long, [c_int, c_int, c_int]),
+    "xfm_layernorm_bwd": (c_int, [ctypes.POINTER(LnBwdArgs), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_long, c_void_p]),
+    "xfm_attn_fwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
+    "xfm_attn_bwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
+    "xfm_relpos_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),
+    "xfm_relpos_scatter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),
+    "xfm_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "xfm_embed_ln_fwd": (c_int, [ctypes.POINTER(EmbedArgs), c_int, c_void_p]),
+    "xfm_embed_ln_bwd_workspace": (c_long, [c_int, c_int]),
+    "xfm_embed_ln_bwd": (c_int, [ctypes.POINTER(EmbedArgs), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long,
+                                 c_void_p]),
+    "xfm_ce_fwd": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xfm_ce_bwd": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "xfm_adamw": (c_int, [ctypes.POINTER(AdamWArgs), c_void_p]),
+    "xfm_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class XfmHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library.  Fails loudly when the HIP extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise XfmHipError(f"{LIB_PATH} not found: build it with `python -m xfm_amd.build` "
+                          f"(there is no CPU / eager fallback for the XFM hot path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise XfmHipError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.xfm_abi_version() != ABI_VERSION:
+        raise XfmHipError(f"ABI mismatch: library {lib.xfm_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().xfm_last_error().decode(errors="replace")
+        raise XfmHipError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,168 @@
+"""Flat parameter / gradient arenas and bf16 weight caches.
+
+MI355X-first memory plan (288 GB HBM3E per GPU): all fp32 master parameters of a model live in ONE flat buffer and
+all gradients in another of the same layout, so that
+  * weight gradients are accumulated in place by the wgrad kernels (no per-parameter autograd buffers or add kernels),
+  * the data-parallel exchange is an RCCL all-reduce over contiguous arena ranges (no flatten / unflatten copies),
+  * the optimiser is one elementwise kernel over the arenas,
+  * projections that the reference keeps as separate nn.Linear modules (query/key/value, xroberta.py:170-177) sit
+    back to back and are consumed as one fused [3*768, 768] GEMM operand.
+Every 2-D weight also keeps a bf16 copy and a transposed bf16 copy resident (forward / dgrad operands of the NT GEMM).
+
+`nn.Parameter` objects keep their identity and names (state_dict compatibility with the reference); only their
+storage is re-pointed into the arena.
+"""
+import weakref
+
+import torch
+
+from . import functional as Fx
+
+_ARENAS = weakref.WeakSet()
+_hook_installed = [False]
+
+
+def _install_optimizer_hook():
+    """Any torch optimizer step may rewrite the fp32 masters in place: invalidate every arena's bf16 caches."""
+    if _hook_installed[0]:
+        return
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+
+        def _bump_all(optimizer, args, kwargs):
+            for a in list(_ARENAS):
+                a.bump()
+
+        register_optimizer_step_post_hook(_bump_all)
+    except ImportError:  # very old torch: callers must call arena.bump() after stepping
+        pass
+    _hook_installed[0] = True
+
+ALIGN = 256  # elements; arena segments are 1 KiB aligned (vector loads, per-block optimiser groups)
+
+
+def _round(n, m=ALIGN):
+    return (n + m - 1) // m * m
+
+
+class LinearSlot:
+    """One GEMM operand: a weight that is the row-concatenation of `weights` ([n_i, K] each, or conv [n, ...]) and a
+    bias that is the concatenation of `biases` (Parameters, or an int = that many structural zeros)."""
+
+    def __init__(self, name, weights, biases=None, pad_k_to=1):
+        self.name = name
+        self.weights = list(weights)
+        self.biases = list(biases) if biases is not None else None
+        self.N = sum(w.shape[0] for w in self.weights)
+        self.K = self.weights[0].numel() // self.weights[0].shape[0]
+        self.ldt = _round(self.N, pad_k_to) if pad_k_to > 1 else _round(self.N, 8)
+        self.w = self.dw = self.b = self.db = None
+        self.wb = self.wt = None
+        self._ver = None
+        self.need_t = True
+
+    def refresh(self, ver):
+        if self._ver == ver:
+            return
+        dev = self.w.device
+        if self.wb is None:
+            self.wb = torch.empty((self.N, self.K), dtype=torch.bfloat16, device=dev)
+            self.wt = torch.zeros((self.K, self.ldt), dtype=torch.bfloat16, device=dev) if self.need_t else None
+        Fx.cast_transpose(self.w, self.wb, self.wt)
+        self._ver = ver
+
+
+class ParamArena:
+    def __init__(self, module, slots=(), device=None):
+        params = []
+        seen = set()
+        for name, p in module.named_parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append((name, p))
+        device = device or params[0][1].device
+        self.device = device
+        self.slots = list(slots)
+        # ---- layout: fused groups first (members adjacent, no padding inside a group), then the rest in module order
+        layout = []   # (param or None, numel, offset)
+        placed = set()
+        off = 0
+        group_ranges = []
+        for s in self.slots:
+            for plist in (s.weights, s.biases):
+                if plist is None:
+                    group_ranges.append(None)
+                    continue
+                start = off
+                for p in plist:
+                    if isinstance(p, int):
+                        layout.append((None, p, off))
+                        off += p
+                    else:
+                        assert id(p) not in placed, f"{s.name}: parameter used by two slots"
+                        placed.add(id(p))
+                        layout.append((p, p.numel(), off))
+                        off += p.numel()
+                group_ranges.append((start, off))
+                off = _round(off)
+        for name, p in params:
+            if id(p) in placed:
+                continue
+            placed.add(id(p))
+            layout.append((p, p.numel(), off))
+            off = _round(off + p.numel())
+        self.numel = _round(off)
+        self.data = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.offsets = {}
+        for p, n, o in layout:
+            if p is None:
+                continue
+            view = self.data[o:o + n].view(p.shape)
+            view.copy_(p.data.to(device=device, dtype=torch.float32))
+            p.data = view
+            p._xfm_grad = self.grad[o:o + n].view(p.shape)
+            p.grad = p._xfm_grad
+            self.offsets[id(p)] = (o, n)
+        self.names = {id(p): name for name, p in params}
+        it = iter(group_ranges)
+        for s in self.slots:
+            wr, br = next(it), next(it)
+            s.w = self.data[wr[0]:wr[1]].view(s.N, s.K)
+            s.dw = self.grad[wr[0]:wr[1]].view(s.N, s.K)
+            if br is not None:
+                s.b = self.data[br[0]:br[1]]
+                s.db = self.grad[br[0]:br[1]]
+                assert s.b.numel() == s.N, s.name
+        self._manual_ver = 0
+        self.params = [p for _, p in params]
+        _ARENAS.add(self)
+        _install_optimizer_hook()
+        module.register_load_state_dict_post_hook(lambda mod, keys: self.bump())
+
+    # bf16 caches are valid for one version; bumped by optimiser steps, load_state_dict and explicit bump()
+    def version(self):
+        return self._manual_ver
+
+    def bump(self):
+        self._manual_ver += 1
+
+    def refresh(self):
+        v = self.version()
+        for s in self.slots:
+            s.refresh(v)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p in self.params:
+            if p.grad is not p._xfm_grad:
+                p.grad = p._xfm_grad
+
+    def attached(self):
+        """True while every parameter still lives in the arena (a .to()/.cuda() after finalize() breaks this)."""
+        return all(p.data_ptr() == self.data.data_ptr() + 4 * self.offsets[id(p)][0] for p in self.params)
+
+    def range_of(self, params):
+        lo = min(self.offsets[id(p)][0] for p in params)
+        hi = max(self.offsets[id(p)][0] + self.offsets[id(p)][1] for p in params)
+        return lo, _round(hi)

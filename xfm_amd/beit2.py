@@ -1,0 +1,351 @@
+"""BEiT-v2 vision tower on the HIP hot path, behind the reference's interface.
+
+Mirrors `models/beit2.py::VisionTransformer` of the reference (constructor keywords :272-281, forward :477-481,
+forward_avgpool :423-466, state_dict keys) for the configuration every shipped YAML uses: relative-position bias
+per block, layer-scale gammas, q/v-only bias, mean-pooled pseudo-cls, no absolute position embedding.  The twelve
+blocks run as ONE autograd node whose forward/backward are explicit sequences of C-ABI kernel launches
+(xfm_amd.functional); PyTorch autograd only sees the patch/cls assembly before it and the pooling after it.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as Fx
+from .arena import LinearSlot, ParamArena
+from .ops import linear_slot
+
+
+class BlockMaskGenerator:
+    """Block-wise MIM mask sampler with the distribution of the reference's MaskingGenerator
+    (models/masking_generator.py:27-105): rectangles of area U[min, remaining] and log-uniform aspect in [0.3, 1/0.3],
+    accepted when they add between 1 and `remaining` new patches, then trimmed / topped up to exactly `num_masking`."""
+
+    def __init__(self, input_size, num_masking_patches, min_num_patches=4, min_aspect=0.3, seed=None):
+        self.h = self.w = int(input_size)
+        self.num = num_masking_patches
+        self.min_num = min_num_patches
+        self.log_aspect = (math.log(min_aspect), math.log(1.0 / min_aspect))
+        self.rng = np.random.default_rng(seed)
+
+    def _one(self):
+        rng, H, W = self.rng, self.h, self.w
+        mask = np.zeros((H, W), dtype=bool)
+        count = 0
+        while count < self.num:
+            budget = self.num - count
+            delta = 0
+            for _ in range(10):
+                area = rng.uniform(self.min_num, budget)
+                ar = math.exp(rng.uniform(*self.log_aspect))
+                h, w = int(round(math.sqrt(area * ar))), int(round(math.sqrt(area / ar)))
+                if w < W and h < H:
+                    top, left = int(rng.integers(0, H - h + 1)), int(rng.integers(0, W - w + 1))
+                    sub = mask[top:top + h, left:left + w]
+                    new = h * w - int(sub.sum())
+                    if 0 < new <= budget:
+                        sub[...] = True
+                        delta = new
+                        break
+            if delta == 0:
+                break
+            count += delta
+        flat = mask.reshape(-1)
+        if count < self.num:
+            free = np.flatnonzero(~flat)
+            flat[rng.choice(free, self.num - count, replace=False)] = True
+        elif count > self.num:
+            used = np.flatnonzero(flat)
+            flat[rng.choice(used, count - self.num, replace=False)] = False
+        return flat
+
+    def batch(self, n):
+        return torch.from_numpy(np.stack([self._one() for _ in range(n)], 0))
+
+
+def build_relative_position_index(gh, gw):
+    """[gh*gw+1]^2 int64 index into the (2gh-1)(2gw-1)+3 row bias table; last three rows are cls->tok, tok->cls,
+    cls->cls (same values as beit2.py:92-116)."""
+    n = gh * gw
+    nrd = (2 * gh - 1) * (2 * gw - 1) + 3
+    r = torch.arange(n)
+    y, x = r // gw, r % gw
+    rel = (y[:, None] - y[None, :] + gh - 1) * (2 * gw - 1) + (x[:, None] - x[None, :] + gw - 1)
+    idx = torch.full((n + 1, n + 1), nrd - 1, dtype=torch.int64)
+    idx[1:, 1:] = rel
+    idx[0, 1:] = nrd - 3
+    idx[1:, 0] = nrd - 2
+    return idx
+
+
+class _Affine(nn.Module):
+    """weight/bias container for a LayerNorm (arithmetic runs in the fused HIP kernels)."""
+
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        self.eps = eps
+
+
+class _Dense(nn.Module):
+    """weight/bias container for a Linear."""
+
+    def __init__(self, fin, fout, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.zeros(fout)) if bias else None
+        nn.init.trunc_normal_(self.weight, std=0.02, a=-2.0, b=2.0)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, window_size):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = _Dense(dim, dim * 3, bias=False)
+        self.q_bias = nn.Parameter(torch.zeros(dim))
+        self.v_bias = nn.Parameter(torch.zeros(dim))
+        self.window_size = window_size
+        nrd = (2 * window_size[0] - 1) * (2 * window_size[1] - 1) + 3
+        self.relative_position_bias_table = nn.Parameter(torch.zeros(nrd, num_heads))
+        self.register_buffer("relative_position_index", build_relative_position_index(*window_size))
+        self.proj = _Dense(dim, dim)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = _Dense(dim, hidden)
+        self.fc2 = _Dense(hidden, dim)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio, init_values, window_size, drop_path, eps):
+        super().__init__()
+        self.norm1 = _Affine(dim, eps)
+        self.attn = Attention(dim, num_heads, window_size)
+        self.norm2 = _Affine(dim, eps)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.gamma_1 = nn.Parameter(init_values * torch.ones(dim))
+        self.gamma_2 = nn.Parameter(init_values * torch.ones(dim))
+        self.drop_path_prob = float(drop_path)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.patch_shape = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.patch_shape[0] * self.patch_shape[1]
+        self.proj = nn.Module()
+        self.proj.weight = nn.Parameter(torch.empty(embed_dim, in_chans, patch_size, patch_size))
+        self.proj.bias = nn.Parameter(torch.zeros(embed_dim))
+        nn.init.kaiming_uniform_(self.proj.weight, a=math.sqrt(5))
+
+
+class _TrunkFn(torch.autograd.Function):
+    """All transformer blocks + the final LayerNorm as one node.  x0: fp32 [B, N, D] -> bf16 [B, N, D]."""
+
+    @staticmethod
+    def forward(ctx, x0, vit, dp):
+        B, N, D = x0.shape
+        M, H = B * N, vit.num_heads
+        arena = vit._arena
+        x = x0.reshape(M, D).contiguous()
+        ld = vit._bias_ld
+        blocks = vit.blocks
+        saved = []
+        n0 = blocks[0].norm1
+        y, mean, rstd = Fx.ln_fwd(x, n0.weight, n0.bias, n0.eps)
+        ctx.first = (x, mean, rstd)
+        for i, blk in enumerate(blocks):
+            s = vit._slots[i]
+            dense = Fx.relpos_gather(blk.attn.relative_position_bias_table, vit._index32, H, N, ld)
+            qkv = Fx.gemm_nt(y, s["qkv"].wb, s["qkv"].b)
+            ctxv, lse = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense)
+            h1 = Fx.gemm_nt(ctxv, s["proj"].wb, s["proj"].b)
+            dp1 = None if dp is None else dp[i, 0]
+            dp2 = None if dp is None else dp[i, 1]
+            x1, y2, mean2, rstd2 = Fx.ln_ls_fwd(x, h1, blk.gamma_1, dp1, N, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            hact, u = Fx.gemm_nt(y2, s["fc1"].wb, s["fc1"].b, epi=Fx.EPI_GELU)
+            h2 = Fx.gemm_nt(hact, s["fc2"].wb, s["fc2"].b)
+            nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else vit.fc_norm
+            x2, yn, meann, rstdn = Fx.ln_ls_fwd(x1, h2, blk.gamma_2, dp2, N, nxt.weight, nxt.bias, nxt.eps)
+            saved.append((y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2))
+            x, y = x2, yn
+        ctx.saved, ctx.vit, ctx.shape = saved, vit, (B, N, D)
+        arena_note_use(vit)
+        return y.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dy_out):
+        vit, (B, N, D) = ctx.vit, ctx.shape
+        M, H = B * N, vit.num_heads
+        blocks = vit.blocks
+        ld = vit._bias_ld
+        dy = dy_out.reshape(M, D).contiguous()
+        dstream = torch.zeros((M, D), dtype=torch.float32, device=dy.device)
+        for i in reversed(range(len(blocks))):
+            blk, s = blocks[i], vit._slots[i]
+            (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2) = ctx.saved[i]
+            nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else vit.fc_norm
+            g = _g
+            dh2 = Fx.ln_ls_bwd(dy, dstream, x2, meann, rstdn, nxt.weight, h2, blk.gamma_2, dp2, N, g(nxt.weight), g(nxt.bias),
+                               s["fc2"].db, g(blk.gamma_2))
+            Fx.gemm_tn(dh2, hact, s["fc2"].dw)
+            du = Fx.gemm_nt(dh2, s["fc2"].wt, epi=Fx.EPI_DGELU, aux=u, n=s["fc2"].K)
+            Fx.gemm_tn(du, y2, s["fc1"].dw)
+            Fx.colsum(du, s["fc1"].db)
+            dy2 = Fx.gemm_nt(du, s["fc1"].wt, n=s["fc1"].K)
+            dh1 = Fx.ln_ls_bwd(dy2, dstream, x1, mean2, rstd2, blk.norm2.weight, h1, blk.gamma_1, dp1, N, g(blk.norm2.weight),
+                               g(blk.norm2.bias), s["proj"].db, g(blk.gamma_1))
+            Fx.gemm_tn(dh1, ctxv, s["proj"].dw)
+            dctx = Fx.gemm_nt(dh1, s["proj"].wt, n=s["proj"].K)
+            dqkv = torch.empty_like(qkv)
+            ddense = torch.zeros_like(dense)
+            Fx.attn_bwd(dctx, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ctxv, lse, dqkv[:, :D], dqkv[:, D:2 * D],
+                        dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense)
+            Fx.relpos_scatter(ddense, vit._index32, H, N, ld, g(blk.attn.relative_position_bias_table))
+            Fx.gemm_tn(dqkv, y, s["qkv"].dw)
+            Fx.colsum(dqkv, s["qkv"].db)
+            dy = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K)
+            ctx.saved[i] = None
+        x0, mean0, rstd0 = ctx.first
+        n0 = blocks[0].norm1
+        Fx.ln_bwd(dy, x0, mean0, rstd0, n0.weight, _g(n0.weight), _g(n0.bias), dx32=dstream, dx_accum=True)
+        arena_note_grad(vit)
+        return dstream.view(B, N, D), None, None
+
+
+def _g(p):
+    """gradient view of a parameter inside the arena (re-attached if a caller dropped .grad)."""
+    if p.grad is not p._xfm_grad:
+        p.grad = p._xfm_grad
+    return p._xfm_grad
+
+
+def arena_note_use(mod):
+    hook = getattr(mod, "_use_hook", None)
+    if hook is not None:
+        hook(mod, +1)
+
+
+def arena_note_grad(mod):
+    hook = getattr(mod, "_use_hook", None)
+    if hook is not None:
+        hook(mod, -1)
+
+
+class VisionTransformer(nn.Module):
+    """Drop-in for models.beit2.VisionTransformer (BEiT-v2 configuration used by XFM)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.,
+                 norm_layer=None, init_values=0.1, use_abs_pos_emb=False, use_rel_pos_bias=True,
+                 use_shared_rel_pos_bias=False, use_mean_pooling=True, init_scale=0.001, local_attn_depth=-1,
+                 num_masking_patches=75, min_num_patches=16, layer_norm_eps=1e-6):
+        super().__init__()
+        unsupported = []
+        if use_abs_pos_emb: unsupported.append("use_abs_pos_emb")
+        if not use_rel_pos_bias: unsupported.append("use_rel_pos_bias=False")
+        if use_shared_rel_pos_bias: unsupported.append("use_shared_rel_pos_bias")
+        if not use_mean_pooling: unsupported.append("use_mean_pooling=False")
+        if local_attn_depth > 0: unsupported.append("local_attn_depth>0")
+        if not qkv_bias: unsupported.append("qkv_bias=False")
+        if not init_values or init_values <= 0: unsupported.append("init_values<=0")
+        if drop_rate or attn_drop_rate: unsupported.append("drop_rate/attn_drop_rate")
+        if (embed_dim // num_heads) != 64: unsupported.append("head_dim != 64")
+        if unsupported:
+            raise NotImplementedError("xfm_amd.beit2 implements the BEiT-v2 configuration XFM ships "
+                                      f"(xfm.py:206-234); unsupported: {unsupported}")
+        self.local_attn_depth = local_attn_depth
+        self.depth, self.num_heads = depth, num_heads
+        self.num_features = self.embed_dim = embed_dim
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = None
+        self.generator = BlockMaskGenerator(img_size // patch_size, num_masking_patches, min_num_patches)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, init_values, self.patch_embed.patch_shape,
+                                           dpr[i], layer_norm_eps) for i in range(depth)])
+        self.fc_norm = _Affine(embed_dim, layer_norm_eps)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        nn.init.trunc_normal_(self.mask_token, std=.02)
+        for i, blk in enumerate(self.blocks):  # fix_init_weight, beit2.py:327-333
+            blk.attn.proj.weight.data.div_(math.sqrt(2.0 * (i + 1)))
+            blk.mlp.fc2.weight.data.div_(math.sqrt(2.0 * (i + 1)))
+        self._arena = None
+        self._own_arena = False
+
+    # ---- arena plumbing -----------------------------------------------------------------------
+    def linear_slots(self):
+        D = self.embed_dim
+        self._slots = []
+        out = []
+        self._slot_patch = LinearSlot("patch_embed", [self.patch_embed.proj.weight], [self.patch_embed.proj.bias])
+        self._slot_patch.need_t = False
+        out.append(self._slot_patch)
+        for i, blk in enumerate(self.blocks):
+            s = {"qkv": LinearSlot(f"blocks.{i}.qkv", [blk.attn.qkv.weight], [blk.attn.q_bias, D, blk.attn.v_bias]),
+                 "proj": LinearSlot(f"blocks.{i}.proj", [blk.attn.proj.weight], [blk.attn.proj.bias]),
+                 "fc1": LinearSlot(f"blocks.{i}.fc1", [blk.mlp.fc1.weight], [blk.mlp.fc1.bias]),
+                 "fc2": LinearSlot(f"blocks.{i}.fc2", [blk.mlp.fc2.weight], [blk.mlp.fc2.bias])}
+            self._slots.append(s)
+            out.extend(s.values())
+        return out
+
+    def attach(self, arena):
+        self._arena = arena
+        N = self.patch_embed.num_patches + 1
+        self._bias_ld = (N + 15) // 16 * 16
+        self._index32 = self.blocks[0].attn.relative_position_index.to(device=arena.device, dtype=torch.int32).contiguous()
+
+    def finalize(self, device=None):
+        """Stand-alone use (the XFM wrapper builds one arena for all towers instead)."""
+        device = device or self.cls_token.device
+        arena = ParamArena(self, self.linear_slots(), device)
+        self.attach(arena)
+        self._own_arena = True
+        return self
+
+    def _ready(self):
+        if self._arena is None or not self._arena.attached():
+            if self._arena is not None and not self._own_arena:
+                raise RuntimeError("parameters were moved after the arena was built; call finalize() again")
+            self.finalize()
+        self._arena.refresh()
+
+    # ---- forward --------------------------------------------------------------------------------
+    def forward(self, x, idx_to_group_img=None, image_atts=None, do_mask=False, ids_mask=None, drop_path_scales=None):
+        if idx_to_group_img is not None or image_atts is not None:
+            raise NotImplementedError("region / grouped-image path (beit2.py:467-475) is outside the hot-path scope")
+        self._ready()
+        B = x.shape[0]
+        D = self.embed_dim
+        P = self.patch_embed.patch_size[0]
+        patches = Fx.patchify(x.float().contiguous(), P)
+        tok = linear_slot(patches, self._slot_patch, x_requires_grad=False, out_fp32=True).view(B, -1, D)
+        if do_mask:
+            if ids_mask is None:
+                ids_mask = self.generator.batch(B)
+            ids_mask = ids_mask.to(device=x.device, dtype=torch.bool)
+            w = ids_mask.unsqueeze(-1).to(tok.dtype)
+            tok = tok * (1 - w) + self.mask_token.expand(B, tok.shape[1], -1) * w
+        x0 = torch.cat([self.cls_token.expand(B, -1, -1), tok], dim=1)
+        dp = drop_path_scales
+        if dp is None and self.training:
+            keep = 1.0 - torch.tensor([[b.drop_path_prob] * 2 for b in self.blocks], device=x.device).view(-1, 2, 1)
+            dp = (torch.rand(len(self.blocks), 2, B, device=x.device) < keep).float() / keep
+        y = _TrunkFn.apply(x0, self, dp)             # bf16 [B, N, D], fc_norm applied to every row
+        patches_n = y[:, 1:]
+        out = torch.cat([patches_n.float().mean(dim=1, keepdim=True).to(y.dtype), patches_n], dim=1)
+        return (out, ids_mask) if do_mask else out
+
+
+def beit_base_patch16(img_size, depth=12, **kwargs):
+    return VisionTransformer(img_size=img_size, patch_size=16, embed_dim=768, depth=depth, num_heads=12, mlp_ratio=4,
+                             layer_norm_eps=1e-6, **kwargs)

@@ -1,0 +1,444 @@
+// Fused multi-head attention forward / backward for head_dim 64 (gfx950, bf16 MFMA, fp32 softmax).
+//
+// Reference arithmetic: beit2.py:126-166 (q*scale, + relative-position bias, softmax, attn_drop, @v) and
+// xroberta.py:201-289 (q/sqrt(d) BEFORE q@k^T, + additive -10000 key mask, softmax, dropout, @v; causal variant
+// :772-792).  Scores are never materialised in HBM: each wave owns 16 query rows, keys stream through LDS in chunks
+// of 64 with an online softmax, and S is computed TRANSPOSED (S^T = K.Q^T) so that the fp32 accumulator of one MFMA
+// is already laid out as the B operand of the next one (P^T for O^T = V^T.P^T), with no lane movement.  V is staged
+// row-major and consumed through the transposed LDS read (ds_read_b64_tr_b16).
+//
+// Layouts: q/k/v/o are addressed as ptr[(b*S + s)*row_stride + h*64 + d], i.e. straight out of / into the fused
+// projection GEMM buffers ([B*S, 3*768] for self-attention, [B*Sk, 2*768] for the cross-attention K/V).
+#include "common.h"
+
+#define MASK_NEG (-10000.0f)
+#define EXCL_NEG (-1.0e30f)
+
+typedef xfm_attn_args AttnArgs;
+
+__device__ __forceinline__ int swz_a(int r) { return (r >> 1) & 7; }
+
+// ROWS x 64 bf16 tile, 128-B rows, rows >= nvalid are zero filled
+template <int ROWS>
+__device__ __forceinline__ void stage_tile(char* lds, const bf16* g, long rs, int row0, int nvalid, int tid, int nthreads) {
+  for (int q = tid; q < ROWS * 8; q += nthreads) {
+    const int r = q >> 3, c = q & 7;
+    u32x4 val = u32x4{0, 0, 0, 0};
+    if (row0 + r < nvalid) val = *reinterpret_cast<const u32x4*>(g + (long)(row0 + r) * rs + c * 8);
+    *reinterpret_cast<u32x4*>(lds + r * 128 + ((c ^ swz_a(r)) << 4)) = val;
+  }
+}
+
+// A/B fragment of a row-major tile: lane (lg, lr) -> row (row0 + lr), elements [ks*32 + 8*lg, +8)
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int row0, int ks, int lr, int lg) {
+  const int r = row0 + lr, c = ks * 4 + lg;
+  return *reinterpret_cast<const bf16x8*>(tile + r * 128 + ((c ^ swz_a(r)) << 4));
+}
+
+// transposed fragment: k-slots (lg, j<4) -> rows rowA + 4*lg + j ; (lg, j>=4) -> rows rowB + 4*lg + (j-4); column col0 + lr
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rowA, int rowB, int col0, int lr, int lg) {
+  const int col = col0 + 4 * (lr & 3);
+  const int ra = rowA + 4 * lg + (lr >> 2), rb = rowB + 4 * lg + (lr >> 2);
+  const int offa = ra * 128 + (((col >> 3) ^ swz_a(ra)) << 4) + (col & 7) * 2;
+  const int offb = rb * 128 + (((col >> 3) ^ swz_a(rb)) << 4) + (col & 7) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + offa));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + offb));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { r[j] = f2bf(a[j]); r[4 + j] = f2bf(b[j]); }
+  return r;
+}
+
+__device__ __forceinline__ float group4_max(float v) {  // across the 4 lanes that share lane&15
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group4_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// score post-processing shared by forward and both backward kernels: returns the masked, biased, scaled score
+__device__ __forceinline__ float score_fix(const AttnArgs& a, float raw, int b, int h, int qi, int kj, float biasv) {
+  if (kj >= a.Sk) return EXCL_NEG;
+  float s = raw * a.scale + biasv;
+  bool masked = false;
+  if (a.key_keep != nullptr) masked = a.key_keep[(long)b * a.Sk + kj] == 0;
+  if (a.causal && kj > qi) masked = true;
+  return masked ? s + MASK_NEG : s;
+}
+
+__device__ __forceinline__ bool drop_keep(const AttnArgs& a, int b, int h, int qi, int kj) {
+  const uint64_t idx = (((uint64_t)(b * a.H + h)) * a.Sq + qi) * a.Sk + kj;
+  return rng_keep(rng_u32(a.seed_lo, a.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32)), a.drop_thresh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: grid (q blocks, H, B); block = NW waves, wave w owns query rows [qblk*16*NW + 16*w, +16)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * 128];
+  char* sK = lds;
+  char* sV = lds + 64 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = (blockIdx.x * (nthreads >> 6) + w) * 16;
+  const bool wave_active = q0 < a.Sq;
+  const int qi = q0 + lr;
+  const int qc = qi < a.Sq ? qi : a.Sq - 1;
+  const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
+  const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
+  const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
+  const bf16* kb = a.k + (long)b * a.Sk * a.k_rs + h * 64;
+  const bf16* vb = a.v + (long)b * a.Sk * a.v_rs + h * 64;
+
+  f32x4 oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = EXCL_NEG, l_run = 0.f;
+
+  const int nchunks = (a.Sk + 63) / 64;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    __syncthreads();
+    stage_tile<64>(sK, kb, a.k_rs, kc * 64, a.Sk, tid, nthreads);
+    stage_tile<64>(sV, vb, a.v_rs, kc * 64, a.Sk, tid, nthreads);
+    __syncthreads();
+    if (!wave_active) continue;
+    f32x4 st[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 0, lr, lg), qf0, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 1, lr, lg), qf1, st[t], 0, 0, 0);
+    }
+    float mx = EXCL_NEG;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kj0 = kc * 64 + t * 16 + 4 * lg;
+      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.bias != nullptr && kj0 < a.Sk) bv = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[t][r] = score_fix(a, st[t][r], b, h, qi, kj0 + r, bv[r]);
+        mx = fmaxf(mx, st[t][r]);
+      }
+    }
+    mx = group4_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __expf(st[t][r] - m_new);
+        psum += pv;
+        float pd = pv;
+        if (a.drop_thresh != 0u) pd = drop_keep(a, b, h, qi, kc * 64 + t * 16 + 4 * lg + r) ? pv * a.drop_scale : 0.f;
+        st[t][r] = pd;
+      }
+    psum = group4_sum(psum);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 pf = pack_pair(st[2 * s], st[2 * s + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sV, 32 * s, 32 * s + 16, dt * 16, lr, lg), pf, oacc[dt], 0, 0, 0);
+    }
+  }
+  if (!wave_active || qi >= a.Sq) return;
+  const float inv = 1.0f / l_run;
+  bf16* op = a.o + ((long)b * a.Sq + qi) * a.o_rs + h * 64;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    bf16x4 ov;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ov[r] = f2bf(oacc[dt][r] * inv);
+    *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * lg) = ov;
+  }
+  if (lg == 0) a.lse[((long)b * a.H + h) * a.Sq + qi] = m_run + __logf(l_run);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward 1/2: dQ (+ delta, + dbias).  Same decomposition as the forward.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * 128];
+  char* sK = lds;
+  char* sV = lds + 64 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = (blockIdx.x * (nthreads >> 6) + w) * 16;
+  const bool wave_active = q0 < a.Sq;
+  const int qi = q0 + lr;
+  const bool qvalid = qi < a.Sq;
+  const int qc = qvalid ? qi : a.Sq - 1;
+  const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
+  const bf16* dop = a.dout + ((long)b * a.Sq + qc) * a.do_rs + h * 64;
+  const bf16* op = a.o + ((long)b * a.Sq + qc) * a.o_rs + h * 64;
+  const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
+  const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
+  const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop + 8 * lg);
+  const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32 + 8 * lg);
+  float delta = 0.f;
+  {
+    const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(op + 8 * lg);
+    const bf16x8 o1 = *reinterpret_cast<const bf16x8*>(op + 32 + 8 * lg);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) delta += bf2f(df0[j]) * bf2f(o0[j]) + bf2f(df1[j]) * bf2f(o1[j]);
+    delta = group4_sum(delta);
+  }
+  const long stat_idx = ((long)b * a.H + h) * a.Sq + qc;
+  const float lse = a.lse[stat_idx];
+  if (wave_active && qvalid && lg == 0) a.delta[stat_idx] = delta;
+  const bf16* kb = a.k + (long)b * a.Sk * a.k_rs + h * 64;
+  const bf16* vb = a.v + (long)b * a.Sk * a.v_rs + h * 64;
+
+  f32x4 dqacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = (a.Sk + 63) / 64;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    __syncthreads();
+    stage_tile<64>(sK, kb, a.k_rs, kc * 64, a.Sk, tid, nthreads);
+    stage_tile<64>(sV, vb, a.v_rs, kc * 64, a.Sk, tid, nthreads);
+    __syncthreads();
+    if (!wave_active) continue;
+    f32x4 st[4], dp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 0, lr, lg), qf0, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 1, lr, lg), qf1, st[t], 0, 0, 0);
+      dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 0, lr, lg), df0, dp[t], 0, 0, 0);
+      dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 1, lr, lg), df1, dp[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kj0 = kc * 64 + t * 16 + 4 * lg;
+      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.bias != nullptr && kj0 < a.Sk) bv = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kj = kj0 + r;
+        const float s = score_fix(a, st[t][r], b, h, qi, kj, bv[r]);
+        const float pv = (kj < a.Sk && qvalid) ? __expf(s - lse) : 0.f;
+        float dpv = dp[t][r];
+        if (a.drop_thresh != 0u) dpv = drop_keep(a, b, h, qi, kj) ? dpv * a.drop_scale : 0.f;
+        const float ds = pv * (dpv - delta);
+        st[t][r] = ds;
+        if (a.dbias != nullptr && kj < a.Sk && qvalid) atomicAdd(a.dbias + ((long)h * a.Sq + qi) * a.bias_ld + kj, ds);
+      }
+    }
+    // dQ^T[d, q] += K^T[d, key] . dS^T[key, q]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 pf = pack_pair(st[2 * s], st[2 * s + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK, 32 * s, 32 * s + 16, dt * 16, lr, lg), pf, dqacc[dt], 0, 0, 0);
+    }
+  }
+  if (!wave_active || !qvalid) return;
+  bf16* dqp = a.dq + ((long)b * a.Sq + qi) * a.dq_rs + h * 64;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    bf16x4 ov;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ov[r] = f2bf(dqacc[dt][r] * a.scale);
+    *reinterpret_cast<bf16x4*>(dqp + dt * 16 + 4 * lg) = ov;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward 2/2: dK, dV.  grid (key blocks, H, B); wave w owns keys [kblk*16*NW + 16*w, +16); queries stream in chunks
+// of 64 (Q and dO staged in LDS, read by rows for S / dP and transposed for dK^T / dV^T).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * 128];
+  char* sQ = lds;
+  char* sD = lds + 64 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int k0 = (blockIdx.x * (nthreads >> 6) + w) * 16;
+  const bool wave_active = k0 < a.Sk;
+  const int kj = k0 + lr;
+  const bool kvalid = kj < a.Sk;
+  const int kcl = kvalid ? kj : a.Sk - 1;
+  const bf16* kp = a.k + ((long)b * a.Sk + kcl) * a.k_rs + h * 64;
+  const bf16* vp = a.v + ((long)b * a.Sk + kcl) * a.v_rs + h * 64;
+  const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp + 8 * lg);
+  const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + 32 + 8 * lg);
+  const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vp + 8 * lg);
+  const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vp + 32 + 8 * lg);
+  const bf16* qb = a.q + (long)b * a.Sq * a.q_rs + h * 64;
+  const bf16* db = a.dout + (long)b * a.Sq * a.do_rs + h * 64;
+  const float* lse_b = a.lse + ((long)b * a.H + h) * a.Sq;
+  const float* del_b = a.delta + ((long)b * a.H + h) * a.Sq;
+  bool key_masked = false;
+  if (a.key_keep != nullptr) key_masked = a.key_keep[(long)b * a.Sk + kcl] == 0;
+
+  f32x4 dkacc[4], dvacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nchunks = (a.Sq + 63) / 64;
+  for (int qc = 0; qc < nchunks; ++qc) {
+    __syncthreads();
+    stage_tile<64>(sQ, qb, a.q_rs, qc * 64, a.Sq, tid, nthreads);
+    stage_tile<64>(sD, db, a.do_rs, qc * 64, a.Sq, tid, nthreads);
+    __syncthreads();
+    if (!wave_active) continue;
+    f32x4 st[4], dp[4];  // D[i = query row][j = key col]: lane (lg, lr) -> query 16t + 4lg + r, key lr
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 0, lr, lg), kf0, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 1, lr, lg), kf1, st[t], 0, 0, 0);
+      dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 0, lr, lg), vf0, dp[t], 0, 0, 0);
+      dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 1, lr, lg), vf1, dp[t], 0, 0, 0);
+    }
+    f32x4 pd[4];  // dropped probabilities for dV
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int qi0 = qc * 64 + t * 16 + 4 * lg;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = qi0 + r;
+        const bool ok = qi < a.Sq && kvalid;
+        const int qcl = qi < a.Sq ? qi : a.Sq - 1;
+        float biasv = 0.f;
+        if (a.bias != nullptr && ok) biasv = a.bias[((long)h * a.Sq + qi) * a.bias_ld + kj];
+        float s = st[t][r] * a.scale + biasv;
+        if (key_masked || (a.causal && kj > qi)) s += MASK_NEG;
+        const float pv = ok ? __expf(s - lse_b[qcl]) : 0.f;
+        float keepf = 1.f;
+        if (a.drop_thresh != 0u) keepf = (ok && drop_keep(a, b, h, qi, kj)) ? a.drop_scale : 0.f;
+        pd[t][r] = pv * keepf;
+        st[t][r] = pv * (dp[t][r] * keepf - del_b[qcl]);
+      }
+    }
+    // dV^T[d, key] += dO^T[d, q] . Pd[q, key] ;  dK^T[d, key] += Q^T[d, q] . dS[q, key]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 pf = pack_pair(pd[2 * s], pd[2 * s + 1]);
+      const bf16x8 sf = pack_pair(st[2 * s], st[2 * s + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sD, 32 * s, 32 * s + 16, dt * 16, lr, lg), pf, dvacc[dt], 0, 0, 0);
+        dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sQ, 32 * s, 32 * s + 16, dt * 16, lr, lg), sf, dkacc[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (!wave_active || !kvalid) return;
+  bf16* dkp = a.dk + ((long)b * a.Sk + kj) * a.dk_rs + h * 64;
+  bf16* dvp = a.dv + ((long)b * a.Sk + kj) * a.dv_rs + h * 64;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    bf16x4 ok_, ov_;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ok_[r] = f2bf(dkacc[dt][r] * a.scale); ov_[r] = f2bf(dvacc[dt][r]); }
+    *reinterpret_cast<bf16x4*>(dkp + dt * 16 + 4 * lg) = ok_;
+    *reinterpret_cast<bf16x4*>(dvp + dt * 16 + 4 * lg) = ov_;
+  }
+}
+
+static int attn_check(const AttnArgs& a, bool bwd) {
+  XFM_REQUIRE(a.B > 0 && a.H > 0 && a.Sq > 0 && a.Sk > 0, "attention: empty problem B=%d H=%d Sq=%d Sk=%d", a.B, a.H, a.Sq, a.Sk);
+  XFM_REQUIRE(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.v_rs % 8 == 0 && a.o_rs % 4 == 0, "attention: row strides must be multiples of 8");
+  XFM_REQUIRE(((uintptr_t)a.q % 16) == 0 && ((uintptr_t)a.k % 16) == 0 && ((uintptr_t)a.v % 16) == 0 && ((uintptr_t)a.o % 8) == 0,
+              "attention: q/k/v must be 16-byte aligned");
+  XFM_REQUIRE(a.bias == nullptr || (a.bias_ld % 4 == 0 && a.bias_ld >= a.Sk), "attention: bias_ld must be a multiple of 4 and >= Sk");
+  XFM_REQUIRE(a.B <= 65535 && a.H <= 65535, "attention: B/H exceed grid limits");
+  if (bwd) {
+    XFM_REQUIRE(a.dout && a.dq && a.dk && a.dv && a.delta && a.lse, "attention bwd: missing buffers");
+    XFM_REQUIRE(a.do_rs % 8 == 0 && a.dq_rs % 4 == 0 && a.dk_rs % 4 == 0 && a.dv_rs % 4 == 0, "attention bwd: bad strides");
+  }
+  return XFM_OK;
+}
+
+static void attn_geom(int S, int& nw, int& blocks) {
+  const int tiles = cdiv(S, 16);
+  nw = tiles < 8 ? tiles : 8;
+  // balance waves over blocks (e.g. 13 tiles -> 2 blocks of 7 waves)
+  blocks = cdiv(tiles, nw);
+  nw = cdiv(tiles, blocks);
+}
+
+int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
+  int rc = attn_check(a, false);
+  if (rc != XFM_OK) return rc;
+  int nw, blocks;
+  attn_geom(a.Sq, nw, blocks);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(blocks, a.H, a.B), dim3(nw * 64), 0, st, a);
+  return xfm_check_launch("attn_fwd");
+}
+
+int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
+  int rc = attn_check(a, true);
+  if (rc != XFM_OK) return rc;
+  int nw, blocks;
+  attn_geom(a.Sq, nw, blocks);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(blocks, a.H, a.B), dim3(nw * 64), 0, st, a);
+  rc = xfm_check_launch("attn_bwd_dq");
+  if (rc != XFM_OK) return rc;
+  attn_geom(a.Sk, nw, blocks);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(blocks, a.H, a.B), dim3(nw * 64), 0, st, a);
+  return xfm_check_launch("attn_bwd_dkv");
+}
+
+// ---------------------------------------------------------------------------------------------
+// relative-position bias: dense[h,i,j] = table[index[i,j], h]  (beit2.py:139-145) and its transpose-scatter gradient
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relpos_gather_kernel(const float* __restrict__ table, const int* __restrict__ index, int H,
+                                                            int N, long ld, float* __restrict__ dense) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)H * N * ld;
+  if (t >= total) return;
+  const int j = (int)(t % ld);
+  const int i = (int)((t / ld) % N);
+  const int h = (int)(t / (ld * N));
+  dense[t] = (j < N) ? table[(long)index[i * N + j] * H + h] : 0.f;
+}
+__global__ __launch_bounds__(256) void relpos_scatter_kernel(const float* __restrict__ ddense, const int* __restrict__ index, int H,
+                                                             int N, long ld, float* __restrict__ dtable) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)H * N * N;
+  if (t >= total) return;
+  const int j = (int)(t % N);
+  const int i = (int)((t / N) % N);
+  const int h = (int)(t / ((long)N * N));
+  atomicAdd(dtable + (long)index[i * N + j] * H + h, ddense[((long)h * N + i) * ld + j]);
+}
+
+int xfm_relpos_gather_impl(const float* table, const int* index, int H, int N, long ld, float* dense, hipStream_t st) {
+  XFM_REQUIRE(H > 0 && N > 0 && ld >= N && ld % 4 == 0, "relpos_gather: bad shape H=%d N=%d ld=%ld", H, N, ld);
+  const long total = (long)H * N * ld;
+  hipLaunchKernelGGL(relpos_gather_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, table, index, H, N, ld, dense);
+  return xfm_check_launch("relpos_gather");
+}
+int xfm_relpos_scatter_impl(const float* ddense, const int* index, int H, int N, long ld, float* dtable, hipStream_t st) {
+  XFM_REQUIRE(H > 0 && N > 0 && ld >= N, "relpos_scatter: bad shape");
+  const long total = (long)H * N * N;
+  hipLaunchKernelGGL(relpos_scatter_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ddense, index, H, N, ld, dtable);
+  return xfm_check_launch("relpos_scatter");
+}

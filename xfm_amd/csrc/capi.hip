@@ -1,0 +1,145 @@
+// C-ABI of libxfm_hip.so (see include/xfm_hip.h).  Single translation unit: the kernel files are included here so
+// that no relocatable device code is needed.
+#include "common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void xfm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int xfm_check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    xfm_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return XFM_E_LAUNCH;
+  }
+  return XFM_OK;
+}
+
+#include "gemm.hip"
+#include "layernorm.hip"
+#include "attention.hip"
+#include "elementwise.hip"
+
+#define ST(s) ((hipStream_t)(s))
+#define NOTNULL(p, name) XFM_REQUIRE((p) != nullptr, "%s: null argument struct", name)
+
+extern "C" {
+
+const char* xfm_last_error(void) { return g_err; }
+int xfm_abi_version(void) { return XFM_ABI_VERSION; }
+
+int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* C, long ldc, const float* bias, xfm_bf16* aux,
+                long ldaux, int M, int N, int K, int epilogue, int tile_hint, void* stream) {
+  XFM_REQUIRE(A && B && C, "gemm_nt: null operand");
+  return xfm_gemm_nt_impl(A, lda, B, ldb, C, ldc, bias, aux, ldaux, M, N, K, epilogue, tile_hint, ST(stream));
+}
+
+int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float* dW, long ldw, int M, int N, int K,
+                int splits_hint, void* stream) {
+  XFM_REQUIRE(dY && X && dW, "gemm_tn: null operand");
+  return xfm_gemm_tn_impl(dY, ldy, X, ldx, dW, ldw, M, N, K, splits_hint, ST(stream));
+}
+
+int xfm_cast_transpose(const float* w, int N, int K, xfm_bf16* wb, long ldb, xfm_bf16* wt, long ldt, void* stream) {
+  XFM_REQUIRE(w && (wb || wt), "cast_transpose: null operand");
+  return xfm_cast_transpose_impl(w, N, K, wb, ldb, wt, ldt, ST(stream));
+}
+
+long xfm_colsum_workspace(int M, int N) { return (long)256 * N * 4; }
+int xfm_colsum(const xfm_bf16* Y, long ldy, int M, int N, float* out, float* workspace, long workspace_bytes, void* stream) {
+  XFM_REQUIRE(Y && out, "colsum: null operand");
+  return xfm_colsum_impl(Y, ldy, M, N, out, workspace, workspace_bytes, ST(stream));
+}
+
+int xfm_layernorm_fwd(const xfm_ln_fwd_args* a, int D, int mode, void* stream) {
+  NOTNULL(a, "layernorm_fwd");
+  XFM_REQUIRE(a->w && a->b && a->y && a->mean && a->rstd, "layernorm_fwd: null operand");
+  XFM_REQUIRE(mode != XFM_LN_PLAIN || a->x32 || a->x16, "layernorm_fwd: PLAIN needs x32 or x16");
+  XFM_REQUIRE(mode != XFM_LN_POST || (a->h && a->res && a->z_out), "layernorm_fwd: POST needs h, res, z_out");
+  XFM_REQUIRE(mode != XFM_LN_LS || (a->x32 && a->h && a->ls_gamma && a->x_out && a->rows_per_sample > 0),
+              "layernorm_fwd: LS needs x32, h, ls_gamma, x_out, rows_per_sample");
+  return xfm_ln_fwd_impl(*a, D, mode, ST(stream));
+}
+
+long xfm_layernorm_bwd_workspace(int rows, int D, int mode) {
+  const int nset = mode == XFM_LN_PLAIN ? 2 : (mode == XFM_LN_POST ? 3 : 4);
+  return (long)nset * xfm_ln_bwd_grid(rows) * D * 4;
+}
+int xfm_layernorm_bwd(const xfm_ln_bwd_args* a, int D, int mode, float* dgamma, float* dbeta, float* dbias, float* dls,
+                      float* workspace, long workspace_bytes, void* stream) {
+  NOTNULL(a, "layernorm_bwd");
+  XFM_REQUIRE(a->dy1 && a->mean && a->rstd && a->w && (a->x32 || a->x16), "layernorm_bwd: null operand");
+  XFM_REQUIRE(mode != XFM_LN_POST || a->dh, "layernorm_bwd: POST needs dh");
+  XFM_REQUIRE(mode != XFM_LN_LS || (a->dh && a->dstream && a->h && a->ls_gamma && a->rows_per_sample > 0),
+              "layernorm_bwd: LS needs dh, dstream, h, ls_gamma, rows_per_sample");
+  return xfm_ln_bwd_impl(*a, D, mode, dgamma, dbeta, dbias, dls, workspace, workspace_bytes, ST(stream));
+}
+
+int xfm_attn_fwd(const xfm_attn_args* a, void* stream) {
+  NOTNULL(a, "attn_fwd");
+  XFM_REQUIRE(a->q && a->k && a->v && a->o && a->lse, "attn_fwd: null operand");
+  return xfm_attn_fwd_impl(*a, ST(stream));
+}
+int xfm_attn_bwd(const xfm_attn_args* a, void* stream) {
+  NOTNULL(a, "attn_bwd");
+  XFM_REQUIRE(a->q && a->k && a->v && a->o && a->lse, "attn_bwd: null operand");
+  return xfm_attn_bwd_impl(*a, ST(stream));
+}
+int xfm_relpos_gather(const float* table, const int* index, int H, int N, long ld, float* dense, void* stream) {
+  XFM_REQUIRE(table && index && dense, "relpos_gather: null operand");
+  return xfm_relpos_gather_impl(table, index, H, N, ld, dense, ST(stream));
+}
+int xfm_relpos_scatter(const float* ddense, const int* index, int H, int N, long ld, float* dtable, void* stream) {
+  XFM_REQUIRE(ddense && index && dtable, "relpos_scatter: null operand");
+  return xfm_relpos_scatter_impl(ddense, index, H, N, ld, dtable, ST(stream));
+}
+
+int xfm_patchify(const float* image, int B, int C, int H, int W, int P, xfm_bf16* out, void* stream) {
+  XFM_REQUIRE(image && out, "patchify: null operand");
+  return xfm_patchify_impl(image, B, C, H, W, P, out, ST(stream));
+}
+
+int xfm_embed_ln_fwd(const xfm_embed_args* a, int D, void* stream) {
+  NOTNULL(a, "embed_ln_fwd");
+  XFM_REQUIRE(a->ids && a->word && a->pos && a->type && a->w && a->b && a->y && a->mean && a->rstd && a->pos_ids,
+              "embed_ln_fwd: null operand");
+  return xfm_emb_fwd_impl(*a, D, ST(stream));
+}
+long xfm_embed_ln_bwd_workspace(int rows, int D) { return (long)3 * emb_grid(rows) * D * 4; }
+int xfm_embed_ln_bwd(const xfm_embed_args* a, int D, float* dgamma, float* dbeta, float* dtype, float* workspace,
+                     long workspace_bytes, void* stream) {
+  NOTNULL(a, "embed_ln_bwd");
+  XFM_REQUIRE(a->ids && a->word && a->pos && a->type && a->w && a->dy && a->dword && a->dpos && a->mean && a->rstd && a->pos_ids,
+              "embed_ln_bwd: null operand");
+  return xfm_emb_bwd_impl(*a, D, dgamma, dbeta, dtype, workspace, workspace_bytes, ST(stream));
+}
+
+int xfm_ce_fwd(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, void* stream) {
+  XFM_REQUIRE(logits && labels && lse && loss, "ce_fwd: null operand");
+  return xfm_ce_fwd_impl(logits, ld, R, V, labels, lse, loss, ST(stream));
+}
+int xfm_ce_bwd(const float* logits, long ld, int R, int V, const int64_t* labels, const float* lse, const float* scale,
+               xfm_bf16* dlogits, long ldd, void* stream) {
+  XFM_REQUIRE(logits && labels && lse && scale && dlogits, "ce_bwd: null operand");
+  return xfm_ce_bwd_impl(logits, ld, R, V, labels, lse, scale, dlogits, ldd, ST(stream));
+}
+
+int xfm_adamw(const xfm_adamw_args* a, void* stream) {
+  NOTNULL(a, "adamw");
+  XFM_REQUIRE(a->p && a->g && a->m && a->v && a->group, "adamw: null operand");
+  return xfm_adamw_impl(*a, ST(stream));
+}
+int xfm_sumsq(const float* x, long n, float* out, void* stream) {
+  XFM_REQUIRE(x && out, "sumsq: null operand");
+  return xfm_sumsq_impl(x, n, out, ST(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,347 @@
+// HBM-bound helpers of the XFM hot path (gfx950): patch gather, embedding + LayerNorm, vocabulary cross-entropy,
+// flat-arena AdamW.  All vectorised 8-16 B per lane, one wavefront per row where a row reduction is needed.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Patch gather: NCHW fp32 image -> bf16 patch matrix [B*gh*gw, C*P*P] with column order (c, ky, kx), i.e. the A
+// operand of the patch-embed GEMM against Conv2d.weight.view(D, C*P*P)  (beit2.py:224-230).
+// Each thread converts 8 consecutive kx of one (patch, c, ky): a 32-B coalesced read, a 16-B store.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, int C, int Himg, int Wimg, int P,
+                                                       bf16* __restrict__ out) {
+  const int gh = Himg / P, gw = Wimg / P;
+  const int kcols = C * P * P;
+  const int per_row = kcols / 8;
+  const long total = (long)B * gh * gw * per_row;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int c8 = (int)(t % per_row);
+    const long prow = t / per_row;
+    const int col = c8 * 8;
+    const int c = col / (P * P), ky = (col / P) % P, kx = col % P;
+    const int px = (int)(prow % gw), py = (int)((prow / gw) % gh), b = (int)(prow / ((long)gw * gh));
+    const float* src = img + (((long)b * C + c) * Himg + py * P + ky) * Wimg + px * P + kx;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = f2bf(a0[i]); o[4 + i] = f2bf(a1[i]); }
+    *reinterpret_cast<bf16x8*>(out + prow * kcols + col) = o;
+  }
+}
+
+int xfm_patchify_impl(const float* img, int B, int C, int H, int W, int P, void* out, hipStream_t st) {
+  XFM_REQUIRE(B > 0 && C > 0 && P % 8 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0, "patchify: bad geometry B=%d C=%d H=%d W=%d P=%d", B, C, H, W, P);
+  const long total = (long)B * (H / P) * (W / P) * (C * P * P / 8);
+  int grid = cdiv(total, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid), dim3(256), 0, st, img, B, C, H, W, P, (bf16*)out);
+  return xfm_check_launch("patchify");
+}
+
+// ---------------------------------------------------------------------------------------------
+// RoBERTa embeddings: y = dropout(LN(word[id] + type[0] + pos[p])), p = cumsum(id != pad) * (id != pad) + pad
+// (xroberta.py:104-137, :1747-1757).  One wave per token.
+// ---------------------------------------------------------------------------------------------
+typedef xfm_embed_args EmbArgs;
+
+__device__ __forceinline__ int roberta_pos(const int64_t* ids_row, int t, int pad, int lane) {
+  int cnt = 0;
+  for (int j0 = 0; j0 <= t; j0 += 64) {
+    const int j = j0 + lane;
+    const bool nz = (j <= t) && (ids_row[j] != pad);
+    cnt += __popcll(__ballot(nz));
+  }
+  return (ids_row[t] != pad) ? cnt + pad : pad;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs p) {
+  constexpr int D = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int rows = p.B * p.T;
+  for (int row = wave; row < rows; row += nwaves) {
+    const int b = row / p.T, t = row % p.T;
+    const int64_t* ids_row = p.ids + (long)b * p.T;
+    const int pid = roberta_pos(ids_row, t, p.pad_id, lane);
+    const long wid = ids_row[t];
+    if (lane == 0) p.pos_ids[row] = pid;
+    float v[NCH][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p.word + wid * D + e);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(p.pos + (long)pid * D + e);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(p.type + e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[i][j] = a[j] + d[j] + c[j]; s += v[i][j]; }
+    }
+    const float mu = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mu; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + p.eps);
+    if (lane == 0) { p.mean[row] = mu; p.rstd[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w + e), bv = *reinterpret_cast<const f32x4*>(p.b + e);
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float yv = (v[i][j] - mu) * rstd * wv[j] + bv[j];
+        if (p.drop_thresh != 0u) {
+          const uint64_t idx = (uint64_t)row * D + e + j;
+          yv = rng_keep(rng_u32(p.seed_lo, p.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32)), p.drop_thresh) ? yv * p.drop_scale : 0.f;
+        }
+        o[j] = f2bf(yv);
+      }
+      *reinterpret_cast<bf16x4*>(p.y + (long)row * D + e) = o;
+    }
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void emb_bwd_kernel(EmbArgs p) {
+  constexpr int D = NCH * 256;
+  __shared__ float red[4][D];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int rows = p.B * p.T;
+  float acc[3][NCH][4];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[s][i][j] = 0.f;
+  for (int row = wave; row < rows; row += nwaves) {
+    const long wid = p.ids[row];
+    const int pid = p.pos_ids[row];
+    const float mu = p.mean[row], rstd = p.rstd[row];
+    float dy[NCH][4], xh[NCH][4], wv[NCH][4];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p.word + wid * D + e);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(p.pos + (long)pid * D + e);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(p.type + e);
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.w + e);
+      const bf16x4 g = *reinterpret_cast<const bf16x4*>(p.dy + (long)row * D + e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gv = bf2f(g[j]);
+        if (p.drop_thresh != 0u) {
+          const uint64_t idx = (uint64_t)row * D + e + j;
+          gv = rng_keep(rng_u32(p.seed_lo, p.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32)), p.drop_thresh) ? gv * p.drop_scale : 0.f;
+        }
+        dy[i][j] = gv;
+        wv[i][j] = w4[j];
+        xh[i][j] = (a[j] + d[j] + c[j] - mu) * rstd;
+        const float gw = gv * w4[j];
+        c1 += gw;
+        c2 += gw * xh[i][j];
+        acc[0][i][j] += gv * xh[i][j];
+        acc[1][i][j] += gv;
+      }
+    }
+    c1 = wave_sum(c1) * (1.0f / D);
+    c2 = wave_sum(c2) * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = (i * 64 + lane) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float dz = rstd * (dy[i][j] * wv[i][j] - c1 - xh[i][j] * c2);
+        acc[2][i][j] += dz;
+        // nn.Embedding(padding_idx): the pad row receives no gradient (xroberta.py:80,100-102)
+        if (wid != p.pad_id) atomicAdd(p.dword + wid * D + e + j, dz);
+        if (pid != p.pad_id) atomicAdd(p.dpos + (long)pid * D + e + j, dz);
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wib][(i * 64 + lane) * 4 + j] = acc[s][i][j];
+    __syncthreads();
+    float* dst = p.partial + ((long)s * gridDim.x + blockIdx.x) * D;
+    for (int c = threadIdx.x; c < D; c += 256) dst[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  }
+}
+
+
+static int emb_grid(int rows) {
+  int g = cdiv(rows, 16);
+  if (g > 256) g = 256;
+  return g < 1 ? 1 : g;
+}
+
+int xfm_emb_fwd_impl(const EmbArgs& p, int D, hipStream_t st) {
+  XFM_REQUIRE(D == 768 || D == 1024, "embedding: unsupported width %d", D);
+  XFM_REQUIRE(p.B > 0 && p.T > 0, "embedding: empty batch");
+  int grid = cdiv(p.B * p.T, 4);
+  if (grid > 2048) grid = 2048;
+  if (D == 768) hipLaunchKernelGGL(emb_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(emb_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, p);
+  return xfm_check_launch("emb_fwd");
+}
+
+int xfm_emb_bwd_impl(EmbArgs p, int D, float* dgamma, float* dbeta, float* dtype, float* workspace, long workspace_bytes,
+                     hipStream_t st) {
+  XFM_REQUIRE(D == 768 || D == 1024, "embedding: unsupported width %d", D);
+  const int grid = emb_grid(p.B * p.T);
+  XFM_REQUIRE(workspace != nullptr && workspace_bytes >= (long)3 * grid * D * 4, "embedding bwd: workspace too small");
+  p.partial = workspace;
+  if (D == 768) hipLaunchKernelGGL(emb_bwd_kernel<3>, dim3(grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(emb_bwd_kernel<4>, dim3(grid), dim3(256), 0, st, p);
+  int rc = xfm_check_launch("emb_bwd");
+  if (rc != XFM_OK) return rc;
+  ReduceSets r{workspace, {dgamma, dbeta, dtype, nullptr}, grid, D};
+  hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(D, 256), 3), dim3(256), 0, st, r);
+  return xfm_check_launch("emb_bwd_reduce");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vocabulary cross-entropy on fp32 logits [R, ld] (xroberta.py:1296-1297, CrossEntropyLoss(ignore_index=-100)).
+// forward: per-row logsumexp and loss (0 for ignored rows).  backward: dlogits (bf16) = (softmax - onehot) * scale[0],
+// zero in ignored rows and in the padding columns [V, ldd).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, long ld, int V, const int64_t* __restrict__ labels,
+                                                     float* __restrict__ lse, float* __restrict__ loss) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* x = logits + (long)row * ld;
+  float mx = -3.0e38f;
+  for (int c = tid * 4; c < V; c += 1024) {
+    if (c + 4 <= V) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(x + c);
+      mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+    } else {
+      for (int i = c; i < V; ++i) mx = fmaxf(mx, x[i]);
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = tid * 4; c < V; c += 1024) {
+    if (c + 4 <= V) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(x + c);
+      s += __expf(a[0] - mx) + __expf(a[1] - mx) + __expf(a[2] - mx) + __expf(a[3] - mx);
+    } else {
+      for (int i = c; i < V; ++i) s += __expf(x[i] - mx);
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[w] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const float l = mx + __logf(red[0] + red[1] + red[2] + red[3]);
+    lse[row] = l;
+    const int64_t lab = labels[row];
+    loss[row] = (lab >= 0 && lab < V) ? l - x[lab] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long ld, int V, const int64_t* __restrict__ labels,
+                                                     const float* __restrict__ lse, const float* __restrict__ scale,
+                                                     bf16* __restrict__ dlogits, long ldd) {
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* x = logits + (long)row * ld;
+  bf16* d = dlogits + (long)row * ldd;
+  const int64_t lab = labels[row];
+  const bool valid = lab >= 0 && lab < V;
+  const float l = lse[row], sc = scale[0];
+  for (int c = tid * 8; c < ldd; c += 2048) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int col = c + i;
+      float g = 0.f;
+      if (valid && col < V) g = (__expf(x[col] - l) - (col == lab ? 1.f : 0.f)) * sc;
+      o[i] = f2bf(g);
+    }
+    if (c + 8 <= ldd) *reinterpret_cast<bf16x8*>(d + c) = o;
+    else
+      for (int i = 0; c + i < ldd; ++i) d[c + i] = o[i];
+  }
+}
+
+int xfm_ce_fwd_impl(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, hipStream_t st) {
+  XFM_REQUIRE(R > 0 && V > 0 && ld >= V && ld % 4 == 0, "ce_fwd: bad shape R=%d V=%d ld=%ld", R, V, ld);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(R), dim3(256), 0, st, logits, ld, V, labels, lse, loss);
+  return xfm_check_launch("ce_fwd");
+}
+int xfm_ce_bwd_impl(const float* logits, long ld, int R, int V, const int64_t* labels, const float* lse, const float* scale,
+                    void* dlogits, long ldd, hipStream_t st) {
+  XFM_REQUIRE(R > 0 && V > 0 && ld >= V && ldd >= V && ldd % 8 == 0, "ce_bwd: bad shape R=%d V=%d ld=%ld ldd=%ld", R, V, ld, ldd);
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, st, logits, ld, V, labels, lse, scale, (bf16*)dlogits, ldd);
+  return xfm_check_launch("ce_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flat-arena AdamW (optim.py:4-50 parameter groups; transformers AdamW: correct_bias=True, decoupled decay) with the
+// global-norm clip factor folded in (apex_ddp_accelerator.py:100-110).  Per-element group id selects lr / decay.
+// ---------------------------------------------------------------------------------------------
+typedef xfm_adamw_args AdamArgs;
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+  const float cc = a.clip_coef ? a.clip_coef[0] : 1.f;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (long)gridDim.x * 1024) {
+    const int gid = a.group[i >> 8];
+    const float lr = a.lr[gid], wd = a.wd[gid];
+    f32x4 p = *reinterpret_cast<f32x4*>(a.p + i);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i);
+    f32x4 m = *reinterpret_cast<f32x4*>(a.m + i), v = *reinterpret_cast<f32x4*>(a.v + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = g[j] * cc;
+      m[j] = a.beta1 * m[j] + (1.f - a.beta1) * gj;
+      v[j] = a.beta2 * v[j] + (1.f - a.beta2) * gj * gj;
+      const float step = lr * sqrtf(a.bc2) / a.bc1;
+      p[j] -= step * m[j] / (sqrtf(v[j]) + a.eps);
+      p[j] -= lr * wd * p[j];
+    }
+    *reinterpret_cast<f32x4*>(a.p + i) = p;
+    *reinterpret_cast<f32x4*>(a.m + i) = m;
+    *reinterpret_cast<f32x4*>(a.v + i) = v;
+  }
+}
+int xfm_adamw_impl(const AdamArgs& a, hipStream_t st) {
+  XFM_REQUIRE(a.n > 0 && a.n % 256 == 0, "adamw: arena length %ld must be a positive multiple of 256", a.n);
+  int grid = cdiv(a.n, 1024);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, st, a);
+  return xfm_check_launch("adamw");
+}
+
+// sum of squares of an fp32 vector into out[0] (atomic across blocks; caller zeroes out)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + i);
+    s += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+int xfm_sumsq_impl(const float* x, long n, float* out, hipStream_t st) {
+  XFM_REQUIRE(n > 0 && n % 4 == 0, "sumsq: length %ld must be a positive multiple of 4", n);
+  int grid = cdiv(n, 1024);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, st, x, n, out);
+  return xfm_check_launch("sumsq");
+}

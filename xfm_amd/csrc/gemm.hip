@@ -1,0 +1,420 @@
+// bf16 MFMA GEMMs for the XFM hot path (gfx950).
+//
+//   gemm_nt : C[M,N] = A[M,K] . B[N,K]^T (+bias, +GELU ...)   forward Linear (B = W) and dgrad (B = W^T copy)
+//   gemm_tn : dW[N,K] += dY[M,N]^T . X[M,K]                     wgrad, split over M, fp32 atomics into the grad arena
+//
+// Covers every Linear on the path: beit2.py:131 (qkv), :162 (proj), :64-68 (fc1/fc2), :229 (patch-embed conv as
+// GEMM); xroberta.py:211,224-234 (query/key/value), :301 (attention output), :368 (intermediate), :382 (output),
+// :1326,1331 (LM head); xfm.py:117-120 (itm_head), :617-620 (vision_proj/text_proj).
+//
+// Tiling is for 64-wide wavefronts: 256 threads = 2x2 waves, v_mfma_f32_16x16x32_bf16.  The NT kernel computes
+// C^T tiles (A-operand = weight rows, B-operand = activation rows) so that after the K loop every lane owns 8
+// CONSECUTIVE output columns of one output row: bias/GELU are applied in registers and the row is stored 16 B per lane.
+#include "common.h"
+
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_DGELU = 3, EPI_F32_ACC = 4 };
+
+struct GemmNT {
+  const bf16* A; long lda;
+  const bf16* B; long ldb;
+  void* C; long ldc;
+  const float* bias;
+  bf16* aux; long ldaux;
+  int M, N, K;
+};
+
+// LDS swizzles (16-B chunk index XOR) for 128-B tile rows read with ds_read_b128.
+// X tile: a 16-lane group reads 16 consecutive rows; W tile: rows {0-3,8-11,16-19,24-27}(+4) (see header comment).
+__device__ __forceinline__ int swz_x(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int swz_w(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
+  constexpr int MT = BM / 32, NT = BN / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+
+  auto stage = [&](int buf, int kt) {
+    char* sA = smem + buf * STAGE;
+    char* sB = sA + A_BYTES;
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+      const int blk = i * 4 + w;  // one wave-instruction fills 1 KiB = 8 rows x 128 B, lane-linear
+      const int r = blk * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz_x(r);
+      int gr = m0 + r;
+      gr = gr < g.M ? gr : g.M - 1;
+      const bf16* src = g.A + (long)gr * g.lda + k0 + c * 8;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, src), LDS_PTR(void, sA + blk * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+      const int blk = i * 4 + w;
+      const int r = blk * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz_w(r);
+      int gr = n0 + r;
+      gr = gr < g.N ? gr : g.N - 1;
+      const bf16* src = g.B + (long)gr * g.ldb + k0 + c * 8;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, src), LDS_PTR(void, sB + blk * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane LDS row of each fragment (constant over the K loop)
+  int xrow[MT], wrow[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) xrow[mt] = wm * (BM / 2) + mt * 16 + lr;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = wn * (BN / 2) + (nt >> 1) * 32 + 8 * (lr >> 2) + 4 * (nt & 1) + (lr & 3);
+
+  const int nk = g.K / 64;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sA = smem + cur * STAGE;
+    const char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ks * 4 + lg;
+      bf16x8 xf[MT], wf[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        xf[mt] = *reinterpret_cast<const bf16x8*>(sA + xrow[mt] * 128 + ((c ^ swz_x(xrow[mt])) << 4));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        wf[nt] = *reinterpret_cast<const bf16x8*>(sB + wrow[nt] * 128 + ((c ^ swz_w(wrow[nt])) << 4));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue: lane (lg, lr) owns row m = ..+lr, columns nb .. nb+7 for every (mt, np)
+  const bool vec_c = (g.ldc % 8) == 0;
+#pragma unroll
+  for (int np = 0; np < NT / 2; ++np) {
+    const int nb = n0 + wn * (BN / 2) + np * 32 + 8 * lg;
+    float bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = (g.bias != nullptr && nb + i < g.N) ? g.bias[nb + i] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + wm * (BM / 2) + mt * 16 + lr;
+      if (m >= g.M || nb >= g.N) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = acc[mt][2 * np][i] + bv[i];
+        v[4 + i] = acc[mt][2 * np + 1][i] + bv[4 + i];
+      }
+      const bool full = (nb + 8 <= g.N) && vec_c;
+      if (EPI == EPI_F32 || EPI == EPI_F32_ACC) {
+        float* cp = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + nb;
+        if (EPI == EPI_F32_ACC) {
+          for (int i = 0; i < 8; ++i)
+            if (nb + i < g.N) v[i] += cp[i];
+        }
+        if (full) {
+          *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          for (int i = 0; i < 8; ++i)
+            if (nb + i < g.N) cp[i] = v[i];
+        }
+      } else {
+        bf16* cp = reinterpret_cast<bf16*>(g.C) + (long)m * g.ldc + nb;
+        bf16x8 o;
+        if (EPI == EPI_GELU) {
+          bf16* ap = g.aux + (long)m * g.ldaux + nb;
+          bf16x8 pre;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            pre[i] = f2bf(v[i]);
+            o[i] = f2bf(gelu_f(bf2f(pre[i])));  // GELU of the bf16-rounded pre-activation: bwd recomputes from `aux`
+          }
+          if (full) *reinterpret_cast<bf16x8*>(ap) = pre;
+          else
+            for (int i = 0; i < 8; ++i)
+              if (nb + i < g.N) ap[i] = pre[i];
+        } else if (EPI == EPI_DGELU) {
+          const bf16* ap = g.aux + (long)m * g.ldaux + nb;
+          if (full) {
+            const bf16x8 pre = *reinterpret_cast<const bf16x8*>(ap);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i] * gelu_grad_f(bf2f(pre[i])));
+          } else {
+            for (int i = 0; i < 8; ++i) o[i] = (nb + i < g.N) ? f2bf(v[i] * gelu_grad_f(bf2f(ap[i]))) : f2bf(0.f);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+        }
+        if (full) *reinterpret_cast<bf16x8*>(cp) = o;
+        else
+          for (int i = 0; i < 8; ++i)
+            if (nb + i < g.N) cp[i] = o[i];
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+static int launch_nt(const GemmNT& g, int epi, hipStream_t st) {
+  const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
+  const size_t smem = 2 * (BM + BN) * 128;
+#define XFM_NT_CASE(E)                                                                                         \
+  case E: {                                                                                                    \
+    static bool attr_set = false;                                                                              \
+    if (!attr_set) {                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN, E>),                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
+      attr_set = true;                                                                                         \
+    }                                                                                                          \
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, E>), dim3(tiles), dim3(256), smem, st, g);                      \
+    break;                                                                                                     \
+  }
+  switch (epi) {
+    XFM_NT_CASE(EPI_BF16)
+    XFM_NT_CASE(EPI_F32)
+    XFM_NT_CASE(EPI_GELU)
+    XFM_NT_CASE(EPI_DGELU)
+    XFM_NT_CASE(EPI_F32_ACC)
+    default:
+      xfm_set_error("gemm_nt: bad epilogue %d", epi);
+      return XFM_E_ARG;
+  }
+#undef XFM_NT_CASE
+  return xfm_check_launch("gemm_nt");
+}
+
+int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, long ldc, const float* bias,
+                     void* aux, long ldaux, int M, int N, int K, int epi, int tile_hint, hipStream_t st) {
+  XFM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+  XFM_REQUIRE(K % 64 == 0, "gemm_nt: K=%d must be a multiple of 64", K);
+  XFM_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm_nt: lda=%ld ldb=%ld must be multiples of 8", lda, ldb);
+  XFM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
+              "gemm_nt: operands must be 16-byte aligned");
+  XFM_REQUIRE((epi != EPI_GELU && epi != EPI_DGELU) || aux != nullptr, "gemm_nt: epilogue %d needs aux", epi);
+  GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K};
+  int cfg = tile_hint;
+  if (cfg <= 0) {  // pick the largest tile that still gives >= ~1.5 workgroups per CU
+    if ((long)cdiv(M, 128) * cdiv(N, 128) >= 384) cfg = 1;
+    else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 256) cfg = 2;
+    else cfg = 3;
+  }
+  switch (cfg) {
+    case 1: return launch_nt<128, 128>(g, epi, st);
+    case 2: return launch_nt<64, 128>(g, epi, st);
+    default: return launch_nt<64, 64>(g, epi, st);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad: dW[N,K] += dY[M,N]^T . X[M,K]   (contraction over the row index of both operands)
+// Both tiles are staged row-major ([m][n], [m][k], 256-B rows) and consumed with the gfx950 transposed LDS
+// read ds_read_b64_tr_b16, which hands each lane 4 consecutive m for its own column.
+// ---------------------------------------------------------------------------------------------
+struct GemmTN {
+  const bf16* dY; long ldy;
+  const bf16* X; long ldx;
+  float* dW; long ldw;
+  int M, N, K;
+  int m_per_split;
+};
+
+__device__ __forceinline__ int swz_t(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }  // XOR on the 16-B chunk idx
+
+__device__ __forceinline__ bf16x8 tr_read_pair(const char* tile, int row0, int col0, int lr) {
+  // rows row0..row0+3 then row0+4..row0+7, columns col0..col0+15; lane lr (0..15 in its 16-lane group) gets column lr
+  const int r = row0 + (lr >> 2);
+  const int col = col0 + 4 * (lr & 3);
+  const int off0 = r * 256 + ((((col >> 3)) ^ swz_t(r)) << 4) + (col & 7) * 2;
+  const int r2 = r + 4;
+  const int off1 = r2 * 256 + ((((col >> 3)) ^ swz_t(r2)) << 4) + (col & 7) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + off0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + off1));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
+  constexpr int TILE = 64 * 256;  // 64 m-rows x 128 columns bf16
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wn = w >> 1, wk = w & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int tiles_k = (g.K + 127) / 128, tiles_n = (g.N + 127) / 128;
+  const int per_split = tiles_k * tiles_n;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = wg / per_split, t = wg % per_split;
+  const int n0 = (t / tiles_k) * 128, k0 = (t % tiles_k) * 128;
+  const int mbeg = split * g.m_per_split;
+  int mend = mbeg + g.m_per_split;
+  mend = mend < g.M ? mend : g.M;
+  const int nsteps = (mend - mbeg + 63) / 64;
+
+  u32x4 ry[4], rx[4];
+  auto gload = [&](int step) {
+    const int mb = mbeg + step * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = i * 256 + tid, r = q >> 4, c = q & 15;
+      const int m = mb + r;
+      const bool okm = m < mend;
+      const int nn = n0 + c * 8, kk = k0 + c * 8;
+      ry[i] = u32x4{0, 0, 0, 0};
+      rx[i] = u32x4{0, 0, 0, 0};
+      if (okm && nn < g.N) {
+        if (nn + 8 <= g.N) ry[i] = *reinterpret_cast<const u32x4*>(g.dY + (long)m * g.ldy + nn);
+        else {
+          union { bf16 h[8]; u32x4 v; } u; u.v = u32x4{0, 0, 0, 0};
+          for (int e = 0; e < 8; ++e) if (nn + e < g.N) u.h[e] = g.dY[(long)m * g.ldy + nn + e];
+          ry[i] = u.v;
+        }
+      }
+      if (okm && kk < g.K) rx[i] = *reinterpret_cast<const u32x4*>(g.X + (long)m * g.ldx + kk);  // K % 8 == 0
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* sY = smem + buf * 2 * TILE;
+    char* sX = sY + TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = i * 256 + tid, r = q >> 4, c = q & 15;
+      const int off = r * 256 + ((c ^ swz_t(r)) << 4);
+      *reinterpret_cast<u32x4*>(sY + off) = ry[i];
+      *reinterpret_cast<u32x4*>(sX + off) = rx[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nsteps > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nsteps) gload(s + 1);
+    const char* sY = smem + cur * 2 * TILE;
+    const char* sX = sY + TILE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) af[nt] = tr_read_pair(sY, ks * 32 + 8 * lg, wn * 64 + nt * 16, lr);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) bfr[kt] = tr_read_pair(sX, ks * 32 + 8 * lg, wk * 64 + kt * 16, lr);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+    }
+    if (s + 1 < nsteps) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // D[i = n slot][j = k col]: lane (lg, lr) holds k = ..+lr and n = ..+4*lg+reg
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = k0 + wk * 64 + kt * 16 + lr;
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi) {
+        const int n = n0 + wn * 64 + nt * 16 + 4 * lg + rgi;
+        if (n < g.N && k < g.K) atomicAdd(g.dW + (long)n * g.ldw + k, acc[nt][kt][rgi]);
+      }
+    }
+}
+
+int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, int M, int N, int K,
+                     int splits_hint, hipStream_t st) {
+  XFM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
+  XFM_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "gemm_tn: K=%d ldx=%ld ldy=%ld must be multiples of 8", K, ldx, ldy);
+  XFM_REQUIRE(((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0, "gemm_tn: operands must be 16-byte aligned");
+  const int tiles = cdiv(N, 128) * cdiv(K, 128);
+  int splits = splits_hint;
+  if (splits <= 0) {
+    splits = cdiv(768, tiles);                 // ~3 workgroups per CU in total
+    const int max_splits = cdiv(M, 256);       // at least 4 K-steps per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+  }
+  int mps = cdiv(cdiv(M, splits), 64) * 64;
+  splits = cdiv(M, mps);
+  GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, M, N, K, mps};
+  static bool attr_set = false;
+  const size_t smem = 4 * 64 * 256;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), smem, st, g);
+  return xfm_check_launch("gemm_tn");
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 master weight [N,K] -> bf16 copy [N,Kp] and transposed bf16 copy [K,Np] (zero padded to ld multiples)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ w, int N, int K, bf16* __restrict__ wb,
+                                                             long ldb, bf16* __restrict__ wt, long ldt) {
+  __shared__ float tile[32][33];
+  const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + i * 8, k = k0 + tx;
+    const float v = (n < N && k < K) ? w[(long)n * K + k] : 0.f;
+    tile[ty + i * 8][tx] = v;
+    if (wb != nullptr && n < N && k < ldb) wb[(long)n * ldb + k] = f2bf(v);
+  }
+  __syncthreads();
+  if (wt != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + ty + i * 8, n = n0 + tx;
+      if (k < K && n < ldt) wt[(long)k * ldt + n] = f2bf(tile[tx][ty + i * 8]);
+    }
+  }
+}
+
+int xfm_cast_transpose_impl(const float* w, int N, int K, void* wb, long ldb, void* wt, long ldt, hipStream_t st) {
+  XFM_REQUIRE(N > 0 && K > 0, "cast_transpose: empty");
+  XFM_REQUIRE(wb == nullptr || ldb >= K, "cast_transpose: ldb < K");
+  XFM_REQUIRE(wt == nullptr || ldt >= N, "cast_transpose: ldt < N");
+  // grid covers the padded extents so the zero padding is (re)written too
+  const long kext = (wb != nullptr && ldb > K) ? ldb : K, next = (wt != nullptr && ldt > N) ? ldt : N;
+  hipLaunchKernelGGL(cast_transpose_kernel, dim3(cdiv(kext, 32), cdiv(next, 32)), dim3(256), 0, st, w, N, K, (bf16*)wb, ldb,
+                     (bf16*)wt, ldt);
+  return xfm_check_launch("cast_transpose");
+}
+

@@ -1,0 +1,374 @@
+// Fused LayerNorm family (gfx950).  One 64-lane wavefront owns one row; lane l holds elements
+// (i*64 + l)*4 .. +3 of every 256-element chunk i, so loads are 16 B (fp32) / 8 B (bf16) per lane, row statistics
+// are two wave reductions, and per-column gradient sums stay in registers while a wave walks its rows.
+//
+//   mode PLAIN : y = LN(x)                                   beit2.py:191-206 norm1 / fc_norm :460, xroberta.py:1329,
+//                                                            xfm.py:118 (itm_head LayerNorm)
+//   mode POST  : z = dropout(h) + res ; y = LN(z)            xroberta.py:300-304, :381-385 (post-LN residual blocks)
+//   mode LS    : x' = x + s_b * gamma_ls * h ; y = LN(x')    beit2.py:203-204 (layer-scale + drop-path residual)
+//                                                            fused with the LayerNorm that consumes x' next
+#include "common.h"
+
+enum { LN_PLAIN = 0, LN_POST = 1, LN_LS = 2 };
+
+typedef xfm_ln_fwd_args LnFwd;
+
+template <int NCH, int MODE>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
+  constexpr int D = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  float wv[NCH][4], bv[NCH][4], lsg[NCH][4];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int e = (i * 64 + lane) * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.w + e), c = *reinterpret_cast<const f32x4*>(p.b + e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wv[i][j] = a[j]; bv[i][j] = c[j]; lsg[i][j] = 0.f; }
+    if (MODE == LN_LS) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.ls_gamma + e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lsg[i][j] = g[j];
+    }
+  }
+  for (int row = wave; row < p.rows; row += nwaves) {
+    const long base = (long)row * D;
+    float v[NCH][4];
+    float s = 0.f;
+    float rs = 1.f;
+    if (MODE == LN_LS && p.row_scale != nullptr) rs = p.row_scale[row / p.rows_per_sample];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      if (MODE == LN_PLAIN) {
+        if (p.x32 != nullptr) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(p.x32 + base + e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[i][j] = a[j];
+        } else {
+          const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.x16 + base + e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[i][j] = bf2f(a[j]);
+        }
+      } else if (MODE == LN_POST) {
+        const bf16x4 hh = *reinterpret_cast<const bf16x4*>(p.h + base + e);
+        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res + base + e);
+        bf16x4 zz;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float hv = bf2f(hh[j]);
+          if (p.drop_thresh != 0u) {
+            const uint64_t idx = (uint64_t)base + e + j;
+            const uint32_t r = rng_u32(p.seed_lo, p.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32));
+            hv = rng_keep(r, p.drop_thresh) ? hv * p.drop_scale : 0.f;
+          }
+          v[i][j] = hv + bf2f(rr[j]);
+          zz[j] = f2bf(v[i][j]);
+        }
+        *reinterpret_cast<bf16x4*>(p.z_out + base + e) = zz;
+      } else {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.x32 + base + e);
+        const bf16x4 hh = *reinterpret_cast<const bf16x4*>(p.h + base + e);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[i][j] = a[j] + rs * lsg[i][j] * bf2f(hh[j]); o[j] = v[i][j]; }
+        *reinterpret_cast<f32x4*>(p.x_out + base + e) = o;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += v[i][j];
+    }
+    const float mu = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mu; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + p.eps);
+    if (lane == 0) { p.mean[row] = mu; p.rstd[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      bf16x4 o;
+      f32x4 o32;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o32[j] = (v[i][j] - mu) * rstd * wv[i][j] + bv[i][j]; o[j] = f2bf(o32[j]); }
+      *reinterpret_cast<bf16x4*>(p.y + base + e) = o;
+      if (p.y32 != nullptr) *reinterpret_cast<f32x4*>(p.y32 + base + e) = o32;
+    }
+  }
+}
+
+static int ln_grid(int rows) {
+  int blocks = cdiv(rows, 4);
+  if (blocks > 2048) blocks = 2048;
+  return blocks;
+}
+
+int xfm_ln_fwd_impl(const LnFwd& p, int D, int mode, hipStream_t st) {
+  XFM_REQUIRE(p.rows > 0, "ln_fwd: no rows");
+  XFM_REQUIRE(D == 768 || D == 1536 || D == 1024 || D == 256 || D == 512, "ln_fwd: unsupported width %d", D);
+  const int grid = ln_grid(p.rows);
+#define LN_CASE(NCH, MD) hipLaunchKernelGGL((ln_fwd_kernel<NCH, MD>), dim3(grid), dim3(256), 0, st, p); break;
+#define LN_MODES(NCH)                                                       \
+  switch (mode) {                                                           \
+    case LN_PLAIN: LN_CASE(NCH, LN_PLAIN)                                   \
+    case LN_POST: LN_CASE(NCH, LN_POST)                                     \
+    case LN_LS: LN_CASE(NCH, LN_LS)                                         \
+    default: xfm_set_error("ln_fwd: bad mode %d", mode); return XFM_E_ARG;  \
+  }
+  switch (D) {
+    case 256: LN_MODES(1) break;
+    case 512: LN_MODES(2) break;
+    case 768: LN_MODES(3) break;
+    case 1024: LN_MODES(4) break;
+    default: LN_MODES(6) break;
+  }
+#undef LN_MODES
+#undef LN_CASE
+  return xfm_check_launch("ln_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+typedef xfm_ln_bwd_args LnBwd;
+
+template <int NCH, int MODE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
+  constexpr int D = NCH * 256;
+  constexpr int NSET = (MODE == LN_PLAIN) ? 2 : (MODE == LN_POST ? 3 : 4);
+  __shared__ float red[4][D];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  float wv[NCH][4], lsg[NCH][4];
+  float acc[NSET][NCH][4];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int e = (i * 64 + lane) * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.w + e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wv[i][j] = a[j]; lsg[i][j] = 0.f; }
+    if (MODE == LN_LS) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.ls_gamma + e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lsg[i][j] = g[j];
+    }
+#pragma unroll
+    for (int s = 0; s < NSET; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[s][i][j] = 0.f;
+  }
+  for (int row = wave; row < p.rows; row += nwaves) {
+    const long base = (long)row * D;
+    const float mu = p.mean[row], rstd = p.rstd[row];
+    float dy[NCH][4], xh[NCH][4];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.dy1 + base + e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dy[i][j] = bf2f(a[j]);
+      if (p.dy2 != nullptr) {
+        const bf16x4 b2 = *reinterpret_cast<const bf16x4*>(p.dy2 + base + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dy[i][j] += bf2f(b2[j]);
+      }
+      if (p.dy32 != nullptr) {
+        const f32x4 b3 = *reinterpret_cast<const f32x4*>(p.dy32 + base + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dy[i][j] += b3[j];
+      }
+      if (p.x32 != nullptr) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x32 + base + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xh[i][j] = (xv[j] - mu) * rstd;
+      } else {
+        const bf16x4 xv = *reinterpret_cast<const bf16x4*>(p.x16 + base + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xh[i][j] = (bf2f(xv[j]) - mu) * rstd;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = dy[i][j] * wv[i][j];
+        c1 += g;
+        c2 += g * xh[i][j];
+        acc[0][i][j] += dy[i][j] * xh[i][j];
+        acc[1][i][j] += dy[i][j];
+      }
+    }
+    c1 = wave_sum(c1) * (1.0f / D);
+    c2 = wave_sum(c2) * (1.0f / D);
+    float rs = 1.f;
+    if (MODE == LN_LS && p.row_scale != nullptr) rs = p.row_scale[row / p.rows_per_sample];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      float dz[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dz[j] = rstd * (dy[i][j] * wv[i][j] - c1 - xh[i][j] * c2);
+      if (MODE == LN_PLAIN) {
+        if (p.dx32 != nullptr) {
+          f32x4 o;
+          if (p.dx_accum) {
+            o = *reinterpret_cast<const f32x4*>(p.dx32 + base + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += dz[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = dz[j];
+          }
+          *reinterpret_cast<f32x4*>(p.dx32 + base + e) = o;
+        }
+        if (p.dx16 != nullptr) {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(dz[j]);
+          *reinterpret_cast<bf16x4*>(p.dx16 + base + e) = o;
+        }
+      } else if (MODE == LN_POST) {
+        bf16x4 oh, orr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float dhv = dz[j];
+          if (p.drop_thresh != 0u) {
+            const uint64_t idx = (uint64_t)base + e + j;
+            const uint32_t r = rng_u32(p.seed_lo, p.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32));
+            dhv = rng_keep(r, p.drop_thresh) ? dhv * p.drop_scale : 0.f;
+          }
+          orr[j] = f2bf(dz[j]);
+          oh[j] = f2bf(dhv);
+          acc[2][i][j] += bf2f(oh[j]);
+        }
+        *reinterpret_cast<bf16x4*>(p.dh + base + e) = oh;
+        if (p.dres != nullptr && p.dres != p.dh) *reinterpret_cast<bf16x4*>(p.dres + base + e) = orr;
+      } else {
+        const f32x4 ds = *reinterpret_cast<const f32x4*>(p.dstream + base + e);
+        const bf16x4 hh = *reinterpret_cast<const bf16x4*>(p.h + base + e);
+        f32x4 o;
+        bf16x4 oh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = ds[j] + dz[j];
+          const float dhv = rs * lsg[i][j] * o[j];
+          oh[j] = f2bf(dhv);
+          acc[2][i][j] += bf2f(oh[j]);
+          acc[3][i][j] += rs * bf2f(hh[j]) * o[j];
+        }
+        *reinterpret_cast<f32x4*>(p.dstream + base + e) = o;
+        *reinterpret_cast<bf16x4*>(p.dh + base + e) = oh;
+      }
+    }
+  }
+  // block reduction of the column partial sums, one set at a time, then one slab row per block
+#pragma unroll
+  for (int s = 0; s < NSET; ++s) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wib][(i * 64 + lane) * 4 + j] = acc[s][i][j];
+    __syncthreads();
+    float* dst = p.partial + ((long)s * gridDim.x + blockIdx.x) * D;
+    for (int c = threadIdx.x; c < D; c += 256) dst[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  }
+}
+
+// out[s][c] += sum_b partial[s][b][c]   (each set s has its own destination pointer; null = skip)
+struct ReduceSets { const float* partial; float* out[4]; int nblocks; int D; };
+__global__ __launch_bounds__(256) void reduce_sets_kernel(ReduceSets r) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int s = blockIdx.y;
+  if (c >= r.D || r.out[s] == nullptr) return;
+  const float* src = r.partial + (long)s * r.nblocks * r.D + c;
+  float t = 0.f;
+  for (int b = 0; b < r.nblocks; ++b) t += src[(long)b * r.D];
+  r.out[s][c] += t;
+}
+
+int xfm_ln_bwd_grid(int rows) {
+  int blocks = cdiv(rows, 16);  // >= 4 rows per wave so the column sums amortise
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  return blocks;
+}
+
+int xfm_ln_bwd_impl(LnBwd p, int D, int mode, float* dgamma, float* dbeta, float* dbias, float* dls, float* workspace,
+                    long workspace_bytes, hipStream_t st) {
+  XFM_REQUIRE(p.rows > 0, "ln_bwd: no rows");
+  XFM_REQUIRE(D == 768 || D == 1536 || D == 1024 || D == 256 || D == 512, "ln_bwd: unsupported width %d", D);
+  const int grid = xfm_ln_bwd_grid(p.rows);
+  const int nset = mode == LN_PLAIN ? 2 : (mode == LN_POST ? 3 : 4);
+  XFM_REQUIRE(workspace != nullptr && workspace_bytes >= (long)nset * grid * D * 4, "ln_bwd: workspace too small (%ld bytes)",
+              workspace_bytes);
+  p.partial = workspace;
+#define LNB_CASE(NCH, MD) hipLaunchKernelGGL((ln_bwd_kernel<NCH, MD>), dim3(grid), dim3(256), 0, st, p); break;
+#define LNB_MODES(NCH)                                                      \
+  switch (mode) {                                                           \
+    case LN_PLAIN: LNB_CASE(NCH, LN_PLAIN)                                  \
+    case LN_POST: LNB_CASE(NCH, LN_POST)                                    \
+    case LN_LS: LNB_CASE(NCH, LN_LS)                                        \
+    default: xfm_set_error("ln_bwd: bad mode %d", mode); return XFM_E_ARG;  \
+  }
+  switch (D) {
+    case 256: LNB_MODES(1) break;
+    case 512: LNB_MODES(2) break;
+    case 768: LNB_MODES(3) break;
+    case 1024: LNB_MODES(4) break;
+    default: LNB_MODES(6) break;
+  }
+#undef LNB_MODES
+#undef LNB_CASE
+  int rc = xfm_check_launch("ln_bwd");
+  if (rc != XFM_OK) return rc;
+  ReduceSets r{workspace, {dgamma, dbeta, dbias, dls}, grid, D};
+  hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(D, 256), nset), dim3(256), 0, st, r);
+  return xfm_check_launch("ln_bwd_reduce");
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums via block partials (bias gradients of GELU / QKV linears): out[n] += sum_m Y[m,n]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ y, long ldy, int M, int N,
+                                                             float* __restrict__ partial, int rows_per_block) {
+  const int c8 = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c8 >= N) return;
+  const int mb = blockIdx.y * rows_per_block;
+  int me = mb + rows_per_block;
+  me = me < M ? me : M;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c8 + 8 <= N) {
+    for (int m = mb; m < me; ++m) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + (long)m * ldy + c8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += bf2f(v[i]);
+    }
+  } else {
+    for (int m = mb; m < me; ++m)
+      for (int i = 0; i < 8; ++i)
+        if (c8 + i < N) s[i] += bf2f(y[(long)m * ldy + c8 + i]);
+  }
+  float* dst = partial + (long)blockIdx.y * N;
+  for (int i = 0; i < 8; ++i)
+    if (c8 + i < N) dst[c8 + i] = s[i];
+}
+
+int xfm_colsum_impl(const void* y, long ldy, int M, int N, float* out, float* workspace, long workspace_bytes,
+                    hipStream_t st) {
+  XFM_REQUIRE(M > 0 && N > 0 && ldy % 8 == 0, "colsum: bad shape M=%d N=%d ldy=%ld", M, N, ldy);
+  const int bx = cdiv(N, 256 * 8);
+  int by = cdiv(1024, bx);
+  if (by > cdiv(M, 32)) by = cdiv(M, 32);
+  if (by > 256) by = 256;
+  const int rpb = cdiv(M, by);
+  by = cdiv(M, rpb);
+  XFM_REQUIRE(workspace != nullptr && workspace_bytes >= (long)by * N * 4, "colsum: workspace too small");
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(bx, by), dim3(256), 0, st, (const bf16*)y, ldy, M, N, workspace, rpb);
+  int rc = xfm_check_launch("colsum");
+  if (rc != XFM_OK) return rc;
+  ReduceSets r{workspace, {out, nullptr, nullptr, nullptr}, by, N};
+  hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(N, 256), 1), dim3(256), 0, st, r);
+  return xfm_check_launch("colsum_reduce");
+}

@@ -1,0 +1,311 @@
+"""Raw (non-autograd) tensor-level wrappers over the C ABI.  Device tensors in, kernels enqueued on torch's current
+stream.  PyTorch is used here only for memory, streams and shapes."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AdamWArgs, AttnArgs, EmbedArgs, LnBwdArgs, LnFwdArgs, check
+
+BF16, F32 = torch.bfloat16, torch.float32
+EPI_BF16, EPI_F32, EPI_GELU, EPI_DGELU, EPI_F32_ACC = 0, 1, 2, 3, 4
+LN_PLAIN, LN_POST, LN_LS = 0, 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.XfmHipError("xfm_amd ops need HIP device tensors (no CPU fallback on the product path)")
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device):
+    """Per (device, stream) scratch for the block-partial reductions; grows monotonically."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(int(nbytes) // 4 + 1, 1 << 20), dtype=F32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def drop_params(p, seed):
+    """(thresh, scale, seed_lo, seed_hi) for dropout probability p; thresh 0 disables."""
+    if p <= 0.0:
+        return 0, 1.0, 0, 0
+    thresh = min(int(p * 4294967296.0), 4294967295)
+    return thresh, 1.0 / (1.0 - p), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+
+
+# --------------------------------------------------------------------------------------------- GEMMs
+def gemm_nt(a, b, bias=None, epi=EPI_BF16, aux=None, out=None, n=None, tile_hint=0):
+    """out[M,N] = a[M,K] @ b[N(,pad),K]^T + bias.  a, b bf16 row-major (last dim contiguous)."""
+    _dev(a)
+    assert a.dtype == BF16 and b.dtype == BF16 and a.dim() == 2 and b.dim() == 2
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0] if n is None else n
+    assert b.shape[1] == K, (a.shape, b.shape)
+    if out is None:
+        out = torch.empty((M, N), dtype=F32 if epi in (EPI_F32, EPI_F32_ACC) else BF16, device=a.device)
+    assert out.stride(1) == 1
+    if epi == EPI_GELU and aux is None:
+        aux = torch.empty((M, N), dtype=BF16, device=a.device)
+    check(_lib.load().xfm_gemm_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
+                                  _ptr(bias), _ptr(aux), 0 if aux is None else aux.stride(0), M, N, K, epi, tile_hint,
+                                  _stream()), "gemm_nt")
+    return (out, aux) if epi == EPI_GELU else out
+
+
+def gemm_tn(dy, x, dw, n=None, splits=0):
+    """dw[N,K] (fp32) += dy[M,N]^T @ x[M,K]."""
+    _dev(dy)
+    assert dy.dtype == BF16 and x.dtype == BF16 and dw.dtype == F32
+    assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(-1) == 1
+    M, K = x.shape
+    N = dy.shape[1] if n is None else n
+    assert dy.shape[0] == M and dw.shape[0] >= N and dw.shape[1] == K, (dy.shape, x.shape, dw.shape)
+    check(_lib.load().xfm_gemm_tn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0),
+                                  M, N, K, splits, _stream()), "gemm_tn")
+
+
+def cast_transpose(w, wb=None, wt=None):
+    """fp32 [N,K] -> bf16 wb[N,ldb>=K] and/or wt[K,ldt>=N] (padding columns zeroed)."""
+    _dev(w)
+    assert w.dtype == F32 and w.is_contiguous() and w.dim() == 2
+    N, K = w.shape
+    check(_lib.load().xfm_cast_transpose(w.data_ptr(), N, K, _ptr(wb), 0 if wb is None else wb.stride(0), _ptr(wt),
+                                         0 if wt is None else wt.stride(0), _stream()), "cast_transpose")
+
+
+def colsum(y, out, n=None):
+    """out[n] += sum_m y[m,n]."""
+    M = y.shape[0]
+    N = y.shape[1] if n is None else n
+    lib = _lib.load()
+    nb = lib.xfm_colsum_workspace(M, N)
+    ws = workspace(nb, y.device)
+    check(lib.xfm_colsum(y.data_ptr(), y.stride(0), M, N, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()), "colsum")
+
+
+# --------------------------------------------------------------------------------------------- LayerNorm
+def _ln_out(rows, D, device):
+    return (torch.empty((rows, D), dtype=BF16, device=device), torch.empty(rows, dtype=F32, device=device),
+            torch.empty(rows, dtype=F32, device=device))
+
+
+def ln_fwd(x, w, b, eps, y32=False):
+    """PLAIN: x [rows, D] fp32 or bf16 -> (y bf16, mean, rstd[, y fp32])."""
+    _dev(x)
+    rows, D = x.shape
+    assert x.is_contiguous()
+    y, mean, rstd = _ln_out(rows, D, x.device)
+    yf = torch.empty((rows, D), dtype=F32, device=x.device) if y32 else None
+    a = LnFwdArgs(x32=_ptr(x) if x.dtype == F32 else 0, x16=_ptr(x) if x.dtype == BF16 else 0, w=w.data_ptr(), b=b.data_ptr(),
+                  y=y.data_ptr(), y32=_ptr(yf), mean=mean.data_ptr(), rstd=rstd.data_ptr(), rows=rows, rows_per_sample=1, eps=eps)
+    check(_lib.load().xfm_layernorm_fwd(ctypes.byref(a), D, LN_PLAIN, _stream()), "layernorm_fwd")
+    return (y, mean, rstd, yf) if y32 else (y, mean, rstd)
+
+
+def ln_post_fwd(h, res, w, b, eps, drop=(0, 1.0, 0, 0)):
+    """POST: z = dropout(h) + res; y = LN(z) -> (y, z, mean, rstd), all but stats bf16."""
+    _dev(h)
+    rows, D = h.shape
+    assert h.is_contiguous() and res.is_contiguous() and h.dtype == BF16 and res.dtype == BF16
+    y, mean, rstd = _ln_out(rows, D, h.device)
+    z = torch.empty_like(h)
+    a = LnFwdArgs(h=h.data_ptr(), res=res.data_ptr(), w=w.data_ptr(), b=b.data_ptr(), z_out=z.data_ptr(), y=y.data_ptr(),
+                  mean=mean.data_ptr(), rstd=rstd.data_ptr(), rows=rows, rows_per_sample=1, eps=eps,
+                  drop_thresh=drop[0], drop_scale=drop[1], seed_lo=drop[2], seed_hi=drop[3])
+    check(_lib.load().xfm_layernorm_fwd(ctypes.byref(a), D, LN_POST, _stream()), "layernorm_fwd(post)")
+    return y, z, mean, rstd
+
+
+def ln_ls_fwd(x, h, ls_gamma, row_scale, rows_per_sample, w, b, eps, x_out=None):
+    """LS: x' = x + s_b * gamma * h (fp32 stream); y = LN(x') -> (x', y, mean, rstd)."""
+    _dev(x)
+    rows, D = x.shape
+    assert x.dtype == F32 and h.dtype == BF16 and x.is_contiguous() and h.is_contiguous()
+    y, mean, rstd = _ln_out(rows, D, x.device)
+    if x_out is None:
+        x_out = torch.empty_like(x)
+    a = LnFwdArgs(x32=x.data_ptr(), h=h.data_ptr(), ls_gamma=ls_gamma.data_ptr(), row_scale=_ptr(row_scale), w=w.data_ptr(),
+                  b=b.data_ptr(), x_out=x_out.data_ptr(), y=y.data_ptr(), mean=mean.data_ptr(), rstd=rstd.data_ptr(),
+                  rows=rows, rows_per_sample=rows_per_sample, eps=eps)
+    check(_lib.load().xfm_layernorm_fwd(ctypes.byref(a), D, LN_LS, _stream()), "layernorm_fwd(ls)")
+    return x_out, y, mean, rstd
+
+
+def _ln_bwd_call(a, D, mode, dgamma, dbeta, dbias, dls, device):
+    lib = _lib.load()
+    nb = lib.xfm_layernorm_bwd_workspace(a.rows, D, mode)
+    ws = workspace(nb, device)
+    check(lib.xfm_layernorm_bwd(ctypes.byref(a), D, mode, _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(dls), ws.data_ptr(),
+                                ws.numel() * 4, _stream()), "layernorm_bwd")
+
+
+def ln_bwd(dy, x, mean, rstd, w, dgamma, dbeta, dy2=None, dy32=None, dx32=None, dx16=None, dx_accum=False):
+    """PLAIN backward: writes dx32 (optionally accumulating) and/or dx16; dgamma/dbeta += ."""
+    rows, D = x.shape
+    a = LnBwdArgs(dy1=dy.data_ptr(), dy2=_ptr(dy2), dy32=_ptr(dy32), x32=_ptr(x) if x.dtype == F32 else 0,
+                  x16=_ptr(x) if x.dtype == BF16 else 0, mean=mean.data_ptr(), rstd=rstd.data_ptr(), w=w.data_ptr(),
+                  dx32=_ptr(dx32), dx16=_ptr(dx16), dx_accum=int(dx_accum), rows=rows, rows_per_sample=1)
+    _ln_bwd_call(a, D, LN_PLAIN, dgamma, dbeta, None, None, x.device)
+
+
+def ln_post_bwd(dy, z, mean, rstd, w, dgamma, dbeta, dbias, dy2=None, drop=(0, 1.0, 0, 0)):
+    """POST backward -> (dh, dres) bf16 (same tensor when dropout is off); dgamma/dbeta/dbias += ."""
+    rows, D = z.shape
+    dh = torch.empty_like(z)
+    dres = dh if drop[0] == 0 else torch.empty_like(z)
+    a = LnBwdArgs(dy1=dy.data_ptr(), dy2=_ptr(dy2), x16=z.data_ptr(), mean=mean.data_ptr(), rstd=rstd.data_ptr(),
+                  w=w.data_ptr(), dh=dh.data_ptr(), dres=dres.data_ptr(), rows=rows, rows_per_sample=1,
+                  drop_thresh=drop[0], drop_scale=drop[1], seed_lo=drop[2], seed_hi=drop[3])
+    _ln_bwd_call(a, D, LN_POST, dgamma, dbeta, dbias, None, z.device)
+    return dh, dres
+
+
+def ln_ls_bwd(dy, dstream, x_new, mean, rstd, w, h, ls_gamma, row_scale, rows_per_sample, dgamma, dbeta, dbias, dls,
+              dy2=None):
+    """LS backward: dstream (fp32) updated in place to the gradient w.r.t. the incoming stream; returns dh (bf16)."""
+    rows, D = x_new.shape
+    dh = torch.empty((rows, D), dtype=BF16, device=x_new.device)
+    a = LnBwdArgs(dy1=dy.data_ptr(), dy2=_ptr(dy2), x32=x_new.data_ptr(), mean=mean.data_ptr(), rstd=rstd.data_ptr(),
+                  w=w.data_ptr(), dh=dh.data_ptr(), dstream=dstream.data_ptr(), h=h.data_ptr(), ls_gamma=ls_gamma.data_ptr(),
+                  row_scale=_ptr(row_scale), rows=rows, rows_per_sample=rows_per_sample)
+    _ln_bwd_call(a, D, LN_LS, dgamma, dbeta, dbias, dls, x_new.device)
+    return dh
+
+
+# --------------------------------------------------------------------------------------------- attention
+def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop):
+    for t in (q, k, v, o):
+        assert t.dtype == BF16 and t.stride(-1) == 1 and t.dim() == 2
+    return AttnArgs(q=q.data_ptr(), q_rs=q.stride(0), k=k.data_ptr(), k_rs=k.stride(0), v=v.data_ptr(), v_rs=v.stride(0),
+                    o=o.data_ptr(), o_rs=o.stride(0), lse=lse.data_ptr(), bias=_ptr(bias),
+                    bias_ld=0 if bias is None else bias.stride(1), key_keep=_ptr(key_keep), B=B, H=H, Sq=Sq, Sk=Sk,
+                    scale=scale, causal=int(causal), drop_thresh=drop[0], drop_scale=drop[1], seed_lo=drop[2], seed_hi=drop[3])
+
+
+def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0)):
+    """q [B*Sq, >=H*64] / k, v [B*Sk, ...] are 2-D (possibly strided column slices of fused projection buffers).
+    bias: dense fp32 [H,Sq,ld]; key_keep: int32 [B,Sk].  Returns (o [B*Sq, H*64] bf16, lse [B,H,Sq])."""
+    _dev(q)
+    o = torch.empty((B * Sq, H * 64), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, Sq), dtype=F32, device=q.device)
+    if key_keep is not None:
+        assert key_keep.dtype == torch.int32 and key_keep.is_contiguous()
+    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop)
+    check(_lib.load().xfm_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
+    return o, lse
+
+
+def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, dbias=None, key_keep=None, causal=False,
+             drop=(0, 1.0, 0, 0)):
+    """Writes dq/dk/dv (2-D bf16 views with the same addressing convention as q/k/v); dbias (fp32 [H,Sq,ld]) += ."""
+    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop)
+    delta = torch.empty((B, H, Sq), dtype=F32, device=q.device)
+    assert dout.dtype == BF16 and dout.stride(-1) == 1
+    a.dout, a.do_rs = dout.data_ptr(), dout.stride(0)
+    a.dq, a.dq_rs = dq.data_ptr(), dq.stride(0)
+    a.dk, a.dk_rs = dk.data_ptr(), dk.stride(0)
+    a.dv, a.dv_rs = dv.data_ptr(), dv.stride(0)
+    a.delta, a.dbias = delta.data_ptr(), _ptr(dbias)
+    check(_lib.load().xfm_attn_bwd(ctypes.byref(a), _stream()), "attn_bwd")
+
+
+def relpos_gather(table, index32, H, N, ld):
+    dense = torch.empty((H, N, ld), dtype=F32, device=table.device)
+    check(_lib.load().xfm_relpos_gather(table.data_ptr(), index32.data_ptr(), H, N, ld, dense.data_ptr(), _stream()), "relpos_gather")
+    return dense
+
+
+def relpos_scatter(ddense, index32, H, N, ld, dtable):
+    check(_lib.load().xfm_relpos_scatter(ddense.data_ptr(), index32.data_ptr(), H, N, ld, dtable.data_ptr(), _stream()),
+          "relpos_scatter")
+
+
+# --------------------------------------------------------------------------------------------- misc
+def patchify(image, patch):
+    _dev(image)
+    assert image.dtype == F32 and image.is_contiguous()
+    B, C, H, W = image.shape
+    out = torch.empty((B * (H // patch) * (W // patch), C * patch * patch), dtype=BF16, device=image.device)
+    check(_lib.load().xfm_patchify(image.data_ptr(), B, C, H, W, patch, out.data_ptr(), _stream()), "patchify")
+    return out
+
+
+def _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop):
+    B, T = ids.shape
+    return EmbedArgs(ids=ids.data_ptr(), word=word.data_ptr(), pos=pos.data_ptr(), type=typ.data_ptr(), w=w.data_ptr(),
+                     b=b.data_ptr(), B=B, T=T, pad_id=pad_id, eps=eps, drop_thresh=drop[0], drop_scale=drop[1],
+                     seed_lo=drop[2], seed_hi=drop[3])
+
+
+def embed_ln_fwd(ids, word, pos, typ, w, b, eps, pad_id, drop=(0, 1.0, 0, 0)):
+    _dev(ids)
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    B, T = ids.shape
+    D = word.shape[1]
+    y = torch.empty((B * T, D), dtype=BF16, device=ids.device)
+    mean = torch.empty(B * T, dtype=F32, device=ids.device)
+    rstd = torch.empty(B * T, dtype=F32, device=ids.device)
+    pos_ids = torch.empty(B * T, dtype=torch.int32, device=ids.device)
+    a = _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop)
+    a.y, a.mean, a.rstd, a.pos_ids = y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), pos_ids.data_ptr()
+    check(_lib.load().xfm_embed_ln_fwd(ctypes.byref(a), D, _stream()), "embed_ln_fwd")
+    return y, mean, rstd, pos_ids
+
+
+def embed_ln_bwd(dy, ids, word, pos, typ, w, b, eps, pad_id, mean, rstd, pos_ids, dword, dpos, dtype_, dgamma, dbeta,
+                 drop=(0, 1.0, 0, 0)):
+    D = word.shape[1]
+    a = _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop)
+    a.mean, a.rstd, a.pos_ids = mean.data_ptr(), rstd.data_ptr(), pos_ids.data_ptr()
+    a.dy, a.dword, a.dpos = dy.data_ptr(), dword.data_ptr(), dpos.data_ptr()
+    lib = _lib.load()
+    ws = workspace(lib.xfm_embed_ln_bwd_workspace(a.B * a.T, D), dy.device)
+    check(lib.xfm_embed_ln_bwd(ctypes.byref(a), D, _ptr(dgamma), _ptr(dbeta), _ptr(dtype_), ws.data_ptr(), ws.numel() * 4,
+                               _stream()), "embed_ln_bwd")
+
+
+def ce_fwd(logits, V, labels):
+    """logits fp32 [R, ld>=V]; labels int64 [R] -> (lse [R], loss_rows [R])."""
+    R = logits.shape[0]
+    lse = torch.empty(R, dtype=F32, device=logits.device)
+    loss = torch.empty(R, dtype=F32, device=logits.device)
+    check(_lib.load().xfm_ce_fwd(logits.data_ptr(), logits.stride(0), R, V, labels.data_ptr(), lse.data_ptr(), loss.data_ptr(),
+                                 _stream()), "ce_fwd")
+    return lse, loss
+
+
+def ce_bwd(logits, V, labels, lse, scale, ldd):
+    """-> dlogits bf16 [R, ldd] = (softmax - onehot) * scale[0] (zero in ignored rows / padding columns)."""
+    R = logits.shape[0]
+    d = torch.empty((R, ldd), dtype=BF16, device=logits.device)
+    check(_lib.load().xfm_ce_bwd(logits.data_ptr(), logits.stride(0), R, V, labels.data_ptr(), lse.data_ptr(), scale.data_ptr(),
+                                 d.data_ptr(), ldd, _stream()), "ce_bwd")
+    return d
+
+
+def sumsq(x, out):
+    check(_lib.load().xfm_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "sumsq")
+
+
+def adamw(p, g, m, v, group, lrs, wds, beta1, beta2, eps, step, clip_coef=None):
+    a = AdamWArgs(p=p.data_ptr(), g=g.data_ptr(), m=m.data_ptr(), v=v.data_ptr(), group=group.data_ptr(),
+                  beta1=beta1, beta2=beta2, eps=eps, bc1=1.0 - beta1 ** step, bc2=1.0 - beta2 ** step,
+                  clip_coef=_ptr(clip_coef), n=p.numel())
+    for i in range(4):
+        a.lr[i] = lrs[i] if i < len(lrs) else 0.0
+        a.wd[i] = wds[i] if i < len(wds) else 0.0
+    check(_lib.load().xfm_adamw(ctypes.byref(a), _stream()), "adamw")

@@ -1,0 +1,63 @@
+"""Pre-training model: which losses run and how they are weighted (mirrors models/model_pretrain.py:13-116)."""
+import torch
+
+from .xfm import XFMBase
+
+
+class XFM(XFMBase):
+    def __init__(self, config, load_vision_params=False, load_text_params=False):
+        super().__init__(config, load_vision_params=load_vision_params, load_text_params=load_text_params,
+                         use_contrastive_loss=True, use_matching_loss=True, use_mlm_loss=True, use_bbox_loss=True,
+                         config_text=None)
+        self.weights_map = {k: config.get('w' + k, 1.0) for k in ('region', 'web', 'imagenet', 'image', 'aux')}
+        self.do_image_mask = config.get('do_image_mask', True)
+        self.use_mm_mim_loss = config.get('use_mm_mim_loss', True)
+        self.min_temp = config.get('min_temp', 0.001)
+        self.max_temp = config.get('max_temp', 0.5)
+
+    def forward_multimodal(self, image, text_ids, text_atts, text_ids_masked=None, masked_pos=None, masked_ids=None,
+                           text_ids_2=None, text_atts_2=None, text_ids_masked_2=None, masked_pos_2=None, masked_ids_2=None,
+                           image_atts=None, idx_to_group_img=None, target_bbox=None, is_image=None, ret_mim_loss=False,
+                           ret_bbox_loss=False, ret_match_loss=True, ret_mlm_loss=True, ret_bbox_giou=False,
+                           ret_itc_loss=True, data_source=None, ids_mask=None, neg_idx=None):
+        if ret_bbox_loss or ret_bbox_giou:
+            raise NotImplementedError("bbox / region losses (model_pretrain.py:39-41,81-85) are outside the hot-path scope")
+        if self.learnable_temp:
+            self.temp.data.clamp_(self.min_temp, self.max_temp)  # via .data: leaves the arena's weight version untouched
+        w = self.weights_map.get(data_source, None)
+        zero = torch.tensor(0.0, device=image.device)
+        image_embeds, image_atts = self.get_vision_embeds(image)
+        if data_source != 'imagenet':
+            text_embeds = self.get_text_embeds(text_ids, text_atts)
+            image_feat, text_feat = self.get_features(image_embeds, text_embeds)
+        loss_itc = loss_itm = loss_mlm = loss_mim = zero
+        if ret_itc_loss and data_source != 'imagenet':
+            loss_itc = self.get_contrastive_loss(image_feat, text_feat)
+            if w is not None:
+                loss_itc = loss_itc * w
+        if ret_match_loss and data_source != 'imagenet':
+            loss_itm = self.get_matching_loss(image_embeds, image_atts, image_feat, text_ids, text_atts, text_feat,
+                                              text_embeds=text_embeds, neg_idx=neg_idx)
+            if w is not None:
+                loss_itm = loss_itm * w
+        if ret_mlm_loss and data_source != 'imagenet':
+            loss_mlm = self.get_fuse_mlm_loss(text_ids_masked, text_atts, image_embeds, image_atts, masked_pos, masked_ids)
+            if w is not None:
+                loss_mlm = loss_mlm * w
+        if ret_mim_loss:
+            image_embeds_masked, _, ids_mask = self.get_vision_embeds(image, do_mask=self.do_image_mask, ids_mask=ids_mask)
+            if data_source == 'imagenet' or self.use_mm_mim_loss:
+                loss_mim = self.get_mim_loss(image_embeds_masked, image_embeds, ids_mask)
+            if w is not None:
+                loss_mim = loss_mim * w
+        return {'loss_itc': loss_itc, 'loss_itm': loss_itm, 'loss_mlm': loss_mlm, 'loss_mim': loss_mim,
+                'loss_bbox': zero, 'loss_giou': zero}
+
+    def forward_text(self, text_ids=None, text_atts=None, text_ids_masked=None, masked_pos=None, masked_ids=None):
+        return {'loss_mlm': self.get_mlm_loss(text_ids_masked, text_atts, None, None, masked_pos, masked_ids)}
+
+    def forward(self, image=None, text_ids=None, text_atts=None, text_ids_masked=None, masked_pos=None, masked_ids=None,
+                **kw):
+        if image is None:
+            return self.forward_text(text_ids, text_atts, text_ids_masked, masked_pos, masked_ids)
+        return self.forward_multimodal(image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids, **kw)

@@ -1,0 +1,153 @@
+"""Autograd nodes for the stand-alone ops of the path (heads, LM head + cross-entropy).  Weight / bias gradients are
+accumulated straight into the gradient arena by the wgrad kernels; autograd only carries activation gradients."""
+import math
+
+import torch
+
+from . import functional as Fx
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def grad_view(p):
+    if p.grad is not p._xfm_grad:
+        p.grad = p._xfm_grad
+    return p._xfm_grad
+
+
+class _LinearSlotFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slot, x_requires_grad, out_fp32, anchor):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype != BF16:
+            x2 = x2.to(BF16)
+        x2 = x2.contiguous()
+        y = Fx.gemm_nt(x2, slot.wb, slot.b, epi=Fx.EPI_F32 if out_fp32 else Fx.EPI_BF16)
+        ctx.slot, ctx.x2, ctx.xshape, ctx.need_dx, ctx.xdtype = slot, x2, x.shape, x_requires_grad, x.dtype
+        return y.view(*x.shape[:-1], slot.N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        s = ctx.slot
+        dy2 = dy.reshape(-1, s.N)
+        dy2 = (dy2 if dy2.dtype == BF16 else dy2.to(BF16)).contiguous()
+        Fx.gemm_tn(dy2, ctx.x2, s.dw)
+        if s.db is not None:
+            Fx.colsum(dy2, s.db)
+        dx = None
+        if ctx.need_dx:
+            if s.N % 64 == 0:
+                dx = Fx.gemm_nt(dy2, s.wt, n=s.K)
+            else:  # tiny heads (e.g. 2-way ITM logits): pad the contraction dim to the GEMM's K granularity
+                pad = (s.N + 63) // 64 * 64
+                dyp = torch.zeros((dy2.shape[0], pad), dtype=BF16, device=dy2.device)
+                dyp[:, :s.N] = dy2
+                wtp = torch.zeros((s.K, pad), dtype=BF16, device=dy2.device)
+                wtp[:, :s.N] = s.wt[:, :s.N]
+                dx = Fx.gemm_nt(dyp, wtp, n=s.K)
+            dx = dx.view(ctx.xshape).to(ctx.xdtype)
+        return dx, None, None, None, None
+
+
+def linear_slot(x, slot, x_requires_grad=True, out_fp32=False):
+    """y = x @ W^T + b through the bf16 MFMA GEMM.  `anchor` makes the node differentiable even when x is not."""
+    anchor = slot.weights[0]
+    return _LinearSlotFn.apply(x, slot, x_requires_grad and x.requires_grad, out_fp32, anchor)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        y, mean, rstd = Fx.ln_fwd(x2, mod.weight, mod.bias, mod.eps)
+        ctx.mod, ctx.saved, ctx.shape, ctx.dtype = mod, (x2, mean, rstd), x.shape, x.dtype
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved
+        m = ctx.mod
+        dy2 = dy.reshape(x2.shape)
+        dy2 = (dy2 if dy2.dtype == BF16 else dy2.to(BF16)).contiguous()
+        if ctx.dtype == F32:
+            dx = torch.empty_like(x2)
+            Fx.ln_bwd(dy2, x2, mean, rstd, m.weight, grad_view(m.weight), grad_view(m.bias), dx32=dx)
+        else:
+            dx = torch.empty_like(x2)
+            Fx.ln_bwd(dy2, x2, mean, rstd, m.weight, grad_view(m.weight), grad_view(m.bias), dx16=dx)
+        return dx.view(ctx.shape), None
+
+
+def layer_norm(x, mod):
+    """LayerNorm over the last dim (fp32 or bf16 in, bf16 out) using `mod.weight/bias/eps`."""
+    return _LayerNormFn.apply(x, mod)
+
+
+def gelu_grad(u):
+    u = u.float()
+    return 0.5 * (1.0 + torch.erf(u * (1.0 / math.sqrt(2.0)))) + u * torch.exp(-0.5 * u * u) * (1.0 / math.sqrt(2.0 * math.pi))
+
+
+VOCAB_LD = 64  # logits / dlogits row stride is padded to a multiple of this (the dgrad GEMM contracts over it)
+
+
+class _LMHeadCEFn(torch.autograd.Function):
+    """RobertaLMHead (dense -> GELU -> LayerNorm -> decoder, xroberta.py:1325-1333) fused with the vocabulary
+    cross-entropy (ignore_index=-100, xroberta.py:1296-1297).  Returns (reduced loss, fp32 logits view)."""
+
+    @staticmethod
+    def forward(ctx, x, head, labels, reduction):
+        R, D = x.shape
+        sd, sv = head._slot_dense, head._slot_decoder
+        V = sv.N
+        hact, u = Fx.gemm_nt(x, sd.wb, sd.b, epi=Fx.EPI_GELU)
+        y, mean, rstd = Fx.ln_fwd(hact, head.layer_norm.weight, head.layer_norm.bias, head.layer_norm.eps)
+        ldl = (V + VOCAB_LD - 1) // VOCAB_LD * VOCAB_LD
+        logits = torch.empty((R, ldl), dtype=F32, device=x.device)
+        Fx.gemm_nt(y, sv.wb, sv.b, epi=Fx.EPI_F32, out=logits, n=V)
+        labels = labels.reshape(-1).contiguous()
+        lse, loss_rows = Fx.ce_fwd(logits, V, labels)
+        nvalid = (labels != -100).sum().clamp(min=1).to(F32)
+        ctx.saved = (x, hact, u, y, mean, rstd, logits, labels, lse, nvalid)
+        ctx.head, ctx.reduction = head, reduction
+        ctx.mark_non_differentiable(logits)
+        if reduction == "mean":
+            return loss_rows.sum() / nvalid, logits
+        if reduction == "sum":
+            return loss_rows.sum(), logits
+        return loss_rows, logits
+
+    @staticmethod
+    def backward(ctx, g, _):
+        x, hact, u, y, mean, rstd, logits, labels, lse, nvalid = ctx.saved
+        head = ctx.head
+        sd, sv = head._slot_dense, head._slot_decoder
+        V = sv.N
+        if ctx.reduction == "none":
+            raise NotImplementedError("per-row upstream gradients are handled by the caller via reduction='sum' weights")
+        scale = (g / nvalid if ctx.reduction == "mean" else g).reshape(1).to(F32).contiguous()
+        dlogits = Fx.ce_bwd(logits, V, labels, lse, scale, logits.shape[1])
+        Fx.gemm_tn(dlogits, y, sv.dw, n=V)
+        Fx.colsum(dlogits, sv.db, n=V)
+        dy = Fx.gemm_nt(dlogits, sv.wt, n=sv.K)
+        dhact = torch.empty_like(hact)
+        ln = head.layer_norm
+        Fx.ln_bwd(dy, hact, mean, rstd, ln.weight, grad_view(ln.weight), grad_view(ln.bias), dx16=dhact)
+        du = (dhact.float() * gelu_grad(u)).to(BF16)
+        Fx.gemm_tn(du, x, sd.dw)
+        Fx.colsum(du, sd.db)
+        dx = Fx.gemm_nt(du, sd.wt, n=sd.K)
+        return dx, None, None, None
+
+
+def lm_head_ce(x, head, labels, reduction="mean"):
+    return _LMHeadCEFn.apply(x.contiguous(), head, labels, reduction)
+
+
+def lm_head_logits(x, head):
+    """Inference-only logits (return_logits=True path, xroberta.py:1287-1288)."""
+    sd, sv = head._slot_dense, head._slot_decoder
+    with torch.no_grad():
+        hact, _ = Fx.gemm_nt(x.contiguous(), sd.wb, sd.b, epi=Fx.EPI_GELU)
+        y, _, _ = Fx.ln_fwd(hact, head.layer_norm.weight, head.layer_norm.bias, head.layer_norm.eps)
+        return Fx.gemm_nt(y, sv.wb, sv.b, epi=Fx.EPI_F32)

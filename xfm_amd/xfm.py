@@ -1,0 +1,319 @@
+"""XFMBase on the HIP hot path: three towers + heads + ITC / ITM / MLM / MIM losses, behind the reference's interface.
+
+Mirrors `models/xfm.py::XFMBase` (:471-853): same constructor keywords, `get_*` method names and signatures, and
+state_dict key names, so the reference's task models / train loops drive it unchanged.  Towers are the HIP-backed
+`xfm_amd.beit2.VisionTransformer` and `xfm_amd.xroberta.RobertaForMaskedLM`; all their parameters live in one flat
+arena (xfm_amd.arena).  Deliberate MI355X-first departures, none of which changes a value the reference computes:
+  * hard negatives are drawn with ONE batched device-side torch.multinomial per direction instead of 2B host-synchronous
+    `.item()` draws (xfm.py:736-744) -- same per-row categorical distribution, no pipeline stall;
+  * the ITM positive (B) and negative (2B) fusion passes (xfm.py:788-793) run as one 3B-row pass;
+  * the MIM loss masks with a weight tensor instead of boolean indexing (no device->host sync).
+"""
+import json
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .arena import LinearSlot, ParamArena
+from .beit2 import _Affine, beit_base_patch16
+from .ops import layer_norm, linear_slot
+from .xroberta import RobertaConfig, RobertaForMaskedLM, _Lin
+
+BF16 = torch.bfloat16
+
+
+class AllGather(torch.autograd.Function):
+    """all_gather with a slice-only backward (xfm.py:81-101).  backend 'nccl' is RCCL over xGMI on ROCm."""
+
+    @staticmethod
+    def forward(ctx, tensor, rank, world_size):
+        output = [torch.empty_like(tensor) for _ in range(world_size)]
+        dist.all_gather(output, tensor.contiguous())
+        ctx.rank, ctx.batch_size = rank, tensor.shape[0]
+        return torch.cat(output, 0)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output[ctx.batch_size * ctx.rank: ctx.batch_size * (ctx.rank + 1)], None, None
+
+
+def allgather(t):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return AllGather.apply(t, dist.get_rank(), dist.get_world_size())
+    return t
+
+
+class _Mlp(nn.Module):
+    """build_mlp (xfm.py:115-121) with reference key names 0 / 1 / 3."""
+
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        setattr(self, "0", _Lin(input_dim, input_dim * 2, 0.02))
+        setattr(self, "1", _Affine(input_dim * 2, 1e-5))
+        setattr(self, "3", _Lin(input_dim * 2, output_dim, 0.02))
+
+    def linear_slots(self, prefix):
+        l0, l3 = getattr(self, "0"), getattr(self, "3")
+        self._s0 = LinearSlot(prefix + "0", [l0.weight], [l0.bias])
+        self._s3 = LinearSlot(prefix + "3", [l3.weight], [l3.bias])
+        return [self._s0, self._s3]
+
+    def forward(self, x):
+        h = layer_norm(linear_slot(x, self._s0), getattr(self, "1"))
+        return linear_slot(F.gelu(h.float()).to(BF16), self._s3, out_fp32=True)
+
+
+def build_mlp(input_dim, output_dim):
+    return _Mlp(input_dim, output_dim)
+
+
+def _read_json(path, default):
+    if path and os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return dict(default)
+
+
+def build_vision_encoder(config, load_params=False):
+    """xfm.py:124-255, BEiT-v2 branch (the only one a shipped config selects)."""
+    if not config.get('use_beit_v2', False):
+        raise ValueError("only use_beit_v2 vision encoders are implemented (xfm.py:206-234)")
+    if load_params:
+        raise NotImplementedError("checkpoint loading (beit2.py:572-849) is outside the hot-path scope; load a state_dict instead")
+    vision_config = _read_json(config.get('vision_config'), {"vision_width": 768, "patch_size": 16})
+    assert config['patch_size'] == vision_config['patch_size']
+    enc = beit_base_patch16(img_size=config['image_res'], drop_rate=0.0, drop_path_rate=0.1, attn_drop_rate=0.0,
+                            use_mean_pooling=True, init_scale=0.001, use_rel_pos_bias=True, use_abs_pos_emb=False,
+                            init_values=0.1, qkv_bias=True, local_attn_depth=config.get('local_attn_depth', -1),
+                            num_masking_patches=config.get('num_masking_patches', 75),
+                            min_num_patches=config.get('min_num_patches', 16), depth=config.get('vision_depth', 12))
+    return enc, vision_config['vision_width']
+
+
+def _text_config(config):
+    if 'text_config' in config:
+        return RobertaConfig(**config['text_config'])
+    path = os.path.join(config.get('text_encoder', ''), 'config.json')
+    if os.path.exists(path):
+        return RobertaConfig.from_json_file(path)
+    return RobertaConfig()  # public roberta-base hyper-parameters
+
+
+def build_text_encoder(config, vision_width, load_text_params=False, use_mlm_loss=False, config_text=None):
+    """xfm.py:258-405, roberta branch."""
+    if 'roberta' not in config.get('text_encoder', 'roberta-base'):
+        raise NotImplementedError("bert-named text encoders (xbert.py) are not wired into the model builder yet")
+    if load_text_params:
+        raise NotImplementedError("checkpoint loading is outside the hot-path scope; load a state_dict instead")
+    if config_text is None:
+        config_text = _text_config(config)
+        config_text.num_hidden_layers = config.get('text_num_hidden_layers', 12)
+        config_text.fusion_layer = config.get('text_fusion_start_at', config_text.num_hidden_layers // 2)
+    config_text.encoder_width = vision_width
+    return RobertaForMaskedLM(config_text), []
+
+
+class XFMBase(nn.Module):
+    def __init__(self, config=None, load_vision_params=False, load_text_params=False, use_contrastive_loss=False,
+                 use_matching_loss=False, use_mlm_loss=False, use_bbox_loss=False, config_text=None):
+        super().__init__()
+        self.init_params = []
+        self.vision_encoder, vision_width = build_vision_encoder(config, load_params=load_vision_params)
+        self.text_encoder, init_params = build_text_encoder(config, vision_width=vision_width,
+                                                            load_text_params=load_text_params, use_mlm_loss=use_mlm_loss,
+                                                            config_text=config_text)
+        self.init_params.extend(init_params)
+        self.num_text_layers = self.text_encoder.config.fusion_layer
+        self.num_cross_layers = self.text_encoder.config.num_hidden_layers - self.num_text_layers
+        self.vision_width = vision_width
+        self.text_width = self.text_encoder.config.hidden_size
+        self.use_vision_tokenizer = config.get('use_vision_tokenizer', False)
+        if self.use_vision_tokenizer:
+            raise NotImplementedError("VQ-KD visual tokenizer (model_vqkd.py) is outside the hot-path scope")
+        if use_contrastive_loss:
+            self.embed_dim = config['embed_dim']
+            self.vision_proj = _Lin(self.vision_width, self.embed_dim, 0.02)
+            self.text_proj = _Lin(self.text_width, self.embed_dim, 0.02)
+            self.init_params.extend(['vision_proj.' + n for n, _ in self.vision_proj.named_parameters()])
+            self.init_params.extend(['text_proj.' + n for n, _ in self.text_proj.named_parameters()])
+            self.learnable_temp = config.get('learnable_temp', True)
+            if not self.learnable_temp:
+                self.temp = config.get('temp', 0.07)
+            else:
+                self.temp = nn.Parameter(torch.ones([]) * config['temp'])
+            self.init_params.extend(['temp'])
+        if use_matching_loss:
+            self.itm_head = build_mlp(input_dim=self.text_width, output_dim=2)
+            self.init_params.extend(['itm_head.' + n for n, _ in self.itm_head.named_parameters()])
+        if use_bbox_loss:
+            self.bbox_head = build_mlp(input_dim=self.text_width, output_dim=4)
+            self.init_params.extend(['bbox_head.' + n for n, _ in self.bbox_head.named_parameters()])
+        config_fusion = _text_config(config)
+        config_fusion.num_hidden_layers = config['fusion_num_hidden_layers']
+        config_fusion.fusion_layer = config['fusion_fusion_start_at']
+        config_fusion.encoder_width = self.vision_width
+        self.fusion_layers = config_fusion.num_hidden_layers
+        self.text_layers = config['text_num_hidden_layers']
+        self.fusion_encoder = RobertaForMaskedLM(config=config_fusion)
+        self.detach_text_forMLM = config.get('detach_text_forMLM', True)
+        self.mim_cls_only = config.get('mim_cls_only', False)
+        if self.vision_width != self.text_width:
+            raise NotImplementedError("fusion_proj (vision_width != text_width) is not on the base-model path")
+        self._arena = None
+
+    # ---- arena ----------------------------------------------------------------------------------
+    def finalize(self, device=None):
+        """Build the flat parameter / gradient arenas on `device` (call after .cuda() / .to(device))."""
+        device = device or next(self.parameters()).device
+        slots = self.vision_encoder.linear_slots()
+        slots += self.text_encoder.linear_slots("text_encoder.")
+        slots += self.fusion_encoder.linear_slots("fusion_encoder.")
+        if hasattr(self, "vision_proj"):
+            self._s_vproj = LinearSlot("vision_proj", [self.vision_proj.weight], [self.vision_proj.bias])
+            self._s_tproj = LinearSlot("text_proj", [self.text_proj.weight], [self.text_proj.bias])
+            slots += [self._s_vproj, self._s_tproj]
+        if hasattr(self, "itm_head"):
+            slots += self.itm_head.linear_slots("itm_head.")
+        if hasattr(self, "bbox_head"):
+            slots += self.bbox_head.linear_slots("bbox_head.")
+        self._arena = ParamArena(self, slots, device)
+        self.vision_encoder.attach(self._arena)
+        self.text_encoder.attach(self._arena)
+        self.fusion_encoder.attach(self._arena)
+        return self
+
+    def _ready(self):
+        if self._arena is None or not self._arena.attached():
+            self.finalize()
+        self._arena.refresh()
+
+    def zero_grad(self, set_to_none=False):
+        if self._arena is not None:
+            self._arena.zero_grad()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    # ---- towers ---------------------------------------------------------------------------------
+    def get_vision_embeds(self, image, image_atts=None, idx_to_group_img=None, do_mask=False, ids_mask=None):
+        if idx_to_group_img is not None:
+            raise NotImplementedError("region path (xfm.py:574-597) is outside the hot-path scope")
+        self._ready()
+        if do_mask:
+            image_embeds, id_masked = self.vision_encoder(image, do_mask=True, ids_mask=ids_mask)
+            image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
+            return image_embeds, image_atts, id_masked
+        image_embeds = self.vision_encoder(image)
+        image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
+        return image_embeds, image_atts
+
+    def get_text_embeds(self, text_ids, text_atts):
+        assert text_atts is not None
+        self._ready()
+        return self.text_encoder.bert(text_ids, attention_mask=text_atts, encoder_hidden_states=None,
+                                      encoder_attention_mask=None, return_dict=True).last_hidden_state
+
+    def get_features(self, image_embeds=None, text_embeds=None):
+        out = []
+        if image_embeds is not None:
+            out.append(F.normalize(linear_slot(image_embeds[:, 0, :], self._s_vproj, out_fp32=True), dim=-1))
+        if text_embeds is not None:
+            out.append(F.normalize(linear_slot(text_embeds[:, 0, :], self._s_tproj, out_fp32=True), dim=-1))
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def get_cross_embeds(self, image_embeds, image_atts, text_ids=None, text_embeds=None, text_atts=None, is_pretrain=True):
+        self._ready()
+        enc = self.fusion_encoder.bert
+        if text_embeds is None:
+            return enc(text_ids, attention_mask=text_atts, encoder_hidden_states=image_embeds,
+                       encoder_attention_mask=image_atts, return_dict=True).last_hidden_state
+        encoder_embeds = text_embeds.detach() if is_pretrain else text_embeds
+        return enc(encoder_embeds=encoder_embeds, attention_mask=text_atts, encoder_hidden_states=image_embeds,
+                   encoder_attention_mask=image_atts, return_dict=True).last_hidden_state
+
+    # ---- losses ---------------------------------------------------------------------------------
+    def get_contrastive_loss(self, image_feat, text_feat, idx=None):
+        assert image_feat.size(-1) == self.embed_dim and text_feat.size(-1) == self.embed_dim
+        image_feat_all, text_feat_all = allgather(image_feat), allgather(text_feat)
+        logits = image_feat_all @ text_feat_all.t() / self.temp
+        bsz = image_feat_all.shape[0]
+        if idx is None:
+            labels = torch.arange(bsz, device=image_feat.device)
+            return (F.cross_entropy(logits, labels) + F.cross_entropy(logits.t(), labels)) / 2
+        idx = idx.view(-1, 1)
+        assert idx.size(0) == image_feat.size(0)
+        idx_all = allgather(idx)
+        pos_idx = torch.eq(idx_all, idx_all.t()).float()
+        labels = pos_idx / pos_idx.sum(1, keepdim=True)
+        loss_i2t = -torch.sum(F.log_softmax(logits, dim=1) * labels, dim=1).mean()
+        loss_t2i = -torch.sum(F.log_softmax(logits.t(), dim=1) * labels, dim=1).mean()
+        return (loss_i2t + loss_t2i) / 2
+
+    def get_hard_negatives(self, image_feat, text_feat, idx=None):
+        """Returns device index tensors (image_neg_idx, text_neg_idx), each [B] int64."""
+        with torch.no_grad():
+            sim_i2t = image_feat @ text_feat.t() / self.temp
+            weights_i2t = F.softmax(sim_i2t, dim=1) + 1e-5
+            weights_t2i = F.softmax(sim_i2t.t(), dim=1) + 1e-5
+            if idx is None:
+                weights_i2t.fill_diagonal_(0)
+                weights_t2i.fill_diagonal_(0)
+            else:
+                mask = torch.eq(idx.view(-1, 1), idx.view(1, -1))
+                weights_i2t.masked_fill_(mask, 0)
+                weights_t2i.masked_fill_(mask, 0)
+            image_neg_idx = torch.multinomial(weights_t2i, 1).view(-1)
+            text_neg_idx = torch.multinomial(weights_i2t, 1).view(-1)
+        return image_neg_idx, text_neg_idx
+
+    def get_matching_loss(self, image_embeds, image_atts, image_feat, text_ids, text_atts, text_feat, idx=None,
+                          return_cross_embeds=False, text_embeds=None, is_pretrain=True, neg_idx=None):
+        assert text_ids.dim() == 2, "X-Brain uses text_ids for matching."
+        if text_embeds is None:
+            raise NotImplementedError("matching on text_ids through the fusion embeddings is not used by any XFM task model")
+        if neg_idx is None:
+            image_neg_idx, text_neg_idx = self.get_hard_negatives(image_feat, text_feat, idx=idx)
+        else:
+            image_neg_idx = torch.as_tensor(neg_idx[0], dtype=torch.long, device=image_embeds.device)
+            text_neg_idx = torch.as_tensor(neg_idx[1], dtype=torch.long, device=image_embeds.device)
+        bs = image_feat.size(0)
+        # rows [0,B): positives ; [B,2B): (negative image, text) ; [2B,3B): (image, negative text)   xfm.py:781-793
+        image_all = torch.cat([image_embeds, image_embeds.index_select(0, image_neg_idx), image_embeds], dim=0)
+        image_atts_all = torch.cat([image_atts, image_atts.index_select(0, image_neg_idx), image_atts], dim=0)
+        text_all = torch.cat([text_embeds, text_embeds, text_embeds.index_select(0, text_neg_idx)], dim=0)
+        text_atts_all = torch.cat([text_atts, text_atts, text_atts.index_select(0, text_neg_idx)], dim=0)
+        cross = self.get_cross_embeds(image_all, image_atts_all, text_embeds=text_all, text_atts=text_atts_all,
+                                      is_pretrain=is_pretrain)[:, 0, :]
+        output = self.itm_head(cross)
+        itm_labels = torch.cat([torch.ones(bs, dtype=torch.long), torch.zeros(2 * bs, dtype=torch.long)], dim=0).to(image_embeds.device)
+        loss = F.cross_entropy(output, itm_labels)
+        if return_cross_embeds:
+            return loss, cross[:bs]
+        return loss
+
+    def get_mlm_loss(self, text_ids_masked, text_atts, image_embeds, image_atts, masked_pos, masked_ids):
+        self._ready()
+        return self.text_encoder(text_ids_masked, attention_mask=text_atts, encoder_hidden_states=image_embeds,
+                                 encoder_attention_mask=image_atts, return_dict=True, labels=masked_ids,
+                                 masked_pos=masked_pos).loss
+
+    def get_fuse_mlm_loss(self, text_ids_masked, text_atts, image_embeds, image_atts, masked_pos, masked_ids):
+        encoder_embeds = self.get_text_embeds(text_ids_masked, text_atts)
+        if self.detach_text_forMLM:
+            encoder_embeds = encoder_embeds.detach()
+        return self.fusion_encoder(encoder_embeds=encoder_embeds, attention_mask=text_atts, encoder_hidden_states=image_embeds,
+                                   encoder_attention_mask=image_atts, return_dict=True, labels=masked_ids,
+                                   masked_pos=masked_pos).loss
+
+    def get_mim_loss(self, image_embeds_masked, targets, mask_tokens):
+        """MSE(masked patches) + MSE(pooled cls), xfm.py:624-635; sync-free masked mean."""
+        t = targets.detach().float()
+        x = image_embeds_masked.float()
+        w = mask_tokens.to(x.dtype).unsqueeze(-1)
+        diff2 = (x[:, 1:, :] - t[:, 1:, :]) ** 2
+        loss_patch = (diff2 * w).sum() / (w.sum() * x.shape[-1]).clamp(min=1.0)
+        if self.mim_cls_only:
+            return loss_patch
+        return loss_patch + F.mse_loss(x[:, 0, :], t[:, 0, :])

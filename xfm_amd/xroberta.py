@@ -1,0 +1,410 @@
+"""RoBERTa text / fusion towers on the HIP hot path, behind the reference's interface.
+
+Mirrors `models/xroberta.py` of the reference: RobertaModel.forward (:817-957, incl. the `encoder_embeds` bypass
+:920-929 and `mode` layer ranges :504-516), RobertaForMaskedLM (:1157-1310, `.bert()` method, `masked_pos` gather,
+two LM heads), RobertaForCausalLM-style decoding mask (`is_decoder`), and the state_dict key names.  The layer stack
+runs as ONE autograd node: per layer a fused QKV GEMM, LDS-resident attention, output GEMM, fused
+dropout+residual+LayerNorm, (cross-attention with a fused K/V GEMM over the image tokens), GELU-fused FFN.
+`scale_after_qk=True` selects the xbert.py:329-330 ordering (same kernels: the scale is applied to the fp32 scores).
+"""
+import json
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fx
+from .arena import LinearSlot, ParamArena
+from .beit2 import _Affine, arena_note_grad, arena_note_use
+from .ops import grad_view, lm_head_ce, lm_head_logits
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class RobertaConfig:
+    """The subset of transformers' RobertaConfig the path reads (xfm.py:273-284,482-486,528-531)."""
+
+    def __init__(self, **kw):
+        d = dict(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                 hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=514,
+                 type_vocab_size=1, initializer_range=0.02, layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0,
+                 eos_token_id=2, fusion_layer=12, encoder_width=768, add_cross_attention=False)
+        d.update(kw)
+        self.__dict__.update(d)
+
+    @classmethod
+    def from_json_file(cls, path):
+        with open(path) as f:
+            return cls(**json.load(f))
+
+
+_seed_counter = [0]
+
+
+def _next_seed():
+    _seed_counter[0] += 1
+    return ((torch.initial_seed() & 0xFFFFFFFF) << 32) | (_seed_counter[0] & 0xFFFFFFFF)
+
+
+class _Lin(nn.Module):
+    def __init__(self, fin, fout, std):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin).normal_(0.0, std))
+        self.bias = nn.Parameter(torch.zeros(fout))
+
+
+class _Emb(nn.Module):
+    def __init__(self, n, dim, std, padding_idx=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, dim).normal_(0.0, std))
+        self.padding_idx = padding_idx
+        if padding_idx is not None:
+            with torch.no_grad():
+                self.weight[padding_idx].zero_()
+
+
+class RobertaEmbeddings(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        std = config.initializer_range
+        self.word_embeddings = _Emb(config.vocab_size, config.hidden_size, std, config.pad_token_id)
+        self.position_embeddings = _Emb(config.max_position_embeddings, config.hidden_size, std, config.pad_token_id)
+        self.token_type_embeddings = _Emb(config.type_vocab_size, config.hidden_size, std)
+        self.LayerNorm = _Affine(config.hidden_size, config.layer_norm_eps)
+        self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
+        self.padding_idx = config.pad_token_id
+        self.p_drop = config.hidden_dropout_prob
+
+
+class _EmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, emb, input_ids, drop):
+        ids = input_ids.contiguous()
+        ln = emb.LayerNorm
+        y, mean, rstd, pos_ids = Fx.embed_ln_fwd(ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
+                                                 emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps,
+                                                 emb.padding_idx, drop)
+        ctx.emb, ctx.saved, ctx.drop = emb, (ids, mean, rstd, pos_ids), drop
+        return y.view(ids.shape[0], ids.shape[1], -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        emb = ctx.emb
+        ids, mean, rstd, pos_ids = ctx.saved
+        ln = emb.LayerNorm
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        Fx.embed_ln_bwd(dy2, ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
+                        emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps, emb.padding_idx, mean, rstd, pos_ids,
+                        grad_view(emb.word_embeddings.weight), grad_view(emb.position_embeddings.weight),
+                        grad_view(emb.token_type_embeddings.weight).view(-1), grad_view(ln.weight), grad_view(ln.bias), ctx.drop)
+        return None, None, None, None
+
+
+class RobertaSelfAttention(nn.Module):
+    def __init__(self, config, is_cross_attention):
+        super().__init__()
+        std = config.initializer_range
+        kv_in = config.encoder_width if is_cross_attention else config.hidden_size
+        self.query = _Lin(config.hidden_size, config.hidden_size, std)
+        self.key = _Lin(kv_in, config.hidden_size, std)
+        self.value = _Lin(kv_in, config.hidden_size, std)
+
+
+class RobertaSelfOutput(nn.Module):
+    def __init__(self, config, fin=None):
+        super().__init__()
+        self.dense = _Lin(fin or config.hidden_size, config.hidden_size, config.initializer_range)
+        self.LayerNorm = _Affine(config.hidden_size, config.layer_norm_eps)
+
+
+class RobertaAttention(nn.Module):
+    def __init__(self, config, is_cross_attention=False):
+        super().__init__()
+        self.self = RobertaSelfAttention(config, is_cross_attention)
+        self.output = RobertaSelfOutput(config)
+
+
+class RobertaIntermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = _Lin(config.hidden_size, config.intermediate_size, config.initializer_range)
+
+
+class RobertaLayer(nn.Module):
+    def __init__(self, config, layer_num):
+        super().__init__()
+        self.attention = RobertaAttention(config)
+        self.has_cross_attention = layer_num >= config.fusion_layer
+        if self.has_cross_attention:
+            self.layer_num = layer_num
+            self.crossattention = RobertaAttention(config, is_cross_attention=True)
+        self.intermediate = RobertaIntermediate(config)
+        self.output = RobertaSelfOutput(config, fin=config.intermediate_size)
+
+    def linear_slots(self, prefix):
+        a = self.attention
+        s = {"qkv": LinearSlot(prefix + "qkv", [a.self.query.weight, a.self.key.weight, a.self.value.weight],
+                               [a.self.query.bias, a.self.key.bias, a.self.value.bias]),
+             "o": LinearSlot(prefix + "o", [a.output.dense.weight], [a.output.dense.bias]),
+             "i": LinearSlot(prefix + "i", [self.intermediate.dense.weight], [self.intermediate.dense.bias]),
+             "out": LinearSlot(prefix + "out", [self.output.dense.weight], [self.output.dense.bias])}
+        if self.has_cross_attention:
+            c = self.crossattention
+            s["q2"] = LinearSlot(prefix + "q2", [c.self.query.weight], [c.self.query.bias])
+            s["kv2"] = LinearSlot(prefix + "kv2", [c.self.key.weight, c.self.value.weight], [c.self.key.bias, c.self.value.bias])
+            s["o2"] = LinearSlot(prefix + "o2", [c.output.dense.weight], [c.output.dense.bias])
+        self._s = s
+        return list(s.values())
+
+
+class RobertaEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.layer = nn.ModuleList([RobertaLayer(config, i) for i in range(config.num_hidden_layers)])
+
+
+class _EncoderFn(torch.autograd.Function):
+    """Layers [lo, hi) of a RobertaEncoder.  x: bf16 [B*T, D]; enc: bf16 [B*N, D] or None."""
+
+    @staticmethod
+    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training):
+        cfg = model.config
+        D, H = cfg.hidden_size, cfg.num_attention_heads
+        scale = 1.0 / math.sqrt(D // H)
+        p_att = cfg.attention_probs_dropout_prob if training else 0.0
+        p_hid = cfg.hidden_dropout_prob if training else 0.0
+        need_dx, need_denc = x.requires_grad, (enc is not None and enc.requires_grad)
+        saved = []
+        x = x.contiguous()
+        if enc is not None:
+            enc = enc.contiguous()
+        for li in range(lo, hi):
+            layer = model.encoder.layer[li]
+            s = layer._s
+            att, co = layer.attention, None
+            d_att, d_h1 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
+            qkv = Fx.gemm_nt(x, s["qkv"].wb, s["qkv"].b)
+            c1, lse1 = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep,
+                                   causal=causal, drop=d_att)
+            h1 = Fx.gemm_nt(c1, s["o"].wb, s["o"].b)
+            ln1 = att.output.LayerNorm
+            y1, z1, m1, r1 = Fx.ln_post_fwd(h1, x, ln1.weight, ln1.bias, ln1.eps, d_h1)
+            rec = {"x": x, "qkv": qkv, "c1": c1, "lse1": lse1, "z1": z1, "m1": m1, "r1": r1, "y1": y1, "d_att": d_att, "d_h1": d_h1}
+            y2 = y1
+            if layer.has_cross_attention and enc is not None:
+                co = layer.crossattention
+                d_att2, d_h2 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
+                q2 = Fx.gemm_nt(y1, s["q2"].wb, s["q2"].b)
+                kv = Fx.gemm_nt(enc, s["kv2"].wb, s["kv2"].b)
+                c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2)
+                h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
+                ln2 = co.output.LayerNorm
+                y2, z2, m2, r2 = Fx.ln_post_fwd(h2, y1, ln2.weight, ln2.bias, ln2.eps, d_h2)
+                rec.update(q2=q2, kv=kv, c2=c2, lse2=lse2, z2=z2, m2=m2, r2=r2, y2=y2, d_att2=d_att2, d_h2=d_h2)
+            d_h3 = Fx.drop_params(p_hid, _next_seed())
+            hact, u = Fx.gemm_nt(y2, s["i"].wb, s["i"].b, epi=Fx.EPI_GELU)
+            h3 = Fx.gemm_nt(hact, s["out"].wb, s["out"].b)
+            ln3 = layer.output.LayerNorm
+            y3, z3, m3, r3 = Fx.ln_post_fwd(h3, y2, ln3.weight, ln3.bias, ln3.eps, d_h3)
+            rec.update(hact=hact, u=u, z3=z3, m3=m3, r3=r3, d_h3=d_h3, cross=co is not None)
+            saved.append(rec)
+            x = y3
+        ctx.saved, ctx.model, ctx.enc = saved, model, enc
+        ctx.meta = (lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale)
+        arena_note_use(model)
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        model, enc = ctx.model, ctx.enc
+        lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale = ctx.meta
+        cfg = model.config
+        D, H = cfg.hidden_size, cfg.num_attention_heads
+        g = grad_view
+        dy_a, dy_b = dy.contiguous(), None
+        denc32 = torch.zeros((enc.shape[0], D), dtype=F32, device=dy.device) if need_denc else None
+        for li in reversed(range(lo, hi)):
+            layer = model.encoder.layer[li]
+            s, r = layer._s, ctx.saved[li - lo]
+            ln3 = layer.output.LayerNorm
+            dh3, dres3 = Fx.ln_post_bwd(dy_a, r["z3"], r["m3"], r["r3"], ln3.weight, g(ln3.weight), g(ln3.bias), s["out"].db,
+                                        dy2=dy_b, drop=r["d_h3"])
+            Fx.gemm_tn(dh3, r["hact"], s["out"].dw)
+            du = Fx.gemm_nt(dh3, s["out"].wt, epi=Fx.EPI_DGELU, aux=r["u"], n=s["out"].K)
+            y2 = r["y2"] if r["cross"] else r["y1"]
+            Fx.gemm_tn(du, y2, s["i"].dw)
+            Fx.colsum(du, s["i"].db)
+            d1a, d1b = Fx.gemm_nt(du, s["i"].wt, n=s["i"].K), dres3
+            if r["cross"]:
+                ln2 = layer.crossattention.output.LayerNorm
+                dh2, dres2 = Fx.ln_post_bwd(d1a, r["z2"], r["m2"], r["r2"], ln2.weight, g(ln2.weight), g(ln2.bias), s["o2"].db,
+                                            dy2=d1b, drop=r["d_h2"])
+                Fx.gemm_tn(dh2, r["c2"], s["o2"].dw)
+                dc2 = Fx.gemm_nt(dh2, s["o2"].wt, n=s["o2"].K)
+                dq2, dkv = torch.empty_like(r["q2"]), torch.empty_like(r["kv"])
+                kv = r["kv"]
+                Fx.attn_bwd(dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc,
+                            scale, key_keep=enc_keep, drop=r["d_att2"])
+                Fx.gemm_tn(dq2, r["y1"], s["q2"].dw)
+                Fx.colsum(dq2, s["q2"].db)
+                Fx.gemm_tn(dkv, enc, s["kv2"].dw)
+                Fx.colsum(dkv, s["kv2"].db)
+                if need_denc:
+                    Fx.gemm_nt(dkv, s["kv2"].wt, epi=Fx.EPI_F32_ACC, out=denc32, n=s["kv2"].K)
+                d1a, d1b = Fx.gemm_nt(dq2, s["q2"].wt, n=s["q2"].K), dres2
+            ln1 = layer.attention.output.LayerNorm
+            dh1, dres1 = Fx.ln_post_bwd(d1a, r["z1"], r["m1"], r["r1"], ln1.weight, g(ln1.weight), g(ln1.bias), s["o"].db,
+                                        dy2=d1b, drop=r["d_h1"])
+            Fx.gemm_tn(dh1, r["c1"], s["o"].dw)
+            dc1 = Fx.gemm_nt(dh1, s["o"].wt, n=s["o"].K)
+            qkv = r["qkv"]
+            dqkv = torch.empty_like(qkv)
+            Fx.attn_bwd(dc1, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], r["c1"], r["lse1"], dqkv[:, :D], dqkv[:, D:2 * D],
+                        dqkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep, causal=causal, drop=r["d_att"])
+            Fx.gemm_tn(dqkv, r["x"], s["qkv"].dw)
+            Fx.colsum(dqkv, s["qkv"].db)
+            if li > lo or need_dx:
+                dy_a, dy_b = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K), dres1
+            ctx.saved[li - lo] = None
+        dx = (dy_a.float() + dy_b.float()).to(BF16) if need_dx else None
+        denc = denc32.to(BF16) if need_denc else None
+        arena_note_grad(model)
+        return (dx, denc) + (None,) * 10
+
+
+class RobertaModel(nn.Module):
+    def __init__(self, config, add_pooling_layer=False):
+        super().__init__()
+        if add_pooling_layer:
+            raise NotImplementedError("pooler is never built on the XFM path (xroberta.py:1167)")
+        if config.hidden_size // config.num_attention_heads != 64:
+            raise NotImplementedError("head_dim must be 64")
+        self.config = config
+        self.embeddings = RobertaEmbeddings(config)
+        self.encoder = RobertaEncoder(config)
+        self.pooler = None
+        self._arena = None
+
+    def linear_slots(self, prefix=""):
+        out = []
+        for i, layer in enumerate(self.encoder.layer):
+            out.extend(layer.linear_slots(f"{prefix}layer.{i}."))
+        return out
+
+    def attach(self, arena):
+        self._arena = arena
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
+                inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
+                is_decoder=False, mode='multi_modal'):
+        if any(v is not None for v in (token_type_ids, position_ids, head_mask, inputs_embeds, past_key_values)):
+            raise NotImplementedError("token_type_ids/position_ids/head_mask/inputs_embeds/past_key_values are not used on the XFM path")
+        if isinstance(encoder_hidden_states, (list, tuple)):
+            raise NotImplementedError("per-layer encoder_hidden_states lists (xroberta.py:435-444) are outside the hot-path scope")
+        if self._arena is None:
+            raise RuntimeError("RobertaModel is not attached to a parameter arena; build it through XFMBase or call finalize()")
+        self._arena.refresh()
+        cfg = self.config
+        if encoder_embeds is None:
+            if input_ids is None:
+                raise ValueError("You have to specify either input_ids or inputs_embeds")
+            B, T = input_ids.shape
+            drop = Fx.drop_params(cfg.hidden_dropout_prob if self.training else 0.0, _next_seed())
+            x = _EmbedFn.apply(self.embeddings.word_embeddings.weight, self.embeddings, input_ids, drop)
+        else:
+            B, T = encoder_embeds.shape[:2]
+            x = encoder_embeds if encoder_embeds.dtype == BF16 else encoder_embeds.to(BF16)
+        dev = x.device
+        key_keep = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int32).contiguous()
+        enc, enc_keep, Nenc = None, None, 0
+        if encoder_hidden_states is not None:
+            enc = encoder_hidden_states if encoder_hidden_states.dtype == BF16 else encoder_hidden_states.to(BF16)
+            Nenc = enc.shape[1]
+            enc = enc.reshape(-1, enc.shape[-1])
+            if encoder_attention_mask is not None:
+                enc_keep = encoder_attention_mask.to(device=dev, dtype=torch.int32).contiguous()
+        if mode == 'text':
+            lo, hi = 0, cfg.fusion_layer
+        elif mode == 'fusion':
+            lo, hi = cfg.fusion_layer, cfg.num_hidden_layers
+        elif mode == 'multi_modal':
+            lo, hi = 0, cfg.num_hidden_layers
+        else:
+            raise ValueError(f"mode {mode} is not supported")
+        y = x.reshape(B * T, -1)
+        if hi > lo:
+            y = _EncoderFn.apply(y, enc, self, key_keep, enc_keep, lo, hi, bool(is_decoder), B, T, Nenc, self.training)
+        return SimpleNamespace(last_hidden_state=y.view(B, T, -1), pooler_output=None, past_key_values=None,
+                               hidden_states=None, attentions=None, cross_attentions=None)
+
+
+class RobertaLMHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        std = config.initializer_range
+        self.dense = _Lin(config.hidden_size, config.hidden_size, std)
+        self.layer_norm = _Affine(config.hidden_size, config.layer_norm_eps)
+        self.decoder = _Lin(config.hidden_size, config.vocab_size, std)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
+        self.decoder.bias = self.bias  # tied, xroberta.py:1322-1323
+
+    def linear_slots(self, prefix):
+        self._slot_dense = LinearSlot(prefix + "dense", [self.dense.weight], [self.dense.bias])
+        self._slot_decoder = LinearSlot(prefix + "decoder", [self.decoder.weight], [self.bias], pad_k_to=64)
+        return [self._slot_dense, self._slot_decoder]
+
+
+class RobertaForMaskedLM(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.roberta = RobertaModel(config, add_pooling_layer=False)
+        self.lm_head = RobertaLMHead(config)
+        self.lm_cap_head = RobertaLMHead(config)
+        self._arena = None
+
+    def linear_slots(self, prefix=""):
+        return self.roberta.linear_slots(prefix + "roberta.") + self.lm_head.linear_slots(prefix + "lm_head.") + \
+            self.lm_cap_head.linear_slots(prefix + "lm_cap_head.")
+
+    def attach(self, arena):
+        self._arena = arena
+        self.roberta.attach(arena)
+
+    def finalize(self, device=None):
+        device = device or self.lm_head.bias.device
+        self.attach(ParamArena(self, self.linear_slots(), device))
+        return self
+
+    def bert(self, input_ids=None, **kw):
+        return self.roberta(input_ids, **kw)
+
+    def gather_seq_out_by_pos(self, seq, pos):
+        return torch.gather(seq, 1, pos.unsqueeze(2).expand(-1, -1, seq.size(-1)))
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
+                inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                labels=None, output_attentions=None, output_hidden_states=None, return_dict=None, is_decoder=False,
+                reduction='mean', mode='multi_modal', return_logits=False, masked_pos=None):
+        outputs = self.roberta(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids,
+                               position_ids=position_ids, head_mask=head_mask, inputs_embeds=inputs_embeds,
+                               encoder_embeds=encoder_embeds, encoder_hidden_states=encoder_hidden_states,
+                               encoder_attention_mask=encoder_attention_mask, is_decoder=is_decoder, mode=mode)
+        seq = outputs.last_hidden_state
+        if masked_pos is not None:
+            seq = self.gather_seq_out_by_pos(seq, masked_pos)
+        head = self.lm_cap_head if is_decoder else self.lm_head
+        V = self.config.vocab_size
+        if return_logits or labels is None:
+            logits = lm_head_logits(seq.reshape(-1, seq.shape[-1]), head).view(*seq.shape[:2], V)
+            if return_logits:
+                return logits
+            return SimpleNamespace(loss=None, logits=logits, hidden_states=None, attentions=None)
+        if is_decoder:
+            seq, labels = seq[:, :-1, :], labels[:, 1:]
+        Bq, Tq = seq.shape[:2]
+        loss, logits = lm_head_ce(seq.reshape(-1, seq.shape[-1]), head, labels.reshape(-1), reduction)
+        return SimpleNamespace(loss=loss, logits=logits[:, :V].view(Bq, Tq, V), hidden_states=None, attentions=None)
