@@ -138,8 +138,10 @@ def roberta_position_ids(input_ids, padding_idx=1):
 def roberta_embeddings(P, pre, input_ids, eps=1e-5, padding_idx=1):
     """xroberta.py:104-137 (token_type_ids all zero; dropout is eval-mode identity here)."""
     pos = roberta_position_ids(input_ids, padding_idx)
-    e = P[pre + "word_embeddings.weight"][input_ids] + P[pre + "token_type_embeddings.weight"][0] \
-        + P[pre + "position_embeddings.weight"][pos]
+    # nn.Embedding(padding_idx=pad): the pad row takes no gradient (xroberta.py:80,100-102)
+    e = F.embedding(input_ids, P[pre + "word_embeddings.weight"], padding_idx=padding_idx) \
+        + P[pre + "token_type_embeddings.weight"][0] \
+        + F.embedding(pos, P[pre + "position_embeddings.weight"], padding_idx=padding_idx)
     return _ln(P, pre + "LayerNorm", e, eps)
 
 

@@ -1,0 +1,148 @@
+"""The CPU oracle (oracle/xfm_oracle.py) against golden vectors produced by the real reference
+(tools/oracle/gen_golden.py).  fp32, same op order => 1e-5-level agreement.  Runs without a GPU."""
+import pytest
+import torch
+
+from oracle import xfm_oracle as O
+from xfm_amd import synthetic as syn
+
+from golden_util import check, load, state_from_spec
+
+ATOL = 2e-5
+RTOL = 2e-4  # relative to the tensor's rms (gradients of sums over many rows carry larger absolute values)
+
+
+def _params(spec, requires_grad=True):
+    P = state_from_spec(spec)
+    for k, v in P.items():
+        if v.dtype.is_floating_point and requires_grad:
+            v.requires_grad_(True)
+    # tied decoder bias (xroberta.py:1322-1323): one tensor under two names
+    for k in list(P):
+        if k.endswith("decoder.bias"):
+            P[k] = P[k[: -len("decoder.bias")] + "bias"]
+    return P
+
+
+def _check_grads(z, prefix, P, name_prefix=""):
+    n = 0
+    for key in [k for k in z.files if k.startswith(prefix + "/") and k.endswith("/probe")]:
+        name = key[len(prefix) + 1: -len("/probe")]
+        g = P[name_prefix + name].grad
+        assert g is not None, f"oracle produced no grad for {name}"
+        check(z, f"{prefix}/{name}", g, ATOL, RTOL, what="grad ")
+        n += 1
+    assert n > 0
+
+
+def test_beit_blocks_and_mask_path():
+    z, meta = load("beit_2blk")
+    B, depth = meta["B"], meta["depth"]
+    P = _params(meta["spec"])
+    image = syn.gaussian("beit.image", (B, 3, 224, 224))
+    cot = syn.symmetric("beit.cot", (B, 197, 768), 1.0)
+    y = O.beit_forward(P, "", image, depth=depth)
+    check(z, "out", y, ATOL, RTOL)
+    (y * cot).sum().backward()
+    _check_grads(z, "grad", P)
+    for v in P.values():
+        v.grad = None
+    masks = syn.mim_block_mask(B, 14, 75, seed=7)
+    ym = O.beit_forward(P, "", image, depth=depth, ids_mask=masks)
+    check(z, "out_masked", ym, ATOL, RTOL)
+    (ym * cot).sum().backward()
+    _check_grads(z, "grad_masked", P)
+
+
+def test_roberta_text_tower_and_mlm_head():
+    z, meta = load("roberta_text_2L")
+    B, L = meta["B"], meta["layers"]
+    P = _params(meta["spec"])
+    b = syn.pretrain_batch(B, seed=11, with_image=False)
+    emb = O.roberta_embeddings(P, "roberta.embeddings.", b["text_ids"])
+    check(z, "embeddings", emb, ATOL, RTOL)
+    h = O.roberta_model(P, "roberta.", input_ids=b["text_ids"], att=b["text_atts"], num_layers=L, fusion_layer=L)
+    check(z, "hidden", h, ATOL, RTOL)
+    cot = syn.symmetric("roberta.cot", tuple(h.shape), 1.0)
+    (h * cot).sum().backward()
+    _check_grads(z, "grad_hidden", P)
+    for v in P.values():
+        v.grad = None
+    seq = O.roberta_model(P, "roberta.", input_ids=b["text_ids_masked"], att=b["text_atts"], num_layers=L, fusion_layer=L)
+    loss, logits = O.masked_lm_loss(P, "", seq, b["masked_pos"], b["masked_ids"])
+    assert abs(float(loss) - float(z["mlm_loss"])) < 1e-4
+    check(z, "mlm_logits", logits, ATOL, RTOL)
+    loss.backward()
+    _check_grads(z, "grad_mlm", P)
+
+
+def test_fusion_tower_cross_attention_and_causal_decoder():
+    z, meta = load("fusion_2L")
+    B, L = meta["B"], meta["layers"]
+    P = _params(meta["spec"])
+    b = syn.pretrain_batch(B, seed=12, with_image=False)
+    T = b["text_ids"].shape[1]
+    emb = syn.gaussian("fusion.encoder_embeds", (B, T, 768), 0.7).requires_grad_(True)
+    img = syn.gaussian("fusion.image_embeds", (B, 197, 768), 0.7).requires_grad_(True)
+    img_atts = torch.ones(B, 197, dtype=torch.long)
+    img_atts[1, 150:] = 0
+    img_atts[3, 100:] = 0
+    seq = O.roberta_model(P, "roberta.", att=b["text_atts"], encoder_embeds=emb, enc=img, enc_att=img_atts, num_layers=L,
+                          fusion_layer=0)
+    loss, _ = O.masked_lm_loss(P, "", seq, b["masked_pos"], b["masked_ids"])
+    assert abs(float(loss) - float(z["mlm_loss"])) < 1e-4
+    loss.backward()
+    _check_grads(z, "grad_mlm", P)
+    check(z, "grad_mlm_in/encoder_embeds", emb.grad, ATOL, RTOL)
+    check(z, "grad_mlm_in/image_embeds", img.grad, ATOL, RTOL)
+    for v in list(P.values()) + [emb, img]:
+        v.grad = None
+    h = O.roberta_model(P, "roberta.", att=b["text_atts"], encoder_embeds=emb, enc=img, enc_att=img_atts, num_layers=L,
+                        fusion_layer=0)
+    check(z, "hidden", h, ATOL, RTOL)
+    cot = syn.symmetric("fusion.cot", tuple(h.shape), 1.0)
+    (h * cot).sum().backward()
+    _check_grads(z, "grad_hidden", P)
+    check(z, "grad_hidden_in/encoder_embeds", emb.grad, ATOL, RTOL)
+    check(z, "grad_hidden_in/image_embeds", img.grad, ATOL, RTOL)
+    for v in P.values():
+        v.grad = None
+    seq = O.roberta_model(P, "roberta.", input_ids=b["text_ids"], att=b["text_atts"], enc=img.detach(), enc_att=img_atts,
+                          num_layers=L, fusion_layer=0, causal=True)
+    labels = b["text_ids"].masked_fill(b["text_atts"] == 0, -100)
+    loss, _ = O.masked_lm_loss(P, "", seq, None, labels, head="lm_cap_head", causal_shift=True)
+    assert abs(float(loss) - float(z["causal_loss"])) < 1e-4
+    loss.backward()
+    _check_grads(z, "grad_causal", P)
+
+
+def _pretrain(name):
+    z, meta = load(name)
+    B = meta["B"]
+    P = _params(meta["spec"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    b = syn.pretrain_batch(B, seed=1234)
+    masks = syn.mim_block_mask(B, 14, 75, seed=1234)
+    out = O.pretrain_forward(P, cfg, b, meta["image_neg_idx"], meta["text_neg_idx"], masks)
+    total = 0
+    for k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim"):
+        assert abs(float(out[k]) - float(z[k])) < 2e-4 * max(1.0, abs(float(z[k]))), (k, float(out[k]), float(z[k]))
+        total = total + out[k]
+    total.backward()
+    _check_grads(z, "grad", P)
+    unused = set(meta["unused"])
+    for k, v in P.items():
+        if v.dtype.is_floating_point and k in unused:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, f"{k} should receive no gradient"
+
+
+def test_pretrain_step_small():
+    _pretrain("pretrain_small")
+
+
+def test_pretrain_step_full_depth():
+    import os
+    from golden_util import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, "pretrain_full.npz")):
+        pytest.skip("pretrain_full.npz not generated")
+    _pretrain("pretrain_full")

@@ -1,0 +1,241 @@
+"""Generate tests/golden/*.npz from the REAL reference (imported from /root/reference behind ref_shim).
+
+Run in the build container only:   python tools/oracle/gen_golden.py [--only NAME] [--full]
+Every fixture stores: the state_dict spec (key -> shape, dtype) of the reference module, strided probes + moments of
+each output / gradient, and the captured random draws.  Weights and inputs are NOT stored: both sides regenerate them
+from xfm_amd.synthetic (formula weights loaded into the reference with load_state_dict(strict=True)).
+"""
+import argparse
+import json
+import os
+import sys
+from functools import partial
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_shim  # noqa: E402
+from xfm_amd import synthetic as syn  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+NPROBE = 2048
+
+
+def probe_index(n, k):
+    k = min(k, n)
+    if k <= 1:
+        return torch.zeros(1, dtype=torch.long)
+    return (torch.arange(k, dtype=torch.long) * (n - 1)) // (k - 1)
+
+
+def probe(t, k=NPROBE):
+    t = t.detach().double().reshape(-1)
+    n = t.numel()
+    idx = probe_index(n, k)
+    return {"probe": t[idx].float().numpy(), "sum": float(t.sum()), "abs": float(t.abs().sum()), "sq": float((t * t).sum()),
+            "n": n}
+
+
+def pack(prefix, t, out, nprobe=NPROBE):
+    for k, v in probe(t, nprobe).items():
+        out[f"{prefix}/{k}"] = np.asarray(v)
+
+
+def spec_of(module):
+    return {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in module.state_dict().items()}
+
+
+def load_formula(module):
+    sd = syn.formula_state_dict(module.state_dict())
+    module.load_state_dict(sd, strict=True)
+    return sd
+
+
+def grads_of(module, out, prefix="grad"):
+    for name, p in module.named_parameters():
+        if p.grad is not None:
+            pack(f"{prefix}/{name}", p.grad, out, 256)
+
+
+class FixedMasks:
+    """Stands in for MaskingGenerator(): returns the rows of a pre-drawn mask tensor one by one (beit2.py:432-435)."""
+
+    def __init__(self, masks, grid):
+        self.masks, self.grid, self.i = masks.numpy().astype(np.int32), grid, 0
+
+    def __call__(self):
+        m = self.masks[self.i % len(self.masks)].reshape(self.grid, self.grid)
+        self.i += 1
+        return m
+
+
+def save(name, out, meta):
+    os.makedirs(OUT, exist_ok=True)
+    out["meta"] = np.asarray(json.dumps(meta))
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
+def gen_beit(depth=2, B=4):
+    import torch.nn as nn
+    from models.beit2 import VisionTransformer
+    torch.manual_seed(0)
+    m = VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=depth, num_heads=12, mlp_ratio=4,
+                          norm_layer=partial(nn.LayerNorm, eps=1e-6), drop_rate=0.0, drop_path_rate=0.1, attn_drop_rate=0.0,
+                          use_mean_pooling=True, init_scale=0.001, use_rel_pos_bias=True, use_abs_pos_emb=False,
+                          init_values=0.1, qkv_bias=True, local_attn_depth=-1, num_masking_patches=75, min_num_patches=16)
+    load_formula(m)
+    m.eval()
+    image = syn.gaussian("beit.image", (B, 3, 224, 224))
+    cot = syn.symmetric("beit.cot", (B, 197, 768), 1.0)
+    out = {}
+    y = m(image)
+    pack("out", y, out)
+    (y * cot).sum().backward()
+    grads_of(m, out)
+    m.zero_grad()
+    masks = syn.mim_block_mask(B, 14, 75, seed=7)
+    m.generator = FixedMasks(masks, 14)
+    ym, ids = m(image, do_mask=True)
+    assert torch.equal(ids, masks)
+    pack("out_masked", ym, out)
+    (ym * cot).sum().backward()
+    grads_of(m, out, "grad_masked")
+    save(f"beit_{depth}blk", out, {"spec": spec_of(m), "B": B, "depth": depth})
+
+
+def roberta_cfg(layers, fusion_layer):
+    from models.xroberta import RobertaConfig
+    cfg = RobertaConfig(**ref_shim.ROBERTA_BASE_CONFIG)
+    cfg.num_hidden_layers, cfg.fusion_layer, cfg.encoder_width = layers, fusion_layer, 768
+    return cfg
+
+
+def gen_roberta_text(layers=2, B=4):
+    from models.xroberta import RobertaForMaskedLM
+    torch.manual_seed(0)
+    m = RobertaForMaskedLM(roberta_cfg(layers, layers))
+    load_formula(m)
+    m.eval()
+    b = syn.pretrain_batch(B, seed=11, with_image=False)
+    out = {}
+    emb = m.roberta.embeddings(input_ids=b["text_ids"])
+    pack("embeddings", emb, out)
+    h = m.bert(b["text_ids"], attention_mask=b["text_atts"], return_dict=True).last_hidden_state
+    pack("hidden", h, out)
+    cot = syn.symmetric("roberta.cot", tuple(h.shape), 1.0)
+    (h * cot).sum().backward()
+    grads_of(m, out, "grad_hidden")
+    m.zero_grad()
+    res = m(b["text_ids_masked"], attention_mask=b["text_atts"], return_dict=True, labels=b["masked_ids"],
+            masked_pos=b["masked_pos"])
+    out["mlm_loss"] = np.asarray(float(res.loss))
+    pack("mlm_logits", res.logits, out)
+    res.loss.backward()
+    grads_of(m, out, "grad_mlm")
+    save(f"roberta_text_{layers}L", out, {"spec": spec_of(m), "B": B, "layers": layers})
+
+
+def gen_fusion(layers=2, B=4):
+    from models.xroberta import RobertaForMaskedLM
+    torch.manual_seed(0)
+    m = RobertaForMaskedLM(roberta_cfg(layers, 0))
+    load_formula(m)
+    m.eval()
+    b = syn.pretrain_batch(B, seed=12, with_image=False)
+    T = b["text_ids"].shape[1]
+    emb = syn.gaussian("fusion.encoder_embeds", (B, T, 768), 0.7).requires_grad_(True)
+    img = syn.gaussian("fusion.image_embeds", (B, 197, 768), 0.7).requires_grad_(True)
+    img_atts = torch.ones(B, 197, dtype=torch.long)
+    img_atts[1, 150:] = 0
+    img_atts[3, 100:] = 0
+    out = {}
+    res = m(encoder_embeds=emb, attention_mask=b["text_atts"], encoder_hidden_states=img, encoder_attention_mask=img_atts,
+            return_dict=True, labels=b["masked_ids"], masked_pos=b["masked_pos"])
+    out["mlm_loss"] = np.asarray(float(res.loss))
+    res.loss.backward()
+    grads_of(m, out, "grad_mlm")
+    pack("grad_mlm_in/encoder_embeds", emb.grad, out)
+    pack("grad_mlm_in/image_embeds", img.grad, out)
+    m.zero_grad()
+    emb.grad = img.grad = None
+    h = m.bert(encoder_embeds=emb, attention_mask=b["text_atts"], encoder_hidden_states=img,
+               encoder_attention_mask=img_atts, return_dict=True).last_hidden_state
+    pack("hidden", h, out)
+    cot = syn.symmetric("fusion.cot", tuple(h.shape), 1.0)
+    (h * cot).sum().backward()
+    grads_of(m, out, "grad_hidden")
+    pack("grad_hidden_in/encoder_embeds", emb.grad, out)
+    pack("grad_hidden_in/image_embeds", img.grad, out)
+    # causal decoder variant (is_decoder=True: causal self mask, lm_cap_head, shifted CE; xroberta.py:1283-1295)
+    m.zero_grad()
+    res = m(b["text_ids"], attention_mask=b["text_atts"], encoder_hidden_states=img.detach(), encoder_attention_mask=img_atts,
+            return_dict=True, labels=b["text_ids"].masked_fill(b["text_atts"] == 0, -100), is_decoder=True)
+    out["causal_loss"] = np.asarray(float(res.loss))
+    res.loss.backward()
+    grads_of(m, out, "grad_causal")
+    save(f"fusion_{layers}L", out, {"spec": spec_of(m), "B": B, "layers": layers})
+
+
+def gen_pretrain(name, text_layers, fusion_layers, B=4):
+    from models.model_pretrain import XFM
+    ref_shim.init_single_process_group()
+    torch.manual_seed(0)
+    cfg = ref_shim.pretrain_config(text_layers=text_layers, fusion_layers=fusion_layers)
+    m = XFM(cfg, load_vision_params=False, load_text_params=False)
+    load_formula(m)
+    m.eval()
+    b = syn.pretrain_batch(B, seed=1234)
+    masks = syn.mim_block_mask(B, 14, 75, seed=1234)
+    m.vision_encoder.generator = FixedMasks(masks, 14)
+    captured = {}
+    orig = m.get_hard_negatives
+
+    def capture(*a, **kw):
+        torch.manual_seed(4321)
+        r = orig(*a, **kw)
+        captured["image_neg_idx"], captured["text_neg_idx"] = list(r[0]), list(r[1])
+        return r
+
+    m.get_hard_negatives = capture
+    losses = m(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"], masked_pos=b["masked_pos"],
+               masked_ids=b["masked_ids"], ret_mim_loss=True, ret_bbox_loss=False, ret_bbox_giou=False, data_source="image")
+    out = {}
+    total = 0
+    for k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim"):
+        out[k] = np.asarray(float(losses[k]))
+        total = total + losses[k]
+        print(k, float(losses[k]), flush=True)
+    total.backward()
+    grads_of(m, out)
+    unused = [n for n, p in m.named_parameters() if p.grad is None]
+    save(name, out, {"spec": spec_of(m), "B": B, "text_layers": text_layers, "fusion_layers": fusion_layers,
+                     "image_neg_idx": [int(i) for i in captured["image_neg_idx"]],
+                     "text_neg_idx": [int(i) for i in captured["text_neg_idx"]], "unused": unused})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--full", action="store_true", help="also emit the 12/12/12 end-to-end step (slow)")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    ref_shim.install()
+    jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2)}
+    if a.full:
+        jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
+    for k, fn in jobs.items():
+        if a.only is None or a.only == k:
+            print("==", k, flush=True)
+            fn()
+
+
+if __name__ == "__main__":
+    main()
