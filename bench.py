@@ -1,0 +1,224 @@
+"""Headline benchmark: image-text pairs/s of the XFM-base pre-training step (ITC + ITM + MLM + MIM, 224 px / 30 tokens),
+forward + backward (+ gradient all-reduce for N > 1, + clip/AdamW step), one process per GPU over RCCL.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     bf16-MFMA roofline of the dominant kernel (gemm_nt: forward + dgrad GEMMs), from HIP events recorded on
+               the launch stream around every gemm_nt launch of one instrumented step run right after the timed region;
+  cpu_baseline the CPU oracle (a port, not the reference itself) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PAIR_GFLOP = 376.1          # fwd 128.8 + bwd 247.3 GFLOP per image-text pair
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md), never the 2:1-sparse figure
+
+FULL_CFG = {"use_beit_v2": True, "image_res": 224, "patch_size": 16, "local_attn_depth": -1, "text_encoder": "roberta-base",
+            "text_num_hidden_layers": 12, "text_fusion_start_at": 12, "fusion_num_hidden_layers": 12, "fusion_fusion_start_at": 0,
+            "num_masking_patches": 75, "min_num_patches": 16, "embed_dim": 256, "temp": 0.07, "learnable_temp": True,
+            "max_temp": 0.5, "min_temp": 0.001, "max_tokens": 30, "max_masks": 15}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU (north-star: 64)")
+    ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward(+all-reduce) only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--eval-mode", action="store_true", help="disable dropout / drop-path (not the headline setting)")
+    return ap.parse_args()
+
+
+def build_model(device):
+    from xfm_amd.model_pretrain import XFM
+    torch.manual_seed(1234)
+    model = XFM(FULL_CFG)
+    model.to(device)
+    return model
+
+
+def make_optimizer(model):
+    """optim.py:4-50: AdamW, lr 1e-4, wd 0.01, no decay on bias / LayerNorm, lr_mult 2 on init_params."""
+    no_decay = ("bias", "LayerNorm.bias", "LayerNorm.weight", "norm1", "norm2", "fc_norm", "layer_norm")
+    init = set(model.init_params)
+    groups = [[], [], [], []]
+    for n, p in model.named_parameters():
+        nd = any(t in n for t in no_decay) or p.dim() < 2
+        groups[(2 if n in init else 0) + (1 if nd else 0)].append(p)
+    lr, wd, mult = 1e-4, 0.01, 2
+    pg = [{"params": groups[0], "weight_decay": wd, "lr": lr}, {"params": groups[1], "weight_decay": 0.0, "lr": lr},
+          {"params": groups[2], "weight_decay": wd, "lr": lr * mult}, {"params": groups[3], "weight_decay": 0.0, "lr": lr * mult}]
+    return torch.optim.AdamW(pg, lr=lr, betas=(0.9, 0.98), eps=1e-8)
+
+
+class GemmTimer:
+    """Wraps xfm_amd.functional.gemm_nt with HIP events on the current (= launch) stream."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        from xfm_amd import functional as Fx
+        import xfm_amd.beit2 as b2, xfm_amd.xroberta as xr, xfm_amd.ops as ops
+        self.Fx, self.orig = Fx, Fx.gemm_nt
+
+        def timed(a, b, bias=None, epi=0, aux=None, out=None, n=None, tile_hint=0):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self.orig(a, b, bias, epi, aux, out, n, tile_hint)
+            e.record()
+            N = b.shape[0] if n is None else n
+            self.records.append((s, e, 2.0 * a.shape[0] * N * a.shape[1]))
+            return r
+
+        Fx.gemm_nt = timed
+        return self
+
+    def __exit__(self, *a):
+        self.Fx.gemm_nt = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return len(self.records), ms, fl
+
+
+def cpu_baseline(model, batch_size):
+    """The CPU oracle on the same architecture, same synthetic batch generator; bounded sample."""
+    from oracle import xfm_oracle as O
+    from xfm_amd import synthetic as syn
+    P = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    for k in list(P):
+        if k.endswith("decoder.bias"):
+            P[k] = P[k[:-len("decoder.bias")] + "bias"]
+    for v in P.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    cfg = O.default_cfg(12, 12, 12)
+    b = syn.pretrain_batch(batch_size, seed=1234)
+    masks = syn.mim_block_mask(batch_size, 14, 75, seed=1234)
+    times = []
+    for it in range(3):
+        t0 = time.time()
+        out = O.pretrain_forward(P, cfg, b, ids_mask=masks)
+        total = out["loss_itc"] + out["loss_itm"] + out["loss_mlm"] + out["loss_mim"]
+        total.backward()
+        for v in P.values():
+            v.grad = None
+        times.append(time.time() - t0)
+    best = min(times[1:])
+    return {"value": round(batch_size / best, 4), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32 full pre-train step fwd+bwd, B={batch_size}, 1 warm-up + 2 timed steps, best of 2 "
+                      f"({best:.2f} s/step, {batch_size * PAIR_GFLOP / best / 1000:.3f} TFLOP/s)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", world_size=world, rank=rank)
+
+    from xfm_amd import synthetic as syn
+    from xfm_amd.accelerators import RCCLDDPAccelerator
+
+    model = build_model(device)
+    optimizer = make_optimizer(model)
+    acc = RCCLDDPAccelerator({"RNG_SEED": 42 + rank, "CLIP_GRAD_NORM": 1.0, "GRAD_ACCUMULATE_STEPS": 1})
+    wrapped, optimizer, _ = acc.set_up(model, optimizer, None, local_rank, world, rank)
+    model.train(not args.eval_mode)
+
+    B = args.batch
+    batch = {k: v.to(device) for k, v in syn.pretrain_batch(B, seed=1234 + rank).items()}
+
+    def step():
+        losses = wrapped(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
+                         masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], ret_mim_loss=True,
+                         data_source="image")
+        total = losses["loss_itc"] + losses["loss_itm"] + losses["loss_mlm"] + losses["loss_mim"]
+        acc.backward_step(total, optimizer)
+        if args.no_optimizer:
+            model.zero_grad()
+        else:
+            acc.optimizer_step(optimizer, model)
+        return losses
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        losses = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
+    loss_vals = {k: round(float(v), 4) for k, v in losses.items() if k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim")}
+
+    # one instrumented step (outside the timed region): HIP events around every gemm_nt launch on the launch stream
+    with GemmTimer() as gt:
+        step()
+    nlaunch, gemm_ms, gemm_flop = gt.summary()
+    achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank == 0:
+        out = {
+            "metric": "image-text pairs/sec fwd+bwd, XFM-base 224px/30tok",
+            "value": round(B * world * args.steps / elapsed, 2),
+            "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Pretrain.py full multimodal step (ITC+ITM+MLM+MIM), XFM-base, synthetic 224px images + 30-token captions, random init",
+                       "pairs_per_gpu": B, "global_batch": B * world, "image_res": 224, "max_tokens": 30,
+                       "dropout": not args.eval_mode, "optimizer_step_in_timed_region": not args.no_optimizer,
+                       "grad_allreduce": world > 1, "parallelism": f"dp{world}"},
+            "step_tflops_per_gpu": round(B * PAIR_GFLOP / ms_per_step, 2),
+            "mfma_frac_whole_step": round(B * PAIR_GFLOP / ms_per_step / BF16_DENSE_PEAK_TFLOPS, 4),
+            "losses_last_step": loss_vals,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (all forward + dgrad GEMM launches of one step)",
+                         "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches": nlaunch, "kernel_ms_per_step": round(gemm_ms, 3),
+                         "flop_per_step": gemm_flop},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, args.cpu_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

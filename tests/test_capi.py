@@ -1,0 +1,81 @@
+"""CPU-side checks of the C-ABI boundary: the library builds for gfx950, loads, and exports exactly the symbols that
+include/xfm_hip.h declares; the ctypes binding mirrors the header; the product path refuses to run without the HIP
+extension or on CPU tensors (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "xfm_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(xfm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from xfm_amd import build
+    lib_path = build.build()
+    assert os.path.exists(lib_path)
+    lib = ctypes.CDLL(lib_path)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/xfm_hip.h but not exported"
+
+
+def test_binding_covers_the_header_and_abi_version():
+    from xfm_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+    lib = _lib.load()
+    assert lib.xfm_abi_version() == _lib.ABI_VERSION
+    hdr = open(HEADER).read()
+    assert f"#define XFM_ABI_VERSION {_lib.ABI_VERSION}" in hdr
+
+
+def test_struct_layouts_match_header_field_order():
+    from xfm_amd import _lib
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for cname, struct in (("xfm_ln_fwd_args", _lib.LnFwdArgs), ("xfm_ln_bwd_args", _lib.LnBwdArgs),
+                          ("xfm_attn_args", _lib.AttnArgs), ("xfm_embed_args", _lib.EmbedArgs), ("xfm_adamw_args", _lib.AdamWArgs)):
+        end = hdr.index("} " + cname + ";")
+        body = hdr[hdr.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                name = re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[\d+\])?\s*$", part.strip())
+                fields.append(name[0])
+        assert fields == [f[0] for f in struct._fields_], cname
+
+
+def test_argument_errors_are_reported_not_crashed():
+    from xfm_amd import _lib
+    lib = _lib.load()
+    rc = lib.xfm_gemm_nt(None, 0, None, 0, None, 0, None, None, 0, 1, 1, 64, 0, 0, None)
+    assert rc == -1 and b"null operand" in lib.xfm_last_error()
+    rc = lib.xfm_layernorm_fwd(None, 768, 0, None)
+    assert rc == -1
+
+
+def test_product_path_refuses_cpu_tensors():
+    from xfm_amd import _lib, functional as Fx
+    a = torch.zeros(4, 64, dtype=torch.bfloat16)
+    with pytest.raises(_lib.XfmHipError):
+        Fx.gemm_nt(a, a)
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "xfm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("tools/oracle", ""), f"{f} references the oracle"

@@ -83,34 +83,41 @@ class ParamArena:
         device = device or params[0][1].device
         self.device = device
         self.slots = list(slots)
-        # ---- layout: fused groups first (members adjacent, no padding inside a group), then the rest in module order
+        # ---- layout: module (= tower) order; a fused group is placed, members adjacent and unpadded, where its first
+        # member appears, so every tower owns ONE contiguous arena range (per-tower collectives, accelerators/)
         layout = []   # (param or None, numel, offset)
         placed = set()
         off = 0
-        group_ranges = []
+        group_of = {}
         for s in self.slots:
-            for plist in (s.weights, s.biases):
+            for kind, plist in (("w", s.weights), ("b", s.biases)):
                 if plist is None:
-                    group_ranges.append(None)
                     continue
-                start = off
                 for p in plist:
-                    if isinstance(p, int):
-                        layout.append((None, p, off))
-                        off += p
-                    else:
-                        assert id(p) not in placed, f"{s.name}: parameter used by two slots"
-                        placed.add(id(p))
-                        layout.append((p, p.numel(), off))
-                        off += p.numel()
-                group_ranges.append((start, off))
-                off = _round(off)
+                    if not isinstance(p, int):
+                        assert id(p) not in group_of, f"{s.name}: parameter used by two slots"
+                        group_of[id(p)] = (s, kind, plist)
+        group_ranges = {}
         for name, p in params:
             if id(p) in placed:
                 continue
-            placed.add(id(p))
-            layout.append((p, p.numel(), off))
-            off = _round(off + p.numel())
+            if id(p) in group_of:
+                s, kind, plist = group_of[id(p)]
+                start = off
+                for q in plist:
+                    if isinstance(q, int):
+                        layout.append((None, q, off))
+                        off += q
+                    else:
+                        placed.add(id(q))
+                        layout.append((q, q.numel(), off))
+                        off += q.numel()
+                group_ranges[(id(s), kind)] = (start, off)
+                off = _round(off)
+            else:
+                placed.add(id(p))
+                layout.append((p, p.numel(), off))
+                off = _round(off + p.numel())
         self.numel = _round(off)
         self.data = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.numel, dtype=torch.float32, device=device)
@@ -125,9 +132,8 @@ class ParamArena:
             p.grad = p._xfm_grad
             self.offsets[id(p)] = (o, n)
         self.names = {id(p): name for name, p in params}
-        it = iter(group_ranges)
         for s in self.slots:
-            wr, br = next(it), next(it)
+            wr, br = group_ranges[(id(s), "w")], group_ranges.get((id(s), "b"))
             s.w = self.data[wr[0]:wr[1]].view(s.N, s.K)
             s.dw = self.grad[wr[0]:wr[1]].view(s.N, s.K)
             if br is not None:
@@ -159,8 +165,9 @@ class ParamArena:
                 p.grad = p._xfm_grad
 
     def attached(self):
-        """True while every parameter still lives in the arena (a .to()/.cuda() after finalize() breaks this)."""
-        return all(p.data_ptr() == self.data.data_ptr() + 4 * self.offsets[id(p)][0] for p in self.params)
+        """True while the parameters still live in the arena (a .to()/.cuda() after finalize() breaks this; probing the
+        first and last parameter is enough because Module._apply moves all of them)."""
+        return all(p.data_ptr() == self.data.data_ptr() + 4 * self.offsets[id(p)][0] for p in (self.params[0], self.params[-1]))
 
     def range_of(self, params):
         lo = min(self.offsets[id(p)][0] for p in params)

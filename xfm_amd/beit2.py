@@ -177,7 +177,9 @@ class _TrunkFn(torch.autograd.Function):
             saved.append((y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2))
             x, y = x2, yn
         ctx.saved, ctx.vit, ctx.shape = saved, vit, (B, N, D)
-        arena_note_use(vit)
+        ctx.noted = bool(ctx.needs_input_grad[0])
+        if ctx.noted:
+            arena_note_use(vit)
         return y.view(B, N, D)
 
     @staticmethod
@@ -216,7 +218,8 @@ class _TrunkFn(torch.autograd.Function):
         x0, mean0, rstd0 = ctx.first
         n0 = blocks[0].norm1
         Fx.ln_bwd(dy, x0, mean0, rstd0, n0.weight, _g(n0.weight), _g(n0.bias), dx32=dstream, dx_accum=True)
-        arena_note_grad(vit)
+        if ctx.noted:
+            arena_note_grad(vit)
         return dstream.view(B, N, D), None, None
 
 

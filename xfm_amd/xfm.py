@@ -300,7 +300,9 @@ class XFMBase(nn.Module):
                                  masked_pos=masked_pos).loss
 
     def get_fuse_mlm_loss(self, text_ids_masked, text_atts, image_embeds, image_atts, masked_pos, masked_ids):
-        encoder_embeds = self.get_text_embeds(text_ids_masked, text_atts)
+        # the detached text pass needs no autograd graph at all: run it without saving activations
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not self.detach_text_forMLM):
+            encoder_embeds = self.get_text_embeds(text_ids_masked, text_atts)
         if self.detach_text_forMLM:
             encoder_embeds = encoder_embeds.detach()
         return self.fusion_encoder(encoder_embeds=encoder_embeds, attention_mask=text_atts, encoder_hidden_states=image_embeds,

@@ -79,8 +79,11 @@ class RobertaEmbeddings(nn.Module):
 
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, emb, input_ids, drop):
+    def forward(ctx, anchor, emb, input_ids, drop, owner):
         ids = input_ids.contiguous()
+        ctx.owner = owner if ctx.needs_input_grad[0] else None
+        if ctx.owner is not None:
+            arena_note_use(owner)
         ln = emb.LayerNorm
         y, mean, rstd, pos_ids = Fx.embed_ln_fwd(ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
                                                  emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps,
@@ -98,7 +101,9 @@ class _EmbedFn(torch.autograd.Function):
                         emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps, emb.padding_idx, mean, rstd, pos_ids,
                         grad_view(emb.word_embeddings.weight), grad_view(emb.position_embeddings.weight),
                         grad_view(emb.token_type_embeddings.weight).view(-1), grad_view(ln.weight), grad_view(ln.bias), ctx.drop)
-        return None, None, None, None
+        if ctx.owner is not None:
+            arena_note_grad(ctx.owner)
+        return None, None, None, None, None
 
 
 class RobertaSelfAttention(nn.Module):
@@ -213,7 +218,9 @@ class _EncoderFn(torch.autograd.Function):
             x = y3
         ctx.saved, ctx.model, ctx.enc = saved, model, enc
         ctx.meta = (lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale)
-        arena_note_use(model)
+        ctx.noted = need_dx or need_denc
+        if ctx.noted:
+            arena_note_use(model)
         return x
 
     @staticmethod
@@ -270,7 +277,8 @@ class _EncoderFn(torch.autograd.Function):
             ctx.saved[li - lo] = None
         dx = (dy_a.float() + dy_b.float()).to(BF16) if need_dx else None
         denc = denc32.to(BF16) if need_denc else None
-        arena_note_grad(model)
+        if ctx.noted:
+            arena_note_grad(model)
         return (dx, denc) + (None,) * 10
 
 
@@ -313,7 +321,7 @@ class RobertaModel(nn.Module):
                 raise ValueError("You have to specify either input_ids or inputs_embeds")
             B, T = input_ids.shape
             drop = Fx.drop_params(cfg.hidden_dropout_prob if self.training else 0.0, _next_seed())
-            x = _EmbedFn.apply(self.embeddings.word_embeddings.weight, self.embeddings, input_ids, drop)
+            x = _EmbedFn.apply(self.embeddings.word_embeddings.weight, self.embeddings, input_ids, drop, self)
         else:
             B, T = encoder_embeds.shape[:2]
             x = encoder_embeds if encoder_embeds.dtype == BF16 else encoder_embeds.to(BF16)
