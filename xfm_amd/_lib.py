@@ -6,6 +6,10 @@ loading fails loudly, and every op refuses non-CUDA(HIP) tensors.
 import ctypes
 import os
 
+# torch FIRST: the PyTorch-ROCm wheel bundles its own HIP runtime; loading libxfm_hip.so before it would bind the
+# system libamdhip64 and leave two runtimes in one process ("no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxfm_hip.so")
 ABI_VERSION = 1

@@ -37,7 +37,7 @@ class BlockMaskGenerator:
             budget = self.num - count
             delta = 0
             for _ in range(10):
-                area = rng.uniform(self.min_num, budget)
+                area = self.min_num + (budget - self.min_num) * rng.random()  # like random.uniform: fine when budget < min
                 ar = math.exp(rng.uniform(*self.log_aspect))
                 h, w = int(round(math.sqrt(area * ar))), int(round(math.sqrt(area / ar)))
                 if w < W and h < H:

@@ -31,17 +31,22 @@ class _LinearSlotFn(torch.autograd.Function):
         s = ctx.slot
         dy2 = dy.reshape(-1, s.N)
         dy2 = (dy2 if dy2.dtype == BF16 else dy2.to(BF16)).contiguous()
-        Fx.gemm_tn(dy2, ctx.x2, s.dw)
+        if s.N % 8 != 0:  # tiny heads (e.g. the 2-way ITM logits): pad the columns to the kernels' 16-byte granularity
+            pad = (s.N + 63) // 64 * 64
+            dyp = torch.zeros((dy2.shape[0], pad), dtype=BF16, device=dy2.device)
+            dyp[:, :s.N] = dy2
+            dy2 = dyp
+        Fx.gemm_tn(dy2, ctx.x2, s.dw, n=s.N)
         if s.db is not None:
-            Fx.colsum(dy2, s.db)
+            Fx.colsum(dy2, s.db, n=s.N)
         dx = None
         if ctx.need_dx:
-            if s.N % 64 == 0:
-                dx = Fx.gemm_nt(dy2, s.wt, n=s.K)
-            else:  # tiny heads (e.g. 2-way ITM logits): pad the contraction dim to the GEMM's K granularity
-                pad = (s.N + 63) // 64 * 64
+            if dy2.shape[1] % 64 == 0 and dy2.shape[1] <= s.wt.shape[1]:
+                dx = Fx.gemm_nt(dy2, s.wt[:, :dy2.shape[1]], n=s.K)
+            else:  # contraction dim must be a multiple of 64: zero-pad both operands
+                pad = (dy2.shape[1] + 63) // 64 * 64
                 dyp = torch.zeros((dy2.shape[0], pad), dtype=BF16, device=dy2.device)
-                dyp[:, :s.N] = dy2
+                dyp[:, :dy2.shape[1]] = dy2
                 wtp = torch.zeros((s.K, pad), dtype=BF16, device=dy2.device)
                 wtp[:, :s.N] = s.wt[:, :s.N]
                 dx = Fx.gemm_nt(dyp, wtp, n=s.K)
