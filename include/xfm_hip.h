@@ -113,6 +113,7 @@ typedef struct {
   xfm_bf16* dq; long dq_rs; xfm_bf16* dk; long dk_rs; xfm_bf16* dv; long dv_rs;
   float* delta;                   /* [B,H,Sq] scratch */
   float* dbias;                   /* [H,Sq,bias_ld] fp32, += over the batch, or NULL */
+  float* o32;                     /* optional fp32 copy of o, dense [B*Sq, H*64]: written by fwd, read by bwd (delta) */
 } xfm_attn_args;
 
 int xfm_attn_fwd(const xfm_attn_args* a, void* stream);

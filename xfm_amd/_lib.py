@@ -42,7 +42,8 @@ class AttnArgs(ctypes.Structure):
                 ("scale", c_float), ("causal", c_int),
                 ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32),
                 ("dout", c_void_p), ("do_rs", c_long), ("dq", c_void_p), ("dq_rs", c_long), ("dk", c_void_p),
-                ("dk_rs", c_long), ("dv", c_void_p), ("dv_rs", c_long), ("delta", c_void_p), ("dbias", c_void_p)]
+                ("dk_rs", c_long), ("dv", c_void_p), ("dv_rs", c_long), ("delta", c_void_p), ("dbias", c_void_p),
+                ("o32", c_void_p)]
 
 
 class EmbedArgs(ctypes.Structure):

@@ -163,107 +163,170 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
   if (!wave_active || qi >= a.Sq) return;
   const float inv = 1.0f / l_run;
   bf16* op = a.o + ((long)b * a.Sq + qi) * a.o_rs + h * 64;
+  float* op32 = a.o32 ? a.o32 + ((long)b * a.Sq + qi) * (a.H * 64) + h * 64 : nullptr;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     bf16x4 ov;
+    f32x4 of;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ov[r] = f2bf(oacc[dt][r] * inv);
+    for (int r = 0; r < 4; ++r) { of[r] = oacc[dt][r] * inv; ov[r] = f2bf(of[r]); }
     *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * lg) = ov;
+    if (op32 != nullptr) *reinterpret_cast<f32x4*>(op32 + dt * 16 + 4 * lg) = of;
   }
   if (lg == 0) a.lse[((long)b * a.H + h) * a.Sq + qi] = m_run + __logf(l_run);
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward 1/2: dQ (+ delta, + dbias).  Same decomposition as the forward.
+// NKC > 0 selects the bias-gradient variant (Sk <= 64*NKC): one workgroup walks `nb_per_block` batch entries and keeps
+// sum_b dS in registers, then flushes it through a wave-private LDS transpose so that every atomic wave-instruction
+// adds 64 consecutive keys of one bias row (256 contiguous bytes; MI355X_MICROARCH "Global float atomics").
+// delta_i = sum_d dO_id * O_id uses the forward's fp32 copy of O when present: with the bf16-rounded O the identity
+// sum_j P_ij (dP_ij - delta_i) = 0 is broken by ~2^-9 |dO||O| per row, which dominates small dS.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * 128];
+template <int NKC>
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per_block) {
+  constexpr bool DBIAS = NKC > 0;
+  constexpr int NACC = DBIAS ? NKC : 1;
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * 128 + (DBIAS ? 8 * 4096 : 0)];
   char* sK = lds;
   char* sV = lds + 64 * 128;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
   const int lr = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int h = blockIdx.y;
   const int q0 = (blockIdx.x * (nthreads >> 6) + w) * 16;
   const bool wave_active = q0 < a.Sq;
   const int qi = q0 + lr;
   const bool qvalid = qi < a.Sq;
   const int qc = qvalid ? qi : a.Sq - 1;
-  const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
-  const bf16* dop = a.dout + ((long)b * a.Sq + qc) * a.do_rs + h * 64;
-  const bf16* op = a.o + ((long)b * a.Sq + qc) * a.o_rs + h * 64;
-  const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
-  const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
-  const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop + 8 * lg);
-  const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32 + 8 * lg);
-  float delta = 0.f;
-  {
-    const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(op + 8 * lg);
-    const bf16x8 o1 = *reinterpret_cast<const bf16x8*>(op + 32 + 8 * lg);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) delta += bf2f(df0[j]) * bf2f(o0[j]) + bf2f(df1[j]) * bf2f(o1[j]);
-    delta = group4_sum(delta);
-  }
-  const long stat_idx = ((long)b * a.H + h) * a.Sq + qc;
-  const float lse = a.lse[stat_idx];
-  if (wave_active && qvalid && lg == 0) a.delta[stat_idx] = delta;
-  const bf16* kb = a.k + (long)b * a.Sk * a.k_rs + h * 64;
-  const bf16* vb = a.v + (long)b * a.Sk * a.v_rs + h * 64;
-
-  f32x4 dqacc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   const int nchunks = (a.Sk + 63) / 64;
-  for (int kc = 0; kc < nchunks; ++kc) {
-    __syncthreads();
-    stage_tile<64>(sK, kb, a.k_rs, kc * 64, a.Sk, tid, nthreads);
-    stage_tile<64>(sV, vb, a.v_rs, kc * 64, a.Sk, tid, nthreads);
-    __syncthreads();
-    if (!wave_active) continue;
-    f32x4 st[4], dp[4];
+
+  f32x4 dsacc[NACC][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 0, lr, lg), qf0, st[t], 0, 0, 0);
-      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 1, lr, lg), qf1, st[t], 0, 0, 0);
-      dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 0, lr, lg), df0, dp[t], 0, 0, 0);
-      dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 1, lr, lg), df1, dp[t], 0, 0, 0);
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dsacc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int bi = 0; bi < nb_per_block; ++bi) {
+    const int b = blockIdx.z * nb_per_block + bi;
+    if (b >= a.B) break;
+    const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
+    const bf16* dop = a.dout + ((long)b * a.Sq + qc) * a.do_rs + h * 64;
+    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
+    const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
+    const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop + 8 * lg);
+    const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32 + 8 * lg);
+    float delta = 0.f;
+    if (a.o32 != nullptr) {
+      const float* op = a.o32 + ((long)b * a.Sq + qc) * (a.H * 64) + h * 64;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(op + half * 32 + 8 * lg);
+        const f32x4 o1 = *reinterpret_cast<const f32x4*>(op + half * 32 + 8 * lg + 4);
+        const bf16x8& d = half ? df1 : df0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) delta += bf2f(d[j]) * o0[j] + bf2f(d[4 + j]) * o1[j];
+      }
+    } else {
+      const bf16* op = a.o + ((long)b * a.Sq + qc) * a.o_rs + h * 64;
+      const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(op + 8 * lg);
+      const bf16x8 o1 = *reinterpret_cast<const bf16x8*>(op + 32 + 8 * lg);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += bf2f(df0[j]) * bf2f(o0[j]) + bf2f(df1[j]) * bf2f(o1[j]);
     }
+    delta = group4_sum(delta);
+    const long stat_idx = ((long)b * a.H + h) * a.Sq + qc;
+    const float lse = a.lse[stat_idx];
+    if (wave_active && qvalid && lg == 0) a.delta[stat_idx] = delta;
+    const bf16* kb = a.k + (long)b * a.Sk * a.k_rs + h * 64;
+    const bf16* vb = a.v + (long)b * a.Sk * a.v_rs + h * 64;
+
+    f32x4 dqacc[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int kj0 = kc * 64 + t * 16 + 4 * lg;
-      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a.bias != nullptr && kj0 < a.Sk) bv = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
+    for (int i = 0; i < 4; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto chunk = [&](int kc) {
+      __syncthreads();
+      stage_tile<64>(sK, kb, a.k_rs, kc * 64, a.Sk, tid, nthreads);
+      stage_tile<64>(sV, vb, a.v_rs, kc * 64, a.Sk, tid, nthreads);
+      __syncthreads();
+      if (!wave_active) return;
+      f32x4 st[4], dp[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kj = kj0 + r;
-        const float s = score_fix(a, st[t][r], b, h, qi, kj, bv[r]);
-        const float pv = (kj < a.Sk && qvalid) ? __expf(s - lse) : 0.f;
-        float dpv = dp[t][r];
-        if (a.drop_thresh != 0u) dpv = drop_keep(a, b, h, qi, kj) ? dpv * a.drop_scale : 0.f;
-        const float ds = pv * (dpv - delta);
-        st[t][r] = ds;
-        if (a.dbias != nullptr && kj < a.Sk && qvalid) atomicAdd(a.dbias + ((long)h * a.Sq + qi) * a.bias_ld + kj, ds);
+      for (int t = 0; t < 4; ++t) {
+        st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 0, lr, lg), qf0, st[t], 0, 0, 0);
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 1, lr, lg), qf1, st[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 0, lr, lg), df0, dp[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 1, lr, lg), df1, dp[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int kj0 = kc * 64 + t * 16 + 4 * lg;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr && kj0 < a.Sk) bv = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kj = kj0 + r;
+          const float s = score_fix(a, st[t][r], b, h, qi, kj, bv[r]);
+          const float pv = (kj < a.Sk && qvalid) ? __expf(s - lse) : 0.f;
+          float dpv = dp[t][r];
+          if (a.drop_thresh != 0u) dpv = drop_keep(a, b, h, qi, kj) ? dpv * a.drop_scale : 0.f;
+          const float ds = pv * (dpv - delta);
+          st[t][r] = ds;
+          if (!DBIAS && a.dbias != nullptr && kj < a.Sk && qvalid) atomicAdd(a.dbias + ((long)h * a.Sq + qi) * a.bias_ld + kj, ds);
+        }
+      }
+      if (DBIAS) {  // static register indices only: a wave-uniform compare selects the chunk's accumulator
+#pragma unroll
+        for (int c = 0; c < NACC; ++c)
+          if (c == kc) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dsacc[c][t] += st[t];
+          }
+      }
+      // dQ^T[d, q] += K^T[d, key] . dS^T[key, q]
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = pack_pair(st[2 * s2], st[2 * s2 + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK, 32 * s2, 32 * s2 + 16, dt * 16, lr, lg), pf, dqacc[dt], 0, 0, 0);
+      }
+    };
+
+    for (int kc = 0; kc < nchunks; ++kc) chunk(kc);
+    if (wave_active && qvalid) {
+      bf16* dqp = a.dq + ((long)b * a.Sq + qi) * a.dq_rs + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = f2bf(dqacc[dt][r] * a.scale);
+        *reinterpret_cast<bf16x4*>(dqp + dt * 16 + 4 * lg) = ov;
       }
     }
-    // dQ^T[d, q] += K^T[d, key] . dS^T[key, q]
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8 pf = pack_pair(st[2 * s], st[2 * s + 1]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK, 32 * s, 32 * s + 16, dt * 16, lr, lg), pf, dqacc[dt], 0, 0, 0);
-    }
   }
-  if (!wave_active || !qvalid) return;
-  bf16* dqp = a.dq + ((long)b * a.Sq + qi) * a.dq_rs + h * 64;
+
+  if (DBIAS) {
+    float* fl = reinterpret_cast<float*>(lds + 2 * 64 * 128 + w * 4096);  // wave-private [16 q][64 keys]
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    bf16x4 ov;
+    for (int kc = 0; kc < NACC; ++kc) {
+      if (kc < nchunks) {
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ov[r] = f2bf(dqacc[dt][r] * a.scale);
-    *reinterpret_cast<bf16x4*>(dqp + dt * 16 + 4 * lg) = ov;
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(fl + lr * 64 + t * 16 + 4 * lg) = dsacc[kc][t];
+        __syncthreads();
+        if (wave_active && a.dbias != nullptr) {
+          const int kj = kc * 64 + lane;
+          for (int row = 0; row < 16; ++row) {
+            const int q = q0 + row;
+            if (q < a.Sq && kj < a.Sk) atomicAdd(a.dbias + ((long)h * a.Sq + q) * a.bias_ld + kj, fl[row * 64 + lane]);
+          }
+        }
+      }
+    }
   }
 }
 
@@ -398,7 +461,12 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
   if (rc != XFM_OK) return rc;
   int nw, blocks;
   attn_geom(a.Sq, nw, blocks);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(blocks, a.H, a.B), dim3(nw * 64), 0, st, a);
+  if (a.dbias != nullptr && a.Sk <= 256) {
+    int nb = a.B >= 64 ? 8 : (a.B >= 16 ? 4 : 1);  // batch entries whose dS one workgroup sums before touching HBM
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3(blocks, a.H, cdiv(a.B, nb)), dim3(nw * 64), 0, st, a, nb);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<0>, dim3(blocks, a.H, a.B), dim3(nw * 64), 0, st, a, 1);
+  }
   rc = xfm_check_launch("attn_bwd_dq");
   if (rc != XFM_OK) return rc;
   attn_geom(a.Sk, nw, blocks);

@@ -206,7 +206,7 @@ int xfm_emb_bwd_impl(EmbArgs p, int D, float* dgamma, float* dbeta, float* dtype
   int rc = xfm_check_launch("emb_bwd");
   if (rc != XFM_OK) return rc;
   ReduceSets r{workspace, {dgamma, dbeta, dtype, nullptr}, grid, D};
-  hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(D, 256), 3), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(D, 64), 3), dim3(256), 0, st, r);
   return xfm_check_launch("emb_bwd_reduce");
 }
 

@@ -216,8 +216,8 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
   XFM_REQUIRE((epi != EPI_GELU && epi != EPI_DGELU) || aux != nullptr, "gemm_nt: epilogue %d needs aux", epi);
   GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K};
   int cfg = tile_hint;
-  if (cfg <= 0) {  // pick the largest tile that still gives >= ~1.5 workgroups per CU
-    if ((long)cdiv(M, 128) * cdiv(N, 128) >= 384) cfg = 1;
+  if (cfg <= 0) {  // measured on MI355X (tools/tune_gemm.py): 128x128 pays from ~3 workgroups per CU, else go smaller
+    if ((long)cdiv(M, 128) * cdiv(N, 128) >= 800) cfg = 1;
     else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 256) cfg = 2;
     else cfg = 3;
   }
@@ -363,8 +363,8 @@ int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* d
   const int tiles = cdiv(N, 128) * cdiv(K, 128);
   int splits = splits_hint;
   if (splits <= 0) {
-    splits = cdiv(768, tiles);                 // ~3 workgroups per CU in total
-    const int max_splits = cdiv(M, 256);       // at least 4 K-steps per split
+    splits = (432 + tiles / 2) / tiles;        // measured optimum: ~432 workgroups in total (tools/tune_gemm.py)
+    const int max_splits = M / 480;            // ... while every split still walks >= ~8 K-steps
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
   }

@@ -196,7 +196,7 @@ def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, dro
                     scale=scale, causal=int(causal), drop_thresh=drop[0], drop_scale=drop[1], seed_lo=drop[2], seed_hi=drop[3])
 
 
-def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0)):
+def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0), save_o32=False):
     """q [B*Sq, >=H*64] / k, v [B*Sk, ...] are 2-D (possibly strided column slices of fused projection buffers).
     bias: dense fp32 [H,Sq,ld]; key_keep: int32 [B,Sk].  Returns (o [B*Sq, H*64] bf16, lse [B,H,Sq])."""
     _dev(q)
@@ -205,12 +205,16 @@ def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=Fals
     if key_keep is not None:
         assert key_keep.dtype == torch.int32 and key_keep.is_contiguous()
     a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop)
+    o32 = None
+    if save_o32:  # fp32 copy of the output for the backward's delta = rowsum(dO * O) (training only)
+        o32 = torch.empty((B * Sq, H * 64), dtype=F32, device=q.device)
+        a.o32 = o32.data_ptr()
     check(_lib.load().xfm_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
-    return o, lse
+    return (o, lse, o32) if save_o32 else (o, lse)
 
 
 def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, dbias=None, key_keep=None, causal=False,
-             drop=(0, 1.0, 0, 0)):
+             drop=(0, 1.0, 0, 0), o32=None):
     """Writes dq/dk/dv (2-D bf16 views with the same addressing convention as q/k/v); dbias (fp32 [H,Sq,ld]) += ."""
     a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop)
     delta = torch.empty((B, H, Sq), dtype=F32, device=q.device)
@@ -219,7 +223,7 @@ def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, 
     a.dq, a.dq_rs = dq.data_ptr(), dq.stride(0)
     a.dk, a.dk_rs = dk.data_ptr(), dk.stride(0)
     a.dv, a.dv_rs = dv.data_ptr(), dv.stride(0)
-    a.delta, a.dbias = delta.data_ptr(), _ptr(dbias)
+    a.delta, a.dbias, a.o32 = delta.data_ptr(), _ptr(dbias), _ptr(o32)
     check(_lib.load().xfm_attn_bwd(ctypes.byref(a), _stream()), "attn_bwd")
 
 

@@ -191,23 +191,24 @@ class _EncoderFn(torch.autograd.Function):
             att, co = layer.attention, None
             d_att, d_h1 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
             qkv = Fx.gemm_nt(x, s["qkv"].wb, s["qkv"].b)
-            c1, lse1 = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep,
-                                   causal=causal, drop=d_att)
+            c1, lse1, o32_1 = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep,
+                                          causal=causal, drop=d_att, save_o32=True)
             h1 = Fx.gemm_nt(c1, s["o"].wb, s["o"].b)
             ln1 = att.output.LayerNorm
             y1, z1, m1, r1 = Fx.ln_post_fwd(h1, x, ln1.weight, ln1.bias, ln1.eps, d_h1)
-            rec = {"x": x, "qkv": qkv, "c1": c1, "lse1": lse1, "z1": z1, "m1": m1, "r1": r1, "y1": y1, "d_att": d_att, "d_h1": d_h1}
+            rec = {"x": x, "qkv": qkv, "c1": c1, "lse1": lse1, "z1": z1, "m1": m1, "r1": r1, "y1": y1, "d_att": d_att, "d_h1": d_h1, "o32_1": o32_1}
             y2 = y1
             if layer.has_cross_attention and enc is not None:
                 co = layer.crossattention
                 d_att2, d_h2 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
                 q2 = Fx.gemm_nt(y1, s["q2"].wb, s["q2"].b)
                 kv = Fx.gemm_nt(enc, s["kv2"].wb, s["kv2"].b)
-                c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2)
+                c2, lse2, o32_2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2,
+                                              save_o32=True)
                 h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
                 ln2 = co.output.LayerNorm
                 y2, z2, m2, r2 = Fx.ln_post_fwd(h2, y1, ln2.weight, ln2.bias, ln2.eps, d_h2)
-                rec.update(q2=q2, kv=kv, c2=c2, lse2=lse2, z2=z2, m2=m2, r2=r2, y2=y2, d_att2=d_att2, d_h2=d_h2)
+                rec.update(q2=q2, kv=kv, c2=c2, lse2=lse2, z2=z2, m2=m2, r2=r2, y2=y2, d_att2=d_att2, d_h2=d_h2, o32_2=o32_2)
             d_h3 = Fx.drop_params(p_hid, _next_seed())
             hact, u = Fx.gemm_nt(y2, s["i"].wb, s["i"].b, epi=Fx.EPI_GELU)
             h3 = Fx.gemm_nt(hact, s["out"].wb, s["out"].b)
@@ -253,7 +254,7 @@ class _EncoderFn(torch.autograd.Function):
                 dq2, dkv = torch.empty_like(r["q2"]), torch.empty_like(r["kv"])
                 kv = r["kv"]
                 Fx.attn_bwd(dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc,
-                            scale, key_keep=enc_keep, drop=r["d_att2"])
+                            scale, key_keep=enc_keep, drop=r["d_att2"], o32=r["o32_2"])
                 Fx.gemm_tn(dq2, r["y1"], s["q2"].dw)
                 Fx.colsum(dq2, s["q2"].db)
                 Fx.gemm_tn(dkv, enc, s["kv2"].dw)
@@ -269,7 +270,7 @@ class _EncoderFn(torch.autograd.Function):
             qkv = r["qkv"]
             dqkv = torch.empty_like(qkv)
             Fx.attn_bwd(dc1, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], r["c1"], r["lse1"], dqkv[:, :D], dqkv[:, D:2 * D],
-                        dqkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep, causal=causal, drop=r["d_att"])
+                        dqkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep, causal=causal, drop=r["d_att"], o32=r["o32_1"])
             Fx.gemm_tn(dqkv, r["x"], s["qkv"].dw)
             Fx.colsum(dqkv, s["qkv"].db)
             if li > lo or need_dx:
