@@ -43,9 +43,10 @@ enum { XFM_EPI_BF16 = 0, XFM_EPI_F32 = 1, XFM_EPI_GELU = 2, XFM_EPI_DGELU = 3, X
 int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* C, long ldc, const float* bias,
                 xfm_bf16* aux, long ldaux, int M, int N, int K, int epilogue, int tile_hint, void* stream);
 
-/* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]   (weight gradient; split over M, atomically accumulated). */
-int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float* dW, long ldw, int M, int N, int K,
-                int splits_hint, void* stream);
+/* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]   (weight gradient; split over M, atomically accumulated).
+ * dbias (optional, fp32 [N]) += column sums of dY: the bias gradient rides along in the same pass over dY. */
+int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float* dW, long ldw, float* dbias, int M, int N,
+                int K, int splits_hint, void* stream);
 
 /* fp32 master weight [N,K] -> bf16 copy wb[N,ldb] and/or transposed bf16 copy wt[K,ldt] (zero padded). */
 int xfm_cast_transpose(const float* w, int N, int K, xfm_bf16* wb, long ldb, xfm_bf16* wt, long ldt, void* stream);
@@ -103,7 +104,7 @@ typedef struct {
   const xfm_bf16* k; long k_rs;
   const xfm_bf16* v; long v_rs;
   xfm_bf16* o; long o_rs;
-  float* lse;                     /* [B,H,Sq] log-sum-exp of the final scores */
+  float* lse;                     /* [B,H,stat_ld] log-sum-exp of the final scores */
   const float* bias; long bias_ld;/* dense additive bias [H,Sq,bias_ld] or NULL */
   const int* key_keep;            /* [B,Sk] 1 attend / 0 padded (adds -10000) or NULL */
   int B, H, Sq, Sk;
@@ -111,15 +112,19 @@ typedef struct {
   uint32_t drop_thresh; float drop_scale; uint32_t seed_lo, seed_hi;
   const xfm_bf16* dout; long do_rs;
   xfm_bf16* dq; long dq_rs; xfm_bf16* dk; long dk_rs; xfm_bf16* dv; long dv_rs;
-  float* delta;                   /* [B,H,Sq] scratch */
+  float* delta;                   /* [B,H,stat_ld] scratch */
   float* dbias;                   /* [H,Sq,bias_ld] fp32, += over the batch, or NULL */
-  float* o32;                     /* optional fp32 copy of o, dense [B*Sq, H*64]: written by fwd, read by bwd (delta) */
+  float* o32;                     /* optional fp32 copy of o, dense [B*Sq, H*64], written by fwd */
+  long stat_ld;                   /* row stride of lse / delta ([B,H,stat_ld]): multiple of 4, >= Sq */
+  const float* bias_t; long bias_t_ld; /* optional transposed copy of bias [H,Sk,bias_t_ld] (vector loads in dK/dV) */
 } xfm_attn_args;
 
 int xfm_attn_fwd(const xfm_attn_args* a, void* stream);
 int xfm_attn_bwd(const xfm_attn_args* a, void* stream);
-/* dense[h,i,j] = table[index[i*N+j]*H + h] (beit2.py:139-145), rows padded to ld; and its scatter-add gradient. */
-int xfm_relpos_gather(const float* table, const int* index, int H, int N, long ld, float* dense, void* stream);
+/* dense[h,i,j] = table[index[i*N+j]*H + h] (beit2.py:139-145), rows padded to ld (dense_t: optional [h,j,i] copy);
+ * and its scatter-add gradient. */
+int xfm_relpos_gather(const float* table, const int* index, int H, int N, long ld, float* dense, float* dense_t,
+                      void* stream);
 int xfm_relpos_scatter(const float* ddense, const int* index, int H, int N, long ld, float* dtable, void* stream);
 
 /* ---- Patch gather for the patch-embed GEMM (beit2.py:224-230) --------------------------------------------------- */

@@ -85,9 +85,11 @@ def test_gemm_tn_wgrad_accumulates(M, N, K, splits):
     Fx = _fx()
     dy, x = _rand((M, N), seed=10), _rand((M, K), seed=11)
     dw = torch.ones((N, K), dtype=F32, device="cuda")
-    Fx.gemm_tn(dy, x, dw, splits=splits)
+    db = torch.ones((N,), dtype=F32, device="cuda")
+    Fx.gemm_tn(dy, x, dw, splits=splits, dbias=db)
     ref = dy.float().t() @ x.float() + 1.0
     _close(dw, ref, 2e-4, "wgrad")
+    _close(db, dy.float().sum(0) + 1.0, 2e-4, "bias grad fused into wgrad")
 
 
 def test_gemm_tn_exact_integers_catch_layout_errors():
@@ -280,6 +282,15 @@ def test_attention_fwd_bwd(B, H, Sq, Sk, use_bias, use_keep, causal):
     _close(dkv[:, D:], vr.grad, 2e-2, "dv")
     if use_bias:
         _close(dbias[:, :, :Sk], br.grad[:, :, :Sk], 2e-2, "dbias")
+        # same backward with the transposed bias copy (vector loads in the dK/dV kernel)
+        ldt = (Sq + 15) // 16 * 16
+        bias_t = torch.zeros((H, Sk, ldt), dtype=F32, device="cuda")
+        bias_t[:, :, :Sq] = bias[:, :, :Sk].transpose(1, 2)
+        dq2, dkv2 = torch.empty_like(dq), torch.empty_like(dkv)
+        Fx.attn_bwd(dout, q, k, v, o, lse, dq2, dkv2[:, :D], dkv2[:, D:], B, H, Sq, Sk, scale, bias=bias, dbias=torch.zeros_like(bias),
+                    key_keep=keep, causal=causal, bias_t=bias_t)
+        _close(dkv2[:, :D], kr.grad, 2e-2, "dk (bias_t)")
+        _close(dkv2[:, D:], vr.grad, 2e-2, "dv (bias_t)")
 
 
 def test_attention_dropout_mask_consistency():

@@ -40,6 +40,12 @@ def _check_grads(z, prefix, module, name_prefix="", skip=("self.key.bias",), min
     bad, n, worst = [], 0, (0.0, 1.0)
     tol, cos_tol = tol or GRAD_TOL, cos_tol or COS_TOL
     params = dict(module.named_parameters())
+    # "negligible gradient" floor: tensors whose reference gradient is < 1% of the fixture's median gradient rms (e.g. the
+    # Q/K weights of saturated text self-attention layers, which shrink ~5x per layer down to 1e-10) sit at the bf16
+    # noise floor in ABSOLUTE terms; a relative comparison there says nothing about the kernels.
+    all_rms = sorted((float(z[k[:-6] + "/sq"]) / int(z[k[:-6] + "/n"])) ** 0.5
+                     for k in z.files if k.startswith(prefix + "/") and k.endswith("/probe"))
+    min_rms = max(min_rms, 1e-2 * all_rms[len(all_rms) // 2])
     for key in [k for k in z.files if k.startswith(prefix + "/") and k.endswith("/probe")]:
         name = key[len(prefix) + 1: -len("/probe")]
         if any(s in name for s in skip):

@@ -1,0 +1,25 @@
+"""Attention kernels at the ViT shape of the pre-training step (B=64, H=12, N=197), for rocprofv3 --pmc runs."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from xfm_amd import functional as Fx
+
+B, H, N, D = 64, 12, 197, 768
+qkv = torch.randn(B * N, 3 * D, device="cuda").bfloat16()
+bias = torch.randn(H, N, 208, device="cuda")
+dout = torch.randn(B * N, D, device="cuda").bfloat16()
+dqkv = torch.empty_like(qkv)
+dbias = torch.zeros_like(bias)
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+for it in range(iters):
+    o, lse = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, 0.125, bias=bias)
+    Fx.attn_bwd(dout, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                B, H, N, N, 0.125, bias=bias, dbias=dbias)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for it in range(iters):
+    o, lse = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, 0.125, bias=bias)
+e.record()
+torch.cuda.synchronize()
+print("fwd us", s.elapsed_time(e) / iters * 1e3)

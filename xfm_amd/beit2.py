@@ -163,10 +163,10 @@ class _TrunkFn(torch.autograd.Function):
         ctx.first = (x, mean, rstd)
         for i, blk in enumerate(blocks):
             s = vit._slots[i]
-            dense = Fx.relpos_gather(blk.attn.relative_position_bias_table, vit._index32, H, N, ld)
+            dense, dense_t = Fx.relpos_gather(blk.attn.relative_position_bias_table, vit._index32, H, N, ld, transposed=True)
             qkv = Fx.gemm_nt(y, s["qkv"].wb, s["qkv"].b)
-            ctxv, lse, o32 = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense,
-                                         save_o32=True)
+            ctxv, lse = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense,
+                                         )
             h1 = Fx.gemm_nt(ctxv, s["proj"].wb, s["proj"].b)
             dp1 = None if dp is None else dp[i, 0]
             dp2 = None if dp is None else dp[i, 1]
@@ -175,7 +175,7 @@ class _TrunkFn(torch.autograd.Function):
             h2 = Fx.gemm_nt(hact, s["fc2"].wb, s["fc2"].b)
             nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else vit.fc_norm
             x2, yn, meann, rstdn = Fx.ln_ls_fwd(x1, h2, blk.gamma_2, dp2, N, nxt.weight, nxt.bias, nxt.eps)
-            saved.append((y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, o32))
+            saved.append((y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t))
             x, y = x2, yn
         ctx.saved, ctx.vit, ctx.shape = saved, vit, (B, N, D)
         ctx.noted = bool(ctx.needs_input_grad[0])
@@ -193,15 +193,14 @@ class _TrunkFn(torch.autograd.Function):
         dstream = torch.zeros((M, D), dtype=torch.float32, device=dy.device)
         for i in reversed(range(len(blocks))):
             blk, s = blocks[i], vit._slots[i]
-            (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, o32) = ctx.saved[i]
+            (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t) = ctx.saved[i]
             nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else vit.fc_norm
             g = _g
             dh2 = Fx.ln_ls_bwd(dy, dstream, x2, meann, rstdn, nxt.weight, h2, blk.gamma_2, dp2, N, g(nxt.weight), g(nxt.bias),
                                s["fc2"].db, g(blk.gamma_2))
             Fx.gemm_tn(dh2, hact, s["fc2"].dw)
             du = Fx.gemm_nt(dh2, s["fc2"].wt, epi=Fx.EPI_DGELU, aux=u, n=s["fc2"].K)
-            Fx.gemm_tn(du, y2, s["fc1"].dw)
-            Fx.colsum(du, s["fc1"].db)
+            Fx.gemm_tn(du, y2, s["fc1"].dw, dbias=s["fc1"].db)
             dy2 = Fx.gemm_nt(du, s["fc1"].wt, n=s["fc1"].K)
             dh1 = Fx.ln_ls_bwd(dy2, dstream, x1, mean2, rstd2, blk.norm2.weight, h1, blk.gamma_1, dp1, N, g(blk.norm2.weight),
                                g(blk.norm2.bias), s["proj"].db, g(blk.gamma_1))
@@ -210,10 +209,9 @@ class _TrunkFn(torch.autograd.Function):
             dqkv = torch.empty_like(qkv)
             ddense = torch.zeros_like(dense)
             Fx.attn_bwd(dctx, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ctxv, lse, dqkv[:, :D], dqkv[:, D:2 * D],
-                        dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense, o32=o32)
+                        dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense, bias_t=dense_t)
             Fx.relpos_scatter(ddense, vit._index32, H, N, ld, g(blk.attn.relative_position_bias_table))
-            Fx.gemm_tn(dqkv, y, s["qkv"].dw)
-            Fx.colsum(dqkv, s["qkv"].db)
+            Fx.gemm_tn(dqkv, y, s["qkv"].dw, dbias=s["qkv"].db)
             dy = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K)
             ctx.saved[i] = None
         x0, mean0, rstd0 = ctx.first

@@ -13,20 +13,67 @@
 
 #define MASK_NEG (-10000.0f)
 #define EXCL_NEG (-1.0e30f)
+#define ATTN_TILE (64 * 128)       // one 64-row x 64-column bf16 tile
+#define ATTN_SLOT (2 * ATTN_TILE)  // K tile + V tile (or Q tile + dO tile)
+#define ATTN_RES_MAX 4             // up to 256 rows stay LDS-resident (64 KiB); longer sequences stream chunk by chunk
 
 typedef xfm_attn_args AttnArgs;
 
 __device__ __forceinline__ int swz_a(int r) { return (r >> 1) & 7; }
 
-// ROWS x 64 bf16 tile, 128-B rows, rows >= nvalid are zero filled
-template <int ROWS>
-__device__ __forceinline__ void stage_tile(char* lds, const bf16* g, long rs, int row0, int nvalid, int tid, int nthreads) {
-  for (int q = tid; q < ROWS * 8; q += nthreads) {
-    const int r = q >> 3, c = q & 7;
-    u32x4 val = u32x4{0, 0, 0, 0};
-    if (row0 + r < nvalid) val = *reinterpret_cast<const u32x4*>(g + (long)(row0 + r) * rs + c * 8);
-    *reinterpret_cast<u32x4*>(lds + r * 128 + ((c ^ swz_a(r)) << 4)) = val;
+// Two ROWS x 64 bf16 tiles (K and V, or Q and dO), 128-B rows, rows >= nvalid zero filled.  All global loads of the
+// pair are issued before the first LDS store, so one thread keeps up to 8 x 16 B in flight instead of paying the
+// memory latency once per 16 B (the kernels are HBM/L2-bound: 64-row tiles of the fused projection buffers).
+template <int ROWS, int MAXIT>
+__device__ __forceinline__ void stage_pair(char* lds0, const bf16* g0, long rs0, char* lds1, const bf16* g1, long rs1, int row0,
+                                           int nvalid, int tid, int nthreads) {
+  constexpr int CH = ROWS * 8;
+  for (int base = 0; base < CH; base += MAXIT * nthreads) {  // one trip unless the workgroup is a single wave
+    u32x4 v0[MAXIT], v1[MAXIT];
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) {
+      const int q = base + tid + i * nthreads;
+      v0[i] = u32x4{0, 0, 0, 0};
+      v1[i] = u32x4{0, 0, 0, 0};
+      if (q < CH) {
+        const int r = q >> 3, c = q & 7;
+        if (row0 + r < nvalid) {
+          v0[i] = *reinterpret_cast<const u32x4*>(g0 + (long)(row0 + r) * rs0 + c * 8);
+          v1[i] = *reinterpret_cast<const u32x4*>(g1 + (long)(row0 + r) * rs1 + c * 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) {
+      const int q = base + tid + i * nthreads;
+      if (q < CH) {
+        const int r = q >> 3, c = q & 7;
+        const int off = r * 128 + ((c ^ swz_a(r)) << 4);
+        *reinterpret_cast<u32x4*>(lds0 + off) = v0[i];
+        *reinterpret_cast<u32x4*>(lds1 + off) = v1[i];
+      }
+    }
   }
+}
+
+// One LDS slot = two 64 x 64 bf16 tiles (K|V or Q|dO), filled by direct-to-LDS loads (global_load_lds_dwordx4): no
+// staging registers, every wave's loads for the whole slot are in flight together.  Wave-instruction j (0..15)
+// fills rows 8*(j&7).. +7 of tile j>>3, lane-linear; the XOR swizzle is applied on the SOURCE chunk.  Rows past
+// `nvalid` re-read the last valid row (finite data; their scores / probabilities are masked to exactly 0).
+__device__ __forceinline__ void stage_slot(char* slot, const bf16* g0, long rs0, const bf16* g1, long rs1, int row0, int nvalid,
+                                           int w, int nw, int lane) {
+  for (int j = w; j < 16; j += nw) {
+    const int r = (j & 7) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz_a(r);
+    int gr = row0 + r;
+    gr = gr < nvalid ? gr : nvalid - 1;
+    const bf16* src = ((j >> 3) ? g1 + (long)gr * rs1 : g0 + (long)gr * rs0) + c * 8;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(void, src), LDS_PTR(void, slot + (j >> 3) * ATTN_TILE + (j & 7) * 1024), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ void stage_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 }
 
 // A/B fragment of a row-major tile: lane (lg, lr) -> row (row0 + lr), elements [ks*32 + 8*lg, +8)
@@ -83,10 +130,9 @@ __device__ __forceinline__ bool drop_keep(const AttnArgs& a, int b, int h, int q
 // ---------------------------------------------------------------------------------------------
 // forward: grid (q blocks, H, B); block = NW waves, wave w owns query rows [qblk*16*NW + 16*w, +16)
 // ---------------------------------------------------------------------------------------------
+template <bool RES>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * 128];
-  char* sK = lds;
-  char* sV = lds + 64 * 128;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
   const int lr = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -106,13 +152,29 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
   float m_run = EXCL_NEG, l_run = 0.f;
 
   const int nchunks = (a.Sk + 63) / 64;
+  constexpr bool resident = RES;  // all chunks of this (b,h) staged once, one barrier (host: Sk <= 256, >= 4 waves)
+  const int nw = nthreads >> 6;
+  if (resident) {
+    for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, a.Sk, w, nw, lane);
+    stage_wait();
+  } else {
+    stage_slot(lds, kb, a.k_rs, vb, a.v_rs, 0, a.Sk, w, nw, lane);
+  }
   for (int kc = 0; kc < nchunks; ++kc) {
-    __syncthreads();
-    stage_tile<64>(sK, kb, a.k_rs, kc * 64, a.Sk, tid, nthreads);
-    stage_tile<64>(sV, vb, a.v_rs, kc * 64, a.Sk, tid, nthreads);
-    __syncthreads();
+    if (!resident) {  // double buffer: chunk kc has landed, everyone is done with chunk kc-1 -> refill its slot
+      stage_wait();
+      if (kc + 1 < nchunks) stage_slot(lds + ((kc + 1) & 1) * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, (kc + 1) * 64, a.Sk, w, nw, lane);
+    }
+    const char* sK = lds + (resident ? kc : (kc & 1)) * ATTN_SLOT;
+    const char* sV = sK + ATTN_TILE;
     if (!wave_active) continue;
-    f32x4 st[4];
+    f32x4 st[4], bvs[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {  // bias loads first: their L2 latency hides under the QK^T MFMAs
+      const int kj0 = kc * 64 + t * 16 + 4 * lg;
+      bvs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.bias != nullptr && kj0 < a.Sk) bvs[t] = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -123,8 +185,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int kj0 = kc * 64 + t * 16 + 4 * lg;
-      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a.bias != nullptr && kj0 < a.Sk) bv = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
+      const f32x4 bv = bvs[t];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         st[t][r] = score_fix(a, st[t][r], b, h, qi, kj0 + r, bv[r]);
@@ -173,7 +234,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
     *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * lg) = ov;
     if (op32 != nullptr) *reinterpret_cast<f32x4*>(op32 + dt * 16 + 4 * lg) = of;
   }
-  if (lg == 0) a.lse[((long)b * a.H + h) * a.Sq + qi] = m_run + __logf(l_run);
+  if (lg == 0) a.lse[((long)b * a.H + h) * a.stat_ld + qi] = m_run + __logf(l_run);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -184,13 +245,11 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
 // delta_i = sum_d dO_id * O_id uses the forward's fp32 copy of O when present: with the bf16-rounded O the identity
 // sum_j P_ij (dP_ij - delta_i) = 0 is broken by ~2^-9 |dO||O| per row, which dominates small dS.
 // ---------------------------------------------------------------------------------------------
-template <int NKC>
+template <int NKC, bool RES>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per_block) {
   constexpr bool DBIAS = NKC > 0;
   constexpr int NACC = DBIAS ? NKC : 1;
-  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * 128 + (DBIAS ? 8 * 4096 : 0)];
-  char* sK = lds;
-  char* sV = lds + 64 * 128;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
   const int lr = lane & 15, lg = lane >> 4;
   const int h = blockIdx.y;
@@ -200,6 +259,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
   const bool qvalid = qi < a.Sq;
   const int qc = qvalid ? qi : a.Sq - 1;
   const int nchunks = (a.Sk + 63) / 64;
+  constexpr bool resident = RES;
 
   f32x4 dsacc[NACC][4];
 #pragma unroll
@@ -216,42 +276,37 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
     const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
     const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop + 8 * lg);
     const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32 + 8 * lg);
-    float delta = 0.f;
-    if (a.o32 != nullptr) {
-      const float* op = a.o32 + ((long)b * a.Sq + qc) * (a.H * 64) + h * 64;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const f32x4 o0 = *reinterpret_cast<const f32x4*>(op + half * 32 + 8 * lg);
-        const f32x4 o1 = *reinterpret_cast<const f32x4*>(op + half * 32 + 8 * lg + 4);
-        const bf16x8& d = half ? df1 : df0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) delta += bf2f(d[j]) * o0[j] + bf2f(d[4 + j]) * o1[j];
-      }
-    } else {
-      const bf16* op = a.o + ((long)b * a.Sq + qc) * a.o_rs + h * 64;
-      const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(op + 8 * lg);
-      const bf16x8 o1 = *reinterpret_cast<const bf16x8*>(op + 32 + 8 * lg);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) delta += bf2f(df0[j]) * bf2f(o0[j]) + bf2f(df1[j]) * bf2f(o1[j]);
-    }
-    delta = group4_sum(delta);
-    const long stat_idx = ((long)b * a.H + h) * a.Sq + qc;
+    const long stat_idx = ((long)b * a.H + h) * a.stat_ld + qc;
     const float lse = a.lse[stat_idx];
-    if (wave_active && qvalid && lg == 0) a.delta[stat_idx] = delta;
     const bf16* kb = a.k + (long)b * a.Sk * a.k_rs + h * 64;
     const bf16* vb = a.v + (long)b * a.Sk * a.v_rs + h * 64;
 
-    f32x4 dqacc[4];
+    const int nw = nthreads >> 6;
+    if (resident) {
+      __syncthreads();  // previous batch entry's readers are done
+      for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, a.Sk, w, nw, lane);
+      stage_wait();
+    }
+    // streaming mode: double-buffered slots; `first` issues chunk 0 of a pass, `next` waits for chunk kc and refills
+    auto stream_first = [&]() {
+      __syncthreads();
+      stage_slot(lds, kb, a.k_rs, vb, a.v_rs, 0, a.Sk, w, nw, lane);
+    };
+    auto stream_next = [&](int kc) {
+      stage_wait();
+      if (kc + 1 < nchunks) stage_slot(lds + ((kc + 1) & 1) * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, (kc + 1) * 64, a.Sk, w, nw, lane);
+    };
+    // probabilities P (recomputed from the forward's log-sum-exp) and dropped dP = (dO . V^T) * keep/(1-p) of one chunk
+    auto probs = [&](int kc, f32x4 (&st)[4], f32x4 (&dp)[4]) {
+      const char* sK = lds + (resident ? kc : (kc & 1)) * ATTN_SLOT;
+      const char* sV = sK + ATTN_TILE;
+      f32x4 bvs[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto chunk = [&](int kc) {
-      __syncthreads();
-      stage_tile<64>(sK, kb, a.k_rs, kc * 64, a.Sk, tid, nthreads);
-      stage_tile<64>(sV, vb, a.v_rs, kc * 64, a.Sk, tid, nthreads);
-      __syncthreads();
-      if (!wave_active) return;
-      f32x4 st[4], dp[4];
+      for (int t = 0; t < 4; ++t) {
+        const int kj0 = kc * 64 + t * 16 + 4 * lg;
+        bvs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr && kj0 < a.Sk) bvs[t] = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -264,16 +319,55 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int kj0 = kc * 64 + t * 16 + 4 * lg;
-        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.bias != nullptr && kj0 < a.Sk) bv = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
+        const f32x4 bv = bvs[t];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kj = kj0 + r;
-          const float s = score_fix(a, st[t][r], b, h, qi, kj, bv[r]);
-          const float pv = (kj < a.Sk && qvalid) ? __expf(s - lse) : 0.f;
-          float dpv = dp[t][r];
-          if (a.drop_thresh != 0u) dpv = drop_keep(a, b, h, qi, kj) ? dpv * a.drop_scale : 0.f;
-          const float ds = pv * (dpv - delta);
+          const float sc = score_fix(a, st[t][r], b, h, qi, kj, bv[r]);
+          st[t][r] = (kj < a.Sk && qvalid) ? __expf(sc - lse) : 0.f;
+          if (a.drop_thresh != 0u) dp[t][r] = drop_keep(a, b, h, qi, kj) ? dp[t][r] * a.drop_scale : 0.f;
+        }
+      }
+    };
+
+    // pass 1: delta_i = sum_j P_ij dP_ij from the SAME P and dP that form dS below, so that sum_j dS_ij = 0 holds to
+    // fp32 rounding (rowsum(dO*O) with a bf16-rounded O breaks it by ~2^-9 |dO||O| and swamps small dS)
+    float delta = 0.f;
+    f32x4 st[4], dp[4];
+    if (!resident) stream_first();
+    for (int kc = 0; kc < nchunks; ++kc) {
+      if (!resident) stream_next(kc);
+      if (wave_active) {
+        probs(kc, st, dp);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) delta += st[t][r] * dp[t][r];
+      }
+    }
+    delta = group4_sum(delta);
+    if (wave_active && qvalid && lg == 0) a.delta[stat_idx] = delta;
+
+    f32x4 dqacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // pass 2: dS, dbias, dQ   (a single-chunk problem keeps pass 1's registers and its staged tile)
+    if (!resident && nchunks > 1) stream_first();
+    for (int kc = 0; kc < nchunks; ++kc) {
+      if (nchunks > 1) {
+        if (!resident) stream_next(kc);
+        if (wave_active) probs(kc, st, dp);
+      }
+      if (!wave_active) continue;
+      const char* sK = lds + (resident ? kc : (kc & 1)) * ATTN_SLOT;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int kj0 = kc * 64 + t * 16 + 4 * lg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kj = kj0 + r;
+          const float ds = st[t][r] * (dp[t][r] - delta);
           st[t][r] = ds;
           if (!DBIAS && a.dbias != nullptr && kj < a.Sk && qvalid) atomicAdd(a.dbias + ((long)h * a.Sq + qi) * a.bias_ld + kj, ds);
         }
@@ -294,9 +388,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
         for (int dt = 0; dt < 4; ++dt)
           dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK, 32 * s2, 32 * s2 + 16, dt * 16, lr, lg), pf, dqacc[dt], 0, 0, 0);
       }
-    };
-
-    for (int kc = 0; kc < nchunks; ++kc) chunk(kc);
+    }
     if (wave_active && qvalid) {
       bf16* dqp = a.dq + ((long)b * a.Sq + qi) * a.dq_rs + h * 64;
 #pragma unroll
@@ -310,7 +402,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
   }
 
   if (DBIAS) {
-    float* fl = reinterpret_cast<float*>(lds + 2 * 64 * 128 + w * 4096);  // wave-private [16 q][64 keys]
+    float* fl = reinterpret_cast<float*>(lds + w * 4096);  // wave-private [16 q][64 keys], aliases the K/V slots (done with)
 #pragma unroll
     for (int kc = 0; kc < NACC; ++kc) {
       if (kc < nchunks) {
@@ -334,10 +426,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
 // backward 2/2: dK, dV.  grid (key blocks, H, B); wave w owns keys [kblk*16*NW + 16*w, +16); queries stream in chunks
 // of 64 (Q and dO staged in LDS, read by rows for S / dP and transposed for dK^T / dV^T).
 // ---------------------------------------------------------------------------------------------
+template <bool RES>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * 128];
-  char* sQ = lds;
-  char* sD = lds + 64 * 128;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
   const int lr = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -354,8 +445,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
   const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vp + 32 + 8 * lg);
   const bf16* qb = a.q + (long)b * a.Sq * a.q_rs + h * 64;
   const bf16* db = a.dout + (long)b * a.Sq * a.do_rs + h * 64;
-  const float* lse_b = a.lse + ((long)b * a.H + h) * a.Sq;
-  const float* del_b = a.delta + ((long)b * a.H + h) * a.Sq;
+  const float* lse_b = a.lse + ((long)b * a.H + h) * a.stat_ld;
+  const float* del_b = a.delta + ((long)b * a.H + h) * a.stat_ld;
   bool key_masked = false;
   if (a.key_keep != nullptr) key_masked = a.key_keep[(long)b * a.Sk + kcl] == 0;
 
@@ -364,13 +455,34 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
   for (int i = 0; i < 4; ++i) { dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nchunks = (a.Sq + 63) / 64;
+  constexpr bool resident = RES;
+  const int nw = nthreads >> 6;
+  if (resident) {
+    for (int qc = 0; qc < nchunks; ++qc) stage_slot(lds + qc * ATTN_SLOT, qb, a.q_rs, db, a.do_rs, qc * 64, a.Sq, w, nw, lane);
+    stage_wait();
+  } else {
+    stage_slot(lds, qb, a.q_rs, db, a.do_rs, 0, a.Sq, w, nw, lane);
+  }
   for (int qc = 0; qc < nchunks; ++qc) {
-    __syncthreads();
-    stage_tile<64>(sQ, qb, a.q_rs, qc * 64, a.Sq, tid, nthreads);
-    stage_tile<64>(sD, db, a.do_rs, qc * 64, a.Sq, tid, nthreads);
-    __syncthreads();
+    if (!resident) {
+      stage_wait();
+      if (qc + 1 < nchunks) stage_slot(lds + ((qc + 1) & 1) * ATTN_SLOT, qb, a.q_rs, db, a.do_rs, (qc + 1) * 64, a.Sq, w, nw, lane);
+    }
+    const char* sQ = lds + (resident ? qc : (qc & 1)) * ATTN_SLOT;
+    const char* sD = sQ + ATTN_TILE;
     if (!wave_active) continue;
     f32x4 st[4], dp[4];  // D[i = query row][j = key col]: lane (lg, lr) -> query 16t + 4lg + r, key lr
+    f32x4 lsev[4], delv[4], bvt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {  // row statistics and bias for this lane's 4 consecutive queries: 16-B loads, issued early
+      const int qi0 = qc * 64 + t * 16 + 4 * lg;
+      lsev[t] = delv[t] = bvt[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (qi0 < a.Sq) {
+        lsev[t] = *reinterpret_cast<const f32x4*>(lse_b + qi0);
+        delv[t] = *reinterpret_cast<const f32x4*>(del_b + qi0);
+        if (a.bias_t != nullptr && kvalid) bvt[t] = *reinterpret_cast<const f32x4*>(a.bias_t + ((long)h * a.Sk + kj) * a.bias_t_ld + qi0);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -388,16 +500,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int qi = qi0 + r;
         const bool ok = qi < a.Sq && kvalid;
-        const int qcl = qi < a.Sq ? qi : a.Sq - 1;
-        float biasv = 0.f;
-        if (a.bias != nullptr && ok) biasv = a.bias[((long)h * a.Sq + qi) * a.bias_ld + kj];
+        float biasv = bvt[t][r];
+        if (a.bias != nullptr && a.bias_t == nullptr && ok) biasv = a.bias[((long)h * a.Sq + qi) * a.bias_ld + kj];
         float s = st[t][r] * a.scale + biasv;
         if (key_masked || (a.causal && kj > qi)) s += MASK_NEG;
-        const float pv = ok ? __expf(s - lse_b[qcl]) : 0.f;
+        const float pv = ok ? __expf(s - lsev[t][r]) : 0.f;
         float keepf = 1.f;
         if (a.drop_thresh != 0u) keepf = (ok && drop_keep(a, b, h, qi, kj)) ? a.drop_scale : 0.f;
         pd[t][r] = pv * keepf;
-        st[t][r] = pv * (dp[t][r] * keepf - del_b[qcl]);
+        st[t][r] = pv * (dp[t][r] * keepf - delv[t][r]);
       }
     }
     // dV^T[d, key] += dO^T[d, q] . Pd[q, key] ;  dK^T[d, key] += Q^T[d, q] . dS[q, key]
@@ -432,11 +543,29 @@ static int attn_check(const AttnArgs& a, bool bwd) {
               "attention: q/k/v must be 16-byte aligned");
   XFM_REQUIRE(a.bias == nullptr || (a.bias_ld % 4 == 0 && a.bias_ld >= a.Sk), "attention: bias_ld must be a multiple of 4 and >= Sk");
   XFM_REQUIRE(a.B <= 65535 && a.H <= 65535, "attention: B/H exceed grid limits");
+  XFM_REQUIRE(a.stat_ld >= a.Sq && a.stat_ld % 4 == 0 && ((uintptr_t)a.lse % 16) == 0, "attention: stat_ld must be a multiple of 4 and >= Sq, lse 16-byte aligned");
+  XFM_REQUIRE(a.bias_t == nullptr || (a.bias != nullptr && a.bias_t_ld % 4 == 0 && a.bias_t_ld >= a.Sq), "attention: bad transposed bias");
   if (bwd) {
     XFM_REQUIRE(a.dout && a.dq && a.dk && a.dv && a.delta && a.lse, "attention bwd: missing buffers");
     XFM_REQUIRE(a.do_rs % 8 == 0 && a.dq_rs % 4 == 0 && a.dk_rs % 4 == 0 && a.dv_rs % 4 == 0, "attention bwd: bad strides");
   }
   return XFM_OK;
+}
+
+static bool attn_resident(int S, int nw) { return cdiv(S, 64) <= ATTN_RES_MAX && nw >= 4; }
+
+static size_t attn_lds_bytes(int S, int nw, size_t at_least) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int mx = ATTN_RES_MAX * ATTN_SLOT;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    attr_set = true;
+  }
+  size_t b = (size_t)(attn_resident(S, nw) ? cdiv(S, 64) : 2) * ATTN_SLOT;
+  return b > at_least ? b : at_least;
 }
 
 static void attn_geom(int S, int& nw, int& blocks) {
@@ -452,7 +581,9 @@ int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
   if (rc != XFM_OK) return rc;
   int nw, blocks;
   attn_geom(a.Sq, nw, blocks);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(blocks, a.H, a.B), dim3(nw * 64), 0, st, a);
+  const dim3 grid(blocks, a.H, a.B), blk(nw * 64);
+  if (attn_resident(a.Sk, nw)) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, blk, attn_lds_bytes(a.Sk, nw, 0), st, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, blk, attn_lds_bytes(a.Sk, nw, 0), st, a);
   return xfm_check_launch("attn_fwd");
 }
 
@@ -461,16 +592,22 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
   if (rc != XFM_OK) return rc;
   int nw, blocks;
   attn_geom(a.Sq, nw, blocks);
-  if (a.dbias != nullptr && a.Sk <= 256) {
-    int nb = a.B >= 64 ? 8 : (a.B >= 16 ? 4 : 1);  // batch entries whose dS one workgroup sums before touching HBM
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3(blocks, a.H, cdiv(a.B, nb)), dim3(nw * 64), 0, st, a, nb);
+  const bool res = attn_resident(a.Sk, nw);
+  if (a.dbias != nullptr && res) {
+    int nb = a.B >= 32 ? 4 : (a.B >= 8 ? 2 : 1);  // batch entries whose dS one workgroup sums before touching HBM
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<4, true>), dim3(blocks, a.H, cdiv(a.B, nb)), dim3(nw * 64),
+                       attn_lds_bytes(a.Sk, nw, 8 * 4096), st, a, nb);
+  } else if (res) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<0, true>), dim3(blocks, a.H, a.B), dim3(nw * 64), attn_lds_bytes(a.Sk, nw, 0), st, a, 1);
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<0>, dim3(blocks, a.H, a.B), dim3(nw * 64), 0, st, a, 1);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<0, false>), dim3(blocks, a.H, a.B), dim3(nw * 64), attn_lds_bytes(a.Sk, nw, 0), st, a, 1);
   }
   rc = xfm_check_launch("attn_bwd_dq");
   if (rc != XFM_OK) return rc;
   attn_geom(a.Sk, nw, blocks);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(blocks, a.H, a.B), dim3(nw * 64), 0, st, a);
+  const dim3 grid(blocks, a.H, a.B), blk(nw * 64);
+  if (attn_resident(a.Sq, nw)) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, blk, attn_lds_bytes(a.Sq, nw, 0), st, a);
+  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, blk, attn_lds_bytes(a.Sq, nw, 0), st, a);
   return xfm_check_launch("attn_bwd_dkv");
 }
 
@@ -478,7 +615,7 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
 // relative-position bias: dense[h,i,j] = table[index[i,j], h]  (beit2.py:139-145) and its transpose-scatter gradient
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void relpos_gather_kernel(const float* __restrict__ table, const int* __restrict__ index, int H,
-                                                            int N, long ld, float* __restrict__ dense) {
+                                                            int N, long ld, float* __restrict__ dense, float* __restrict__ dense_t) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const long total = (long)H * N * ld;
   if (t >= total) return;
@@ -486,6 +623,7 @@ __global__ __launch_bounds__(256) void relpos_gather_kernel(const float* __restr
   const int i = (int)((t / ld) % N);
   const int h = (int)(t / (ld * N));
   dense[t] = (j < N) ? table[(long)index[i * N + j] * H + h] : 0.f;
+  if (dense_t != nullptr) dense_t[t] = (j < N) ? table[(long)index[j * N + i] * H + h] : 0.f;  // [h][key i][query j]
 }
 __global__ __launch_bounds__(256) void relpos_scatter_kernel(const float* __restrict__ ddense, const int* __restrict__ index, int H,
                                                              int N, long ld, float* __restrict__ dtable) {
@@ -498,10 +636,10 @@ __global__ __launch_bounds__(256) void relpos_scatter_kernel(const float* __rest
   atomicAdd(dtable + (long)index[i * N + j] * H + h, ddense[((long)h * N + i) * ld + j]);
 }
 
-int xfm_relpos_gather_impl(const float* table, const int* index, int H, int N, long ld, float* dense, hipStream_t st) {
+int xfm_relpos_gather_impl(const float* table, const int* index, int H, int N, long ld, float* dense, float* dense_t, hipStream_t st) {
   XFM_REQUIRE(H > 0 && N > 0 && ld >= N && ld % 4 == 0, "relpos_gather: bad shape H=%d N=%d ld=%ld", H, N, ld);
   const long total = (long)H * N * ld;
-  hipLaunchKernelGGL(relpos_gather_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, table, index, H, N, ld, dense);
+  hipLaunchKernelGGL(relpos_gather_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, table, index, H, N, ld, dense, dense_t);
   return xfm_check_launch("relpos_gather");
 }
 int xfm_relpos_scatter_impl(const float* ddense, const int* index, int H, int N, long ld, float* dtable, hipStream_t st) {

@@ -42,10 +42,10 @@ int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* 
   return xfm_gemm_nt_impl(A, lda, B, ldb, C, ldc, bias, aux, ldaux, M, N, K, epilogue, tile_hint, ST(stream));
 }
 
-int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float* dW, long ldw, int M, int N, int K,
-                int splits_hint, void* stream) {
+int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float* dW, long ldw, float* dbias, int M, int N,
+                int K, int splits_hint, void* stream) {
   XFM_REQUIRE(dY && X && dW, "gemm_tn: null operand");
-  return xfm_gemm_tn_impl(dY, ldy, X, ldx, dW, ldw, M, N, K, splits_hint, ST(stream));
+  return xfm_gemm_tn_impl(dY, ldy, X, ldx, dW, ldw, dbias, M, N, K, splits_hint, ST(stream));
 }
 
 int xfm_cast_transpose(const float* w, int N, int K, xfm_bf16* wb, long ldb, xfm_bf16* wt, long ldt, void* stream) {
@@ -93,9 +93,9 @@ int xfm_attn_bwd(const xfm_attn_args* a, void* stream) {
   XFM_REQUIRE(a->q && a->k && a->v && a->o && a->lse, "attn_bwd: null operand");
   return xfm_attn_bwd_impl(*a, ST(stream));
 }
-int xfm_relpos_gather(const float* table, const int* index, int H, int N, long ld, float* dense, void* stream) {
+int xfm_relpos_gather(const float* table, const int* index, int H, int N, long ld, float* dense, float* dense_t, void* stream) {
   XFM_REQUIRE(table && index && dense, "relpos_gather: null operand");
-  return xfm_relpos_gather_impl(table, index, H, N, ld, dense, ST(stream));
+  return xfm_relpos_gather_impl(table, index, H, N, ld, dense, dense_t, ST(stream));
 }
 int xfm_relpos_scatter(const float* ddense, const int* index, int H, int N, long ld, float* dtable, void* stream) {
   XFM_REQUIRE(ddense && index && dtable, "relpos_scatter: null operand");

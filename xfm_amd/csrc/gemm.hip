@@ -237,6 +237,7 @@ struct GemmTN {
   const bf16* dY; long ldy;
   const bf16* X; long ldx;
   float* dW; long ldw;
+  float* dbias;  // optional: dbias[n] += sum_m dY[m,n] (bias gradient), folded into the k-tile-0 workgroups
   int M, N, K;
   int m_per_split;
 };
@@ -274,6 +275,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
   mend = mend < g.M ? mend : g.M;
   const int nsteps = (mend - mbeg + 63) / 64;
 
+  const bool do_bias = g.dbias != nullptr && k0 == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this thread's 8 dY columns (chunk tid & 15), over its rows
   u32x4 ry[4], rx[4];
   auto gload = [&](int step) {
     const int mb = mbeg + step * 64;
@@ -305,6 +308,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
       const int off = r * 256 + ((c ^ swz_t(r)) << 4);
       *reinterpret_cast<u32x4*>(sY + off) = ry[i];
       *reinterpret_cast<u32x4*>(sX + off) = rx[i];
+      if (do_bias) {  // consumed here (after the MFMAs), never at the load site: the loads must stay in flight
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bsum[2 * e] += __uint_as_float(ry[i][e] << 16);
+          bsum[2 * e + 1] += __uint_as_float(ry[i][e] & 0xFFFF0000u);
+        }
+      }
     }
   };
 
@@ -341,6 +351,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
     __syncthreads();
   }
 
+  if (do_bias) {  // fold the 16 row-slices of each column chunk through LDS (the tiles are no longer needed)
+    float* red = reinterpret_cast<float*>(smem);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 128 && n0 + tid < g.N) {
+      float t2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t2 += red[r * 128 + tid];
+      atomicAdd(g.dbias + n0 + tid, t2);
+    }
+  }
   // D[i = n slot][j = k col]: lane (lg, lr) holds k = ..+lr and n = ..+4*lg+reg
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
@@ -355,7 +378,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
     }
 }
 
-int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, int M, int N, int K,
+int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, float* dbias, int M, int N, int K,
                      int splits_hint, hipStream_t st) {
   XFM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
   XFM_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "gemm_tn: K=%d ldx=%ld ldy=%ld must be multiples of 8", K, ldx, ldy);
@@ -370,7 +393,7 @@ int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* d
   }
   int mps = cdiv(cdiv(M, splits), 64) * 64;
   splits = cdiv(M, mps);
-  GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, M, N, K, mps};
+  GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, dbias, M, N, K, mps};
   static bool attr_set = false;
   const size_t smem = 4 * 64 * 256;
   if (!attr_set) {

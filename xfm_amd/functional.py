@@ -66,8 +66,8 @@ def gemm_nt(a, b, bias=None, epi=EPI_BF16, aux=None, out=None, n=None, tile_hint
     return (out, aux) if epi == EPI_GELU else out
 
 
-def gemm_tn(dy, x, dw, n=None, splits=0):
-    """dw[N,K] (fp32) += dy[M,N]^T @ x[M,K]."""
+def gemm_tn(dy, x, dw, n=None, splits=0, dbias=None):
+    """dw[N,K] (fp32) += dy[M,N]^T @ x[M,K]; optionally dbias[N] (fp32) += dy.sum(0) in the same pass."""
     _dev(dy)
     assert dy.dtype == BF16 and x.dtype == BF16 and dw.dtype == F32
     assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(-1) == 1
@@ -75,7 +75,7 @@ def gemm_tn(dy, x, dw, n=None, splits=0):
     N = dy.shape[1] if n is None else n
     assert dy.shape[0] == M and dw.shape[0] >= N and dw.shape[1] == K, (dy.shape, x.shape, dw.shape)
     check(_lib.load().xfm_gemm_tn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0),
-                                  M, N, K, splits, _stream()), "gemm_tn")
+                                  _ptr(dbias), M, N, K, splits, _stream()), "gemm_tn")
 
 
 def cast_transpose(w, wb=None, wt=None):
@@ -187,10 +187,16 @@ def ln_ls_bwd(dy, dstream, x_new, mean, rstd, w, h, ls_gamma, row_scale, rows_pe
 
 
 # --------------------------------------------------------------------------------------------- attention
-def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop):
+def _stat_ld(Sq):
+    return (Sq + 3) // 4 * 4
+
+
+def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t=None):
     for t in (q, k, v, o):
         assert t.dtype == BF16 and t.stride(-1) == 1 and t.dim() == 2
-    return AttnArgs(q=q.data_ptr(), q_rs=q.stride(0), k=k.data_ptr(), k_rs=k.stride(0), v=v.data_ptr(), v_rs=v.stride(0),
+    assert lse.shape[-1] == _stat_ld(Sq)
+    return AttnArgs(stat_ld=lse.shape[-1], bias_t=_ptr(bias_t), bias_t_ld=0 if bias_t is None else bias_t.stride(1),
+                    q=q.data_ptr(), q_rs=q.stride(0), k=k.data_ptr(), k_rs=k.stride(0), v=v.data_ptr(), v_rs=v.stride(0),
                     o=o.data_ptr(), o_rs=o.stride(0), lse=lse.data_ptr(), bias=_ptr(bias),
                     bias_ld=0 if bias is None else bias.stride(1), key_keep=_ptr(key_keep), B=B, H=H, Sq=Sq, Sk=Sk,
                     scale=scale, causal=int(causal), drop_thresh=drop[0], drop_scale=drop[1], seed_lo=drop[2], seed_hi=drop[3])
@@ -201,7 +207,7 @@ def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=Fals
     bias: dense fp32 [H,Sq,ld]; key_keep: int32 [B,Sk].  Returns (o [B*Sq, H*64] bf16, lse [B,H,Sq])."""
     _dev(q)
     o = torch.empty((B * Sq, H * 64), dtype=BF16, device=q.device)
-    lse = torch.empty((B, H, Sq), dtype=F32, device=q.device)
+    lse = torch.empty((B, H, _stat_ld(Sq)), dtype=F32, device=q.device)
     if key_keep is not None:
         assert key_keep.dtype == torch.int32 and key_keep.is_contiguous()
     a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop)
@@ -214,10 +220,10 @@ def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=Fals
 
 
 def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, dbias=None, key_keep=None, causal=False,
-             drop=(0, 1.0, 0, 0), o32=None):
+             drop=(0, 1.0, 0, 0), o32=None, bias_t=None):
     """Writes dq/dk/dv (2-D bf16 views with the same addressing convention as q/k/v); dbias (fp32 [H,Sq,ld]) += ."""
-    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop)
-    delta = torch.empty((B, H, Sq), dtype=F32, device=q.device)
+    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t)
+    delta = torch.zeros((B, H, lse.shape[-1]), dtype=F32, device=q.device)
     assert dout.dtype == BF16 and dout.stride(-1) == 1
     a.dout, a.do_rs = dout.data_ptr(), dout.stride(0)
     a.dq, a.dq_rs = dq.data_ptr(), dq.stride(0)
@@ -227,10 +233,13 @@ def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, 
     check(_lib.load().xfm_attn_bwd(ctypes.byref(a), _stream()), "attn_bwd")
 
 
-def relpos_gather(table, index32, H, N, ld):
+def relpos_gather(table, index32, H, N, ld, transposed=False):
+    """dense[h,i,j] = table[index[i,j], h] (rows padded to ld); transposed=True also returns the [h,j,i] copy."""
     dense = torch.empty((H, N, ld), dtype=F32, device=table.device)
-    check(_lib.load().xfm_relpos_gather(table.data_ptr(), index32.data_ptr(), H, N, ld, dense.data_ptr(), _stream()), "relpos_gather")
-    return dense
+    dense_t = torch.empty((H, N, ld), dtype=F32, device=table.device) if transposed else None
+    check(_lib.load().xfm_relpos_gather(table.data_ptr(), index32.data_ptr(), H, N, ld, dense.data_ptr(), _ptr(dense_t),
+                                        _stream()), "relpos_gather")
+    return (dense, dense_t) if transposed else dense
 
 
 def relpos_scatter(ddense, index32, H, N, ld, dtable):

@@ -36,9 +36,7 @@ class _LinearSlotFn(torch.autograd.Function):
             dyp = torch.zeros((dy2.shape[0], pad), dtype=BF16, device=dy2.device)
             dyp[:, :s.N] = dy2
             dy2 = dyp
-        Fx.gemm_tn(dy2, ctx.x2, s.dw, n=s.N)
-        if s.db is not None:
-            Fx.colsum(dy2, s.db, n=s.N)
+        Fx.gemm_tn(dy2, ctx.x2, s.dw, n=s.N, dbias=s.db)
         dx = None
         if ctx.need_dx:
             if dy2.shape[1] % 64 == 0 and dy2.shape[1] <= s.wt.shape[1]:
@@ -132,15 +130,13 @@ class _LMHeadCEFn(torch.autograd.Function):
             raise NotImplementedError("per-row upstream gradients are handled by the caller via reduction='sum' weights")
         scale = (g / nvalid if ctx.reduction == "mean" else g).reshape(1).to(F32).contiguous()
         dlogits = Fx.ce_bwd(logits, V, labels, lse, scale, logits.shape[1])
-        Fx.gemm_tn(dlogits, y, sv.dw, n=V)
-        Fx.colsum(dlogits, sv.db, n=V)
+        Fx.gemm_tn(dlogits, y, sv.dw, n=V, dbias=sv.db)
         dy = Fx.gemm_nt(dlogits, sv.wt, n=sv.K)
         dhact = torch.empty_like(hact)
         ln = head.layer_norm
         Fx.ln_bwd(dy, hact, mean, rstd, ln.weight, grad_view(ln.weight), grad_view(ln.bias), dx16=dhact)
         du = (dhact.float() * gelu_grad(u)).to(BF16)
-        Fx.gemm_tn(du, x, sd.dw)
-        Fx.colsum(du, sd.db)
+        Fx.gemm_tn(du, x, sd.dw, dbias=sd.db)
         dx = Fx.gemm_nt(du, sd.wt, n=sd.K)
         return dx, None, None, None
 

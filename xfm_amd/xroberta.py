@@ -191,8 +191,8 @@ class _EncoderFn(torch.autograd.Function):
             att, co = layer.attention, None
             d_att, d_h1 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
             qkv = Fx.gemm_nt(x, s["qkv"].wb, s["qkv"].b)
-            c1, lse1, o32_1 = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep,
-                                          causal=causal, drop=d_att, save_o32=True)
+            c1, lse1 = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep,
+                                          causal=causal, drop=d_att); o32_1 = None
             h1 = Fx.gemm_nt(c1, s["o"].wb, s["o"].b)
             ln1 = att.output.LayerNorm
             y1, z1, m1, r1 = Fx.ln_post_fwd(h1, x, ln1.weight, ln1.bias, ln1.eps, d_h1)
@@ -203,8 +203,7 @@ class _EncoderFn(torch.autograd.Function):
                 d_att2, d_h2 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
                 q2 = Fx.gemm_nt(y1, s["q2"].wb, s["q2"].b)
                 kv = Fx.gemm_nt(enc, s["kv2"].wb, s["kv2"].b)
-                c2, lse2, o32_2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2,
-                                              save_o32=True)
+                c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2); o32_2 = None; o32 = None
                 h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
                 ln2 = co.output.LayerNorm
                 y2, z2, m2, r2 = Fx.ln_post_fwd(h2, y1, ln2.weight, ln2.bias, ln2.eps, d_h2)
@@ -242,8 +241,7 @@ class _EncoderFn(torch.autograd.Function):
             Fx.gemm_tn(dh3, r["hact"], s["out"].dw)
             du = Fx.gemm_nt(dh3, s["out"].wt, epi=Fx.EPI_DGELU, aux=r["u"], n=s["out"].K)
             y2 = r["y2"] if r["cross"] else r["y1"]
-            Fx.gemm_tn(du, y2, s["i"].dw)
-            Fx.colsum(du, s["i"].db)
+            Fx.gemm_tn(du, y2, s["i"].dw, dbias=s["i"].db)
             d1a, d1b = Fx.gemm_nt(du, s["i"].wt, n=s["i"].K), dres3
             if r["cross"]:
                 ln2 = layer.crossattention.output.LayerNorm
@@ -255,10 +253,8 @@ class _EncoderFn(torch.autograd.Function):
                 kv = r["kv"]
                 Fx.attn_bwd(dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc,
                             scale, key_keep=enc_keep, drop=r["d_att2"], o32=r["o32_2"])
-                Fx.gemm_tn(dq2, r["y1"], s["q2"].dw)
-                Fx.colsum(dq2, s["q2"].db)
-                Fx.gemm_tn(dkv, enc, s["kv2"].dw)
-                Fx.colsum(dkv, s["kv2"].db)
+                Fx.gemm_tn(dq2, r["y1"], s["q2"].dw, dbias=s["q2"].db)
+                Fx.gemm_tn(dkv, enc, s["kv2"].dw, dbias=s["kv2"].db)
                 if need_denc:
                     Fx.gemm_nt(dkv, s["kv2"].wt, epi=Fx.EPI_F32_ACC, out=denc32, n=s["kv2"].K)
                 d1a, d1b = Fx.gemm_nt(dq2, s["q2"].wt, n=s["q2"].K), dres2
@@ -271,8 +267,7 @@ class _EncoderFn(torch.autograd.Function):
             dqkv = torch.empty_like(qkv)
             Fx.attn_bwd(dc1, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], r["c1"], r["lse1"], dqkv[:, :D], dqkv[:, D:2 * D],
                         dqkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep, causal=causal, drop=r["d_att"], o32=r["o32_1"])
-            Fx.gemm_tn(dqkv, r["x"], s["qkv"].dw)
-            Fx.colsum(dqkv, s["qkv"].db)
+            Fx.gemm_tn(dqkv, r["x"], s["qkv"].dw, dbias=s["qkv"].db)
             if li > lo or need_dx:
                 dy_a, dy_b = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K), dres1
             ctx.saved[li - lo] = None
