@@ -184,11 +184,11 @@ def _pretrain_cfg(meta):
             "learnable_temp": True, "max_temp": 0.5, "min_temp": 0.001}
 
 
-def _pretrain(name, tol=None, cos_tol=None):
+def _pretrain(name, tol=None, cos_tol=None, batch_passes=True):
     from xfm_amd.model_pretrain import XFM
     z, meta = load(name)
     B = meta["B"]
-    m = XFM(_pretrain_cfg(meta))
+    m = XFM(dict(_pretrain_cfg(meta), batch_passes=batch_passes))
     _load_into(m, meta["spec"])
     m.cuda().finalize().eval()
     b = {k: v.cuda() for k, v in syn.pretrain_batch(B, seed=1234).items()}
@@ -221,6 +221,11 @@ def _pretrain(name, tol=None, cos_tol=None):
 
 def test_pretrain_step_small_vs_golden():
     _pretrain("pretrain_small")
+
+
+def test_pretrain_step_small_reference_call_order_vs_golden():
+    """batch_passes=False: the reference's own sequence of tower calls (2 ViT passes, ITM and MLM fusion passes apart)."""
+    _pretrain("pretrain_small", batch_passes=False)
 
 
 def test_pretrain_step_full_depth_vs_golden():

@@ -14,6 +14,9 @@ class XFM(XFMBase):
         self.use_mm_mim_loss = config.get('use_mm_mim_loss', True)
         self.min_temp = config.get('min_temp', 0.001)
         self.max_temp = config.get('max_temp', 0.5)
+        # MI355X-first batching (identical arithmetic per sample): the clean and the MIM-masked image go through the ViT as
+        # one 2B batch, the ITM (3B) and MLM (B) fusion passes as one 4B batch.  Set False to run the reference's call order.
+        self.batch_passes = config.get('batch_passes', True)
 
     def forward_multimodal(self, image, text_ids, text_atts, text_ids_masked=None, masked_pos=None, masked_ids=None,
                            text_ids_2=None, text_atts_2=None, text_ids_masked_2=None, masked_pos_2=None, masked_ids_2=None,
@@ -26,7 +29,19 @@ class XFM(XFMBase):
             self.temp.data.clamp_(self.min_temp, self.max_temp)  # via .data: leaves the arena's weight version untouched
         w = self.weights_map.get(data_source, None)
         zero = torch.tensor(0.0, device=image.device)
-        image_embeds, image_atts = self.get_vision_embeds(image)
+        do_mim = ret_mim_loss and (data_source == 'imagenet' or self.use_mm_mim_loss)
+        image_embeds_masked = None
+        if self.batch_passes and do_mim and self.do_image_mask:
+            B = image.shape[0]
+            if ids_mask is None:
+                ids_mask = self.vision_encoder.generator.batch(B)
+            ids_mask = ids_mask.to(device=image.device, dtype=torch.bool)
+            both, _, _ = self.get_vision_embeds(torch.cat([image, image], dim=0), do_mask=True,
+                                                ids_mask=torch.cat([torch.zeros_like(ids_mask), ids_mask], dim=0))
+            image_embeds, image_embeds_masked = both[:B], both[B:]
+            image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
+        else:
+            image_embeds, image_atts = self.get_vision_embeds(image)
         if data_source != 'imagenet':
             text_embeds = self.get_text_embeds(text_ids, text_atts)
             image_feat, text_feat = self.get_features(image_embeds, text_embeds)
@@ -35,18 +50,26 @@ class XFM(XFMBase):
             loss_itc = self.get_contrastive_loss(image_feat, text_feat)
             if w is not None:
                 loss_itc = loss_itc * w
-        if ret_match_loss and data_source != 'imagenet':
-            loss_itm = self.get_matching_loss(image_embeds, image_atts, image_feat, text_ids, text_atts, text_feat,
-                                              text_embeds=text_embeds, neg_idx=neg_idx)
+        if self.batch_passes and ret_match_loss and ret_mlm_loss and data_source != 'imagenet':
+            loss_itm, loss_mlm = self.get_matching_and_fuse_mlm_loss(image_embeds, image_atts, image_feat, text_ids, text_atts,
+                                                                     text_feat, text_embeds, text_ids_masked, masked_pos,
+                                                                     masked_ids, neg_idx=neg_idx)
             if w is not None:
-                loss_itm = loss_itm * w
-        if ret_mlm_loss and data_source != 'imagenet':
-            loss_mlm = self.get_fuse_mlm_loss(text_ids_masked, text_atts, image_embeds, image_atts, masked_pos, masked_ids)
-            if w is not None:
-                loss_mlm = loss_mlm * w
+                loss_itm, loss_mlm = loss_itm * w, loss_mlm * w
+        else:
+            if ret_match_loss and data_source != 'imagenet':
+                loss_itm = self.get_matching_loss(image_embeds, image_atts, image_feat, text_ids, text_atts, text_feat,
+                                                  text_embeds=text_embeds, neg_idx=neg_idx)
+                if w is not None:
+                    loss_itm = loss_itm * w
+            if ret_mlm_loss and data_source != 'imagenet':
+                loss_mlm = self.get_fuse_mlm_loss(text_ids_masked, text_atts, image_embeds, image_atts, masked_pos, masked_ids)
+                if w is not None:
+                    loss_mlm = loss_mlm * w
         if ret_mim_loss:
-            image_embeds_masked, _, ids_mask = self.get_vision_embeds(image, do_mask=self.do_image_mask, ids_mask=ids_mask)
-            if data_source == 'imagenet' or self.use_mm_mim_loss:
+            if image_embeds_masked is None:
+                image_embeds_masked, _, ids_mask = self.get_vision_embeds(image, do_mask=self.do_image_mask, ids_mask=ids_mask)
+            if do_mim:
                 loss_mim = self.get_mim_loss(image_embeds_masked, image_embeds, ids_mask)
             if w is not None:
                 loss_mim = loss_mim * w
