@@ -39,7 +39,7 @@ enum { XFM_EPI_BF16 = 0, XFM_EPI_F32 = 1, XFM_EPI_GELU = 2, XFM_EPI_DGELU = 3, X
 
 /* C[M,N] = A[M,K] . B[N,K]^T + bias.  A, B bf16 (K contiguous).  Epilogues: bf16 out | fp32 out |
  * aux = pre-activation (bf16), C = gelu(aux)  | C = acc * gelu'(aux) | fp32 C += acc.  K % 64 == 0; lda, ldb % 8 == 0.
- * tile_hint: 0 = auto, 1 = 128x128, 2 = 64x128, 3 = 64x64. */
+ * tile_hint: 0 = auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x128 with a 3-slot LDS ring (large M). */
 int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* C, long ldc, const float* bias,
                 xfm_bf16* aux, long ldaux, int M, int N, int K, int epilogue, int tile_hint, void* stream);
 
@@ -117,12 +117,16 @@ typedef struct {
   float* o32;                     /* optional fp32 copy of o, dense [B*Sq, H*64], written by fwd */
   long stat_ld;                   /* row stride of lse / delta ([B,H,stat_ld]): multiple of 4, >= Sq */
   const float* bias_t; long bias_t_ld; /* optional transposed copy of bias [H,Sk,bias_t_ld] (vector loads in dK/dV) */
+  const int* kv_index;            /* optional [B]: query batch row b reads keys/values (and key_keep) of source kv_index[b];
+                                     dk/dv stay per query row (fold them with xfm_rows_index_sum) */
 } xfm_attn_args;
 
 int xfm_attn_fwd(const xfm_attn_args* a, void* stream);
 int xfm_attn_bwd(const xfm_attn_args* a, void* stream);
 /* dense[h,i,j] = table[index[i*N+j]*H + h] (beit2.py:139-145), rows padded to ld (dense_t: optional [h,j,i] copy);
  * and its scatter-add gradient. */
+/* dst[u,:] = sum_{r: index[r]==u} src[r,:]  (bf16 rows of `len` elements, fp32 accumulation). */
+int xfm_rows_index_sum(const xfm_bf16* src, const int* index, int R, int U, long len, xfm_bf16* dst, void* stream);
 int xfm_relpos_gather(const float* table, const int* index, int H, int N, long ld, float* dense, float* dense_t,
                       void* stream);
 int xfm_relpos_scatter(const float* ddense, const int* index, int H, int N, long ld, float* dtable, void* stream);

@@ -33,7 +33,7 @@ def gelu_grad(u):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 200, 128), (1920, 768, 768), (788, 2304, 768), (64, 50265, 64), (5, 3, 64)])
-@pytest.mark.parametrize("hint", [0, 1, 2, 3])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4])
 def test_gemm_nt_bias_bf16_and_f32(M, N, K, hint):
     Fx = _fx()
     a, b = _rand((M, K), seed=1), _rand((N, K), 0.05, seed=2)
@@ -56,7 +56,7 @@ def test_gemm_nt_identity_catches_transposed_maps():
     K = 128
     a = torch.eye(K, dtype=BF16, device="cuda")
     b = (torch.arange(200 * K, device="cuda").reshape(200, K) % 251).to(BF16)  # exact small integers
-    for hint in (1, 2, 3):
+    for hint in (1, 2, 3, 4):
         out = Fx.gemm_nt(a, b, tile_hint=hint)
         assert torch.equal(out.float(), b.float().t().contiguous()), f"tile config {hint}"
 
@@ -420,3 +420,32 @@ def test_adamw_and_sumsq_flat_arena():
     # transformers' AdamW applies the decay after the Adam update, torch's before: identical to first order in lr*wd
     _close(p[mask], ref_a, 1e-4, "adamw group 0")
     _close(p[~mask], ref_b, 1e-4, "adamw group 1")
+
+
+def test_attention_shared_kv_sources_and_row_fold():
+    """kv_index: several query batch rows read one key/value source; folding the per-row dK/dV equals attending to gathered copies."""
+    Fx = _fx()
+    B, U, H, Sq, Sk = 6, 3, 4, 30, 197
+    D = H * 64
+    idx = torch.tensor([0, 2, 1, 0, 0, 2], dtype=torch.int32, device="cuda")
+    q = _rand((B * Sq, D), seed=200)
+    kv = _rand((U * Sk, 2 * D), seed=201)
+    keep = torch.ones(U, Sk, dtype=torch.int32, device="cuda")
+    keep[1, 150:] = 0
+    dout = _rand((B * Sq, D), seed=202)
+    # reference: gather K/V per query row
+    kvg = kv.view(U, Sk, 2 * D)[idx.long()].reshape(B * Sk, 2 * D).contiguous()
+    keepg = keep[idx.long()].contiguous()
+    o_ref, lse_ref = Fx.attn_fwd(q, kvg[:, :D], kvg[:, D:], B, H, Sq, Sk, 0.125, key_keep=keepg)
+    o, lse = Fx.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, Sq, Sk, 0.125, key_keep=keep, kv_index=idx)
+    assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref)
+    dq_ref, dkv_ref = torch.empty_like(q), torch.empty_like(kvg)
+    Fx.attn_bwd(dout, q, kvg[:, :D], kvg[:, D:], o_ref, lse_ref, dq_ref, dkv_ref[:, :D], dkv_ref[:, D:], B, H, Sq, Sk, 0.125, key_keep=keepg)
+    dq, dkv = torch.empty_like(q), torch.empty((B * Sk, 2 * D), dtype=BF16, device="cuda")
+    Fx.attn_bwd(dout, q, kv[:, :D], kv[:, D:], o, lse, dq, dkv[:, :D], dkv[:, D:], B, H, Sq, Sk, 0.125, key_keep=keep, kv_index=idx)
+    assert torch.equal(dq, dq_ref)
+    assert not bool(torch.isnan(dkv.float()).any())
+    _close(dkv, dkv_ref, 1e-6, "per-row dK/dV with shared sources")
+    folded = Fx.rows_index_sum(dkv, idx, U, Sk)
+    ref = torch.zeros(U, Sk * 2 * D, device="cuda").index_add_(0, idx.long(), dkv_ref.float().view(B, -1)).view(U * Sk, 2 * D)
+    _close(folded, ref, 1e-2, "folded dK/dV")

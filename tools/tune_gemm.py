@@ -18,33 +18,52 @@ def timeit(fn, iters=20):
 
 
 def main():
-    B = 64
+    B = 128
+    cold = len(sys.argv) > 1 and sys.argv[1] == 'cold'
     shapes_nt = [(B * 197, 2304, 768), (B * 197, 768, 768), (B * 197, 3072, 768), (B * 197, 768, 3072),
                  (B * 30, 2304, 768), (B * 30, 768, 768), (B * 30, 3072, 768), (B * 30, 768, 3072),
                  (3 * B * 30, 2304, 768), (3 * B * 30, 768, 768), (3 * B * 30, 3072, 768), (3 * B * 30, 768, 3072),
                  (3 * B * 197, 1536, 768), (B * 197, 1536, 768), (3 * B * 197, 768, 1536), (B * 15, 50265, 768), (B * 15, 768, 50304)]
-    print("== gemm_nt  (M,N,K): us / TFLOP/s per tile config [auto,128x128,64x128,64x64]")
+    print("== gemm_nt  (M,N,K): us / TFLOP/s per tile config [auto,128x128,64x128,64x64,ring256x128]")
     for M, N, K in shapes_nt:
-        a = torch.randn(M, K, device="cuda").bfloat16()
-        b = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
-        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        # cold mode: rotate through enough distinct operand sets to defeat the 256 MiB Infinity Cache (as in the real step,
+        # where every layer brings its own activations and weights from HBM)
+        nbuf = max(2, int(1.5e9 / ((M * K + N * K + M * N) * 2))) if cold else 1
+        As = [torch.randn(M, K, device="cuda").bfloat16() for _ in range(nbuf)]
+        Bs = [(torch.randn(N, K, device="cuda") * 0.05).bfloat16() for _ in range(nbuf)]
+        Os = [torch.empty(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(nbuf)]
         res = []
-        for hint in (0, 1, 2, 3):
-            us = timeit(lambda: Fx.gemm_nt(a, b, out=out, tile_hint=hint))
+        for hint in (0, 1, 2, 3, 4):
+            cnt = [0]
+
+            def run():
+                i = cnt[0] % nbuf
+                cnt[0] += 1
+                Fx.gemm_nt(As[i], Bs[i], out=Os[i], tile_hint=hint)
+            us = timeit(run)
             res.append(f"{us:7.1f}us {2.0 * M * N * K / us / 1e6:6.0f}TF")
+        del As, Bs, Os
         print(f"{M:6d} {N:6d} {K:6d} | " + " | ".join(res), flush=True)
     print("== gemm_tn  (M,N,K): us / TFLOP/s per split count [auto,1,2,3,4,6,8,12,16]")
     shapes_tn = [(B * 197, 2304, 768), (B * 197, 768, 768), (B * 197, 3072, 768), (B * 197, 768, 3072),
                  (B * 30, 2304, 768), (B * 30, 768, 768), (B * 30, 3072, 768), (3 * B * 30, 2304, 768), (3 * B * 30, 768, 768),
                  (3 * B * 30, 3072, 768), (3 * B * 197, 1536, 768)]
     for M, N, K in shapes_tn:
-        dy = torch.randn(M, N, device="cuda").bfloat16()
-        x = torch.randn(M, K, device="cuda").bfloat16()
+        nbuf = max(2, int(1.5e9 / ((M * K + M * N) * 2))) if cold else 1
+        dys = [torch.randn(M, N, device="cuda").bfloat16() for _ in range(nbuf)]
+        xs = [torch.randn(M, K, device="cuda").bfloat16() for _ in range(nbuf)]
         dw = torch.zeros(N, K, device="cuda")
         res = []
         for sp in (0, 1, 2, 3, 4, 6, 8, 12, 16):
-            us = timeit(lambda: Fx.gemm_tn(dy, x, dw, splits=sp))
+            cnt = [0]
+
+            def run():
+                i = cnt[0] % nbuf
+                cnt[0] += 1
+                Fx.gemm_tn(dys[i], xs[i], dw, splits=sp)
+            us = timeit(run)
             res.append(f"{us:6.1f}/{2.0 * M * N * K / us / 1e6:4.0f}")
+        del dys, xs
         print(f"{M:6d} {N:6d} {K:6d} | " + " | ".join(res), flush=True)
 
 

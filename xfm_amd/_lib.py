@@ -43,7 +43,7 @@ class AttnArgs(ctypes.Structure):
                 ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32),
                 ("dout", c_void_p), ("do_rs", c_long), ("dq", c_void_p), ("dq_rs", c_long), ("dk", c_void_p),
                 ("dk_rs", c_long), ("dv", c_void_p), ("dv_rs", c_long), ("delta", c_void_p), ("dbias", c_void_p),
-                ("o32", c_void_p), ("stat_ld", c_long), ("bias_t", c_void_p), ("bias_t_ld", c_long)]
+                ("o32", c_void_p), ("stat_ld", c_long), ("bias_t", c_void_p), ("bias_t_ld", c_long), ("kv_index", c_void_p)]
 
 
 class EmbedArgs(ctypes.Structure):
@@ -77,6 +77,7 @@ SIGNATURES = {
                                   c_void_p, c_long, c_void_p]),
     "xfm_attn_fwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
     "xfm_attn_bwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
+    "xfm_rows_index_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),
     "xfm_relpos_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "xfm_relpos_scatter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),
     "xfm_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

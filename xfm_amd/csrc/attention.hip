@@ -113,11 +113,11 @@ __device__ __forceinline__ float group4_sum(float v) {
 }
 
 // score post-processing shared by forward and both backward kernels: returns the masked, biased, scaled score
-__device__ __forceinline__ float score_fix(const AttnArgs& a, float raw, int b, int h, int qi, int kj, float biasv) {
+__device__ __forceinline__ float score_fix(const AttnArgs& a, float raw, int kvb, int h, int qi, int kj, float biasv) {
   if (kj >= a.Sk) return EXCL_NEG;
   float s = raw * a.scale + biasv;
   bool masked = false;
-  if (a.key_keep != nullptr) masked = a.key_keep[(long)b * a.Sk + kj] == 0;
+  if (a.key_keep != nullptr) masked = a.key_keep[(long)kvb * a.Sk + kj] == 0;
   if (a.causal && kj > qi) masked = true;
   return masked ? s + MASK_NEG : s;
 }
@@ -143,8 +143,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
   const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
   const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
   const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
-  const bf16* kb = a.k + (long)b * a.Sk * a.k_rs + h * 64;
-  const bf16* vb = a.v + (long)b * a.Sk * a.v_rs + h * 64;
+  const int kvb = a.kv_index ? a.kv_index[b] : b;  // several query rows may share one key/value source (deduplicated images)
+  const bf16* kb = a.k + (long)kvb * a.Sk * a.k_rs + h * 64;
+  const bf16* vb = a.v + (long)kvb * a.Sk * a.v_rs + h * 64;
 
   f32x4 oacc[4];
 #pragma unroll
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
       const f32x4 bv = bvs[t];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        st[t][r] = score_fix(a, st[t][r], b, h, qi, kj0 + r, bv[r]);
+        st[t][r] = score_fix(a, st[t][r], kvb, h, qi, kj0 + r, bv[r]);
         mx = fmaxf(mx, st[t][r]);
       }
     }
@@ -278,8 +279,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
     const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32 + 8 * lg);
     const long stat_idx = ((long)b * a.H + h) * a.stat_ld + qc;
     const float lse = a.lse[stat_idx];
-    const bf16* kb = a.k + (long)b * a.Sk * a.k_rs + h * 64;
-    const bf16* vb = a.v + (long)b * a.Sk * a.v_rs + h * 64;
+    const int kvb = a.kv_index ? a.kv_index[b] : b;
+    const bf16* kb = a.k + (long)kvb * a.Sk * a.k_rs + h * 64;
+    const bf16* vb = a.v + (long)kvb * a.Sk * a.v_rs + h * 64;
 
     const int nw = nthreads >> 6;
     if (resident) {
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kj = kj0 + r;
-          const float sc = score_fix(a, st[t][r], b, h, qi, kj, bv[r]);
+          const float sc = score_fix(a, st[t][r], kvb, h, qi, kj, bv[r]);
           st[t][r] = (kj < a.Sk && qvalid) ? __expf(sc - lse) : 0.f;
           if (a.drop_thresh != 0u) dp[t][r] = drop_keep(a, b, h, qi, kj) ? dp[t][r] * a.drop_scale : 0.f;
         }
@@ -437,8 +439,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int kj = k0 + lr;
   const bool kvalid = kj < a.Sk;
   const int kcl = kvalid ? kj : a.Sk - 1;
-  const bf16* kp = a.k + ((long)b * a.Sk + kcl) * a.k_rs + h * 64;
-  const bf16* vp = a.v + ((long)b * a.Sk + kcl) * a.v_rs + h * 64;
+  const int kvb = a.kv_index ? a.kv_index[b] : b;
+  const bf16* kp = a.k + ((long)kvb * a.Sk + kcl) * a.k_rs + h * 64;
+  const bf16* vp = a.v + ((long)kvb * a.Sk + kcl) * a.v_rs + h * 64;
   const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp + 8 * lg);
   const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + 32 + 8 * lg);
   const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vp + 8 * lg);
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
   const float* lse_b = a.lse + ((long)b * a.H + h) * a.stat_ld;
   const float* del_b = a.delta + ((long)b * a.H + h) * a.stat_ld;
   bool key_masked = false;
-  if (a.key_keep != nullptr) key_masked = a.key_keep[(long)b * a.Sk + kcl] == 0;
+  if (a.key_keep != nullptr) key_masked = a.key_keep[(long)kvb * a.Sk + kcl] == 0;
 
   f32x4 dkacc[4], dvacc[4];
 #pragma unroll
@@ -609,6 +612,34 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
   if (attn_resident(a.Sq, nw)) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, blk, attn_lds_bytes(a.Sq, nw, 0), st, a);
   else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, blk, attn_lds_bytes(a.Sq, nw, 0), st, a);
   return xfm_check_launch("attn_bwd_dkv");
+}
+
+// ---------------------------------------------------------------------------------------------
+// dst[u, :] = sum over r with index[r] == u of src[r, :]   (bf16 in/out, fp32 accumulation; rows of `len` elements).
+// Folds the per-query-row dK/dV of deduplicated key/value sources back onto the unique sources.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_index_sum_kernel(const bf16* __restrict__ src, const int* __restrict__ index, int R,
+                                                             long len, bf16* __restrict__ dst) {
+  const int u = blockIdx.y;
+  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (e >= len) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < R; ++r) {
+    if (index[r] != u) continue;  // block-uniform
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (long)r * len + e);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += bf2f(v[i]);
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = f2bf(acc[i]);
+  *reinterpret_cast<bf16x8*>(dst + (long)u * len + e) = o;
+}
+
+int xfm_rows_index_sum_impl(const void* src, const int* index, int R, int U, long len, void* dst, hipStream_t st) {
+  XFM_REQUIRE(R > 0 && U > 0 && len > 0 && len % 8 == 0 && U <= 65535, "rows_index_sum: bad shape R=%d U=%d len=%ld", R, U, len);
+  hipLaunchKernelGGL(rows_index_sum_kernel, dim3(cdiv(len, 256 * 8), U), dim3(256), 0, st, (const bf16*)src, index, R, len, (bf16*)dst);
+  return xfm_check_launch("rows_index_sum");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -93,6 +93,10 @@ int xfm_attn_bwd(const xfm_attn_args* a, void* stream) {
   XFM_REQUIRE(a->q && a->k && a->v && a->o && a->lse, "attn_bwd: null operand");
   return xfm_attn_bwd_impl(*a, ST(stream));
 }
+int xfm_rows_index_sum(const xfm_bf16* src, const int* index, int R, int U, long len, xfm_bf16* dst, void* stream) {
+  XFM_REQUIRE(src && index && dst, "rows_index_sum: null operand");
+  return xfm_rows_index_sum_impl(src, index, R, U, len, dst, ST(stream));
+}
 int xfm_relpos_gather(const float* table, const int* index, int H, int N, long ld, float* dense, float* dense_t, void* stream) {
   XFM_REQUIRE(table && index && dense, "relpos_gather: null operand");
   return xfm_relpos_gather_impl(table, index, H, N, ld, dense, dense_t, ST(stream));

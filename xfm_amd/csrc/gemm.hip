@@ -28,6 +28,79 @@ struct GemmNT {
 __device__ __forceinline__ int swz_x(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int swz_w(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
 
+// Epilogue of one wave's (MT*16) x (NT*16) sub-tile: lane (lg, lr) owns row m_base + mt*16 + lr and the 8 consecutive
+// columns n_base + np*32 + 8*lg .. +7 of every (mt, np): bias / GELU in registers, one 16-B store per (mt, np).
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmNT& g, f32x4 (&acc)[MT][NT], int m_base, int n_base, int lr, int lg) {
+  const bool vec_c = (g.ldc % 8) == 0;
+#pragma unroll
+  for (int np = 0; np < NT / 2; ++np) {
+    const int nb = n_base + np * 32 + 8 * lg;
+    float bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = (g.bias != nullptr && nb + i < g.N) ? g.bias[nb + i] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m_base + mt * 16 + lr;
+      if (m >= g.M || nb >= g.N) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = acc[mt][2 * np][i] + bv[i];
+        v[4 + i] = acc[mt][2 * np + 1][i] + bv[4 + i];
+      }
+      const bool full = (nb + 8 <= g.N) && vec_c;
+      if (EPI == EPI_F32 || EPI == EPI_F32_ACC) {
+        float* cp = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + nb;
+        if (EPI == EPI_F32_ACC) {
+          for (int i = 0; i < 8; ++i)
+            if (nb + i < g.N) v[i] += cp[i];
+        }
+        if (full) {
+          *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          for (int i = 0; i < 8; ++i)
+            if (nb + i < g.N) cp[i] = v[i];
+        }
+      } else {
+        bf16* cp = reinterpret_cast<bf16*>(g.C) + (long)m * g.ldc + nb;
+        bf16x8 o;
+        if (EPI == EPI_GELU) {
+          bf16* ap = g.aux + (long)m * g.ldaux + nb;
+          bf16x8 pre;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            pre[i] = f2bf(v[i]);
+            o[i] = f2bf(gelu_f(bf2f(pre[i])));  // GELU of the bf16-rounded pre-activation: bwd recomputes from `aux`
+          }
+          if (full) *reinterpret_cast<bf16x8*>(ap) = pre;
+          else
+            for (int i = 0; i < 8; ++i)
+              if (nb + i < g.N) ap[i] = pre[i];
+        } else if (EPI == EPI_DGELU) {
+          const bf16* ap = g.aux + (long)m * g.ldaux + nb;
+          if (full) {
+            const bf16x8 pre = *reinterpret_cast<const bf16x8*>(ap);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i] * gelu_grad_f(bf2f(pre[i])));
+          } else {
+            for (int i = 0; i < 8; ++i) o[i] = (nb + i < g.N) ? f2bf(v[i] * gelu_grad_f(bf2f(ap[i]))) : f2bf(0.f);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+        }
+        if (full) *reinterpret_cast<bf16x8*>(cp) = o;
+        else
+          for (int i = 0; i < 8; ++i)
+            if (nb + i < g.N) cp[i] = o[i];
+      }
+    }
+  }
+}
+
+
 template <int BM, int BN, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
   constexpr int MT = BM / 32, NT = BN / 32;
@@ -108,73 +181,122 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
     __syncthreads();
   }
 
-  // epilogue: lane (lg, lr) owns row m = ..+lr, columns nb .. nb+7 for every (mt, np)
-  const bool vec_c = (g.ldc % 8) == 0;
+  gemm_epilogue<MT, NT, EPI>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), lr, lg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Large-M variant: 256 x 128 tile, 8 waves (4 x 2, the same 64 x 64 micro-kernel per wave), one workgroup per CU, and a
+// 3-slot LDS ring (3 x 48 KiB) filled by direct-to-LDS loads that stay in flight ACROSS the per-step barrier: a counted
+// s_waitcnt vmcnt(6) retires only the slot about to be read while the next slot's 6 loads per wave keep flying, and
+// the slot after that is issued right behind the barrier.  The projections of this model sit at the MI355X ridge
+// (N = 768, K = 768: ~370 FLOP/B), so bytes in flight per CU, not MFMA issue, decide their speed.
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmNT g) {
+  constexpr int BM = 256, BN = 128, MT = 4, NT = 4;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;  // 48 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+
+  auto stage = [&](int slot, int kt) {  // 48 wave-instructions of 1 KiB: 6 per wave (4 of A, 2 of B)
+    char* sA = smem + slot * STAGE;
+    char* sB = sA + A_BYTES;
+    const int k0 = kt * 64;
 #pragma unroll
-  for (int np = 0; np < NT / 2; ++np) {
-    const int nb = n0 + wn * (BN / 2) + np * 32 + 8 * lg;
-    float bv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bv[i] = (g.bias != nullptr && nb + i < g.N) ? g.bias[nb + i] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = m0 + wm * (BM / 2) + mt * 16 + lr;
-      if (m >= g.M || nb >= g.N) continue;
-      float v[8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        v[i] = acc[mt][2 * np][i] + bv[i];
-        v[4 + i] = acc[mt][2 * np + 1][i] + bv[4 + i];
-      }
-      const bool full = (nb + 8 <= g.N) && vec_c;
-      if (EPI == EPI_F32 || EPI == EPI_F32_ACC) {
-        float* cp = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + nb;
-        if (EPI == EPI_F32_ACC) {
-          for (int i = 0; i < 8; ++i)
-            if (nb + i < g.N) v[i] += cp[i];
-        }
-        if (full) {
-          *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        } else {
-          for (int i = 0; i < 8; ++i)
-            if (nb + i < g.N) cp[i] = v[i];
-        }
-      } else {
-        bf16* cp = reinterpret_cast<bf16*>(g.C) + (long)m * g.ldc + nb;
-        bf16x8 o;
-        if (EPI == EPI_GELU) {
-          bf16* ap = g.aux + (long)m * g.ldaux + nb;
-          bf16x8 pre;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            pre[i] = f2bf(v[i]);
-            o[i] = f2bf(gelu_f(bf2f(pre[i])));  // GELU of the bf16-rounded pre-activation: bwd recomputes from `aux`
-          }
-          if (full) *reinterpret_cast<bf16x8*>(ap) = pre;
-          else
-            for (int i = 0; i < 8; ++i)
-              if (nb + i < g.N) ap[i] = pre[i];
-        } else if (EPI == EPI_DGELU) {
-          const bf16* ap = g.aux + (long)m * g.ldaux + nb;
-          if (full) {
-            const bf16x8 pre = *reinterpret_cast<const bf16x8*>(ap);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i] * gelu_grad_f(bf2f(pre[i])));
-          } else {
-            for (int i = 0; i < 8; ++i) o[i] = (nb + i < g.N) ? f2bf(v[i] * gelu_grad_f(bf2f(ap[i]))) : f2bf(0.f);
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
-        }
-        if (full) *reinterpret_cast<bf16x8*>(cp) = o;
-        else
-          for (int i = 0; i < 8; ++i)
-            if (nb + i < g.N) cp[i] = o[i];
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int blk = i * 8 + w;
+      const int r = blk * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz_x(r);
+      int gr = m0 + r;
+      gr = gr < g.M ? gr : g.M - 1;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, g.A + (long)gr * g.lda + k0 + c * 8), LDS_PTR(void, sA + blk * 1024), 16, 0, 0);
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int blk = i * 8 + w;
+      const int r = blk * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz_w(r);
+      int gr = n0 + r;
+      gr = gr < g.N ? gr : g.N - 1;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, g.B + (long)gr * g.ldb + k0 + c * 8), LDS_PTR(void, sB + blk * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int xrow[MT], wrow[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) xrow[mt] = wm * 64 + mt * 16 + lr;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = wn * 64 + (nt >> 1) * 32 + 8 * (lr >> 2) + 4 * (nt & 1) + (lr & 3);
+
+  const int nk = g.K / 64;
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // retire slot `kt` (this wave's share), keep the 6 loads of slot kt+1 in flight across the barrier
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's share of slot kt has landed; everyone is done reading slot kt-1
+    if (kt + 2 < nk) stage(slot == 0 ? 2 : slot - 1, kt + 2);  // (kt+2) % 3 == (kt-1) % 3: the slot just released
+    const char* sA = smem + slot * STAGE;
+    const char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ks * 4 + lg;
+      bf16x8 xf[MT], wf[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        xf[mt] = *reinterpret_cast<const bf16x8*>(sA + xrow[mt] * 128 + ((c ^ swz_x(xrow[mt])) << 4));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        wf[nt] = *reinterpret_cast<const bf16x8*>(sB + wrow[nt] * 128 + ((c ^ swz_w(wrow[nt])) << 4));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+    }
+    slot = slot == 2 ? 0 : slot + 1;
   }
+  gemm_epilogue<MT, NT, EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, lr, lg);
+}
+
+static int launch_nt_ring(const GemmNT& g, int epi, hipStream_t st) {
+  const int tiles = cdiv(g.M, 256) * cdiv(g.N, 128);
+  const size_t smem = 3 * (256 + 128) * 128;
+#define XFM_RING_CASE(E)                                                                                       \
+  case E: {                                                                                                    \
+    static bool attr_set = false;                                                                              \
+    if (!attr_set) {                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<E>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
+      attr_set = true;                                                                                         \
+    }                                                                                                          \
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<E>), dim3(tiles), dim3(512), smem, st, g);                         \
+    break;                                                                                                     \
+  }
+  switch (epi) {
+    XFM_RING_CASE(EPI_BF16)
+    XFM_RING_CASE(EPI_F32)
+    XFM_RING_CASE(EPI_GELU)
+    XFM_RING_CASE(EPI_DGELU)
+    XFM_RING_CASE(EPI_F32_ACC)
+    default:
+      xfm_set_error("gemm_nt: bad epilogue %d", epi);
+      return XFM_E_ARG;
+  }
+#undef XFM_RING_CASE
+  return xfm_check_launch("gemm_nt_ring");
 }
 
 template <int BM, int BN>
@@ -217,13 +339,15 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
   GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K};
   int cfg = tile_hint;
   if (cfg <= 0) {  // measured on MI355X (tools/tune_gemm.py): 128x128 pays from ~3 workgroups per CU, else go smaller
-    if ((long)cdiv(M, 128) * cdiv(N, 128) >= 800) cfg = 1;
+    if ((long)cdiv(M, 256) * cdiv(N, 128) >= 768) cfg = 4;  // >= 3 rounds of 256x128 tiles: the 3-slot ring wins on cold operands
+    else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 800) cfg = 1;
     else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 256) cfg = 2;
     else cfg = 3;
   }
   switch (cfg) {
     case 1: return launch_nt<128, 128>(g, epi, st);
     case 2: return launch_nt<64, 128>(g, epi, st);
+    case 4: return launch_nt_ring(g, epi, st);
     default: return launch_nt<64, 64>(g, epi, st);
   }
 }

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void reduce_sets_kernel(ReduceSets r) {
 
 int xfm_ln_bwd_grid(int rows) {
   int blocks = cdiv(rows, 16);  // >= 4 rows per wave so the column sums amortise
-  if (blocks > 256) blocks = 256;
+  if (blocks > 768) blocks = 768;  // 3 blocks (12 waves) per CU: the kernel is HBM-bound and needs the loads in flight
   if (blocks < 1) blocks = 1;
   return blocks;
 }

@@ -191,18 +191,22 @@ def _stat_ld(Sq):
     return (Sq + 3) // 4 * 4
 
 
-def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t=None):
+def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t=None, kv_index=None):
     for t in (q, k, v, o):
         assert t.dtype == BF16 and t.stride(-1) == 1 and t.dim() == 2
     assert lse.shape[-1] == _stat_ld(Sq)
+    if kv_index is not None:
+        assert kv_index.dtype == torch.int32 and kv_index.numel() == B and kv_index.is_contiguous()
     return AttnArgs(stat_ld=lse.shape[-1], bias_t=_ptr(bias_t), bias_t_ld=0 if bias_t is None else bias_t.stride(1),
+                    kv_index=_ptr(kv_index),
                     q=q.data_ptr(), q_rs=q.stride(0), k=k.data_ptr(), k_rs=k.stride(0), v=v.data_ptr(), v_rs=v.stride(0),
                     o=o.data_ptr(), o_rs=o.stride(0), lse=lse.data_ptr(), bias=_ptr(bias),
                     bias_ld=0 if bias is None else bias.stride(1), key_keep=_ptr(key_keep), B=B, H=H, Sq=Sq, Sk=Sk,
                     scale=scale, causal=int(causal), drop_thresh=drop[0], drop_scale=drop[1], seed_lo=drop[2], seed_hi=drop[3])
 
 
-def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0), save_o32=False):
+def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0), save_o32=False,
+             kv_index=None):
     """q [B*Sq, >=H*64] / k, v [B*Sk, ...] are 2-D (possibly strided column slices of fused projection buffers).
     bias: dense fp32 [H,Sq,ld]; key_keep: int32 [B,Sk].  Returns (o [B*Sq, H*64] bf16, lse [B,H,Sq])."""
     _dev(q)
@@ -210,7 +214,7 @@ def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=Fals
     lse = torch.empty((B, H, _stat_ld(Sq)), dtype=F32, device=q.device)
     if key_keep is not None:
         assert key_keep.dtype == torch.int32 and key_keep.is_contiguous()
-    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop)
+    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, kv_index=kv_index)
     o32 = None
     if save_o32:  # fp32 copy of the output for the backward's delta = rowsum(dO * O) (training only)
         o32 = torch.empty((B * Sq, H * 64), dtype=F32, device=q.device)
@@ -220,9 +224,9 @@ def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=Fals
 
 
 def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, dbias=None, key_keep=None, causal=False,
-             drop=(0, 1.0, 0, 0), o32=None, bias_t=None):
+             drop=(0, 1.0, 0, 0), o32=None, bias_t=None, kv_index=None):
     """Writes dq/dk/dv (2-D bf16 views with the same addressing convention as q/k/v); dbias (fp32 [H,Sq,ld]) += ."""
-    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t)
+    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t, kv_index)
     delta = torch.zeros((B, H, lse.shape[-1]), dtype=F32, device=q.device)
     assert dout.dtype == BF16 and dout.stride(-1) == 1
     a.dout, a.do_rs = dout.data_ptr(), dout.stride(0)
@@ -231,6 +235,17 @@ def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, 
     a.dv, a.dv_rs = dv.data_ptr(), dv.stride(0)
     a.delta, a.dbias, a.o32 = delta.data_ptr(), _ptr(dbias), _ptr(o32)
     check(_lib.load().xfm_attn_bwd(ctypes.byref(a), _stream()), "attn_bwd")
+
+
+def rows_index_sum(src, index, U, rows_per_item):
+    """src bf16 [R*rows_per_item, C] -> [U*rows_per_item, C]: item u = sum of the items r with index[r] == u."""
+    R = index.numel()
+    C = src.shape[1]
+    assert src.is_contiguous() and src.dtype == BF16 and src.shape[0] == R * rows_per_item
+    dst = torch.empty((U * rows_per_item, C), dtype=BF16, device=src.device)
+    check(_lib.load().xfm_rows_index_sum(src.data_ptr(), index.data_ptr(), R, U, rows_per_item * C, dst.data_ptr(), _stream()),
+          "rows_index_sum")
+    return dst
 
 
 def relpos_gather(table, index32, H, N, ld, transposed=False):

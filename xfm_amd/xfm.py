@@ -309,13 +309,16 @@ class XFMBase(nn.Module):
         if self.detach_text_forMLM:
             mlm_embeds = mlm_embeds.detach()
         itm_text = text_embeds.detach() if is_pretrain else text_embeds
-        image_all = torch.cat([image_embeds, image_embeds.index_select(0, image_neg_idx), image_embeds, image_embeds], dim=0)
-        image_atts_all = torch.cat([image_atts, image_atts.index_select(0, image_neg_idx), image_atts, image_atts], dim=0)
+        # every fusion row attends to one of the B unique images: project K/V once per image and layer and let the
+        # attention kernels gather them by index (the reference re-projects the duplicated image rows 4x, xfm.py:781-793)
+        ar = torch.arange(bs, device=image_embeds.device)
+        enc_index = torch.cat([ar, image_neg_idx, ar, ar]).to(torch.int32)
         text_all = torch.cat([itm_text, itm_text, itm_text.index_select(0, text_neg_idx), mlm_embeds], dim=0)
         text_atts_all = torch.cat([text_atts, text_atts, text_atts.index_select(0, text_neg_idx), text_atts], dim=0)
         self._ready()
-        seq = self.fusion_encoder.bert(encoder_embeds=text_all, attention_mask=text_atts_all, encoder_hidden_states=image_all,
-                                       encoder_attention_mask=image_atts_all, return_dict=True).last_hidden_state
+        seq = self.fusion_encoder.bert(encoder_embeds=text_all, attention_mask=text_atts_all, encoder_hidden_states=image_embeds,
+                                       encoder_attention_mask=image_atts, return_dict=True,
+                                       encoder_batch_index=enc_index).last_hidden_state
         output = self.itm_head(seq[:3 * bs, 0, :])
         itm_labels = torch.cat([torch.ones(bs, dtype=torch.long), torch.zeros(2 * bs, dtype=torch.long)], dim=0).to(image_embeds.device)
         loss_itm = F.cross_entropy(output, itm_labels)

@@ -174,7 +174,7 @@ class _EncoderFn(torch.autograd.Function):
     """Layers [lo, hi) of a RobertaEncoder.  x: bf16 [B*T, D]; enc: bf16 [B*N, D] or None."""
 
     @staticmethod
-    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training):
+    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index):
         cfg = model.config
         D, H = cfg.hidden_size, cfg.num_attention_heads
         scale = 1.0 / math.sqrt(D // H)
@@ -203,7 +203,7 @@ class _EncoderFn(torch.autograd.Function):
                 d_att2, d_h2 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
                 q2 = Fx.gemm_nt(y1, s["q2"].wb, s["q2"].b)
                 kv = Fx.gemm_nt(enc, s["kv2"].wb, s["kv2"].b)
-                c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2); o32_2 = None; o32 = None
+                c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, kv_index=enc_index); o32_2 = None
                 h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
                 ln2 = co.output.LayerNorm
                 y2, z2, m2, r2 = Fx.ln_post_fwd(h2, y1, ln2.weight, ln2.bias, ln2.eps, d_h2)
@@ -217,7 +217,7 @@ class _EncoderFn(torch.autograd.Function):
             saved.append(rec)
             x = y3
         ctx.saved, ctx.model, ctx.enc = saved, model, enc
-        ctx.meta = (lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale)
+        ctx.meta = (lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index)
         ctx.noted = need_dx or need_denc
         if ctx.noted:
             arena_note_use(model)
@@ -226,7 +226,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         model, enc = ctx.model, ctx.enc
-        lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale = ctx.meta
+        lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index = ctx.meta
         cfg = model.config
         D, H = cfg.hidden_size, cfg.num_attention_heads
         g = grad_view
@@ -249,10 +249,13 @@ class _EncoderFn(torch.autograd.Function):
                                             dy2=d1b, drop=r["d_h2"])
                 Fx.gemm_tn(dh2, r["c2"], s["o2"].dw)
                 dc2 = Fx.gemm_nt(dh2, s["o2"].wt, n=s["o2"].K)
-                dq2, dkv = torch.empty_like(r["q2"]), torch.empty_like(r["kv"])
                 kv = r["kv"]
+                dq2 = torch.empty_like(r["q2"])
+                dkv = torch.empty((B * Nenc, 2 * D), dtype=BF16, device=dq2.device)  # per query row
                 Fx.attn_bwd(dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc,
-                            scale, key_keep=enc_keep, drop=r["d_att2"], o32=r["o32_2"])
+                            scale, key_keep=enc_keep, drop=r["d_att2"], kv_index=enc_index)
+                if enc_index is not None:  # fold onto the unique key/value sources
+                    dkv = Fx.rows_index_sum(dkv, enc_index, enc.shape[0] // Nenc, Nenc)
                 Fx.gemm_tn(dq2, r["y1"], s["q2"].dw, dbias=s["q2"].db)
                 Fx.gemm_tn(dkv, enc, s["kv2"].dw, dbias=s["kv2"].db)
                 if need_denc:
@@ -275,7 +278,7 @@ class _EncoderFn(torch.autograd.Function):
         denc = denc32.to(BF16) if need_denc else None
         if ctx.noted:
             arena_note_grad(model)
-        return (dx, denc) + (None,) * 10
+        return (dx, denc) + (None,) * 11
 
 
 class RobertaModel(nn.Module):
@@ -303,7 +306,9 @@ class RobertaModel(nn.Module):
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
                 inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
-                is_decoder=False, mode='multi_modal'):
+                is_decoder=False, mode='multi_modal', encoder_batch_index=None):
+        """`encoder_batch_index` (extension, default None = reference behaviour): int tensor [B] mapping every text row to the
+        row of `encoder_hidden_states` it attends to, so duplicated images are projected to K/V once per layer."""
         if any(v is not None for v in (token_type_ids, position_ids, head_mask, inputs_embeds, past_key_values)):
             raise NotImplementedError("token_type_ids/position_ids/head_mask/inputs_embeds/past_key_values are not used on the XFM path")
         if isinstance(encoder_hidden_states, (list, tuple)):
@@ -330,6 +335,9 @@ class RobertaModel(nn.Module):
             enc = enc.reshape(-1, enc.shape[-1])
             if encoder_attention_mask is not None:
                 enc_keep = encoder_attention_mask.to(device=dev, dtype=torch.int32).contiguous()
+            if encoder_batch_index is not None:
+                encoder_batch_index = encoder_batch_index.to(device=dev, dtype=torch.int32).contiguous()
+                assert encoder_batch_index.numel() == B
         if mode == 'text':
             lo, hi = 0, cfg.fusion_layer
         elif mode == 'fusion':
@@ -340,7 +348,8 @@ class RobertaModel(nn.Module):
             raise ValueError(f"mode {mode} is not supported")
         y = x.reshape(B * T, -1)
         if hi > lo:
-            y = _EncoderFn.apply(y, enc, self, key_keep, enc_keep, lo, hi, bool(is_decoder), B, T, Nenc, self.training)
+            y = _EncoderFn.apply(y, enc, self, key_keep, enc_keep, lo, hi, bool(is_decoder), B, T, Nenc, self.training,
+                                 encoder_batch_index if enc is not None else None)
         return SimpleNamespace(last_hidden_state=y.view(B, T, -1), pooler_output=None, past_key_values=None,
                                hidden_states=None, attentions=None, cross_attentions=None)
 
@@ -383,7 +392,7 @@ class RobertaForMaskedLM(nn.Module):
         self.attach(ParamArena(self, self.linear_slots(), device))
         return self
 
-    def bert(self, input_ids=None, **kw):
+    def bert(self, input_ids=None, **kw):  # accepts the reference's keywords plus `encoder_batch_index`
         return self.roberta(input_ids, **kw)
 
     def gather_seq_out_by_pos(self, seq, pos):
