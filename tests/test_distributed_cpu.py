@@ -1,0 +1,131 @@
+"""N > 1 path on CPU: world_size-2 `gloo` runs of the pieces that talk across ranks --
+  * RCCLDDPAccelerator: weight broadcast at set_up, live-range discovery, arena all-reduce (mean), skip of never-used ranges,
+    `.module` wrapper, clip -> step -> zero_grad contract (accelerators/ddp_accelerator.py:34-98 of the reference);
+  * the ITC all-gather with slice-only backward (xfm.py:81-101) against a single-process loss on the concatenated batch.
+The arena / accelerator code is device-agnostic; only the kernels need a GPU."""
+import os
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Tiny(nn.Module):
+    """Two 'towers' + an unused head, laid out in a ParamArena like XFMBase."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.fusion_encoder = nn.Module()
+        self.fusion_encoder.roberta = nn.Linear(8, 8)
+        self.text_encoder = nn.Module()
+        self.text_encoder.roberta = nn.Linear(8, 8)
+        self.vision_encoder = nn.Linear(8, 8)
+        self.unused_head = nn.Linear(8, 300)   # never receives a gradient (cf. lm_cap_head / bbox_head in XFM)
+        self._arena = None
+
+    def finalize(self, device=None):
+        from xfm_amd.arena import ParamArena
+        self._arena = ParamArena(self, (), device or torch.device("cpu"))
+        return self
+
+    def forward(self, x):
+        return self.fusion_encoder.roberta(self.text_encoder.roberta(self.vision_encoder(x)))
+
+
+def _accelerator_worker(rank, world, init_file, out):
+    from xfm_amd.accelerators import ACCELERATOR_MAP
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    model = Tiny()
+    if rank == 1:  # perturb rank 1: set_up must broadcast rank 0's weights
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    acc = ACCELERATOR_MAP["RCCLDDP"]({"RNG_SEED": 1, "CLIP_GRAD_NORM": 0.0, "GRAD_ACCUMULATE_STEPS": 1})
+    wrapped, opt, _ = acc.set_up(model, opt, None, local_rank=rank, world_size=world, rank=rank)
+    assert wrapped.module is model
+    w0 = model.vision_encoder.weight.detach().clone()
+    torch.manual_seed(100 + rank)
+    x = torch.randn(4, 8)
+    loss = wrapped(x).pow(2).mean()
+    acc.backward_step(loss, opt)
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    live = list(acc._live)
+    acc.optimizer_step(opt, model)
+    torch.save({"w0": w0, "grads": grads, "live": live, "x": x, "numel": model._arena.numel,
+                "unused_range": model._arena.range_of(list(model.unused_head.parameters())),
+                "w1": model.vision_encoder.weight.detach().clone(),
+                "grad_after": float(model._arena.grad.abs().max())}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def _spawn(fn, *args):
+    with tempfile.TemporaryDirectory() as d:
+        init = os.path.join(d, "init")
+        out = os.path.join(d, "out")
+        mp.spawn(fn, args=(2, init, out) + args, nprocs=2, join=True)
+        return [torch.load(out + f".{r}") for r in range(2)]
+
+
+def test_accelerator_broadcast_allreduce_and_step_world2():
+    r0, r1 = _spawn(_accelerator_worker)
+    assert torch.equal(r0["w0"], r1["w0"]), "set_up must broadcast rank 0's weights"
+    # reference: single process, mean of the two ranks' gradients
+    ref = Tiny()
+    gs = []
+    for r in (r0, r1):
+        ref.zero_grad()
+        ref(r["x"]).pow(2).mean().backward()
+        gs.append({n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None})
+    for n in gs[0]:
+        if n.startswith("unused_head"):
+            continue
+        want = (gs[0][n] + gs[1][n]) / 2
+        assert torch.allclose(r0["grads"][n], want, atol=1e-6), n
+        assert torch.allclose(r1["grads"][n], want, atol=1e-6), n
+    # the never-used head is outside every live chunk -> not exchanged
+    lo, hi = r0["unused_range"]
+    for a, b in r0["live"]:
+        assert b <= lo or a >= hi, f"live chunk {(a, b)} overlaps the unused range {(lo, hi)}"
+    assert r0["live"] == r1["live"]
+    # SGD step applied with the averaged gradient, identically on both ranks; gradients zeroed afterwards
+    want_w1 = r0["w0"] - 0.1 * (gs[0]["vision_encoder.weight"] + gs[1]["vision_encoder.weight"]) / 2
+    assert torch.allclose(r0["w1"], want_w1, atol=1e-6) and torch.equal(r0["w1"], r1["w1"])
+    assert r0["grad_after"] == 0.0
+
+
+def _itc_worker(rank, world, init_file, out):
+    from xfm_amd.xfm import allgather
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.manual_seed(7)
+    img_all = F.normalize(torch.randn(8, 16), dim=-1)
+    txt_all = F.normalize(torch.randn(8, 16), dim=-1)
+    img = img_all[rank * 4:(rank + 1) * 4].clone().requires_grad_(True)
+    txt = txt_all[rank * 4:(rank + 1) * 4].clone().requires_grad_(True)
+    ia, ta = allgather(img), allgather(txt)
+    logits = ia @ ta.t() / 0.07
+    labels = torch.arange(8)
+    loss = (F.cross_entropy(logits, labels) + F.cross_entropy(logits.t(), labels)) / 2
+    loss.backward()
+    torch.save({"loss": float(loss), "gi": img.grad, "gt": txt.grad, "img_all": img_all, "txt_all": txt_all}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_itc_allgather_slice_backward_world2():
+    from oracle import xfm_oracle as O
+    r0, r1 = _spawn(_itc_worker)
+    img = r0["img_all"].clone().requires_grad_(True)
+    txt = r0["txt_all"].clone().requires_grad_(True)
+    ref = O.contrastive_loss(img, txt, torch.tensor(0.07))
+    ref.backward()
+    assert abs(r0["loss"] - float(ref)) < 1e-6 and abs(r1["loss"] - float(ref)) < 1e-6
+    # slice-only backward (xfm.py:93-98): each rank keeps d(loss_on_this_rank)/d(its own slice), no reduce-scatter;
+    # the full-batch gradient is the SUM over ranks of those slices' contributions, i.e. world * (averaged DDP gradient)
+    # for the rows a rank owns it sees exactly the single-process gradient of those rows
+    assert torch.allclose(r0["gi"], img.grad[:4], atol=1e-6) and torch.allclose(r1["gi"], img.grad[4:], atol=1e-6)
+    assert torch.allclose(r0["gt"], txt.grad[:4], atol=1e-6) and torch.allclose(r1["gt"], txt.grad[4:], atol=1e-6)

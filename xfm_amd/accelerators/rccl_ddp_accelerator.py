@@ -215,7 +215,11 @@ class RCCLDDPAccelerator(Accelerator):
         if arena is None or not arena.grad.is_cuda:
             total = torch.nn.utils.clip_grad_norm_(model.parameters(), self.clip if self.clip > 0 else float("inf"))
             optimizer.step()
-            optimizer.zero_grad()
+            if arena is not None:
+                arena.bump()
+                arena.zero_grad()  # keeps .grad attached to the arena (optimizer.zero_grad() would drop the views)
+            else:
+                optimizer.zero_grad()
             return float(total)
         norm = self._grad_norm_sq().sqrt()
         clip_coef = None
