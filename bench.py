@@ -102,7 +102,7 @@ def cpu_baseline(model, batch_size):
     """The CPU oracle on the same architecture, same synthetic batch generator; bounded sample."""
     from oracle import xfm_oracle as O
     from xfm_amd import synthetic as syn
-    P = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    P = {k: (v.detach().float() if v.dtype.is_floating_point else v.detach()).cpu().clone() for k, v in model.state_dict().items()}
     for k in list(P):
         if k.endswith("decoder.bias"):
             P[k] = P[k[:-len("decoder.bias")] + "bias"]
@@ -181,7 +181,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t)
-    loss_vals = {k: round(float(v), 4) for k, v in losses.items() if k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim")}
+    loss_vals = {k: round(float(v.detach()), 4) for k, v in losses.items() if k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim")}
 
     # one instrumented step (outside the timed region): HIP events around every gemm_nt launch on the launch stream
     with GemmTimer() as gt:
