@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from xfm_amd import functional as Fx
 
-B, H, N, D = 64, 12, 197, 768
+B, H, N, D = 128, 12, 197, 768
 qkv = torch.randn(B * N, 3 * D, device="cuda").bfloat16()
 bias = torch.randn(H, N, 208, device="cuda")
 dout = torch.randn(B * N, D, device="cuda").bfloat16()
@@ -23,3 +23,10 @@ for it in range(iters):
 e.record()
 torch.cuda.synchronize()
 print("fwd us", s.elapsed_time(e) / iters * 1e3)
+s.record()
+for it in range(iters):
+    Fx.attn_bwd(dout, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                B, H, N, N, 0.125, bias=bias, dbias=dbias)
+e.record()
+torch.cuda.synchronize()
+print("bwd (dq + dkv) us", s.elapsed_time(e) / iters * 1e3)

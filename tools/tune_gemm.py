@@ -44,7 +44,7 @@ def main():
             res.append(f"{us:7.1f}us {2.0 * M * N * K / us / 1e6:6.0f}TF")
         del As, Bs, Os
         print(f"{M:6d} {N:6d} {K:6d} | " + " | ".join(res), flush=True)
-    print("== gemm_tn  (M,N,K): us / TFLOP/s per split count [auto,1,2,3,4,6,8,12,16]")
+    print("== gemm_tn  (M,N,K): us / TFLOP/s per split count [auto,-2(ring),2,3,4,6,8,12,16]")
     shapes_tn = [(B * 197, 2304, 768), (B * 197, 768, 768), (B * 197, 3072, 768), (B * 197, 768, 3072),
                  (B * 30, 2304, 768), (B * 30, 768, 768), (B * 30, 3072, 768), (3 * B * 30, 2304, 768), (3 * B * 30, 768, 768),
                  (3 * B * 30, 3072, 768), (3 * B * 197, 1536, 768)]
@@ -54,7 +54,7 @@ def main():
         xs = [torch.randn(M, K, device="cuda").bfloat16() for _ in range(nbuf)]
         dw = torch.zeros(N, K, device="cuda")
         res = []
-        for sp in (0, 1, 2, 3, 4, 6, 8, 12, 16):
+        for sp in (0, -2, 2, 3, 4, 6, 8, 12, 16):
             cnt = [0]
 
             def run():

@@ -10,6 +10,7 @@
 // Layouts: q/k/v/o are addressed as ptr[(b*S + s)*row_stride + h*64 + d], i.e. straight out of / into the fused
 // projection GEMM buffers ([B*S, 3*768] for self-attention, [B*Sk, 2*768] for the cross-attention K/V).
 #include "common.h"
+#include <stdlib.h>
 
 #define MASK_NEG (-10000.0f)
 #define EXCL_NEG (-1.0e30f)
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
   } else {
     stage_slot(lds, qb, a.q_rs, db, a.do_rs, 0, a.Sq, w, nw, lane);
   }
-  for (int qc = 0; qc < nchunks; ++qc) {
+  _Pragma("unroll 1") for (int qc = 0; qc < nchunks; ++qc) {
     if (!resident) {
       stage_wait();
       if (qc + 1 < nchunks) stage_slot(lds + ((qc + 1) & 1) * ATTN_SLOT, qb, a.q_rs, db, a.do_rs, (qc + 1) * 64, a.Sq, w, nw, lane);
@@ -474,55 +475,56 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
     const char* sQ = lds + (resident ? qc : (qc & 1)) * ATTN_SLOT;
     const char* sD = sQ + ATTN_TILE;
     if (!wave_active) continue;
-    f32x4 st[4], dp[4];  // D[i = query row][j = key col]: lane (lg, lr) -> query 16t + 4lg + r, key lr
-    f32x4 lsev[4], delv[4], bvt[4];
+    // one 32-query k-step at a time (two 16-query tiles): D[i = query row][j = key col], lane (lg, lr) -> query
+    // 16t + 4lg + r, key lr.  Half the live registers of a whole-chunk formulation, so two workgroups fit per CU.
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {  // row statistics and bias for this lane's 4 consecutive queries: 16-B loads, issued early
-      const int qi0 = qc * 64 + t * 16 + 4 * lg;
-      lsev[t] = delv[t] = bvt[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (qi0 < a.Sq) {
-        lsev[t] = *reinterpret_cast<const f32x4*>(lse_b + qi0);
-        delv[t] = *reinterpret_cast<const f32x4*>(del_b + qi0);
-        if (a.bias_t != nullptr && kvalid) bvt[t] = *reinterpret_cast<const f32x4*>(a.bias_t + ((long)h * a.Sk + kj) * a.bias_t_ld + qi0);
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f32x4 st[2], dp[2], pd[2], lsev[2], delv[2], bvt[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {  // row statistics / bias of this lane's 4 consecutive queries: 16-B loads, issued early
+        const int qi0 = qc * 64 + (2 * s2 + u) * 16 + 4 * lg;
+        lsev[u] = delv[u] = bvt[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (qi0 < a.Sq) {
+          lsev[u] = *reinterpret_cast<const f32x4*>(lse_b + qi0);
+          delv[u] = *reinterpret_cast<const f32x4*>(del_b + qi0);
+          if (a.bias_t != nullptr && kvalid) bvt[u] = *reinterpret_cast<const f32x4*>(a.bias_t + ((long)h * a.Sk + kj) * a.bias_t_ld + qi0);
+        }
       }
-    }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 0, lr, lg), kf0, st[t], 0, 0, 0);
-      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 1, lr, lg), kf1, st[t], 0, 0, 0);
-      dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 0, lr, lg), vf0, dp[t], 0, 0, 0);
-      dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 1, lr, lg), vf1, dp[t], 0, 0, 0);
-    }
-    f32x4 pd[4];  // dropped probabilities for dV
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int qi0 = qc * 64 + t * 16 + 4 * lg;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qi = qi0 + r;
-        const bool ok = qi < a.Sq && kvalid;
-        float biasv = bvt[t][r];
-        if (a.bias != nullptr && a.bias_t == nullptr && ok) biasv = a.bias[((long)h * a.Sq + qi) * a.bias_ld + kj];
-        float s = st[t][r] * a.scale + biasv;
-        if (key_masked || (a.causal && kj > qi)) s += MASK_NEG;
-        const float pv = ok ? __expf(s - lsev[t][r]) : 0.f;
-        float keepf = 1.f;
-        if (a.drop_thresh != 0u) keepf = (ok && drop_keep(a, b, h, qi, kj)) ? a.drop_scale : 0.f;
-        pd[t][r] = pv * keepf;
-        st[t][r] = pv * (dp[t][r] * keepf - delv[t][r]);
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * s2 + u;
+        st[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 0, lr, lg), kf0, st[u], 0, 0, 0);
+        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 1, lr, lg), kf1, st[u], 0, 0, 0);
+        dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 0, lr, lg), vf0, dp[u], 0, 0, 0);
+        dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 1, lr, lg), vf1, dp[u], 0, 0, 0);
       }
-    }
-    // dV^T[d, key] += dO^T[d, q] . Pd[q, key] ;  dK^T[d, key] += Q^T[d, q] . dS[q, key]
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8 pf = pack_pair(pd[2 * s], pd[2 * s + 1]);
-      const bf16x8 sf = pack_pair(st[2 * s], st[2 * s + 1]);
+      for (int u = 0; u < 2; ++u) {
+        const int qi0 = qc * 64 + (2 * s2 + u) * 16 + 4 * lg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = qi0 + r;
+          const bool ok = qi < a.Sq && kvalid;
+          float biasv = bvt[u][r];
+          if (a.bias != nullptr && a.bias_t == nullptr && ok) biasv = a.bias[((long)h * a.Sq + qi) * a.bias_ld + kj];
+          float sc = st[u][r] * a.scale + biasv;
+          if (key_masked || (a.causal && kj > qi)) sc += MASK_NEG;
+          const float pv = ok ? __expf(sc - lsev[u][r]) : 0.f;
+          float keepf = 1.f;
+          if (a.drop_thresh != 0u) keepf = (ok && drop_keep(a, b, h, qi, kj)) ? a.drop_scale : 0.f;
+          pd[u][r] = pv * keepf;
+          st[u][r] = pv * (dp[u][r] * keepf - delv[u][r]);
+        }
+      }
+      // dV^T[d, key] += dO^T[d, q] . Pd[q, key] ;  dK^T[d, key] += Q^T[d, q] . dS[q, key]
+      const bf16x8 pf = pack_pair(pd[0], pd[1]);
+      const bf16x8 sf = pack_pair(st[0], st[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sD, 32 * s, 32 * s + 16, dt * 16, lr, lg), pf, dvacc[dt], 0, 0, 0);
-        dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sQ, 32 * s, 32 * s + 16, dt * 16, lr, lg), sf, dkacc[dt], 0, 0, 0);
+        dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sD, 32 * s2, 32 * s2 + 16, dt * 16, lr, lg), pf, dvacc[dt], 0, 0, 0);
+        dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sQ, 32 * s2, 32 * s2 + 16, dt * 16, lr, lg), sf, dkacc[dt], 0, 0, 0);
       }
     }
   }
@@ -609,8 +611,9 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
   if (rc != XFM_OK) return rc;
   attn_geom(a.Sk, nw, blocks);
   const dim3 grid(blocks, a.H, a.B), blk(nw * 64);
-  if (attn_resident(a.Sq, nw)) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, blk, attn_lds_bytes(a.Sq, nw, 0), st, a);
-  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, blk, attn_lds_bytes(a.Sq, nw, 0), st, a);
+  static const bool dkv_res = getenv("XFM_ATTN_DKV_RES") ? atoi(getenv("XFM_ATTN_DKV_RES")) != 0 : true;  // tuning knob
+  if (dkv_res && attn_resident(a.Sq, nw)) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, blk, attn_lds_bytes(a.Sq, nw, 0), st, a);
+  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, blk, 2 * ATTN_SLOT, st, a);
   return xfm_check_launch("attn_bwd_dkv");
 }
 

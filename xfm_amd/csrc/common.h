@@ -39,12 +39,28 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
 
-// exact erf GELU (transformers ACT2FN["gelu"], torch.nn.GELU default) and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (transformers ACT2FN["gelu"], torch.nn.GELU default) and its derivative.  The GEMM epilogues evaluate them on
+// 64 elements per lane, so libm's erff (~45 VALU instructions per element) costs as much as the whole K = 768 MFMA loop.
+// erf is evaluated with Abramowitz-Stegun 7.1.25, |delta erf| <= 2.5e-5 -- two orders below the bf16 resolution (2^-9)
+// of the stored activation -- and shares its exp(-x^2/2) with the Gaussian density of the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.33267f, ax, 1.0f));              // 1 / (1 + 0.47047 |x| / sqrt(2))
+  const float e = __builtin_amdgcn_exp2f(-0.72134752f * x * x);                 // exp(-x^2 / 2)
+  const float poly = t * fmaf(t, fmaf(t, 0.7478556f, -0.0958798f), 0.3480242f);
+  const float erf_abs = fmaf(-poly, e, 1.0f);                                   // erf(|x| / sqrt(2))
+  cdf = fmaf(copysignf(0.5f, x), erf_abs, 0.5f);
+  pdf = 0.39894228040143267f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143267f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return fmaf(x, pdf, cdf);
 }
 
 // stateless 32-bit mixer for dropout masks: keep(element) is a pure function of (seed, element id)

@@ -502,13 +502,172 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large-M wgrad: 256 (n) x 128 (k) output tile, 8 waves, one workgroup per CU, 3-slot LDS ring (dY 64 x 256 + X 64 x 128
+// per slot = 48 KiB) filled by direct-to-LDS loads that stay in flight across the per-step barrier (counted vmcnt(6)).
+// The bias gradient rides along as MFMAs against an all-ones B fragment (sum_m dY[m,n] = dY^T . 1) in the k-tile-0
+// workgroups -- no extra pass over dY and no LDS re-reads.
+// ---------------------------------------------------------------------------------------------
+template <int ROW_BYTES>
+__device__ __forceinline__ bf16x8 tr_read_pair_rs(const char* tile, int row0, int col0, int lr) {
+  const int r = row0 + (lr >> 2);
+  const int col = col0 + 4 * (lr & 3);
+  const int off0 = r * ROW_BYTES + ((((col >> 3)) ^ swz_t(r)) << 4) + (col & 7) * 2;
+  const int r2 = r + 4;
+  const int off1 = r2 * ROW_BYTES + ((((col >> 3)) ^ swz_t(r2)) << 4) + (col & 7) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + off0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + off1));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmTN g) {
+  constexpr int Y_BYTES = 64 * 512, X_BYTES = 64 * 256, STAGE = Y_BYTES + X_BYTES;  // 48 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wn = w >> 1, wk = w & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int tiles_k = (g.K + 127) / 128, tiles_n = (g.N + 255) / 256;
+  const int per_split = tiles_k * tiles_n;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = wg / per_split, t = wg % per_split;
+  const int n0 = (t / tiles_k) * 256, k0 = (t % tiles_k) * 128;
+  const int mbeg = split * g.m_per_split;
+  int mend = mbeg + g.m_per_split;
+  mend = mend < g.M ? mend : g.M;
+  const int nsteps = (mend - mbeg + 63) / 64;
+  const bool do_bias = g.dbias != nullptr && k0 == 0 && wk == 0;
+
+  auto stage = [&](int slot, int step) {  // 32 wave-instructions for dY (2 rows each) + 16 for X (4 rows each): 6 per wave
+    char* sY = smem + slot * STAGE;
+    char* sX = sY + Y_BYTES;
+    const int mb = mbeg + step * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int blk = i * 8 + w;
+      const int r = blk * 2 + (lane >> 5);
+      const int c = (lane & 31) ^ swz_t(r);
+      int m = mb + r;
+      m = m < mend ? m : mend - 1;                 // tail rows are zeroed in LDS after they land (see below)
+      int nn = n0 + c * 8;
+      nn = nn < g.N ? nn : 0;                      // columns past N only feed masked outputs; keep the address in range
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, g.dY + (long)m * g.ldy + nn), LDS_PTR(void, sY + blk * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int blk = i * 8 + w;
+      const int r = blk * 4 + (lane >> 4);
+      const int c = (lane & 15) ^ swz_t(r);
+      int m = mb + r;
+      m = m < mend ? m : mend - 1;
+      int kk = k0 + c * 8;
+      kk = kk < g.K ? kk : 0;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, g.X + (long)m * g.ldx + kk), LDS_PTR(void, sX + blk * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4], bacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = f2bf(1.0f);
+
+  if (nsteps > 0) stage(0, 0);
+  if (nsteps > 1) stage(1, 1);
+  int slot = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < nsteps) stage(slot == 0 ? 2 : slot - 1, s + 2);
+    char* sY = smem + slot * STAGE;
+    char* sX = sY + Y_BYTES;
+    const int valid = mend - (mbeg + s * 64);  // rows of this step that exist
+    if (valid < 64) {                            // ragged last step: zero the duplicated rows of the dY tile
+      for (int q = tid; q < (64 - valid) * 32; q += 512) {
+        const int r = valid + (q >> 5), c = q & 31;
+        *reinterpret_cast<u32x4*>(sY + r * 512 + (c << 4)) = u32x4{0, 0, 0, 0};
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) af[nt] = tr_read_pair_rs<512>(sY, ks * 32 + 8 * lg, wn * 64 + nt * 16, lr);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) bfr[kt] = tr_read_pair_rs<256>(sX, ks * 32 + 8 * lg, wk * 64 + kt * 16, lr);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], ones, bacc[nt], 0, 0, 0);
+      }
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = k0 + wk * 64 + kt * 16 + lr;
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi) {
+        const int n = n0 + wn * 64 + nt * 16 + 4 * lg + rgi;
+        if (n < g.N && k < g.K) atomicAdd(g.dW + (long)n * g.ldw + k, acc[nt][kt][rgi]);
+      }
+    }
+    if (do_bias && lr == 0) {  // every column of the ones-product holds the row sum: take column 0
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi) {
+        const int n = n0 + wn * 64 + nt * 16 + 4 * lg + rgi;
+        if (n < g.N) atomicAdd(g.dbias + n, bacc[nt][rgi]);
+      }
+    }
+  }
+}
+
 int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, float* dbias, int M, int N, int K,
                      int splits_hint, hipStream_t st) {
   XFM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
   XFM_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "gemm_tn: K=%d ldx=%ld ldy=%ld must be multiples of 8", K, ldx, ldy);
   XFM_REQUIRE(((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0, "gemm_tn: operands must be 16-byte aligned");
+  // splits_hint == -2 selects the experimental 256 x 128 ring variant (one workgroup per CU).  Measured on MI355X it is
+  // 10-25 % SLOWER than two co-resident 128 x 128 workgroups per CU: with a single round of lock-stepped workgroups the fp32
+  // atomic epilogue (128 KiB per workgroup) is fully exposed instead of overlapping the neighbour's MFMA loop.  Kept for
+  // tuning; the default is the register-staged 128 x 128 kernel below.
+  const int rtiles = cdiv(N, 256) * cdiv(K, 128);
+  if (splits_hint == -2 && M >= 4096 && rtiles <= 128 && N >= 256) {
+    int splits = 256 / rtiles;
+    const int max_splits = M / 512;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int mps = cdiv(cdiv(M, splits), 64) * 64;
+    splits = cdiv(M, mps);
+    GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, dbias, M, N, K, mps};
+    static bool ring_attr = false;
+    const size_t rsmem = 3 * 48 * 1024;
+    if (!ring_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)rsmem);
+      ring_attr = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(rtiles * splits), dim3(512), rsmem, st, g);
+    return xfm_check_launch("gemm_tn_ring");
+  }
   const int tiles = cdiv(N, 128) * cdiv(K, 128);
-  int splits = splits_hint;
+  int splits = splits_hint < 0 ? 0 : splits_hint;
   if (splits <= 0) {
     splits = (432 + tiles / 2) / tiles;        // measured optimum: ~432 workgroups in total (tools/tune_gemm.py)
     const int max_splits = M / 480;            // ... while every split still walks >= ~8 K-steps
