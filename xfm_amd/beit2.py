@@ -60,8 +60,13 @@ class BlockMaskGenerator:
             flat[rng.choice(used, count - self.num, replace=False)] = False
         return flat
 
-    def batch(self, n):
-        return torch.from_numpy(np.stack([self._one() for _ in range(n)], 0))
+    def batch(self, n, device=None):
+        """[n, h*w] bool.  With `device` the masks go up through pinned memory with a non-blocking copy, so the host thread
+        never waits for the GPU queue to drain (a pageable H2D copy is stream-ordered AND host-blocking)."""
+        m = torch.from_numpy(np.stack([self._one() for _ in range(n)], 0))
+        if device is not None and torch.device(device).type == "cuda":
+            return m.pin_memory().to(device, non_blocking=True)
+        return m
 
 
 def build_relative_position_index(gh, gw):
@@ -333,14 +338,17 @@ class VisionTransformer(nn.Module):
         tok = linear_slot(patches, self._slot_patch, x_requires_grad=False, out_fp32=True).view(B, -1, D)
         if do_mask:
             if ids_mask is None:
-                ids_mask = self.generator.batch(B)
+                ids_mask = self.generator.batch(B, x.device)
             ids_mask = ids_mask.to(device=x.device, dtype=torch.bool)
             w = ids_mask.unsqueeze(-1).to(tok.dtype)
             tok = tok * (1 - w) + self.mask_token.expand(B, tok.shape[1], -1) * w
         x0 = torch.cat([self.cls_token.expand(B, -1, -1), tok], dim=1)
         dp = drop_path_scales
         if dp is None and self.training:
-            keep = 1.0 - torch.tensor([[b.drop_path_prob] * 2 for b in self.blocks], device=x.device).view(-1, 2, 1)
+            keep = getattr(self, "_dp_keep", None)
+            if keep is None or keep.device != x.device:  # built once: a per-forward torch.tensor(..., device=cuda) would sync
+                keep = 1.0 - torch.tensor([[b.drop_path_prob] * 2 for b in self.blocks], device=x.device).view(-1, 2, 1)
+                self._dp_keep = keep
             dp = (torch.rand(len(self.blocks), 2, B, device=x.device) < keep).float() / keep
         y = _TrunkFn.apply(x0, self, dp)             # bf16 [B, N, D], fc_norm applied to every row
         patches_n = y[:, 1:]

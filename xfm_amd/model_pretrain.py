@@ -28,13 +28,13 @@ class XFM(XFMBase):
         if self.learnable_temp:
             self.temp.data.clamp_(self.min_temp, self.max_temp)  # via .data: leaves the arena's weight version untouched
         w = self.weights_map.get(data_source, None)
-        zero = torch.tensor(0.0, device=image.device)
+        zero = torch.zeros((), device=image.device)
         do_mim = ret_mim_loss and (data_source == 'imagenet' or self.use_mm_mim_loss)
         image_embeds_masked = None
         if self.batch_passes and do_mim and self.do_image_mask:
             B = image.shape[0]
             if ids_mask is None:
-                ids_mask = self.vision_encoder.generator.batch(B)
+                ids_mask = self.vision_encoder.generator.batch(B, image.device)
             ids_mask = ids_mask.to(device=image.device, dtype=torch.bool)
             both, _, _ = self.get_vision_embeds(torch.cat([image, image], dim=0), do_mask=True,
                                                 ids_mask=torch.cat([torch.zeros_like(ids_mask), ids_mask], dim=0))

@@ -287,7 +287,8 @@ class XFMBase(nn.Module):
         cross = self.get_cross_embeds(image_all, image_atts_all, text_embeds=text_all, text_atts=text_atts_all,
                                       is_pretrain=is_pretrain)[:, 0, :]
         output = self.itm_head(cross)
-        itm_labels = torch.cat([torch.ones(bs, dtype=torch.long), torch.zeros(2 * bs, dtype=torch.long)], dim=0).to(image_embeds.device)
+        dev = image_embeds.device  # built on the device: a host tensor + .to(device) is a blocking pageable copy
+        itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
         loss = F.cross_entropy(output, itm_labels)
         if return_cross_embeds:
             return loss, cross[:bs]
@@ -320,7 +321,8 @@ class XFMBase(nn.Module):
                                        encoder_attention_mask=image_atts, return_dict=True,
                                        encoder_batch_index=enc_index).last_hidden_state
         output = self.itm_head(seq[:3 * bs, 0, :])
-        itm_labels = torch.cat([torch.ones(bs, dtype=torch.long), torch.zeros(2 * bs, dtype=torch.long)], dim=0).to(image_embeds.device)
+        dev = image_embeds.device  # built on the device: a host tensor + .to(device) is a blocking pageable copy
+        itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
         loss_itm = F.cross_entropy(output, itm_labels)
         mlm_seq = self.fusion_encoder.gather_seq_out_by_pos(seq[3 * bs:], masked_pos)
         from .ops import lm_head_ce
