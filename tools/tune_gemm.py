@@ -67,5 +67,32 @@ def main():
         print(f"{M:6d} {N:6d} {K:6d} | " + " | ".join(res), flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "epi"):
     main()
+
+
+def epilogues():
+    """GELU / DGELU epilogue variants, cold operands: 128x128 (two workgroups per CU) vs the 256x128 ring (one per CU)."""
+    M, N, K = 25216, 3072, 768
+    nbuf = 6
+    As = [torch.randn(M, K, device="cuda").bfloat16() for _ in range(nbuf)]
+    Bs = [(torch.randn(N, K, device="cuda") * 0.05).bfloat16() for _ in range(nbuf)]
+    Os = [torch.empty(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(nbuf)]
+    Us = [torch.randn(M, N, device="cuda").bfloat16() for _ in range(nbuf)]
+    bias = torch.randn(N, device="cuda")
+    for name, epi in (("plain", Fx.EPI_BF16), ("gelu", Fx.EPI_GELU), ("dgelu", Fx.EPI_DGELU)):
+        res = []
+        for hint in (1, 2, 4):
+            cnt = [0]
+
+            def run():
+                i = cnt[0] % nbuf
+                cnt[0] += 1
+                Fx.gemm_nt(As[i], Bs[i], bias if epi != Fx.EPI_DGELU else None, epi=epi, aux=Us[i], out=Os[i], tile_hint=hint)
+            us = timeit(run)
+            res.append(f"hint{hint}: {us:7.1f}us {2.0 * M * N * K / us / 1e6:5.0f}TF")
+        print(f"{name:6s} {M}x{N}x{K} | " + " | ".join(res), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "epi":
+    epilogues()

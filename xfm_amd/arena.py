@@ -57,19 +57,33 @@ class LinearSlot:
         self.K = self.weights[0].numel() // self.weights[0].shape[0]
         self.ldt = _round(self.N, pad_k_to) if pad_k_to > 1 else _round(self.N, 8)
         self.w = self.dw = self.b = self.db = None
-        self.wb = self.wt = None
+        self._wb = self._wt = None
         self._ver = None
+        self._arena = None
         self.need_t = True
 
-    def refresh(self, ver):
+    # bf16 operands are (re)built lazily, on first use after the arena version moved: slots a step never touches (the
+    # text tower's LM head, both caption heads, the bbox head) are never cast at all
+    def _ensure(self):
+        ver = self._arena._manual_ver
         if self._ver == ver:
             return
-        dev = self.w.device
-        if self.wb is None:
-            self.wb = torch.empty((self.N, self.K), dtype=torch.bfloat16, device=dev)
-            self.wt = torch.zeros((self.K, self.ldt), dtype=torch.bfloat16, device=dev) if self.need_t else None
-        Fx.cast_transpose(self.w, self.wb, self.wt)
+        if self._wb is None:
+            dev = self.w.device
+            self._wb = torch.empty((self.N, self.K), dtype=torch.bfloat16, device=dev)
+            self._wt = torch.zeros((self.K, self.ldt), dtype=torch.bfloat16, device=dev) if self.need_t else None
+        Fx.cast_transpose(self.w, self._wb, self._wt)
         self._ver = ver
+
+    @property
+    def wb(self):
+        self._ensure()
+        return self._wb
+
+    @property
+    def wt(self):
+        self._ensure()
+        return self._wt
 
 
 class ParamArena:
@@ -133,6 +147,7 @@ class ParamArena:
             self.offsets[id(p)] = (o, n)
         self.names = {id(p): name for name, p in params}
         for s in self.slots:
+            s._arena = self
             wr, br = group_ranges[(id(s), "w")], group_ranges.get((id(s), "b"))
             s.w = self.data[wr[0]:wr[1]].view(s.N, s.K)
             s.dw = self.grad[wr[0]:wr[1]].view(s.N, s.K)
@@ -154,9 +169,7 @@ class ParamArena:
         self._manual_ver += 1
 
     def refresh(self):
-        v = self.version()
-        for s in self.slots:
-            s.refresh(v)
+        """bf16 operand copies refresh themselves lazily (LinearSlot.wb / .wt); kept for callers of the old eager API."""
 
     def zero_grad(self):
         self.grad.zero_()

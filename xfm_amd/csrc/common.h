@@ -92,4 +92,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
 }
+// Grouped tile order (after xcd_remap): consecutive logical ids walk GM row-panels down M before stepping to the next
+// column tile, so the ~32-64 tiles an XCD runs at once share a few A panels AND a few B tiles -- their live working set fits
+// the XCD's private 4 MiB L2 instead of streaming every B tile from the Infinity Cache.
+__device__ __forceinline__ void grouped_tile(int wg, int tiles_m, int tiles_n, int GM, int& tm, int& tn) {
+  const int gsz = GM * tiles_n;
+  const int gid = wg / gsz, in = wg - gid * gsz;
+  const int first = gid * GM;
+  const int gm = (tiles_m - first) < GM ? (tiles_m - first) : GM;
+  tm = first + in % gm;
+  tn = in / gm;
+}
 #endif

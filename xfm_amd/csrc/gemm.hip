@@ -11,6 +11,7 @@
 // C^T tiles (A-operand = weight rows, B-operand = activation rows) so that after the K loop every lane owns 8
 // CONSECUTIVE output columns of one output row: bias/GELU are applied in registers and the row is stored 16 B per lane.
 #include "common.h"
+#include <stdlib.h>
 
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_DGELU = 3, EPI_F32_ACC = 4 };
 
@@ -21,6 +22,7 @@ struct GemmNT {
   const float* bias;
   bf16* aux; long ldaux;
   int M, N, K;
+  int group_m;  // row-panels per tile group (L2 locality of the block order)
 };
 
 // LDS swizzles (16-B chunk index XOR) for 128-B tile rows read with ds_read_b128.
@@ -109,9 +111,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   const int lr = lane & 15, lg = lane >> 4;
-  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+  int tm, tn;
+  grouped_tile(wg, tiles_m, tiles_n, g.group_m, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
 
   auto stage = [&](int buf, int kt) {
     char* sA = smem + buf * STAGE;
@@ -199,9 +203,11 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmNT g) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   const int lr = lane & 15, lg = lane >> 4;
-  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+  int tm, tn;
+  grouped_tile(wg, tiles_m, tiles_n, g.group_m, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
 
   auto stage = [&](int slot, int kt) {  // 48 wave-instructions of 1 KiB: 6 per wave (4 of A, 2 of B)
     char* sA = smem + slot * STAGE;
@@ -336,7 +342,8 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
   XFM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
               "gemm_nt: operands must be 16-byte aligned");
   XFM_REQUIRE((epi != EPI_GELU && epi != EPI_DGELU) || aux != nullptr, "gemm_nt: epilogue %d needs aux", epi);
-  GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K};
+  static const int gm_env = getenv("XFM_GEMM_GROUP_M") ? atoi(getenv("XFM_GEMM_GROUP_M")) : 0;  // tuning knob
+  GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K, gm_env > 0 ? gm_env : 8};
   int cfg = tile_hint;
   if (cfg <= 0) {  // measured on MI355X (tools/tune_gemm.py): 128x128 pays from ~3 workgroups per CU, else go smaller
     if ((long)cdiv(M, 256) * cdiv(N, 128) >= 768) cfg = 4;  // >= 3 rounds of 256x128 tiles: the 3-slot ring wins on cold operands
