@@ -190,6 +190,16 @@ def main():
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     ms_per_step = elapsed / args.steps * 1e3
 
+    traffic, traffic_note = None, None
+    tpath = os.path.join(ROOT, "profiles", "round1_hbm_traffic.json")
+    if os.path.exists(tpath):  # PMC passes are separate rocprofv3 runs of this same command (profiles/README.md)
+        with open(tpath) as f:
+            tj = json.load(f)
+        fam = tj["families"].get("gemm_nt")
+        if fam and abs(fam["launches_per_step"] - nlaunch) <= 0.05 * nlaunch:
+            traffic = fam["hbm_bytes_per_step_corrected"]
+            traffic_note = "bytes beyond L2 per step over the same launches, from committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes " \
+                           "(2 x FETCH_SIZE + WRITE_SIZE, KB); Infinity-Cache hits are counted"
     if rank == 0:
         out = {
             "metric": "image-text pairs/sec fwd+bwd, XFM-base 224px/30tok",
@@ -208,7 +218,7 @@ def main():
             "losses_last_step": loss_vals,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (all forward + dgrad GEMM launches of one step)",
                          "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "launches": nlaunch, "kernel_ms_per_step": round(gemm_ms, 3),
                          "flop_per_step": gemm_flop},
         }
