@@ -114,7 +114,6 @@ typedef struct {
   xfm_bf16* dq; long dq_rs; xfm_bf16* dk; long dk_rs; xfm_bf16* dv; long dv_rs;
   float* delta;                   /* [B,H,stat_ld] scratch */
   float* dbias;                   /* [H,Sq,bias_ld] fp32, += over the batch, or NULL */
-  float* o32;                     /* optional fp32 copy of o, dense [B*Sq, H*64], written by fwd */
   long stat_ld;                   /* row stride of lse / delta ([B,H,stat_ld]): multiple of 4, >= Sq */
   const float* bias_t; long bias_t_ld; /* optional transposed copy of bias [H,Sk,bias_t_ld] (vector loads in dK/dV) */
   const int* kv_index;            /* optional [B]: query batch row b reads keys/values (and key_keep) of source kv_index[b];
@@ -151,8 +150,9 @@ int xfm_embed_ln_bwd(const xfm_embed_args* a, int D, float* dgamma, float* dbeta
 
 /* ---- Vocabulary cross-entropy, ignore_index -100 (xroberta.py:1296-1297, 1107-1114) ------------------------------ */
 int xfm_ce_fwd(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, void* stream);
+/* dlogits = (softmax - onehot) * scale[0]  (per_row_scale = 0: mean / sum reductions) or * scale[row] (reduction 'none'). */
 int xfm_ce_bwd(const float* logits, long ld, int R, int V, const int64_t* labels, const float* lse, const float* scale,
-               xfm_bf16* dlogits, long ldd, void* stream);
+               int per_row_scale, xfm_bf16* dlogits, long ldd, void* stream);
 
 /* ---- Flat-arena optimiser step (optim.py:4-50 + clip, apex_ddp_accelerator.py:100-110) --------------------------- */
 typedef struct {

@@ -43,7 +43,7 @@ class AttnArgs(ctypes.Structure):
                 ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32),
                 ("dout", c_void_p), ("do_rs", c_long), ("dq", c_void_p), ("dq_rs", c_long), ("dk", c_void_p),
                 ("dk_rs", c_long), ("dv", c_void_p), ("dv_rs", c_long), ("delta", c_void_p), ("dbias", c_void_p),
-                ("o32", c_void_p), ("stat_ld", c_long), ("bias_t", c_void_p), ("bias_t_ld", c_long), ("kv_index", c_void_p)]
+                ("stat_ld", c_long), ("bias_t", c_void_p), ("bias_t_ld", c_long), ("kv_index", c_void_p)]
 
 
 class EmbedArgs(ctypes.Structure):
@@ -86,7 +86,7 @@ SIGNATURES = {
     "xfm_embed_ln_bwd": (c_int, [ctypes.POINTER(EmbedArgs), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long,
                                  c_void_p]),
     "xfm_ce_fwd": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "xfm_ce_bwd": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "xfm_ce_bwd": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p]),
     "xfm_adamw": (c_int, [ctypes.POINTER(AdamWArgs), c_void_p]),
     "xfm_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
 }

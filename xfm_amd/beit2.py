@@ -170,8 +170,7 @@ class _TrunkFn(torch.autograd.Function):
             s = vit._slots[i]
             dense, dense_t = Fx.relpos_gather(blk.attn.relative_position_bias_table, vit._index32, H, N, ld, transposed=True)
             qkv = Fx.gemm_nt(y, s["qkv"].wb, s["qkv"].b)
-            ctxv, lse = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense,
-                                         )
+            ctxv, lse = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense)
             h1 = Fx.gemm_nt(ctxv, s["proj"].wb, s["proj"].b)
             dp1 = None if dp is None else dp[i, 0]
             dp2 = None if dp is None else dp[i, 1]

@@ -226,15 +226,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
   if (!wave_active || qi >= a.Sq) return;
   const float inv = 1.0f / l_run;
   bf16* op = a.o + ((long)b * a.Sq + qi) * a.o_rs + h * 64;
-  float* op32 = a.o32 ? a.o32 + ((long)b * a.Sq + qi) * (a.H * 64) + h * 64 : nullptr;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     bf16x4 ov;
-    f32x4 of;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { of[r] = oacc[dt][r] * inv; ov[r] = f2bf(of[r]); }
+    for (int r = 0; r < 4; ++r) ov[r] = f2bf(oacc[dt][r] * inv);
     *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * lg) = ov;
-    if (op32 != nullptr) *reinterpret_cast<f32x4*>(op32 + dt * 16 + 4 * lg) = of;
   }
   if (lg == 0) a.lse[((long)b * a.H + h) * a.stat_ld + qi] = m_run + __logf(l_run);
 }
@@ -244,8 +241,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
 // NKC > 0 selects the bias-gradient variant (Sk <= 64*NKC): one workgroup walks `nb_per_block` batch entries and keeps
 // sum_b dS in registers, then flushes it through a wave-private LDS transpose so that every atomic wave-instruction
 // adds 64 consecutive keys of one bias row (256 contiguous bytes; MI355X_MICROARCH "Global float atomics").
-// delta_i = sum_d dO_id * O_id uses the forward's fp32 copy of O when present: with the bf16-rounded O the identity
-// sum_j P_ij (dP_ij - delta_i) = 0 is broken by ~2^-9 |dO||O| per row, which dominates small dS.
+// delta_i is recomputed exactly as sum_j P_ij dP_ij in a first pass over the keys (see below).
 // ---------------------------------------------------------------------------------------------
 template <int NKC, bool RES>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per_block) {

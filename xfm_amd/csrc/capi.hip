@@ -131,9 +131,9 @@ int xfm_ce_fwd(const float* logits, long ld, int R, int V, const int64_t* labels
   return xfm_ce_fwd_impl(logits, ld, R, V, labels, lse, loss, ST(stream));
 }
 int xfm_ce_bwd(const float* logits, long ld, int R, int V, const int64_t* labels, const float* lse, const float* scale,
-               xfm_bf16* dlogits, long ldd, void* stream) {
+               int per_row_scale, xfm_bf16* dlogits, long ldd, void* stream) {
   XFM_REQUIRE(logits && labels && lse && scale && dlogits, "ce_bwd: null operand");
-  return xfm_ce_bwd_impl(logits, ld, R, V, labels, lse, scale, dlogits, ldd, ST(stream));
+  return xfm_ce_bwd_impl(logits, ld, R, V, labels, lse, scale, per_row_scale, dlogits, ldd, ST(stream));
 }
 
 int xfm_adamw(const xfm_adamw_args* a, void* stream) {

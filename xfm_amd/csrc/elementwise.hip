@@ -256,13 +256,13 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
 
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long ld, int V, const int64_t* __restrict__ labels,
                                                      const float* __restrict__ lse, const float* __restrict__ scale,
-                                                     bf16* __restrict__ dlogits, long ldd) {
+                                                     int per_row_scale, bf16* __restrict__ dlogits, long ldd) {
   const int row = blockIdx.x, tid = threadIdx.x;
   const float* x = logits + (long)row * ld;
   bf16* d = dlogits + (long)row * ldd;
   const int64_t lab = labels[row];
   const bool valid = lab >= 0 && lab < V;
-  const float l = lse[row], sc = scale[0];
+  const float l = lse[row], sc = per_row_scale ? scale[row] : scale[0];
   for (int c = tid * 8; c < ldd; c += 2048) {
     bf16x8 o;
 #pragma unroll
@@ -284,9 +284,9 @@ int xfm_ce_fwd_impl(const float* logits, long ld, int R, int V, const int64_t* l
   return xfm_check_launch("ce_fwd");
 }
 int xfm_ce_bwd_impl(const float* logits, long ld, int R, int V, const int64_t* labels, const float* lse, const float* scale,
-                    void* dlogits, long ldd, hipStream_t st) {
+                    int per_row_scale, void* dlogits, long ldd, hipStream_t st) {
   XFM_REQUIRE(R > 0 && V > 0 && ld >= V && ldd >= V && ldd % 8 == 0, "ce_bwd: bad shape R=%d V=%d ld=%ld ldd=%ld", R, V, ld, ldd);
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, st, logits, ld, V, labels, lse, scale, (bf16*)dlogits, ldd);
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, st, logits, ld, V, labels, lse, scale, per_row_scale, (bf16*)dlogits, ldd);
   return xfm_check_launch("ce_bwd");
 }
 

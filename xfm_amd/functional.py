@@ -205,8 +205,7 @@ def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, dro
                     scale=scale, causal=int(causal), drop_thresh=drop[0], drop_scale=drop[1], seed_lo=drop[2], seed_hi=drop[3])
 
 
-def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0), save_o32=False,
-             kv_index=None):
+def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0), kv_index=None):
     """q [B*Sq, >=H*64] / k, v [B*Sk, ...] are 2-D (possibly strided column slices of fused projection buffers).
     bias: dense fp32 [H,Sq,ld]; key_keep: int32 [B,Sk].  Returns (o [B*Sq, H*64] bf16, lse [B,H,Sq])."""
     _dev(q)
@@ -215,16 +214,12 @@ def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=Fals
     if key_keep is not None:
         assert key_keep.dtype == torch.int32 and key_keep.is_contiguous()
     a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, kv_index=kv_index)
-    o32 = None
-    if save_o32:  # fp32 copy of the output for the backward's delta = rowsum(dO * O) (training only)
-        o32 = torch.empty((B * Sq, H * 64), dtype=F32, device=q.device)
-        a.o32 = o32.data_ptr()
     check(_lib.load().xfm_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
-    return (o, lse, o32) if save_o32 else (o, lse)
+    return o, lse
 
 
 def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, dbias=None, key_keep=None, causal=False,
-             drop=(0, 1.0, 0, 0), o32=None, bias_t=None, kv_index=None):
+             drop=(0, 1.0, 0, 0), bias_t=None, kv_index=None):
     """Writes dq/dk/dv (2-D bf16 views with the same addressing convention as q/k/v); dbias (fp32 [H,Sq,ld]) += ."""
     a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t, kv_index)
     delta = torch.zeros((B, H, lse.shape[-1]), dtype=F32, device=q.device)
@@ -233,7 +228,7 @@ def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, 
     a.dq, a.dq_rs = dq.data_ptr(), dq.stride(0)
     a.dk, a.dk_rs = dk.data_ptr(), dk.stride(0)
     a.dv, a.dv_rs = dv.data_ptr(), dv.stride(0)
-    a.delta, a.dbias, a.o32 = delta.data_ptr(), _ptr(dbias), _ptr(o32)
+    a.delta, a.dbias = delta.data_ptr(), _ptr(dbias)
     check(_lib.load().xfm_attn_bwd(ctypes.byref(a), _stream()), "attn_bwd")
 
 
@@ -317,11 +312,13 @@ def ce_fwd(logits, V, labels):
 
 
 def ce_bwd(logits, V, labels, lse, scale, ldd):
-    """-> dlogits bf16 [R, ldd] = (softmax - onehot) * scale[0] (zero in ignored rows / padding columns)."""
+    """-> dlogits bf16 [R, ldd] = (softmax - onehot) * scale (zero in ignored rows / padding columns);
+    scale: fp32 [1] (one factor) or [R] (per-row upstream gradients, reduction 'none')."""
     R = logits.shape[0]
     d = torch.empty((R, ldd), dtype=BF16, device=logits.device)
+    assert scale.dtype == F32 and scale.numel() in (1, R)
     check(_lib.load().xfm_ce_bwd(logits.data_ptr(), logits.stride(0), R, V, labels.data_ptr(), lse.data_ptr(), scale.data_ptr(),
-                                 d.data_ptr(), ldd, _stream()), "ce_bwd")
+                                 int(scale.numel() == R and R > 1), d.data_ptr(), ldd, _stream()), "ce_bwd")
     return d
 
 

@@ -127,8 +127,9 @@ class _LMHeadCEFn(torch.autograd.Function):
         sd, sv = head._slot_dense, head._slot_decoder
         V = sv.N
         if ctx.reduction == "none":
-            raise NotImplementedError("per-row upstream gradients are handled by the caller via reduction='sum' weights")
-        scale = (g / nvalid if ctx.reduction == "mean" else g).reshape(1).to(F32).contiguous()
+            scale = g.reshape(-1).to(F32).contiguous()  # per-row upstream gradients
+        else:
+            scale = (g / nvalid if ctx.reduction == "mean" else g).reshape(1).to(F32).contiguous()
         dlogits = Fx.ce_bwd(logits, V, labels, lse, scale, logits.shape[1])
         Fx.gemm_tn(dlogits, y, sv.dw, n=V, dbias=sv.db)
         dy = Fx.gemm_nt(dlogits, sv.wt, n=sv.K)

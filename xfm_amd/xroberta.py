@@ -192,22 +192,22 @@ class _EncoderFn(torch.autograd.Function):
             d_att, d_h1 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
             qkv = Fx.gemm_nt(x, s["qkv"].wb, s["qkv"].b)
             c1, lse1 = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep,
-                                          causal=causal, drop=d_att); o32_1 = None
+                                          causal=causal, drop=d_att)
             h1 = Fx.gemm_nt(c1, s["o"].wb, s["o"].b)
             ln1 = att.output.LayerNorm
             y1, z1, m1, r1 = Fx.ln_post_fwd(h1, x, ln1.weight, ln1.bias, ln1.eps, d_h1)
-            rec = {"x": x, "qkv": qkv, "c1": c1, "lse1": lse1, "z1": z1, "m1": m1, "r1": r1, "y1": y1, "d_att": d_att, "d_h1": d_h1, "o32_1": o32_1}
+            rec = {"x": x, "qkv": qkv, "c1": c1, "lse1": lse1, "z1": z1, "m1": m1, "r1": r1, "y1": y1, "d_att": d_att, "d_h1": d_h1}
             y2 = y1
             if layer.has_cross_attention and enc is not None:
                 co = layer.crossattention
                 d_att2, d_h2 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
                 q2 = Fx.gemm_nt(y1, s["q2"].wb, s["q2"].b)
                 kv = Fx.gemm_nt(enc, s["kv2"].wb, s["kv2"].b)
-                c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, kv_index=enc_index); o32_2 = None
+                c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, kv_index=enc_index)
                 h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
                 ln2 = co.output.LayerNorm
                 y2, z2, m2, r2 = Fx.ln_post_fwd(h2, y1, ln2.weight, ln2.bias, ln2.eps, d_h2)
-                rec.update(q2=q2, kv=kv, c2=c2, lse2=lse2, z2=z2, m2=m2, r2=r2, y2=y2, d_att2=d_att2, d_h2=d_h2, o32_2=o32_2)
+                rec.update(q2=q2, kv=kv, c2=c2, lse2=lse2, z2=z2, m2=m2, r2=r2, y2=y2, d_att2=d_att2, d_h2=d_h2)
             d_h3 = Fx.drop_params(p_hid, _next_seed())
             hact, u = Fx.gemm_nt(y2, s["i"].wb, s["i"].b, epi=Fx.EPI_GELU)
             h3 = Fx.gemm_nt(hact, s["out"].wb, s["out"].b)
@@ -269,7 +269,7 @@ class _EncoderFn(torch.autograd.Function):
             qkv = r["qkv"]
             dqkv = torch.empty_like(qkv)
             Fx.attn_bwd(dc1, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], r["c1"], r["lse1"], dqkv[:, :D], dqkv[:, D:2 * D],
-                        dqkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep, causal=causal, drop=r["d_att"], o32=r["o32_1"])
+                        dqkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep, causal=causal, drop=r["d_att"])
             Fx.gemm_tn(dqkv, r["x"], s["qkv"].dw, dbias=s["qkv"].db)
             if li > lo or need_dx:
                 dy_a, dy_b = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K), dres1
@@ -421,3 +421,53 @@ class RobertaForMaskedLM(nn.Module):
         Bq, Tq = seq.shape[:2]
         loss, logits = lm_head_ce(seq.reshape(-1, seq.shape[-1]), head, labels.reshape(-1), reduction)
         return SimpleNamespace(loss=loss, logits=logits[:, :V].view(Bq, Tq, V), hidden_states=None, attentions=None)
+
+
+class RobertaForCausalLM(nn.Module):
+    """Causal decoder with cross-attention to encoder states (the VQA answer decoder): mirrors models/xroberta.py:963-1153 --
+    `roberta` + `lm_head`, causal self-attention mask, next-token shift, `reduction='none'` CE summed per sequence
+    (:1107-1114)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.roberta = RobertaModel(config, add_pooling_layer=False)
+        self.lm_head = RobertaLMHead(config)
+        self._arena = None
+
+    def linear_slots(self, prefix=""):
+        return self.roberta.linear_slots(prefix + "roberta.") + self.lm_head.linear_slots(prefix + "lm_head.")
+
+    def attach(self, arena):
+        self._arena = arena
+        self.roberta.attach(arena)
+
+    def finalize(self, device=None):
+        device = device or self.lm_head.bias.device
+        self.attach(ParamArena(self, self.linear_slots(), device))
+        return self
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
+                inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None, labels=None, past_key_values=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, is_decoder=True,
+                reduction='mean', mode='multi_modal', return_logits=False):
+        if past_key_values is not None or use_cache:
+            raise NotImplementedError("incremental decoding caches (generation) are outside the hot-path scope")
+        outputs = self.roberta(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, position_ids=position_ids,
+                               head_mask=head_mask, inputs_embeds=inputs_embeds, encoder_hidden_states=encoder_hidden_states,
+                               encoder_attention_mask=encoder_attention_mask, is_decoder=is_decoder, mode=mode)
+        seq = outputs.last_hidden_state
+        V = self.config.vocab_size
+        B, T = seq.shape[:2]
+        if return_logits or labels is None:
+            logits = lm_head_logits(seq.reshape(-1, seq.shape[-1]), self.lm_head).view(B, T, V)
+            if return_logits:
+                return logits[:, :-1, :].contiguous()
+            return SimpleNamespace(loss=None, logits=logits, hidden_states=seq, past_key_values=None, attentions=None,
+                                   cross_attentions=None)
+        shifted, lab = seq[:, :-1, :], labels[:, 1:]
+        loss, logits = lm_head_ce(shifted.reshape(-1, seq.shape[-1]), self.lm_head, lab.reshape(-1), reduction)
+        if reduction == 'none':
+            loss = loss.view(B, -1).sum(1)
+        return SimpleNamespace(loss=loss, logits=logits[:, :V].view(B, T - 1, V), hidden_states=seq, past_key_values=None,
+                               attentions=None, cross_attentions=None)
