@@ -233,6 +233,15 @@ def masked_lm_loss(P, model_pre, seq_out, masked_pos, labels, head="lm_head", ca
     return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1), reduction=reduction), logits
 
 
+def causal_lm_loss(P, input_ids, att, enc, enc_att, labels, num_layers, reduction="none"):
+    """RobertaForCausalLM.forward xroberta.py:1025-1113 (the VQA answer decoder, model_generation.py:119-128): causal
+    self mask, cross-attention in every layer, lm_head, logits[:, :-1] vs labels[:, 1:], then view(B, -1).sum(1)."""
+    seq = roberta_model(P, "roberta.", input_ids=input_ids, att=att, enc=enc, enc_att=enc_att, num_layers=num_layers,
+                        fusion_layer=0, causal=True)
+    loss, logits = masked_lm_loss(P, "", seq, None, labels, head="lm_head", causal_shift=True, reduction=reduction)
+    return loss.view(input_ids.shape[0], -1).sum(1), logits
+
+
 # --------------------------------------------------------------------------------------
 # XFMBase glue and losses  (models/xfm.py, models/model_pretrain.py)
 # --------------------------------------------------------------------------------------

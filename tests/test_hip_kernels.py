@@ -396,6 +396,25 @@ def test_cross_entropy_fwd_bwd_ignore_index():
     assert float(d[:, V:].float().abs().max()) == 0.0 and float(d[::5].float().abs().max()) == 0.0
 
 
+def test_cross_entropy_bwd_per_row_scale():
+    """reduction='none' (RobertaForCausalLM, xroberta.py:1107-1110): every row carries its own upstream gradient."""
+    Fx = _fx()
+    R, V, ld = 23, 1000, 1024
+    logits = torch.zeros((R, ld), dtype=F32, device="cuda")
+    logits[:, :V] = _rand((R, V), 2.0, F32, seed=101)
+    labels = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(2)).cuda()
+    labels[::4] = -100
+    w = _rand((R,), 1.0, F32, seed=102)
+    lr = logits[:, :V].clone().requires_grad_(True)
+    ref_rows = torch.nn.functional.cross_entropy(lr, labels, ignore_index=-100, reduction="none")
+    (ref_rows * w).sum().backward()
+    lse, loss_rows = Fx.ce_fwd(logits, V, labels)
+    _close(loss_rows, ref_rows.detach(), 1e-5, "loss rows")
+    d = Fx.ce_bwd(logits, V, labels, lse, w.contiguous(), ld)
+    _close(d[:, :V], lr.grad, 1e-2, "dlogits")
+    assert float(d[::4].float().abs().max()) == 0.0
+
+
 def test_adamw_and_sumsq_flat_arena():
     Fx = _fx()
     n = 256 * 40

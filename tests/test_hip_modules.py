@@ -177,6 +177,36 @@ def test_fusion_tower_vs_golden():
     _check_grads(z, "grad_causal", m)
 
 
+def test_causal_lm_answer_decoder_vs_golden():
+    """RobertaForCausalLM as the VQA answer decoder (model_generation.py:119-128): ragged answers, cross-attention to
+    masked question states, reduction='none' and a weighted per-sequence sum -> exercises the per-row CE gradient."""
+    from xfm_amd.xroberta import RobertaConfig, RobertaForCausalLM
+    z, meta = load("causal_lm_2L")
+    B, L, S = meta["B"], meta["L"], meta["S"]
+    m = RobertaForCausalLM(RobertaConfig(num_hidden_layers=meta["layers"], fusion_layer=0, encoder_width=768))
+    ours = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+    assert ours == meta["spec"]
+    _load_into(m, meta["spec"])
+    m.cuda().finalize().eval()
+    ids, atts, enc_atts = (torch.tensor(meta[k]).cuda() for k in ("ids", "atts", "enc_atts"))
+    enc = syn.gaussian("causal.question_states", (B, S, 768), 0.7).cuda().requires_grad_(True)
+    weights = (syn.gaussian("causal.weights", (B,), 1.0).abs() + 0.1).cuda()
+    with torch.no_grad():
+        full = m(ids, attention_mask=atts, encoder_hidden_states=enc, encoder_attention_mask=enc_atts)
+    _check_out(z, "logits", full.logits)
+    res = m(ids, attention_mask=atts, encoder_hidden_states=enc, encoder_attention_mask=enc_atts,
+            labels=ids.masked_fill(ids == 1, -100), return_dict=True, reduction="none")
+    ref_rows = torch.from_numpy(z["loss_rows"])
+    assert torch.allclose(res.loss.float().cpu(), ref_rows, rtol=3e-3, atol=3e-3), (res.loss, ref_rows)
+    loss = (weights * res.loss).sum() / B
+    ref = float(z["loss"])
+    assert abs(float(loss) - ref) <= 2e-3 * abs(ref), (float(loss), ref)
+    loss.backward()
+    _check_grads(z, "grad", m)
+    err, cos = rel_l2(z, "grad_in/question_states", enc.grad)
+    assert err <= GRAD_TOL and cos >= COS_TOL, (err, cos)
+
+
 def _pretrain_cfg(meta):
     return {"use_beit_v2": True, "image_res": 224, "patch_size": 16, "local_attn_depth": -1, "text_encoder": "roberta-base",
             "text_num_hidden_layers": meta["text_layers"], "text_fusion_start_at": meta["text_layers"],

@@ -1,6 +1,7 @@
 """The CPU oracle (oracle/xfm_oracle.py) against golden vectors produced by the real reference
 (tools/oracle/gen_golden.py).  fp32, same op order => 1e-5-level agreement.  Runs without a GPU."""
 import pytest
+import numpy as np
 import torch
 
 from oracle import xfm_oracle as O
@@ -114,6 +115,23 @@ def test_fusion_tower_cross_attention_and_causal_decoder():
     assert abs(float(loss) - float(z["causal_loss"])) < 1e-4
     loss.backward()
     _check_grads(z, "grad_causal", P)
+
+
+def test_causal_lm_answer_decoder():
+    z, meta = load("causal_lm_2L")
+    B, L, S = meta["B"], meta["L"], meta["S"]
+    P = _params(meta["spec"])
+    ids, atts, enc_atts = (torch.tensor(meta[k]) for k in ("ids", "atts", "enc_atts"))
+    enc = syn.gaussian("causal.question_states", (B, S, 768), 0.7).requires_grad_(True)
+    weights = syn.gaussian("causal.weights", (B,), 1.0).abs() + 0.1
+    rows, logits = O.causal_lm_loss(P, ids, atts, enc, enc_atts, ids.masked_fill(ids == 1, -100), meta["layers"])
+    assert np.allclose(rows.detach().numpy(), z["loss_rows"], rtol=1e-5, atol=1e-4)
+    # the reference returns the UNSHIFTED logits in .logits
+    loss = (weights * rows).sum() / B
+    assert abs(float(loss) - float(z["loss"])) < 1e-4
+    loss.backward()
+    _check_grads(z, "grad", P)
+    check(z, "grad_in/question_states", enc.grad, ATOL, RTOL)
 
 
 def _pretrain(name):

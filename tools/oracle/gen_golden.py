@@ -183,6 +183,39 @@ def gen_fusion(layers=2, B=4):
     save(f"fusion_{layers}L", out, {"spec": spec_of(m), "B": B, "layers": layers})
 
 
+def gen_causal_lm(layers=2, B=6, L=9, S=30):
+    """VQA-style answer decoder (model_generation.py:101-128): RobertaForCausalLM with cross-attention in every layer,
+    causal self mask, shifted CE with reduction='none', per-sequence weighted sum."""
+    from models.xroberta import RobertaForCausalLM
+    torch.manual_seed(0)
+    m = RobertaForCausalLM(roberta_cfg(layers, 0))
+    load_formula(m)
+    m.eval()
+    b = syn.pretrain_batch(B, seed=13, with_image=False)
+    ids = b["text_ids"][:, :L].clone()
+    atts = torch.ones(B, L, dtype=torch.long)
+    for r, n in enumerate([9, 4, 7, 3, 9, 5][:B]):  # ragged answers, padded with <pad>=1
+        atts[r, n:] = 0
+        ids[r, n:] = 1
+    enc = syn.gaussian("causal.question_states", (B, S, 768), 0.7).requires_grad_(True)
+    enc_atts = torch.ones(B, S, dtype=torch.long)
+    enc_atts[1, 20:] = 0
+    enc_atts[4, 11:] = 0
+    weights = syn.gaussian("causal.weights", (B,), 1.0).abs() + 0.1
+    out = {}
+    res = m(ids, attention_mask=atts, encoder_hidden_states=enc, encoder_attention_mask=enc_atts,
+            labels=ids.masked_fill(ids == 1, -100), return_dict=True, reduction="none")
+    out["loss_rows"] = res.loss.detach().numpy().astype(np.float32)
+    loss = (weights * res.loss).sum() / B
+    out["loss"] = np.asarray(float(loss))
+    pack("logits", res.logits, out)
+    loss.backward()
+    grads_of(m, out, "grad")
+    pack("grad_in/question_states", enc.grad, out)
+    save(f"causal_lm_{layers}L", out, {"spec": spec_of(m), "B": B, "L": L, "S": S, "layers": layers,
+                                       "ids": ids.tolist(), "atts": atts.tolist(), "enc_atts": enc_atts.tolist()})
+
+
 def gen_pretrain(name, text_layers, fusion_layers, B=4):
     from models.model_pretrain import XFM
     ref_shim.init_single_process_group()
@@ -228,7 +261,7 @@ def main():
     torch.set_num_threads(8)
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2)}
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2)}
     if a.full:
         jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
     for k, fn in jobs.items():
