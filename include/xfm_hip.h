@@ -142,6 +142,7 @@ typedef struct {
   int B, T, pad_id; float eps;
   uint32_t drop_thresh; float drop_scale; uint32_t seed_lo, seed_hi;
   const xfm_bf16* dy; float* dword; float* dpos; float* partial;
+  int pos_mode; /* 0: RoBERTa pad-aware cumsum positions; 1: BERT absolute positions 0..T-1 (xbert.py:198-199) */
 } xfm_embed_args;
 int xfm_embed_ln_fwd(const xfm_embed_args* a, int D, void* stream);
 long xfm_embed_ln_bwd_workspace(int rows, int D);

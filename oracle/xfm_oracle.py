@@ -243,6 +243,37 @@ def causal_lm_loss(P, input_ids, att, enc, enc_att, labels, num_layers, reductio
 
 
 # --------------------------------------------------------------------------------------
+# xbert variant (models/xbert.py): same layer stack with scores scaled AFTER QK^T, absolute positions, BERT LM head
+# --------------------------------------------------------------------------------------
+def bert_embeddings(P, pre, input_ids, eps=1e-12):
+    """BertEmbeddings.forward xbert.py:188-215: word + token_type[0] + position_ids[:, :T], LayerNorm (dropout off)."""
+    T = input_ids.shape[1]
+    x = F.embedding(input_ids, P[pre + "word_embeddings.weight"], padding_idx=0)
+    x = x + P[pre + "token_type_embeddings.weight"][0] + P[pre + "position_embeddings.weight"][:T].unsqueeze(0)
+    return _ln(P, pre + "LayerNorm", x, eps)
+
+
+def bert_model(P, pre, input_ids, att, enc=None, enc_att=None, eps=1e-12, **kw):
+    """BertModel.forward xbert.py:1023-1130 (non-fp16 branch => scale_after)."""
+    x = bert_embeddings(P, pre + "embeddings.", input_ids, eps)
+    return roberta_encoder(P, pre, x, att, enc, enc_att, eps=eps, scale_after=True, **kw)
+
+
+def bert_lm_head(P, pre, x, eps=1e-12):
+    """BertLMPredictionHead xbert.py:663-697: transform (dense -> GELU -> LayerNorm) then decoder + shared bias."""
+    h = _ln(P, pre + "transform.LayerNorm", gelu_erf(_lin(P, pre + "transform.dense", x)), eps)
+    return F.linear(h, P[pre + "decoder.weight"], P[pre + "bias"])
+
+
+def bert_mlm_loss(P, seq_out, masked_pos, labels):
+    """BertForMaskedLM.forward tail xbert.py:1592-1608."""
+    if masked_pos is not None:
+        seq_out = gather_by_pos(seq_out, masked_pos)
+    logits = bert_lm_head(P, "cls.predictions.", seq_out)
+    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1)), logits
+
+
+# --------------------------------------------------------------------------------------
 # XFMBase glue and losses  (models/xfm.py, models/model_pretrain.py)
 # --------------------------------------------------------------------------------------
 def build_mlp_forward(P, pre, x, eps=1e-5):

@@ -207,6 +207,39 @@ def test_causal_lm_answer_decoder_vs_golden():
     assert err <= GRAD_TOL and cos >= COS_TOL, (err, cos)
 
 
+def test_xbert_variant_vs_golden():
+    """xbert.BertForMaskedLM (B1): absolute positions / token type 0 / pad 0 embeddings, scores scaled after QK^T in the
+    reference, BERT LM head; layer 0 self-only, layer 1 with cross-attention to ragged image tokens."""
+    from xfm_amd.xbert import BertConfig, BertForMaskedLM
+    z, meta = load("xbert_2L")
+    B, L = meta["B"], meta["layers"]
+    m = BertForMaskedLM(BertConfig(num_hidden_layers=L, fusion_layer=meta["fusion_layer"], encoder_width=768))
+    ours = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+    assert ours == meta["spec"]
+    _load_into(m, meta["spec"])
+    m.cuda().finalize().eval()
+    b = {k: v.cuda() for k, v in syn.pretrain_batch(B, seed=14, with_image=False, vocab=30522).items()}
+    ids, ids_masked = b["text_ids"].clone(), b["text_ids_masked"].clone()
+    ids[b["text_atts"] == 0] = 0
+    ids_masked[b["text_atts"] == 0] = 0
+    img = syn.gaussian("xbert.image_embeds", (B, 197, 768), 0.7).cuda().requires_grad_(True)
+    img_atts = torch.ones(B, 197, dtype=torch.long)
+    img_atts[2, 120:] = 0
+    img_atts = img_atts.cuda()
+    with torch.no_grad():
+        h = m.bert(ids, attention_mask=b["text_atts"], return_dict=True, mode="text").last_hidden_state
+    _check_out(z, "hidden_text", h)
+    res = m(ids_masked, attention_mask=b["text_atts"], encoder_hidden_states=img, encoder_attention_mask=img_atts,
+            return_dict=True, labels=b["masked_ids"], masked_pos=b["masked_pos"])
+    ref = float(z["mlm_loss"])
+    assert abs(float(res.loss) - ref) <= 2e-3 * abs(ref), (float(res.loss), ref)
+    _check_out(z, "mlm_logits", res.logits)
+    res.loss.backward()
+    _check_grads(z, "grad_mlm", m)
+    err, cos = rel_l2(z, "grad_mlm_in/image_embeds", img.grad)
+    assert err <= GRAD_TOL and cos >= COS_TOL, (err, cos)
+
+
 def _pretrain_cfg(meta):
     return {"use_beit_v2": True, "image_res": 224, "patch_size": 16, "local_attn_depth": -1, "text_encoder": "roberta-base",
             "text_num_hidden_layers": meta["text_layers"], "text_fusion_start_at": meta["text_layers"],

@@ -134,6 +134,29 @@ def test_causal_lm_answer_decoder():
     check(z, "grad_in/question_states", enc.grad, ATOL, RTOL)
 
 
+def test_xbert_variant():
+    z, meta = load("xbert_2L")
+    B, L = meta["B"], meta["layers"]
+    P = _params(meta["spec"])
+    b = syn.pretrain_batch(B, seed=14, with_image=False, vocab=30522)
+    ids, ids_masked = b["text_ids"].clone(), b["text_ids_masked"].clone()
+    ids[b["text_atts"] == 0] = 0
+    ids_masked[b["text_atts"] == 0] = 0
+    img = syn.gaussian("xbert.image_embeds", (B, 197, 768), 0.7).requires_grad_(True)
+    img_atts = torch.ones(B, 197, dtype=torch.long)
+    img_atts[2, 120:] = 0
+    check(z, "embeddings", O.bert_embeddings(P, "bert.embeddings.", ids), ATOL, RTOL)
+    h = O.bert_model(P, "bert.", ids, b["text_atts"], num_layers=meta["fusion_layer"], fusion_layer=meta["fusion_layer"])
+    check(z, "hidden_text", h, ATOL, RTOL)
+    seq = O.bert_model(P, "bert.", ids_masked, b["text_atts"], img, img_atts, num_layers=L, fusion_layer=meta["fusion_layer"])
+    loss, logits = O.bert_mlm_loss(P, seq, b["masked_pos"], b["masked_ids"])
+    assert abs(float(loss) - float(z["mlm_loss"])) < 1e-4
+    check(z, "mlm_logits", logits, 1e-4, RTOL)
+    loss.backward()
+    _check_grads(z, "grad_mlm", P)
+    check(z, "grad_mlm_in/image_embeds", img.grad, ATOL, RTOL)
+
+
 def _pretrain(name):
     z, meta = load(name)
     B = meta["B"]

@@ -216,6 +216,44 @@ def gen_causal_lm(layers=2, B=6, L=9, S=30):
                                        "ids": ids.tolist(), "atts": atts.tolist(), "enc_atts": enc_atts.tolist()})
 
 
+BERT_BASE_CONFIG = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                        hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                        max_position_embeddings=512, type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-12,
+                        pad_token_id=0)
+
+
+def gen_xbert(layers=2, B=4):
+    """xbert.BertForMaskedLM (xfm.py:263-284 `use_roberta: False` branch): layer 0 self-only, layer 1 with cross-attention
+    (fusion_layer=1); absolute position slice, token type 0, scores scaled AFTER QK^T (xbert.py:329-330), BERT LM head."""
+    from models.xbert import BertConfig, BertForMaskedLM
+    torch.manual_seed(0)
+    cfg = BertConfig(**BERT_BASE_CONFIG)
+    cfg.num_hidden_layers, cfg.fusion_layer, cfg.encoder_width = layers, 1, 768
+    m = BertForMaskedLM(cfg)
+    load_formula(m)
+    m.eval()
+    b = syn.pretrain_batch(B, seed=14, with_image=False, vocab=30522)
+    ids, ids_masked = b["text_ids"].clone(), b["text_ids_masked"].clone()
+    ids[b["text_atts"] == 0] = 0  # BERT pads with id 0
+    ids_masked[b["text_atts"] == 0] = 0
+    img = syn.gaussian("xbert.image_embeds", (B, 197, 768), 0.7).requires_grad_(True)
+    img_atts = torch.ones(B, 197, dtype=torch.long)
+    img_atts[2, 120:] = 0
+    out = {}
+    emb = m.bert.embeddings(input_ids=ids)
+    pack("embeddings", emb, out)
+    h = m.bert(ids, attention_mask=b["text_atts"], return_dict=True, mode="text").last_hidden_state
+    pack("hidden_text", h, out)
+    res = m(ids_masked, attention_mask=b["text_atts"], encoder_hidden_states=img, encoder_attention_mask=img_atts,
+            return_dict=True, labels=b["masked_ids"], masked_pos=b["masked_pos"])
+    out["mlm_loss"] = np.asarray(float(res.loss.detach()))
+    pack("mlm_logits", res.logits, out)
+    res.loss.backward()
+    grads_of(m, out, "grad_mlm")
+    pack("grad_mlm_in/image_embeds", img.grad, out)
+    save(f"xbert_{layers}L", out, {"spec": spec_of(m), "B": B, "layers": layers, "fusion_layer": 1})
+
+
 def gen_pretrain(name, text_layers, fusion_layers, B=4):
     from models.model_pretrain import XFM
     ref_shim.init_single_process_group()
@@ -261,7 +299,7 @@ def main():
     torch.set_num_threads(8)
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2)}
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2)}
     if a.full:
         jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
     for k, fn in jobs.items():

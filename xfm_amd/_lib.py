@@ -51,7 +51,7 @@ class EmbedArgs(ctypes.Structure):
                 ("b", c_void_p), ("y", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("pos_ids", c_void_p),
                 ("B", c_int), ("T", c_int), ("pad_id", c_int), ("eps", c_float),
                 ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32),
-                ("dy", c_void_p), ("dword", c_void_p), ("dpos", c_void_p), ("partial", c_void_p)]
+                ("dy", c_void_p), ("dword", c_void_p), ("dpos", c_void_p), ("partial", c_void_p), ("pos_mode", c_int)]
 
 
 class AdamWArgs(ctypes.Structure):

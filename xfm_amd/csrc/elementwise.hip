@@ -39,7 +39,8 @@ int xfm_patchify_impl(const float* img, int B, int C, int H, int W, int P, void*
 
 // ---------------------------------------------------------------------------------------------
 // RoBERTa embeddings: y = dropout(LN(word[id] + type[0] + pos[p])), p = cumsum(id != pad) * (id != pad) + pad
-// (xroberta.py:104-137, :1747-1757).  One wave per token.
+// (xroberta.py:104-137, :1747-1757); pos_mode 1 = BERT: p = t, no padding row in the position table (xbert.py:188-215).
+// One wave per token.
 // ---------------------------------------------------------------------------------------------
 typedef xfm_embed_args EmbArgs;
 
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs p) {
   for (int row = wave; row < rows; row += nwaves) {
     const int b = row / p.T, t = row % p.T;
     const int64_t* ids_row = p.ids + (long)b * p.T;
-    const int pid = roberta_pos(ids_row, t, p.pad_id, lane);
+    const int pid = p.pos_mode ? t : roberta_pos(ids_row, t, p.pad_id, lane);
     const long wid = ids_row[t];
     if (lane == 0) p.pos_ids[row] = pid;
     float v[NCH][4];
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void emb_bwd_kernel(EmbArgs p) {
         acc[2][i][j] += dz;
         // nn.Embedding(padding_idx): the pad row receives no gradient (xroberta.py:80,100-102)
         if (wid != p.pad_id) atomicAdd(p.dword + wid * D + e + j, dz);
-        if (pid != p.pad_id) atomicAdd(p.dpos + (long)pid * D + e + j, dz);
+        if (p.pos_mode || pid != p.pad_id) atomicAdd(p.dpos + (long)pid * D + e + j, dz);
       }
     }
   }

@@ -267,14 +267,15 @@ def patchify(image, patch):
     return out
 
 
-def _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop):
+def _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop, pos_mode=0):
     B, T = ids.shape
-    return EmbedArgs(ids=ids.data_ptr(), word=word.data_ptr(), pos=pos.data_ptr(), type=typ.data_ptr(), w=w.data_ptr(),
+    assert pos_mode == 0 or T <= pos.shape[0]
+    return EmbedArgs(pos_mode=pos_mode, ids=ids.data_ptr(), word=word.data_ptr(), pos=pos.data_ptr(), type=typ.data_ptr(), w=w.data_ptr(),
                      b=b.data_ptr(), B=B, T=T, pad_id=pad_id, eps=eps, drop_thresh=drop[0], drop_scale=drop[1],
                      seed_lo=drop[2], seed_hi=drop[3])
 
 
-def embed_ln_fwd(ids, word, pos, typ, w, b, eps, pad_id, drop=(0, 1.0, 0, 0)):
+def embed_ln_fwd(ids, word, pos, typ, w, b, eps, pad_id, drop=(0, 1.0, 0, 0), pos_mode=0):
     _dev(ids)
     assert ids.dtype == torch.int64 and ids.is_contiguous()
     B, T = ids.shape
@@ -283,16 +284,16 @@ def embed_ln_fwd(ids, word, pos, typ, w, b, eps, pad_id, drop=(0, 1.0, 0, 0)):
     mean = torch.empty(B * T, dtype=F32, device=ids.device)
     rstd = torch.empty(B * T, dtype=F32, device=ids.device)
     pos_ids = torch.empty(B * T, dtype=torch.int32, device=ids.device)
-    a = _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop)
+    a = _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop, pos_mode)
     a.y, a.mean, a.rstd, a.pos_ids = y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), pos_ids.data_ptr()
     check(_lib.load().xfm_embed_ln_fwd(ctypes.byref(a), D, _stream()), "embed_ln_fwd")
     return y, mean, rstd, pos_ids
 
 
 def embed_ln_bwd(dy, ids, word, pos, typ, w, b, eps, pad_id, mean, rstd, pos_ids, dword, dpos, dtype_, dgamma, dbeta,
-                 drop=(0, 1.0, 0, 0)):
+                 drop=(0, 1.0, 0, 0), pos_mode=0):
     D = word.shape[1]
-    a = _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop)
+    a = _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop, pos_mode)
     a.mean, a.rstd, a.pos_ids = mean.data_ptr(), rstd.data_ptr(), pos_ids.data_ptr()
     a.dy, a.dword, a.dpos = dy.data_ptr(), dword.data_ptr(), dpos.data_ptr()
     lib = _lib.load()

@@ -82,8 +82,9 @@ def formula_state_dict(reference_state, seed=0):
     out = {}
     for k, v in reference_state.items():
         t = formula_tensor(k, v, seed)
-        if k.endswith("lm_head.decoder.bias") or k.endswith("lm_cap_head.decoder.bias"):
-            t = formula_tensor(k[: -len("decoder.bias")] + "bias", v, seed)  # tied to `<head>.bias` (xroberta.py:1322-1323)
+        if k.endswith(("lm_head.decoder.bias", "lm_cap_head.decoder.bias", "predictions.decoder.bias")):
+            # tied to `<head>.bias` (xroberta.py:1322-1323, xbert.py:690-691)
+            t = formula_tensor(k[: -len("decoder.bias")] + "bias", v, seed)
         out[k] = t.to(v.dtype)
     return out
 

@@ -93,27 +93,33 @@ def build_vision_encoder(config, load_params=False):
     return enc, vision_config['vision_width']
 
 
-def _text_config(config):
+def _text_config(config, cls=RobertaConfig):
     if 'text_config' in config:
-        return RobertaConfig(**config['text_config'])
+        return cls(**config['text_config'])
     path = os.path.join(config.get('text_encoder', ''), 'config.json')
     if os.path.exists(path):
-        return RobertaConfig.from_json_file(path)
-    return RobertaConfig()  # public roberta-base hyper-parameters
+        return cls.from_json_file(path)
+    return cls()  # public roberta-base / bert-base-uncased hyper-parameters
 
 
 def build_text_encoder(config, vision_width, load_text_params=False, use_mlm_loss=False, config_text=None):
-    """xfm.py:258-405, roberta branch."""
-    if 'roberta' not in config.get('text_encoder', 'roberta-base'):
-        raise NotImplementedError("bert-named text encoders (xbert.py) are not wired into the model builder yet")
+    """xfm.py:258-405: 'roberta' in config['text_encoder'] -> xroberta towers, 'bert' -> xbert towers."""
+    name = config.get('text_encoder', 'roberta-base')
+    if 'roberta' in name:
+        cfg_cls, model_cls = RobertaConfig, RobertaForMaskedLM
+    elif 'bert' in name:
+        from .xbert import BertConfig, BertForMaskedLM
+        cfg_cls, model_cls = BertConfig, BertForMaskedLM
+    else:
+        raise ValueError(name)
     if load_text_params:
         raise NotImplementedError("checkpoint loading is outside the hot-path scope; load a state_dict instead")
     if config_text is None:
-        config_text = _text_config(config)
+        config_text = _text_config(config, cfg_cls)
         config_text.num_hidden_layers = config.get('text_num_hidden_layers', 12)
         config_text.fusion_layer = config.get('text_fusion_start_at', config_text.num_hidden_layers // 2)
     config_text.encoder_width = vision_width
-    return RobertaForMaskedLM(config_text), []
+    return model_cls(config_text), []
 
 
 class XFMBase(nn.Module):

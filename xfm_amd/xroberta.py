@@ -87,7 +87,7 @@ class _EmbedFn(torch.autograd.Function):
         ln = emb.LayerNorm
         y, mean, rstd, pos_ids = Fx.embed_ln_fwd(ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
                                                  emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps,
-                                                 emb.padding_idx, drop)
+                                                 emb.padding_idx, drop, getattr(emb, "pos_mode", 0))
         ctx.emb, ctx.saved, ctx.drop = emb, (ids, mean, rstd, pos_ids), drop
         return y.view(ids.shape[0], ids.shape[1], -1)
 
@@ -100,7 +100,8 @@ class _EmbedFn(torch.autograd.Function):
         Fx.embed_ln_bwd(dy2, ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
                         emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps, emb.padding_idx, mean, rstd, pos_ids,
                         grad_view(emb.word_embeddings.weight), grad_view(emb.position_embeddings.weight),
-                        grad_view(emb.token_type_embeddings.weight).view(-1), grad_view(ln.weight), grad_view(ln.bias), ctx.drop)
+                        grad_view(emb.token_type_embeddings.weight).view(-1), grad_view(ln.weight), grad_view(ln.bias), ctx.drop,
+                        getattr(emb, "pos_mode", 0))
         if ctx.owner is not None:
             arena_note_grad(ctx.owner)
         return None, None, None, None, None
@@ -282,6 +283,8 @@ class _EncoderFn(torch.autograd.Function):
 
 
 class RobertaModel(nn.Module):
+    embeddings_class = RobertaEmbeddings
+
     def __init__(self, config, add_pooling_layer=False):
         super().__init__()
         if add_pooling_layer:
@@ -289,7 +292,7 @@ class RobertaModel(nn.Module):
         if config.hidden_size // config.num_attention_heads != 64:
             raise NotImplementedError("head_dim must be 64")
         self.config = config
-        self.embeddings = RobertaEmbeddings(config)
+        self.embeddings = self.embeddings_class(config)
         self.encoder = RobertaEncoder(config)
         self.pooler = None
         self._arena = None
