@@ -83,13 +83,36 @@ class GemmTimer:
             e.record()
             N = b.shape[0] if n is None else n
             self.records.append((s, e, 2.0 * a.shape[0] * N * a.shape[1]))
+            self.shapes.append(("nt", a.shape[0], N, a.shape[1], epi, s, e))
             return r
 
+        def timed_tn(dy, x, dw, n=None, dbias=None, splits=0):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self.orig_tn(dy, x, dw, n=n, dbias=dbias, splits=splits)
+            e.record()
+            self.shapes.append(("tn", dy.shape[0], dy.shape[1] if n is None else n, x.shape[1], int(dbias is not None), s, e))
+            return r
+
+        self.shapes = []
+        self.orig_tn = Fx.gemm_tn
         Fx.gemm_nt = timed
+        Fx.gemm_tn = timed_tn
         return self
 
     def __exit__(self, *a):
         self.Fx.gemm_nt = self.orig
+        self.Fx.gemm_tn = self.orig_tn
+
+    def by_shape(self):
+        """{(kind, M, N, K, epi): [calls, total_ms]} for the instrumented step (XFM_BENCH_GEMM_SHAPES=path dumps it)."""
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, M, N, K, epi, s, e in self.shapes:
+            a = agg.setdefault((kind, M, N, K, epi), [0, 0.0])
+            a[0] += 1
+            a[1] += s.elapsed_time(e)
+        return agg
 
     def summary(self):
         torch.cuda.synchronize()
@@ -187,6 +210,11 @@ def main():
     with GemmTimer() as gt:
         step()
     nlaunch, gemm_ms, gemm_flop = gt.summary()
+    if os.environ.get("XFM_BENCH_GEMM_SHAPES") and rank == 0:
+        with open(os.environ["XFM_BENCH_GEMM_SHAPES"], "w") as f:
+            for (kind, M, N, K, epi), (calls, ms) in sorted(gt.by_shape().items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{kind} M={M:6d} N={N:6d} K={K:6d} epi/bias={epi} calls={calls:3d} total={ms:7.3f}ms avg={ms / calls * 1e3:7.1f}us "
+                        f"{2.0 * M * N * K * calls / ms / 1e9:6.0f}TF\n")
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     ms_per_step = elapsed / args.steps * 1e3
 

@@ -39,14 +39,19 @@ enum { XFM_EPI_BF16 = 0, XFM_EPI_F32 = 1, XFM_EPI_GELU = 2, XFM_EPI_DGELU = 3, X
 
 /* C[M,N] = A[M,K] . B[N,K]^T + bias.  A, B bf16 (K contiguous).  Epilogues: bf16 out | fp32 out |
  * aux = pre-activation (bf16), C = gelu(aux)  | C = acc * gelu'(aux) | fp32 C += acc.  K % 64 == 0; lda, ldb % 8 == 0.
- * tile_hint: 0 = auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x128 with a 3-slot LDS ring (large M). */
+ * tile_hint: 0 = auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x128 with a 3-slot LDS ring, 5 = 256x256 phase pipeline
+ * (large M), 6 = 5 as a persistent kernel. */
 int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* C, long ldc, const float* bias,
                 xfm_bf16* aux, long ldaux, int M, int N, int K, int epilogue, int tile_hint, void* stream);
 
-/* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]   (weight gradient; split over M, atomically accumulated).
- * dbias (optional, fp32 [N]) += column sums of dY: the bias gradient rides along in the same pass over dY. */
+/* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]   (weight gradient, split over M).
+ * dbias (optional, fp32 [N]) += column sums of dY: the bias gradient rides along in the same pass over dY.
+ * Large edge-free shapes (M % 64 == 0; N, K % 256 == 0) run on a 256x256 pipelined kernel whose split partials go to
+ * `workspace` (xfm_gemm_tn_workspace bytes, may be 0) and are summed in a fixed order; without a workspace, and for
+ * every other shape, the splits are accumulated with fp32 atomics.  splits_hint: 0 = auto. */
+long xfm_gemm_tn_workspace(int M, int N, int K);
 int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float* dW, long ldw, float* dbias, int M, int N,
-                int K, int splits_hint, void* stream);
+                int K, int splits_hint, float* workspace, long workspace_bytes, void* stream);
 
 /* fp32 master weight [N,K] -> bf16 copy wb[N,ldb] and/or transposed bf16 copy wt[K,ldt] (zero padded). */
 int xfm_cast_transpose(const float* w, int N, int K, xfm_bf16* wb, long ldb, xfm_bf16* wt, long ldt, void* stream);

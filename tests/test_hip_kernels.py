@@ -33,7 +33,7 @@ def gelu_grad(u):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 200, 128), (1920, 768, 768), (788, 2304, 768), (64, 50265, 64), (5, 3, 64)])
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6])
 def test_gemm_nt_bias_bf16_and_f32(M, N, K, hint):
     Fx = _fx()
     a, b = _rand((M, K), seed=1), _rand((N, K), 0.05, seed=2)
@@ -50,38 +50,54 @@ def test_gemm_nt_bias_bf16_and_f32(M, N, K, hint):
     _close(buf[:, :N], 2 * ref - bias, 2e-5, "fp32 accumulate")
 
 
+@pytest.mark.parametrize("M,N,K", [(25216, 768, 3072), (25216, 3072, 768), (7680, 2304, 768), (1000, 1000, 192), (70000, 768, 64)])
+def test_gemm_nt_tile_configs_agree_bitwise(M, N, K):
+    """Every tile config accumulates K in the same order, so outputs must be identical: a race in the pipelined
+    256x256 / ring kernels (a fragment read before its direct-to-LDS load landed) shows up as a mismatch."""
+    Fx = _fx()
+    a, b = _rand((M, K), seed=11), _rand((N, K), 0.05, seed=12)
+    ref = Fx.gemm_nt(a, b, tile_hint=1)
+    for rep in range(3):
+        for hint in (4, 5, 6):
+            out = Fx.gemm_nt(a, b, tile_hint=hint)
+            assert torch.equal(out, ref), f"tile config {hint} rep {rep}: {int((out != ref).sum())} elements differ"
+
+
 def test_gemm_nt_identity_catches_transposed_maps():
     """A = I with an asymmetric B: any swap in the fragment / accumulator maps shows up exactly."""
     Fx = _fx()
     K = 128
     a = torch.eye(K, dtype=BF16, device="cuda")
     b = (torch.arange(200 * K, device="cuda").reshape(200, K) % 251).to(BF16)  # exact small integers
-    for hint in (1, 2, 3, 4):
+    for hint in (1, 2, 3, 4, 5, 6):
         out = Fx.gemm_nt(a, b, tile_hint=hint)
         assert torch.equal(out.float(), b.float().t().contiguous()), f"tile config {hint}"
 
 
+@pytest.mark.parametrize("hint", [0, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1920, 3072, 768)])
-def test_gemm_nt_gelu_and_dgelu(M, N, K):
+def test_gemm_nt_gelu_and_dgelu(M, N, K, hint):
     Fx = _fx()
     a, b = _rand((M, K), seed=4), _rand((N, K), 0.05, seed=5)
     bias = _rand((N,), 0.5, F32, seed=6)
     pre = a.float() @ b.float().t() + bias
-    h, u = Fx.gemm_nt(a, b, bias, epi=Fx.EPI_GELU)
+    h, u = Fx.gemm_nt(a, b, bias, epi=Fx.EPI_GELU, tile_hint=hint)
     _close(u, pre, 1e-2, "pre-activation")
     _close(h, torch.nn.functional.gelu(u.float()), 1e-2, "gelu(pre)")
     # dgrad with the GELU derivative folded in: C = (dY . Wt^T) * gelu'(aux)
     dy = _rand((M, N), seed=7)
     wt = _rand((K, N), 0.05, seed=8)  # plays W^T: [K_out, N_contract]
     aux = _rand((M, K), 1.0, seed=9)
-    got = Fx.gemm_nt(dy, wt, epi=Fx.EPI_DGELU, aux=aux)
+    got = Fx.gemm_nt(dy, wt, epi=Fx.EPI_DGELU, aux=aux, tile_hint=hint)
     ref = (dy.float() @ wt.float().t()) * gelu_grad(aux.float())
     _close(got, ref, 1e-2, "dgelu")
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(788, 200, 136, 0), (1920, 768, 768, 0), (1920, 768, 3072, 3), (64, 136, 64, 1),
                                            (960, 1000, 768, 0),
-                                           (4100, 768, 768, -2), (12608, 2304, 768, -2), (5003, 520, 136, -2), (12608, 768, 768, 0)])
+                                           (4100, 768, 768, -2), (12608, 2304, 768, -2), (5003, 520, 136, -2), (12608, 768, 768, 0),
+                                           (1920, 768, 768, -3), (64, 256, 256, -3), (12608, 2304, 768, -3), (25216, 768, 3072, 0),
+                                           (7680, 3072, 768, 0), (12608, 768, 768, -4)])
 def test_gemm_tn_wgrad_accumulates(M, N, K, splits):
     Fx = _fx()
     dy, x = _rand((M, N), seed=10), _rand((M, K), seed=11)
@@ -101,6 +117,15 @@ def test_gemm_tn_exact_integers_catch_layout_errors():
     dw = torch.zeros((N, K), dtype=F32, device="cuda")
     Fx.gemm_tn(dy, x, dw, splits=1)
     assert torch.equal(dw, dy.float().t() @ x.float())
+    # the 256 x 256 pipelined kernel (forced): asymmetric exact-integer operands, two K-tiles
+    M, N, K = 128, 256, 512
+    dy = ((torch.arange(M * N, device="cuda").reshape(M, N) * 7) % 13).to(BF16)
+    x = ((torch.arange(M * K, device="cuda").reshape(M, K) * 5) % 11).to(BF16)
+    dw = torch.zeros((N, K), dtype=F32, device="cuda")
+    db = torch.zeros((N,), dtype=F32, device="cuda")
+    Fx.gemm_tn(dy, x, dw, splits=-3, dbias=db)
+    assert torch.equal(dw, dy.float().t() @ x.float())
+    assert torch.equal(db, dy.float().sum(0))
 
 
 def test_cast_transpose_and_colsum():

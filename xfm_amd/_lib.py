@@ -67,7 +67,9 @@ SIGNATURES = {
     "xfm_abi_version": (c_int, []),
     "xfm_gemm_nt": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long,
                             c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "xfm_gemm_tn": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "xfm_gemm_tn_workspace": (c_long, [c_int, c_int, c_int]),
+    "xfm_gemm_tn": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int,
+                            c_void_p, c_long, c_void_p]),
     "xfm_cast_transpose": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "xfm_colsum_workspace": (c_long, [c_int, c_int]),
     "xfm_colsum": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_long, c_void_p]),

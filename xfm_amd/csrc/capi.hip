@@ -42,10 +42,12 @@ int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* 
   return xfm_gemm_nt_impl(A, lda, B, ldb, C, ldc, bias, aux, ldaux, M, N, K, epilogue, tile_hint, ST(stream));
 }
 
+long xfm_gemm_tn_workspace(int M, int N, int K) { return xfm_gemm_tn_workspace_impl(M, N, K); }
+
 int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float* dW, long ldw, float* dbias, int M, int N,
-                int K, int splits_hint, void* stream) {
+                int K, int splits_hint, float* workspace, long workspace_bytes, void* stream) {
   XFM_REQUIRE(dY && X && dW, "gemm_tn: null operand");
-  return xfm_gemm_tn_impl(dY, ldy, X, ldx, dW, ldw, dbias, M, N, K, splits_hint, ST(stream));
+  return xfm_gemm_tn_impl(dY, ldy, X, ldx, dW, ldw, dbias, M, N, K, splits_hint, workspace, workspace_bytes, ST(stream));
 }
 
 int xfm_cast_transpose(const float* w, int N, int K, xfm_bf16* wb, long ldb, xfm_bf16* wt, long ldt, void* stream) {

@@ -35,6 +35,19 @@ __device__ __forceinline__ int swz_w(int r) { return ((r >> 1) & 1) | (((r >> 3)
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmNT& g, f32x4 (&acc)[MT][NT], int m_base, int n_base, int lr, int lg) {
   const bool vec_c = (g.ldc % 8) == 0;
+  // DGELU: all pre-activation loads of the sub-tile go out first, so their latency is paid once, not once per (mt, np)
+  bf16x8 pre_all[EPI == EPI_DGELU ? NT / 2 : 1][EPI == EPI_DGELU ? MT : 1];
+  const bool vec_aux = (g.ldaux % 8) == 0;
+  if (EPI == EPI_DGELU && vec_aux) {
+#pragma unroll
+    for (int np = 0; np < NT / 2; ++np)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int nb = n_base + np * 32 + 8 * lg, m = m_base + mt * 16 + lr;
+        const int mc = m < g.M ? m : g.M - 1, nc = nb + 8 <= g.N ? nb : 0;  // clamped: out-of-range lanes are never stored
+        pre_all[np][mt] = *reinterpret_cast<const bf16x8*>(g.aux + (long)mc * g.ldaux + nc);
+      }
+  }
 #pragma unroll
   for (int np = 0; np < NT / 2; ++np) {
     const int nb = n_base + np * 32 + 8 * lg;
@@ -82,8 +95,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNT& g, f32x4 (&acc)[MT][
               if (nb + i < g.N) ap[i] = pre[i];
         } else if (EPI == EPI_DGELU) {
           const bf16* ap = g.aux + (long)m * g.ldaux + nb;
-          if (full) {
-            const bf16x8 pre = *reinterpret_cast<const bf16x8*>(ap);
+          if (full && vec_aux) {
+            const bf16x8 pre = pre_all[np][mt];
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i] * gelu_grad_f(bf2f(pre[i])));
           } else {
@@ -305,6 +318,445 @@ static int launch_nt_ring(const GemmNT& g, int epi, hipStream_t st) {
   return xfm_check_launch("gemm_nt_ring");
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 output block (128 accumulator VGPRs).  Against the
+// 256 x 128 ring this halves the LDS fragment bytes read per MFMA (24 ds_read_b128 per 64 MFMA) and the global->LDS
+// bytes per FLOP -- the two rates that bound the ring kernel.
+//
+// LDS = 2 K-tile buffers x (X 256 rows + W 256 rows) x 128 B = 128 KiB, filled by direct-to-LDS loads in UNITS of 128 rows
+// (16 KiB = 2 wave-instructions per wave), ordered by when the compute phases need them:
+//   U0 = X rows {0-63, 128-191} (the "a0" half of both M-wave rows)      U1 = W rows {wc*64 + 0-31}  ("b0")
+//   U2 = W rows {wc*64 + 32-63} ("b1")                                    U3 = X rows {64-127, 192-255} ("a1")
+// A K-tile is computed in 4 phases of 16 MFMA: P0 reads a0,b0 -> (a0,b0); P1 reads b1 -> (a0,b1); P2 reads a1 ->
+// (a1,b1); P3 reads nothing -> (a1,b0).  Phase index ph = 4*kt + p issues unit ph+5, so every unit flies >= 4 phases and
+// three units (6 loads per wave) stay in flight across every barrier: s_waitcnt vmcnt(6) at the end of a phase retires
+// exactly the unit(s) the NEXT phase reads.  A unit overwrites the unit 8 places back, whose last ds_read was >= 3
+// phases earlier.
+// The two M-wave groups (one wave of each per SIMD) run half a phase apart -- group 1 takes one extra barrier up
+// front -- so one group's MFMA section overlaps the other's ds_read/glds section (two barriers per phase).
+// RAW: a wave's share of a unit is retired by its own counted vmcnt before barrier #1 of phase ph; readers touch it
+// in phase ph+1, i.e. after barrier #2 of phase ph, which every wave of both groups reaches after that wait.
+// ---------------------------------------------------------------------------------------------
+template <int J>
+__device__ __forceinline__ int unit_row(int u) {  // row of the X (J = 0, 3) or W (J = 1, 2) tile held by unit row u
+  if (J == 0) return u + (u & 64);
+  if (J == 3) return u + 64 + (u & 64);
+  if (J == 1) return ((u >> 5) << 6) + (u & 31);
+  return ((u >> 5) << 6) + 32 + (u & 31);
+}
+
+#define XFM_FENCE() asm volatile("" ::: "memory")
+#define XFM_BAR()                    \
+  do {                               \
+    XFM_FENCE();                     \
+    __builtin_amdgcn_s_barrier();    \
+    XFM_FENCE();                     \
+  } while (0)
+
+__device__ __forceinline__ void wait_younger(int y) {  // leave the y youngest units (2 loads each) in flight
+  if (y >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (y == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (y == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g) {
+  constexpr int BM = 256, BN = 256, MT = 8, NT = 4;
+  constexpr int XBYTES = 256 * 128, BUF = 2 * XBYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 2, wc = w & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  grouped_tile(wg, tiles_m, tiles_n, g.group_m, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = g.K / 64;
+  const int total = 4 * nk;  // staging units
+
+  // per-lane global element offsets of the 8 (unit, instruction) loads; the K offset is added per K-tile
+  unsigned soff[4][2];
+  int doff[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = (i * 8 + w) * 8 + (lane >> 3);
+    {
+      const int r = unit_row<0>(u);
+      int gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;
+      soff[0][i] = (unsigned)gr * (unsigned)g.lda + (((lane & 7) ^ swz_x(r)) << 3);
+      doff[0][i] = (r >> 3) * 1024;
+    }
+    {
+      const int r = unit_row<3>(u);
+      int gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;
+      soff[3][i] = (unsigned)gr * (unsigned)g.lda + (((lane & 7) ^ swz_x(r)) << 3);
+      doff[3][i] = (r >> 3) * 1024;
+    }
+    {
+      const int r = unit_row<1>(u);
+      int gr = n0 + r; gr = gr < g.N ? gr : g.N - 1;
+      soff[1][i] = (unsigned)gr * (unsigned)g.ldb + (((lane & 7) ^ swz_w(r)) << 3);
+      doff[1][i] = XBYTES + (r >> 3) * 1024;
+    }
+    {
+      const int r = unit_row<2>(u);
+      int gr = n0 + r; gr = gr < g.N ? gr : g.N - 1;
+      soff[2][i] = (unsigned)gr * (unsigned)g.ldb + (((lane & 7) ^ swz_w(r)) << 3);
+      doff[2][i] = XBYTES + (r >> 3) * 1024;
+    }
+  }
+  auto issue = [&](int s) {  // unit s = (K-tile s >> 2, part s & 3); warp-uniform branch
+    if (s >= total) return;
+    const int kt = s >> 2, j = s & 3;
+    char* base = smem + (kt & 1) * BUF;
+    const bf16* src = ((j == 0 || j == 3) ? g.A : g.B) + kt * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned so = j == 0 ? soff[0][i] : j == 1 ? soff[1][i] : j == 2 ? soff[2][i] : soff[3][i];
+      const int dofs = j == 0 ? doff[0][i] : j == 1 ? doff[1][i] : j == 2 ? doff[2][i] : doff[3][i];
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, src + (size_t)so), LDS_PTR(void, base + __builtin_amdgcn_readfirstlane(dofs)), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane LDS byte offsets of the fragment reads (the 16-B chunk index c = ks*4 + lg is XOR-ed with the row swizzle)
+  const int xr0 = wr * 128 + lr;                                  // + mt*16
+  const int xs = swz_x(xr0);
+  const int wr0 = wc * 64 + 8 * (lr >> 2) + (lr & 3);             // + (nt>>1)*32 + 4*(nt&1)
+  const int ws = swz_w(wr0);
+  const int xbase0 = xr0 * 128 + (((0 + lg) ^ xs) << 4), xbase1 = xr0 * 128 + (((4 + lg) ^ xs) << 4);
+  const int wbase0 = XBYTES + wr0 * 128 + (((0 + lg) ^ ws) << 4), wbase1 = XBYTES + wr0 * 128 + (((4 + lg) ^ ws) << 4);
+
+  bf16x8 xa[4][2], wb0[2][2], wb1[2][2];
+  auto read_x = [&](const char* buf, int half) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      xa[m][0] = *reinterpret_cast<const bf16x8*>(buf + xbase0 + (half * 4 + m) * 2048);
+      xa[m][1] = *reinterpret_cast<const bf16x8*>(buf + xbase1 + (half * 4 + m) * 2048);
+    }
+  };
+  auto read_w = [&](const char* buf, int half, bf16x8 (&wb)[2][2]) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      wb[n][0] = *reinterpret_cast<const bf16x8*>(buf + wbase0 + half * 4096 + n * 512);
+      wb[n][1] = *reinterpret_cast<const bf16x8*>(buf + wbase1 + half * 4096 + n * 512);
+    }
+  };
+#define XFM_QUAD(MH, NH, WB)                                                                                     \
+  do {                                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                                \
+    _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                                \
+      acc[MH * 4 + m][NH * 2 + n] =                                                                              \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[n][ks], xa[m][ks], acc[MH * 4 + m][NH * 2 + n], 0, 0, 0);  \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+  } while (0)
+
+  // prologue: units 0..4 in flight, units 0 and 1 (a0, b0 of K-tile 0) retired and visible
+#pragma unroll
+  for (int s = 0; s < 5; ++s) issue(s);
+  wait_younger((total - 1 < 4 ? total - 1 : 4) - 1);
+  XFM_BAR();
+  if (wr == 1) XFM_BAR();  // stagger the second M-wave group by one barrier
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* buf = smem + (kt & 1) * BUF;
+    const int ph = 4 * kt;
+    int last;
+    // ---- P0: (a0, b0)
+    issue(ph + 5);
+    read_x(buf, 0);
+    read_w(buf, 0, wb0);
+    last = ph + 5 < total ? ph + 5 : total - 1;
+    wait_younger(last - (ph + 2));
+    XFM_BAR();
+    XFM_QUAD(0, 0, wb0);
+    XFM_BAR();
+    // ---- P1: (a0, b1)
+    issue(ph + 6);
+    read_w(buf, 1, wb1);
+    last = ph + 6 < total ? ph + 6 : total - 1;
+    wait_younger(last - (ph + 3));
+    XFM_BAR();
+    XFM_QUAD(0, 1, wb1);
+    XFM_BAR();
+    // ---- P2: (a1, b1)
+    issue(ph + 7);
+    read_x(buf, 1);
+    XFM_BAR();
+    XFM_QUAD(1, 1, wb1);
+    XFM_BAR();
+    // ---- P3: (a1, b0); retire a0, b0 of the next K-tile
+    issue(ph + 8);
+    last = ph + 8 < total ? ph + 8 : total - 1;
+    wait_younger(last - (ph + 5) < 0 ? 0 : last - (ph + 5));
+    XFM_BAR();
+    XFM_QUAD(1, 0, wb0);
+    XFM_BAR();
+  }
+  if (wr == 0) XFM_BAR();
+#undef XFM_QUAD
+  gemm_epilogue<MT, NT, EPI>(g, acc, m0 + wr * 128, n0 + wc * 64, lr, lg);
+}
+
+// Persistent form of the 256 x 256 kernel: one workgroup per CU walks tiles blockIdx, blockIdx + grid, ... and the
+// staging-unit stream simply continues across tile boundaries (unit index = 4 * global K-tile + part), so the next
+// tile's first loads are in flight during the current tile's last phases and its MFMAs start while the epilogue's
+// stores are still draining -- no per-tile prologue bubble, and the C write burst overlaps compute.
+// Stores share the in-order vmcnt queue with the direct-to-LDS loads; they only make the counted waits conservative.
+template <int V>
+struct JTag { static constexpr int value = V; };
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmNT g, int ntiles) {
+  constexpr int BM = 256, BN = 256, MT = 8, NT = 4;
+  constexpr int XBYTES = 256 * 128, BUF = 2 * XBYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 2, wc = w & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  const int G = gridDim.x;
+  const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+  const int nk = g.K / 64;
+  const int total = 4 * nk * my_tiles;  // staging units of this workgroup
+
+  unsigned soff[4][2];
+  int doff[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = (i * 8 + w) * 8 + (lane >> 3);
+    doff[0][i] = (unit_row<0>(u) >> 3) * 1024;
+    doff[3][i] = (unit_row<3>(u) >> 3) * 1024;
+    doff[1][i] = XBYTES + (unit_row<1>(u) >> 3) * 1024;
+    doff[2][i] = XBYTES + (unit_row<2>(u) >> 3) * 1024;
+  }
+  auto tile_origin = [&](int ti, int& m0, int& n0) {
+    const int wg = xcd_remap((int)blockIdx.x + ti * G, ntiles);
+    int tm, tn;
+    grouped_tile(wg, tiles_m, tiles_n, g.group_m, tm, tn);
+    m0 = tm * BM;
+    n0 = tn * BN;
+  };
+  auto set_tile_offsets = [&](int ti) {
+    int m0, n0;
+    tile_origin(ti, m0, n0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = (i * 8 + w) * 8 + (lane >> 3);
+      int r = unit_row<0>(u), gr = m0 + r;
+      gr = gr < g.M ? gr : g.M - 1;
+      soff[0][i] = (unsigned)gr * (unsigned)g.lda + (((lane & 7) ^ swz_x(r)) << 3);
+      r = unit_row<3>(u); gr = m0 + r;
+      gr = gr < g.M ? gr : g.M - 1;
+      soff[3][i] = (unsigned)gr * (unsigned)g.lda + (((lane & 7) ^ swz_x(r)) << 3);
+      r = unit_row<1>(u); gr = n0 + r;
+      gr = gr < g.N ? gr : g.N - 1;
+      soff[1][i] = (unsigned)gr * (unsigned)g.ldb + (((lane & 7) ^ swz_w(r)) << 3);
+      r = unit_row<2>(u); gr = n0 + r;
+      gr = gr < g.N ? gr : g.N - 1;
+      soff[2][i] = (unsigned)gr * (unsigned)g.ldb + (((lane & 7) ^ swz_w(r)) << 3);
+    }
+  };
+  // issue side of the unit stream (all wave-uniform scalars)
+  int issued = 0, i_kt = 0, i_gk = 0, i_tile = 0;
+  auto issue = [&](auto jtag) {
+    constexpr int J = decltype(jtag)::value;
+    if (issued >= total) return;
+    char* base = smem + (i_gk & 1) * BUF;
+    const bf16* src = ((J == 0 || J == 3) ? g.A : g.B) + i_kt * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, src + (size_t)soff[J][i]),
+                                       LDS_PTR(void, base + __builtin_amdgcn_readfirstlane(doff[J][i])), 16, 0, 0);
+    ++issued;
+    if (J == 3) {
+      ++i_gk;
+      if (++i_kt == nk) {
+        i_kt = 0;
+        if (++i_tile < my_tiles) set_tile_offsets(i_tile);
+      }
+    }
+  };
+  auto wait_for = [&](int needed) {  // units up to index `needed` must have landed; younger ones may stay in flight
+    const int y = issued - 1 - needed;
+    if (y >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else wait_younger(y < 0 ? 0 : y);
+  };
+  using J0 = JTag<0>; using J1 = JTag<1>; using J2 = JTag<2>; using J3 = JTag<3>;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int xr0 = wr * 128 + lr;
+  const int xs = swz_x(xr0);
+  const int wr0 = wc * 64 + 8 * (lr >> 2) + (lr & 3);
+  const int ws = swz_w(wr0);
+  const int xbase0 = xr0 * 128 + (((0 + lg) ^ xs) << 4), xbase1 = xr0 * 128 + (((4 + lg) ^ xs) << 4);
+  const int wbase0 = XBYTES + wr0 * 128 + (((0 + lg) ^ ws) << 4), wbase1 = XBYTES + wr0 * 128 + (((4 + lg) ^ ws) << 4);
+
+  bf16x8 xa[4][2], wb0[2][2], wb1[2][2];
+  auto read_x = [&](const char* buf, int half) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      xa[m][0] = *reinterpret_cast<const bf16x8*>(buf + xbase0 + (half * 4 + m) * 2048);
+      xa[m][1] = *reinterpret_cast<const bf16x8*>(buf + xbase1 + (half * 4 + m) * 2048);
+    }
+  };
+  auto read_w = [&](const char* buf, int half, bf16x8 (&wb)[2][2]) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      wb[n][0] = *reinterpret_cast<const bf16x8*>(buf + wbase0 + half * 4096 + n * 512);
+      wb[n][1] = *reinterpret_cast<const bf16x8*>(buf + wbase1 + half * 4096 + n * 512);
+    }
+  };
+#define XFM_QUAD(MH, NH, WB)                                                                                     \
+  do {                                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                                \
+    _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                                \
+      acc[MH * 4 + m][NH * 2 + n] =                                                                              \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[n][ks], xa[m][ks], acc[MH * 4 + m][NH * 2 + n], 0, 0, 0);  \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+  } while (0)
+
+  set_tile_offsets(0);
+  issue(J0{}); issue(J1{}); issue(J2{}); issue(J3{}); issue(J0{});
+  wait_for(1);
+  XFM_BAR();
+  if (wr == 1) XFM_BAR();  // stagger the second M-wave group by one barrier
+
+  const int total_k = nk * my_tiles;
+  int c_kt = 0, c_tile = 0;
+  for (int gk = 0; gk < total_k; ++gk) {
+    const char* buf = smem + (gk & 1) * BUF;
+    const int ph = 4 * gk;
+    // ---- P0: (a0, b0)
+    issue(J1{});
+    read_x(buf, 0);
+    read_w(buf, 0, wb0);
+    wait_for(ph + 2);
+    XFM_BAR();
+    XFM_QUAD(0, 0, wb0);
+    XFM_BAR();
+    // ---- P1: (a0, b1)
+    issue(J2{});
+    read_w(buf, 1, wb1);
+    wait_for(ph + 3);
+    XFM_BAR();
+    XFM_QUAD(0, 1, wb1);
+    XFM_BAR();
+    // ---- P2: (a1, b1)
+    issue(J3{});
+    read_x(buf, 1);
+    XFM_BAR();
+    XFM_QUAD(1, 1, wb1);
+    XFM_BAR();
+    // ---- P3: (a1, b0); retire a0, b0 of the next K-tile
+    issue(J0{});
+    wait_for(ph + 5);
+    XFM_BAR();
+    XFM_QUAD(1, 0, wb0);
+    XFM_BAR();
+    if (++c_kt == nk) {  // tile finished: write it out (stores drain behind the next tile's MFMAs) and restart the accumulators
+      c_kt = 0;
+      int m0, n0;
+      tile_origin(c_tile, m0, n0);
+      ++c_tile;
+      gemm_epilogue<MT, NT, EPI>(g, acc, m0 + wr * 128, n0 + wc * 64, lr, lg);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if (wr == 0) XFM_BAR();
+#undef XFM_QUAD
+}
+
+static int launch_nt_256p(const GemmNT& g, int epi, hipStream_t st) {
+  const int tiles = cdiv(g.M, 256) * cdiv(g.N, 256);
+  const size_t smem = 4 * 256 * 128;
+  if ((unsigned long)g.M * (unsigned long)g.lda >= (1ul << 32) || (unsigned long)g.N * (unsigned long)g.ldb >= (1ul << 32)) {
+    xfm_set_error("gemm_nt: operand too large for the 256x256 kernel's 32-bit element offsets");
+    return XFM_E_ARG;
+  }
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    num_cu = n;
+  }
+  const int grid = tiles < num_cu ? tiles : num_cu;
+#define XFM_256P_CASE(E)                                                                                       \
+  case E: {                                                                                                    \
+    static bool attr_set = false;                                                                              \
+    if (!attr_set) {                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256p_kernel<E>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
+      attr_set = true;                                                                                         \
+    }                                                                                                          \
+    hipLaunchKernelGGL((gemm_nt_256p_kernel<E>), dim3(grid), dim3(512), smem, st, g, tiles);                   \
+    break;                                                                                                     \
+  }
+  switch (epi) {
+    XFM_256P_CASE(EPI_BF16)
+    XFM_256P_CASE(EPI_F32)
+    XFM_256P_CASE(EPI_GELU)
+    XFM_256P_CASE(EPI_DGELU)
+    XFM_256P_CASE(EPI_F32_ACC)
+    default:
+      xfm_set_error("gemm_nt: bad epilogue %d", epi);
+      return XFM_E_ARG;
+  }
+#undef XFM_256P_CASE
+  return xfm_check_launch("gemm_nt_256p");
+}
+
+static int launch_nt_256(const GemmNT& g, int epi, hipStream_t st) {
+  const int tiles = cdiv(g.M, 256) * cdiv(g.N, 256);
+  const size_t smem = 4 * 256 * 128;
+  if ((unsigned long)g.M * (unsigned long)g.lda >= (1ul << 32) || (unsigned long)g.N * (unsigned long)g.ldb >= (1ul << 32)) {
+    xfm_set_error("gemm_nt: operand too large for the 256x256 kernel's 32-bit element offsets");
+    return XFM_E_ARG;
+  }
+#define XFM_256_CASE(E)                                                                                        \
+  case E: {                                                                                                    \
+    static bool attr_set = false;                                                                              \
+    if (!attr_set) {                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<E>),                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
+      attr_set = true;                                                                                         \
+    }                                                                                                          \
+    hipLaunchKernelGGL((gemm_nt_256_kernel<E>), dim3(tiles), dim3(512), smem, st, g);                          \
+    break;                                                                                                     \
+  }
+  switch (epi) {
+    XFM_256_CASE(EPI_BF16)
+    XFM_256_CASE(EPI_F32)
+    XFM_256_CASE(EPI_GELU)
+    XFM_256_CASE(EPI_DGELU)
+    XFM_256_CASE(EPI_F32_ACC)
+    default:
+      xfm_set_error("gemm_nt: bad epilogue %d", epi);
+      return XFM_E_ARG;
+  }
+#undef XFM_256_CASE
+  return xfm_check_launch("gemm_nt_256");
+}
+
 template <int BM, int BN>
 static int launch_nt(const GemmNT& g, int epi, hipStream_t st) {
   const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
@@ -346,7 +798,8 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
   GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K, gm_env > 0 ? gm_env : 8};
   int cfg = tile_hint;
   if (cfg <= 0) {  // measured on MI355X (tools/tune_gemm.py): 128x128 pays from ~3 workgroups per CU, else go smaller
-    if ((long)cdiv(M, 256) * cdiv(N, 128) >= 768) cfg = 4;  // >= 3 rounds of 256x128 tiles: the 3-slot ring wins on cold operands
+    if (M >= 2048 && (long)cdiv(M, 256) * cdiv(N, 256) >= 120) cfg = 5;  // ~half a round of 256x256 tiles already beats the rest
+    else if ((long)cdiv(M, 256) * cdiv(N, 128) >= 768) cfg = 4;  // >= 3 rounds of 256x128 tiles: the 3-slot ring wins on cold operands
     else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 800) cfg = 1;
     else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 256) cfg = 2;
     else cfg = 3;
@@ -355,6 +808,8 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
     case 1: return launch_nt<128, 128>(g, epi, st);
     case 2: return launch_nt<64, 128>(g, epi, st);
     case 4: return launch_nt_ring(g, epi, st);
+    case 5: return launch_nt_256(g, epi, st);
+    case 6: return launch_nt_256p(g, epi, st);
     default: return launch_nt<64, 64>(g, epi, st);
   }
 }
@@ -371,6 +826,7 @@ struct GemmTN {
   float* dbias;  // optional: dbias[n] += sum_m dY[m,n] (bias gradient), folded into the k-tile-0 workgroups
   int M, N, K;
   int m_per_split;
+  float* ws;  // 256x256 kernel only: per-(split, tile) partial tiles in accumulator-register order (null = atomics into dW)
 };
 
 __device__ __forceinline__ int swz_t(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }  // XOR on the 16-B chunk idx
@@ -645,8 +1101,260 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmTN g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// wgrad on the 256 x 256 phase pipeline (see gemm_nt_256_kernel): dW tile 256 (n) x 256 (k), 8 waves as 2 (n) x 4 (k),
+// a K-tile = 64 rows of M.  Staging units are [64 m][128 col] images (256-B rows, swz_t on the source address) of the
+// column subsets each phase consumes: U0 = dY cols {wr*128 + 0..63}, U1 = X cols {wc*64 + 0..31}, U2 = X cols
+// {wc*64 + 32..63}, U3 = dY cols {wr*128 + 64..127}; fragments come out with ds_read_b64_tr_b16.  No bounds checks:
+// the launcher only picks this kernel for M % 64 == 0 and N, K % 256 == 0.  The bias gradient (column sums of dY) rides
+// on the matrix cores: in the k-tile-0 workgroups wave wc multiplies its wc-th dY fragment of each half with a ones
+// fragment (4 extra MFMA per K-tile per wave).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmTN g) {
+  constexpr int UNIT = 64 * 256, BUF = 4 * UNIT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 2, wc = w & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int tiles_k = g.K / 256, tiles_n = g.N / 256;
+  const int per_split = tiles_k * tiles_n;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = wg / per_split, t = wg % per_split;
+  const int n0 = (t / tiles_k) * 256, k0 = (t % tiles_k) * 256;
+  const int mbeg = split * g.m_per_split;
+  int mend = mbeg + g.m_per_split;
+  mend = mend < g.M ? mend : g.M;
+  const int nk = (mend - mbeg) / 64;
+  const int total = 4 * nk;
+  const bool do_bias = g.dbias != nullptr && k0 == 0;
+
+  // per-lane source element offsets (K-tile 0) and wave-uniform LDS destinations of the 8 (unit, instruction) loads
+  unsigned soff[4][2];
+  int doff[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int b = i * 8 + w;                 // 1-KiB block of the unit: rows 4b .. 4b+3
+    const int r = 4 * b + (lane >> 4);
+    const int c = ((lane & 15) ^ swz_t(r)) * 8;  // logical column (0..127) stored at this lane's 16-B slot
+    const unsigned rowy = (unsigned)(mbeg + r) * (unsigned)g.ldy, rowx = (unsigned)(mbeg + r) * (unsigned)g.ldx;
+    soff[0][i] = rowy + n0 + (c >> 6) * 128 + (c & 63);
+    soff[3][i] = rowy + n0 + (c >> 6) * 128 + 64 + (c & 63);
+    soff[1][i] = rowx + k0 + (c >> 5) * 64 + (c & 31);
+    soff[2][i] = rowx + k0 + (c >> 5) * 64 + 32 + (c & 31);
+    doff[0][i] = 0 * UNIT + b * 1024;
+    doff[1][i] = 1 * UNIT + b * 1024;
+    doff[2][i] = 2 * UNIT + b * 1024;
+    doff[3][i] = 3 * UNIT + b * 1024;
+  }
+  auto issue = [&](int s) {
+    if (s >= total) return;
+    const int kt = s >> 2, j = s & 3;
+    char* base = smem + (kt & 1) * BUF;
+    const bool isy = (j == 0 || j == 3);
+    const bf16* src = (isy ? g.dY : g.X) + (size_t)kt * 64 * (size_t)(isy ? g.ldy : g.ldx);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned so = j == 0 ? soff[0][i] : j == 1 ? soff[1][i] : j == 2 ? soff[2][i] : soff[3][i];
+      const int dofs = j == 0 ? doff[0][i] : j == 1 ? doff[1][i] : j == 2 ? doff[2][i] : doff[3][i];
+      // Issued as inline asm on purpose: when the compiler sees a direct-to-LDS load it drains it (s_waitcnt vmcnt(0)) in
+      // front of every ds_read_b64_tr_b16, whose intrinsic carries no alias information -- that serialises the pipeline.
+      const unsigned lds_addr = (unsigned)(uintptr_t)LDS_PTR(void, base) + (unsigned)__builtin_amdgcn_readfirstlane(dofs);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + (size_t)so), "s"(lds_addr) : "memory", "m0");
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = f2bf(1.0f);
+
+  // per-lane byte offsets of the transposed fragment reads inside a unit image (+ ks * 8192, + 1024 for rows +4)
+  const int lrow = 8 * lg + (lr >> 2);
+  const int tsw = swz_t(lrow);
+  int offa[4], offb[2];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int col = wr * 64 + f * 16 + 4 * (lr & 3);
+    offa[f] = lrow * 256 + (((col >> 3) ^ tsw) << 4) + (col & 7) * 2;
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int col = wc * 32 + f * 16 + 4 * (lr & 3);
+    offb[f] = lrow * 256 + (((col >> 3) ^ tsw) << 4) + (col & 7) * 2;
+  }
+  auto tr_pair = [&](const char* p) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p + 1024));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.v;
+  };
+  bf16x8 xa[4][2], wb0[2][2], wb1[2][2];
+  auto read_a = [&](const char* unit) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      xa[f][0] = tr_pair(unit + offa[f]);
+      xa[f][1] = tr_pair(unit + offa[f] + 8192);
+    }
+  };
+  auto read_b = [&](const char* unit, bf16x8 (&wb)[2][2]) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      wb[f][0] = tr_pair(unit + offb[f]);
+      wb[f][1] = tr_pair(unit + offb[f] + 8192);
+    }
+  };
+#define XFM_TQUAD(MH, NH, WB)                                                                                    \
+  do {                                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                                \
+    _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                                \
+      acc[MH * 4 + m][NH * 2 + n] =                                                                              \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[m][ks], WB[n][ks], acc[MH * 4 + m][NH * 2 + n], 0, 0, 0);  \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+  } while (0)
+#define XFM_TBIAS(H)                                                                                             \
+  do {                                                                                                           \
+    if (do_bias) {                                                                                               \
+      _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                              \
+        if (f == wc) {                                                                                           \
+          bacc[H] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[f][0], ones, bacc[H], 0, 0, 0);                  \
+          bacc[H] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[f][1], ones, bacc[H], 0, 0, 0);                  \
+        }                                                                                                        \
+    }                                                                                                            \
+  } while (0)
+
+#pragma unroll
+  for (int s = 0; s < 5; ++s) issue(s);
+  wait_younger((total - 1 < 4 ? total - 1 : 4) - 1);
+  XFM_BAR();
+  if (wr == 1) XFM_BAR();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* buf = smem + (kt & 1) * BUF;
+    const int ph = 4 * kt;
+    int last;
+    // ---- P0: (a0, b0)
+    issue(ph + 5);
+    read_a(buf + 0 * UNIT);
+    read_b(buf + 1 * UNIT, wb0);
+    last = ph + 5 < total ? ph + 5 : total - 1;
+    wait_younger(last - (ph + 2));
+    XFM_BAR();
+    XFM_TQUAD(0, 0, wb0);
+    XFM_TBIAS(0);
+    XFM_BAR();
+    // ---- P1: (a0, b1)
+    issue(ph + 6);
+    read_b(buf + 2 * UNIT, wb1);
+    last = ph + 6 < total ? ph + 6 : total - 1;
+    wait_younger(last - (ph + 3));
+    XFM_BAR();
+    XFM_TQUAD(0, 1, wb1);
+    XFM_BAR();
+    // ---- P2: (a1, b1)
+    issue(ph + 7);
+    read_a(buf + 3 * UNIT);
+    XFM_BAR();
+    XFM_TQUAD(1, 1, wb1);
+    XFM_TBIAS(1);
+    XFM_BAR();
+    // ---- P3: (a1, b0)
+    issue(ph + 8);
+    last = ph + 8 < total ? ph + 8 : total - 1;
+    wait_younger(last - (ph + 5) < 0 ? 0 : last - (ph + 5));
+    XFM_BAR();
+    XFM_TQUAD(1, 0, wb0);
+    XFM_BAR();
+  }
+  if (wr == 0) XFM_BAR();
+#undef XFM_TQUAD
+#undef XFM_TBIAS
+
+  if (do_bias && lr == 0) {  // D[i = n][j]: every column j holds the same sum; lane (lg, lr = 0) owns rows 4*lg .. 4*lg+3
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(g.dbias + n0 + wr * 128 + h * 64 + wc * 16 + 4 * lg + i, bacc[h][i]);
+  }
+  if (g.ws != nullptr) {  // partial tile, one coalesced 16-B store per accumulator register quad; tn_reduce_kernel sums the splits
+    f32x4* wsp = reinterpret_cast<f32x4*>(g.ws) + ((((long)split * per_split + t) * 8 + w) * 32) * 64 + lane;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) wsp[(nt * 4 + kt) * 64] = acc[nt][kt];
+    return;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = k0 + wc * 64 + kt * 16 + lr;
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi) {
+        const int n = n0 + wr * 128 + nt * 16 + 4 * lg + rgi;
+        atomicAdd(g.dW + (long)n * g.ldw + k, acc[nt][kt][rgi]);
+      }
+    }
+}
+
+// dW += sum over splits of the partial tiles written by gemm_tn_256_kernel (deterministic: fixed summation order).
+// One thread per accumulator quad: (tile t, wave w, quad q = nt*4+kt, lane) -> rows n..n+3 at column k.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, long ldw, int tiles_k,
+                                                        int per_split, int splits) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // < per_split * 8 * 32 * 64
+  const int lane = (int)(idx & 63), q = (int)((idx >> 6) & 31), w = (int)((idx >> 11) & 7);
+  const int t = (int)(idx >> 14);
+  if (t >= per_split) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(ws) + idx;
+  const long stride = (long)per_split * 8 * 32 * 64;
+  f32x4 sum = p[0];
+  for (int sp = 1; sp < splits; ++sp) {
+    const f32x4 v = p[sp * stride];
+    sum += v;
+  }
+  const int n0 = (t / tiles_k) * 256, k0 = (t % tiles_k) * 256;
+  const int wr = w >> 2, wc = w & 3, lr = lane & 15, lg = lane >> 4, nt = q >> 2, kt = q & 3;
+  const int k = k0 + wc * 64 + kt * 16 + lr;
+  const int n = n0 + wr * 128 + nt * 16 + 4 * lg;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dW[(long)(n + i) * ldw + k] += sum[i];
+}
+
+static int tn256_plan(int M, int N, int K, int& splits, int& mps) {  // -> number of 256x256 tiles
+  const int t256 = (N / 256) * (K / 256);
+  splits = 256 / t256;
+  const int steps = M / 64;
+  if (splits > steps / 8) splits = steps / 8;
+  if (splits < 1) splits = 1;
+  mps = cdiv(steps, splits) * 64;
+  splits = cdiv(M, mps);
+  return t256;
+}
+
+static bool tn256_eligible(long ldy, long ldx, int M, int N, int K) {
+  return M % 64 == 0 && N % 256 == 0 && K % 256 == 0 && N >= 256 && K >= 256 &&
+         (unsigned long)M * (unsigned long)(ldy > ldx ? ldy : ldx) < (1ul << 32);
+}
+
+// Workspace (bytes) the 256x256 wgrad path wants for this shape; 0 when the shape runs on the atomic 128x128 kernel.
+long xfm_gemm_tn_workspace_impl(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || !tn256_eligible(N, K, M, N, K)) return 0;
+  int splits, mps;
+  const int t256 = tn256_plan(M, N, K, splits, mps);
+  if (!(t256 >= 18 && M >= 4096)) return 0;
+  return (long)splits * N * K * 4;
+}
+
 int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, float* dbias, int M, int N, int K,
-                     int splits_hint, hipStream_t st) {
+                     int splits_hint, float* workspace, long workspace_bytes, hipStream_t st) {
   XFM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
   XFM_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "gemm_tn: K=%d ldx=%ld ldy=%ld must be multiples of 8", K, ldx, ldy);
   XFM_REQUIRE(((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0, "gemm_tn: operands must be 16-byte aligned");
@@ -662,7 +1370,7 @@ int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* d
     if (splits < 1) splits = 1;
     int mps = cdiv(cdiv(M, splits), 64) * 64;
     splits = cdiv(M, mps);
-    GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, dbias, M, N, K, mps};
+    GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, dbias, M, N, K, mps, nullptr};
     static bool ring_attr = false;
     const size_t rsmem = 3 * 48 * 1024;
     if (!ring_attr) {
@@ -672,6 +1380,33 @@ int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* d
     }
     hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(rtiles * splits), dim3(512), rsmem, st, g);
     return xfm_check_launch("gemm_tn_ring");
+  }
+  // 256 x 256 phase-pipelined kernel: shapes without edges and with enough output tiles.  Its split partials go to the
+  // caller's workspace with plain coalesced stores and are summed by tn_reduce_kernel -- fp32 atomics into dW run at
+  // ~0.8 TB/s on this part and would cost more than the MFMA loop.  Without a workspace it is only used when forced
+  // (splits_hint == -3, atomics; tests / tuning); splits_hint == -4 forbids it.
+  if (tn256_eligible(ldy, ldx, M, N, K) && splits_hint != -4) {
+    int splits, mps;
+    const int t256 = tn256_plan(M, N, K, splits, mps);
+    const long need = (long)splits * N * K * 4;
+    const bool have_ws = workspace != nullptr && workspace_bytes >= need;
+    const bool want = splits_hint == -3 || (splits_hint == 0 && t256 >= 18 && M >= 4096 && have_ws);
+    if (want) {
+      GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, dbias, M, N, K, mps, have_ws ? workspace : nullptr};
+      static bool attr256 = false;
+      const size_t smem256 = 2 * 4 * 64 * 256;
+      if (!attr256) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem256);
+        attr256 = true;
+      }
+      hipLaunchKernelGGL(gemm_tn_256_kernel, dim3(t256 * splits), dim3(512), smem256, st, g);
+      int rc = xfm_check_launch("gemm_tn_256");
+      if (rc != XFM_OK || !have_ws) return rc;
+      const long quads = (long)t256 * 8 * 32 * 64;
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, st, workspace, dW, ldw, K / 256, t256, splits);
+      return xfm_check_launch("gemm_tn_reduce");
+    }
   }
   const int tiles = cdiv(N, 128) * cdiv(K, 128);
   int splits = splits_hint < 0 ? 0 : splits_hint;
@@ -683,7 +1418,7 @@ int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* d
   }
   int mps = cdiv(cdiv(M, splits), 64) * 64;
   splits = cdiv(M, mps);
-  GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, dbias, M, N, K, mps};
+  GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, dbias, M, N, K, mps, nullptr};
   static bool attr_set = false;
   const size_t smem = 4 * 64 * 256;
   if (!attr_set) {
