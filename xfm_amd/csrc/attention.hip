@@ -113,14 +113,23 @@ __device__ __forceinline__ float group4_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
-// score post-processing shared by forward and both backward kernels: returns the masked, biased, scaled score
-__device__ __forceinline__ float score_fix(const AttnArgs& a, float raw, int kvb, int h, int qi, int kj, float biasv) {
-  if (kj >= a.Sk) return EXCL_NEG;
-  float s = raw * a.scale + biasv;
-  bool masked = false;
-  if (a.key_keep != nullptr) masked = a.key_keep[(long)kvb * a.Sk + kj] == 0;
-  if (a.causal && kj > qi) masked = true;
-  return masked ? s + MASK_NEG : s;
+// Score post-processing shared by forward and dQ: s = raw*scale + bias (+ MASK_NEG when the key is masked or causally hidden),
+// EXCL_NEG past the last key.  Branch-free: the key-keep flags of a chunk are fetched up front with the bias (16 dwords in
+// flight, one wait) and every condition becomes a select; chunks with nothing to mask (`plain`) are a bare FMA.
+__device__ __forceinline__ void load_keep(const AttnArgs& a, int kvb, int kc, int lg, int (&kk)[4][4]) {
+  const int* row = a.key_keep + (long)kvb * a.Sk;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kj = kc * 64 + t * 16 + 4 * lg + r;
+      kk[t][r] = row[kj < a.Sk ? kj : a.Sk - 1];
+    }
+}
+__device__ __forceinline__ float score_masked(const AttnArgs& a, float raw, float biasv, bool has_mask, int keep, bool causal, int qi, int kj) {
+  const bool masked = (has_mask & (keep == 0)) | (causal & (kj > qi));
+  const float s = fmaf(raw, a.scale, biasv) + (masked ? MASK_NEG : 0.f);
+  return kj >= a.Sk ? EXCL_NEG : s;
 }
 
 __device__ __forceinline__ bool drop_keep(const AttnArgs& a, int b, int h, int qi, int kj) {
@@ -131,7 +140,8 @@ __device__ __forceinline__ bool drop_keep(const AttnArgs& a, int b, int h, int q
 // ---------------------------------------------------------------------------------------------
 // forward: grid (q blocks, H, B); block = NW waves, wave w owns query rows [qblk*16*NW + 16*w, +16)
 // ---------------------------------------------------------------------------------------------
-template <bool RES>
+// PLAIN: no key mask, no causal mask, no dropout (the ViT towers) -- those code paths and their registers are compiled out.
+template <bool RES, bool PLAIN>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
@@ -171,11 +181,18 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
     const char* sV = sK + ATTN_TILE;
     if (!wave_active) continue;
     f32x4 st[4], bvs[4];
+    int kk[PLAIN ? 1 : 4][4];
+    const bool has_mask = !PLAIN && a.key_keep != nullptr;
+    const bool causal = !PLAIN && a.causal != 0;
+    const bool plain = !has_mask && !causal && kc * 64 + 64 <= a.Sk;  // wave-uniform: nothing to mask in this chunk
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {  // bias loads first: their L2 latency hides under the QK^T MFMAs
+    for (int t = 0; t < 4; ++t) {  // bias (and key-keep) loads first: their L2 latency hides under the QK^T MFMAs
       const int kj0 = kc * 64 + t * 16 + 4 * lg;
       bvs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (a.bias != nullptr && kj0 < a.Sk) bvs[t] = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
+    }
+    if constexpr (!PLAIN) {
+      if (has_mask) load_keep(a, kvb, kc, lg, kk);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -184,15 +201,22 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
       st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 1, lr, lg), qf1, st[t], 0, 0, 0);
     }
     float mx = EXCL_NEG;
+    if (plain) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int kj0 = kc * 64 + t * 16 + 4 * lg;
-      const f32x4 bv = bvs[t];
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        st[t][r] = score_fix(a, st[t][r], kvb, h, qi, kj0 + r, bv[r]);
-        mx = fmaxf(mx, st[t][r]);
-      }
+        for (int r = 0; r < 4; ++r) {
+          st[t][r] = fmaf(st[t][r], a.scale, bvs[t][r]);
+          mx = fmaxf(mx, st[t][r]);
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[t][r] = score_masked(a, st[t][r], bvs[t][r], has_mask, has_mask ? kk[PLAIN ? 0 : t][r] : 1, causal, qi, kc * 64 + t * 16 + 4 * lg + r);
+          mx = fmaxf(mx, st[t][r]);
+        }
     }
     mx = group4_max(mx);
     const float m_new = fmaxf(m_run, mx);
@@ -202,12 +226,16 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = __expf(st[t][r] - m_new);
-        psum += pv;
-        float pd = pv;
-        if (a.drop_thresh != 0u) pd = drop_keep(a, b, h, qi, kc * 64 + t * 16 + 4 * lg + r) ? pv * a.drop_scale : 0.f;
-        st[t][r] = pd;
+        st[t][r] = __expf(st[t][r] - m_new);
+        psum += st[t][r];
       }
+    if (!PLAIN && a.drop_thresh != 0u) {  // one wave-uniform branch per chunk; the row sum above is of the undropped probabilities
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          st[t][r] = drop_keep(a, b, h, qi, kc * 64 + t * 16 + 4 * lg + r) ? st[t][r] * a.drop_scale : 0.f;
+    }
     psum = group4_sum(psum);
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -243,7 +271,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
 // adds 64 consecutive keys of one bias row (256 contiguous bytes; MI355X_MICROARCH "Global float atomics").
 // delta_i is recomputed exactly as sum_j P_ij dP_ij in a first pass over the keys (see below).
 // ---------------------------------------------------------------------------------------------
-template <int NKC, bool RES>
+template <int NKC, bool RES, bool PLAIN>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per_block) {
   constexpr bool DBIAS = NKC > 0;
   constexpr int NACC = DBIAS ? NKC : 1;
@@ -300,11 +328,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
       const char* sK = lds + (resident ? kc : (kc & 1)) * ATTN_SLOT;
       const char* sV = sK + ATTN_TILE;
       f32x4 bvs[4];
+      int kk[PLAIN ? 1 : 4][4];
+      const bool has_mask = !PLAIN && a.key_keep != nullptr;
+      const bool causal = !PLAIN && a.causal != 0;
+      const bool plain = !has_mask && !causal && kc * 64 + 64 <= a.Sk;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int kj0 = kc * 64 + t * 16 + 4 * lg;
         bvs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.bias != nullptr && kj0 < a.Sk) bvs[t] = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
+      }
+      if constexpr (!PLAIN) {
+        if (has_mask) load_keep(a, kvb, kc, lg, kk);
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -315,17 +350,25 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
         dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 0, lr, lg), df0, dp[t], 0, 0, 0);
         dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 1, lr, lg), df1, dp[t], 0, 0, 0);
       }
+      const float lse_q = qvalid ? lse : 3.0e38f;  // rows past Sq: exp(s - 3e38) = 0, no per-element select
+      if (plain) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int kj0 = kc * 64 + t * 16 + 4 * lg;
-        const f32x4 bv = bvs[t];
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kj = kj0 + r;
-          const float sc = score_fix(a, st[t][r], kvb, h, qi, kj, bv[r]);
-          st[t][r] = (kj < a.Sk && qvalid) ? __expf(sc - lse) : 0.f;
-          if (a.drop_thresh != 0u) dp[t][r] = drop_keep(a, b, h, qi, kj) ? dp[t][r] * a.drop_scale : 0.f;
-        }
+          for (int r = 0; r < 4; ++r) st[t][r] = __expf(fmaf(st[t][r], a.scale, bvs[t][r]) - lse_q);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)  // excluded keys: exp(EXCL_NEG - lse) = 0
+            st[t][r] = __expf(score_masked(a, st[t][r], bvs[t][r], has_mask, has_mask ? kk[PLAIN ? 0 : t][r] : 1, causal, qi, kc * 64 + t * 16 + 4 * lg + r) - lse_q);
+      }
+      if (!PLAIN && a.drop_thresh != 0u) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            dp[t][r] = drop_keep(a, b, h, qi, kc * 64 + t * 16 + 4 * lg + r) ? dp[t][r] * a.drop_scale : 0.f;
       }
     };
 
@@ -425,7 +468,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
 // backward 2/2: dK, dV.  grid (key blocks, H, B); wave w owns keys [kblk*16*NW + 16*w, +16); queries stream in chunks
 // of 64 (Q and dO staged in LDS, read by rows for S / dP and transposed for dK^T / dV^T).
 // ---------------------------------------------------------------------------------------------
-template <bool RES>
+template <bool RES, bool PLAIN>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
@@ -448,7 +491,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
   const float* lse_b = a.lse + ((long)b * a.H + h) * a.stat_ld;
   const float* del_b = a.delta + ((long)b * a.H + h) * a.stat_ld;
   bool key_masked = false;
-  if (a.key_keep != nullptr) key_masked = a.key_keep[(long)kvb * a.Sk + kcl] == 0;
+  if (!PLAIN && a.key_keep != nullptr) key_masked = a.key_keep[(long)kvb * a.Sk + kcl] == 0;
+  const bool causal = !PLAIN && a.causal != 0;
 
   f32x4 dkacc[4], dvacc[4];
 #pragma unroll
@@ -496,23 +540,47 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
         dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 0, lr, lg), vf0, dp[u], 0, 0, 0);
         dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 1, lr, lg), vf1, dp[u], 0, 0, 0);
       }
+      if (a.bias != nullptr && a.bias_t == nullptr) {  // no transposed bias copy: strided gather (slow path, wave-uniform)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = qc * 64 + (2 * s2 + u) * 16 + 4 * lg + r;
+            if (qi < a.Sq && kvalid) bvt[u][r] = a.bias[((long)h * a.Sq + qi) * a.bias_ld + kj];
+          }
+      }
+      const float key_add = key_masked ? MASK_NEG : 0.f;
+      const bool tail = qc * 64 + 64 > a.Sq;  // wave-uniform: this chunk holds rows past the last query
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int qi0 = qc * 64 + (2 * s2 + u) * 16 + 4 * lg;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qi = qi0 + r;
-          const bool ok = qi < a.Sq && kvalid;
-          float biasv = bvt[u][r];
-          if (a.bias != nullptr && a.bias_t == nullptr && ok) biasv = a.bias[((long)h * a.Sq + qi) * a.bias_ld + kj];
-          float sc = st[u][r] * a.scale + biasv;
-          if (key_masked || (a.causal && kj > qi)) sc += MASK_NEG;
-          const float pv = ok ? __expf(sc - lsev[u][r]) : 0.f;
-          float keepf = 1.f;
-          if (a.drop_thresh != 0u) keepf = (ok && drop_keep(a, b, h, qi, kj)) ? a.drop_scale : 0.f;
-          pd[u][r] = pv * keepf;
-          st[u][r] = pv * (dp[u][r] * keepf - delv[u][r]);
+          float sc = fmaf(st[u][r], a.scale, bvt[u][r]);
+          if (!PLAIN) sc += (causal & (kj > qi)) ? MASK_NEG : key_add;  // masked once, whichever reason (xroberta.py:772-807)
+          float pv = __expf(sc - lsev[u][r]);
+          float dl = delv[u][r];
+          if (tail) {  // the statistics past Sq are unwritten padding: select, never multiply
+            pv = qi < a.Sq ? pv : 0.f;
+            dl = qi < a.Sq ? dl : 0.f;
+          }
+          pv = kvalid ? pv : 0.f;
+          delv[u][r] = dl;
+          pd[u][r] = pv;
+          st[u][r] = pv * (dp[u][r] - dl);
         }
+      }
+      if (!PLAIN && a.drop_thresh != 0u) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = qc * 64 + (2 * s2 + u) * 16 + 4 * lg + r;
+            const float keepf = drop_keep(a, b, h, qi, kj) ? a.drop_scale : 0.f;
+            st[u][r] = pd[u][r] * (dp[u][r] * keepf - delv[u][r]);
+            pd[u][r] *= keepf;
+          }
       }
       // dV^T[d, key] += dO^T[d, q] . Pd[q, key] ;  dK^T[d, key] += Q^T[d, q] . dS[q, key]
       const bf16x8 pf = pack_pair(pd[0], pd[1]);
@@ -559,19 +627,25 @@ static size_t attn_lds_bytes(int S, int nw, size_t at_least) {
   static bool attr_set = false;
   if (!attr_set) {
     const int mx = ATTN_RES_MAX * ATTN_SLOT;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
     attr_set = true;
   }
   size_t b = (size_t)(attn_resident(S, nw) ? cdiv(S, 64) : 2) * ATTN_SLOT;
   return b > at_least ? b : at_least;
 }
 
+static bool attn_plain(const AttnArgs& a) { return a.key_keep == nullptr && a.causal == 0 && a.drop_thresh == 0u; }
+
 static void attn_geom(int S, int& nw, int& blocks) {
+  static const int max_nw = getenv("XFM_ATTN_MAX_NW") ? atoi(getenv("XFM_ATTN_MAX_NW")) : 8;  // tuning knob (8 measured best)
   const int tiles = cdiv(S, 16);
-  nw = tiles < 8 ? tiles : 8;
+  nw = tiles < max_nw ? tiles : max_nw;
   // balance waves over blocks (e.g. 13 tiles -> 2 blocks of 7 waves)
   blocks = cdiv(tiles, nw);
   nw = cdiv(tiles, blocks);
@@ -583,8 +657,14 @@ int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
   int nw, blocks;
   attn_geom(a.Sq, nw, blocks);
   const dim3 grid(blocks, a.H, a.B), blk(nw * 64);
-  if (attn_resident(a.Sk, nw)) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, blk, attn_lds_bytes(a.Sk, nw, 0), st, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, blk, attn_lds_bytes(a.Sk, nw, 0), st, a);
+  const size_t lds = attn_lds_bytes(a.Sk, nw, 0);
+  if (attn_resident(a.Sk, nw)) {
+    if (attn_plain(a)) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, blk, lds, st, a);
+  } else {
+    if (attn_plain(a)) hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, blk, lds, st, a);
+  }
   return xfm_check_launch("attn_fwd");
 }
 
@@ -594,22 +674,30 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
   int nw, blocks;
   attn_geom(a.Sq, nw, blocks);
   const bool res = attn_resident(a.Sk, nw);
-  if (a.dbias != nullptr && res) {
+  const bool plain = attn_plain(a);
+  if (a.dbias != nullptr && res && plain) {
     int nb = a.B >= 32 ? 4 : (a.B >= 8 ? 2 : 1);  // batch entries whose dS one workgroup sums before touching HBM
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<4, true>), dim3(blocks, a.H, cdiv(a.B, nb)), dim3(nw * 64),
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<4, true, true>), dim3(blocks, a.H, cdiv(a.B, nb)), dim3(nw * 64),
                        attn_lds_bytes(a.Sk, nw, 8 * 4096), st, a, nb);
-  } else if (res) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<0, true>), dim3(blocks, a.H, a.B), dim3(nw * 64), attn_lds_bytes(a.Sk, nw, 0), st, a, 1);
+  } else if (res) {  // (a masked / causal / dropped problem with a bias gradient falls back to per-element atomics here)
+    if (plain) hipLaunchKernelGGL((attn_bwd_dq_kernel<0, true, true>), dim3(blocks, a.H, a.B), dim3(nw * 64), attn_lds_bytes(a.Sk, nw, 0), st, a, 1);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<0, true, false>), dim3(blocks, a.H, a.B), dim3(nw * 64), attn_lds_bytes(a.Sk, nw, 0), st, a, 1);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<0, false>), dim3(blocks, a.H, a.B), dim3(nw * 64), attn_lds_bytes(a.Sk, nw, 0), st, a, 1);
+    if (plain) hipLaunchKernelGGL((attn_bwd_dq_kernel<0, false, true>), dim3(blocks, a.H, a.B), dim3(nw * 64), attn_lds_bytes(a.Sk, nw, 0), st, a, 1);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<0, false, false>), dim3(blocks, a.H, a.B), dim3(nw * 64), attn_lds_bytes(a.Sk, nw, 0), st, a, 1);
   }
   rc = xfm_check_launch("attn_bwd_dq");
   if (rc != XFM_OK) return rc;
   attn_geom(a.Sk, nw, blocks);
   const dim3 grid(blocks, a.H, a.B), blk(nw * 64);
   static const bool dkv_res = getenv("XFM_ATTN_DKV_RES") ? atoi(getenv("XFM_ATTN_DKV_RES")) != 0 : true;  // tuning knob
-  if (dkv_res && attn_resident(a.Sq, nw)) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, blk, attn_lds_bytes(a.Sq, nw, 0), st, a);
-  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, blk, 2 * ATTN_SLOT, st, a);
+  if (dkv_res && attn_resident(a.Sq, nw)) {
+    if (plain) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true>), grid, blk, attn_lds_bytes(a.Sq, nw, 0), st, a);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), grid, blk, attn_lds_bytes(a.Sq, nw, 0), st, a);
+  } else {
+    if (plain) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true>), grid, blk, 2 * ATTN_SLOT, st, a);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false>), grid, blk, 2 * ATTN_SLOT, st, a);
+  }
   return xfm_check_launch("attn_bwd_dkv");
 }
 
