@@ -142,7 +142,7 @@ __device__ __forceinline__ bool drop_keep(const AttnArgs& a, int b, int h, int q
 // ---------------------------------------------------------------------------------------------
 // PLAIN: no key mask, no causal mask, no dropout (the ViT towers) -- those code paths and their registers are compiled out.
 template <bool RES, bool PLAIN>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
   const int lr = lane & 15, lg = lane >> 4;
@@ -642,8 +642,7 @@ static size_t attn_lds_bytes(int S, int nw, size_t at_least) {
 
 static bool attn_plain(const AttnArgs& a) { return a.key_keep == nullptr && a.causal == 0 && a.drop_thresh == 0u; }
 
-static void attn_geom(int S, int& nw, int& blocks) {
-  static const int max_nw = getenv("XFM_ATTN_MAX_NW") ? atoi(getenv("XFM_ATTN_MAX_NW")) : 8;  // tuning knob (8 measured best)
+static void attn_geom(int S, int& nw, int& blocks, int max_nw = 8) {
   const int tiles = cdiv(S, 16);
   nw = tiles < max_nw ? tiles : max_nw;
   // balance waves over blocks (e.g. 13 tiles -> 2 blocks of 7 waves)
@@ -655,7 +654,8 @@ int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
   int rc = attn_check(a, false);
   if (rc != XFM_OK) return rc;
   int nw, blocks;
-  attn_geom(a.Sq, nw, blocks);
+  static const int fwd_nw = getenv("XFM_ATTN_FWD_NW") ? atoi(getenv("XFM_ATTN_FWD_NW")) : 8;  // tuning knob
+  attn_geom(a.Sq, nw, blocks, fwd_nw);
   const dim3 grid(blocks, a.H, a.B), blk(nw * 64);
   const size_t lds = attn_lds_bytes(a.Sk, nw, 0);
   if (attn_resident(a.Sk, nw)) {

@@ -798,7 +798,22 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
   GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K, gm_env > 0 ? gm_env : 8};
   int cfg = tile_hint;
   if (cfg <= 0) {  // measured on MI355X (tools/tune_gemm.py): 128x128 pays from ~3 workgroups per CU, else go smaller
-    if (M >= 2048 && (long)cdiv(M, 256) * cdiv(N, 256) >= 120) cfg = 5;  // ~half a round of 256x256 tiles already beats the rest
+    // Tail split: one workgroup per CU, so T tiles of 256x256 cost ceil(T / 256) rounds.  When the last round would be
+    // nearly empty (N = 768: 99 x 3 = 297 tiles = 1.16 rounds), the whole rounds run as 256x256 tiles and the remaining
+    // rows go to the small-tile kernels, which fill every CU for a fraction of a big-tile time.
+    static const int split_env = getenv("XFM_GEMM_TAIL_SPLIT") ? atoi(getenv("XFM_GEMM_TAIL_SPLIT")) : 1;  // tuning knob
+    const long tn256 = cdiv(N, 256), t256 = (long)cdiv(M, 256) * tn256;
+    if (split_env && tile_hint == 0 && M >= 2048 && t256 > 256 && t256 % 256 != 0 && (t256 % 256) * 100 < 35 * 256) {
+      const int rows_a = (int)((t256 / 256) * 256 / tn256) * 256;  // row tiles that exactly fill the whole rounds
+      if (rows_a > 0 && rows_a < M) {
+        int rc = xfm_gemm_nt_impl(A, lda, B, ldb, C, ldc, bias, aux, ldaux, rows_a, N, K, epi, 5, st);
+        if (rc != XFM_OK) return rc;
+        const long esz = (epi == EPI_F32 || epi == EPI_F32_ACC) ? 4 : 2;
+        return xfm_gemm_nt_impl((const bf16*)A + (long)rows_a * lda, lda, B, ldb, (char*)C + (long)rows_a * ldc * esz, ldc, bias,
+                                aux ? (void*)((bf16*)aux + (long)rows_a * ldaux) : nullptr, ldaux, M - rows_a, N, K, epi, -1, st);
+      }
+    }
+    if (M >= 2048 && t256 >= 120) cfg = 5;  // ~half a round of 256x256 tiles already beats the rest
     else if ((long)cdiv(M, 256) * cdiv(N, 128) >= 768) cfg = 4;  // >= 3 rounds of 256x128 tiles: the 3-slot ring wins on cold operands
     else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 800) cfg = 1;
     else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 256) cfg = 2;
