@@ -94,15 +94,31 @@ class GemmTimer:
             self.shapes.append(("tn", dy.shape[0], dy.shape[1] if n is None else n, x.shape[1], int(dbias is not None), s, e))
             return r
 
+        def timed_attn(kind, orig):
+            def f(*args, **kw):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = orig(*args, **kw)
+                e.record()
+                off = 3 if kind == "attn_fwd" else 9  # positional (B, H, Sq, Sk)
+                B_, H_, Sq_, Sk_ = args[off:off + 4]
+                self.shapes.append((kind, B_ * H_, Sq_, Sk_, int(kw.get("kv_index") is not None), s, e))
+                return r
+            return f
+
         self.shapes = []
         self.orig_tn = Fx.gemm_tn
+        self.orig_af, self.orig_ab = Fx.attn_fwd, Fx.attn_bwd
         Fx.gemm_nt = timed
         Fx.gemm_tn = timed_tn
+        Fx.attn_fwd = timed_attn("attn_fwd", self.orig_af)
+        Fx.attn_bwd = timed_attn("attn_bwd", self.orig_ab)
         return self
 
     def __exit__(self, *a):
         self.Fx.gemm_nt = self.orig
         self.Fx.gemm_tn = self.orig_tn
+        self.Fx.attn_fwd, self.Fx.attn_bwd = self.orig_af, self.orig_ab
 
     def by_shape(self):
         """{(kind, M, N, K, epi): [calls, total_ms]} for the instrumented step (XFM_BENCH_GEMM_SHAPES=path dumps it)."""
@@ -213,8 +229,8 @@ def main():
     if os.environ.get("XFM_BENCH_GEMM_SHAPES") and rank == 0:
         with open(os.environ["XFM_BENCH_GEMM_SHAPES"], "w") as f:
             for (kind, M, N, K, epi), (calls, ms) in sorted(gt.by_shape().items(), key=lambda kv: -kv[1][1]):
-                f.write(f"{kind} M={M:6d} N={N:6d} K={K:6d} epi/bias={epi} calls={calls:3d} total={ms:7.3f}ms avg={ms / calls * 1e3:7.1f}us "
-                        f"{2.0 * M * N * K * calls / ms / 1e9:6.0f}TF\n")
+                tf = "" if kind.startswith("attn") else f"{2.0 * M * N * K * calls / ms / 1e9:6.0f}TF"
+                f.write(f"{kind} M={M:6d} N={N:6d} K={K:6d} epi/bias={epi} calls={calls:3d} total={ms:7.3f}ms avg={ms / calls * 1e3:7.1f}us {tf}\n")
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     ms_per_step = elapsed / args.steps * 1e3
 

@@ -123,6 +123,11 @@ typedef struct {
   const float* bias_t; long bias_t_ld; /* optional transposed copy of bias [H,Sk,bias_t_ld] (vector loads in dK/dV) */
   const int* kv_index;            /* optional [B]: query batch row b reads keys/values (and key_keep) of source kv_index[b];
                                      dk/dv stay per query row (fold them with xfm_rows_index_sum) */
+  /* optional GROUPED mode (Sq <= 64, Sk <= 256, no bias / causal / kv_index): group g = query batch rows
+     grp_rows[grp_start[g] .. grp_start[g+1]) and reads key/value source g (k, v, key_keep have n_groups batch entries).
+     One workgroup per (source, head) keeps K/V LDS-resident for all of its rows; dk/dv are summed over the group and
+     written per SOURCE ([n_groups*Sk] rows). */
+  const int* grp_start; const int* grp_rows; int n_groups;
 } xfm_attn_args;
 
 int xfm_attn_fwd(const xfm_attn_args* a, void* stream);

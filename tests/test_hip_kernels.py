@@ -494,3 +494,35 @@ def test_attention_shared_kv_sources_and_row_fold():
     folded = Fx.rows_index_sum(dkv, idx, U, Sk)
     ref = torch.zeros(U, Sk * 2 * D, device="cuda").index_add_(0, idx.long(), dkv_ref.float().view(B, -1)).view(U * Sk, 2 * D)
     _close(folded, ref, 1e-2, "folded dK/dV")
+
+
+@pytest.mark.parametrize("B,U,Sq,Sk,p", [(6, 3, 30, 197, 0.0), (11, 4, 30, 197, 0.1), (5, 5, 40, 64, 0.1), (9, 2, 64, 256, 0.0)])
+def test_attention_grouped_by_kv_source(B, U, Sq, Sk, p):
+    """Grouped mode (one workgroup per key/value source and head, dK/dV summed over the group's rows in registers) against the
+    kv_index path + row fold: same masks, same dropout stream (keyed by the query batch row), empty groups give zero dK/dV."""
+    Fx = _fx()
+    H = 4
+    D = H * 64
+    gen = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, max(U - 1, 1), (B,), generator=gen).to(torch.int32).cuda()  # the last source stays unused when U > 1
+    q = _rand((B * Sq, D), seed=210)
+    kv = _rand((U * Sk, 2 * D), seed=211)
+    keep = torch.ones(U, Sk, dtype=torch.int32, device="cuda")
+    keep[0, Sk - 20:] = 0
+    dout = _rand((B * Sq, D), seed=212)
+    drop = Fx.drop_params(p, 1234567)
+    o_ref, lse_ref = Fx.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, Sq, Sk, 0.125, key_keep=keep, kv_index=idx, drop=drop)
+    groups = Fx.kv_groups(idx, U)
+    o, lse = Fx.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, Sq, Sk, 0.125, key_keep=keep, groups=groups, drop=drop)
+    _close(o, o_ref, 1e-6, "grouped forward")
+    _close(lse[..., :Sq], lse_ref[..., :Sq], 1e-6, "grouped lse")
+    dq_ref, dkv_rows = torch.empty_like(q), torch.empty((B * Sk, 2 * D), dtype=BF16, device="cuda")
+    Fx.attn_bwd(dout, q, kv[:, :D], kv[:, D:], o_ref, lse_ref, dq_ref, dkv_rows[:, :D], dkv_rows[:, D:], B, H, Sq, Sk, 0.125,
+                key_keep=keep, kv_index=idx, drop=drop)
+    ref = torch.zeros(U, Sk * 2 * D, device="cuda").index_add_(0, idx.long(), dkv_rows.float().view(B, -1)).view(U * Sk, 2 * D)
+    dq, dkv = torch.empty_like(q), torch.full((U * Sk, 2 * D), 7.0, dtype=BF16, device="cuda")
+    Fx.attn_bwd(dout, q, kv[:, :D], kv[:, D:], o, lse, dq, dkv[:, :D], dkv[:, D:], B, H, Sq, Sk, 0.125, key_keep=keep, groups=groups, drop=drop)
+    _close(dq, dq_ref, 1e-6, "grouped dQ")
+    _close(dkv, ref, 1e-2, "grouped dK/dV (summed per source)")
+    if U > 1:
+        assert float(dkv.view(U, -1)[U - 1].float().abs().max()) == 0.0, "unused source must get zero gradients"

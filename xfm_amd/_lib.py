@@ -43,7 +43,8 @@ class AttnArgs(ctypes.Structure):
                 ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32),
                 ("dout", c_void_p), ("do_rs", c_long), ("dq", c_void_p), ("dq_rs", c_long), ("dk", c_void_p),
                 ("dk_rs", c_long), ("dv", c_void_p), ("dv_rs", c_long), ("delta", c_void_p), ("dbias", c_void_p),
-                ("stat_ld", c_long), ("bias_t", c_void_p), ("bias_t_ld", c_long), ("kv_index", c_void_p)]
+                ("stat_ld", c_long), ("bias_t", c_void_p), ("bias_t_ld", c_long), ("kv_index", c_void_p),
+                ("grp_start", c_void_p), ("grp_rows", c_void_p), ("n_groups", c_int)]
 
 
 class EmbedArgs(ctypes.Structure):

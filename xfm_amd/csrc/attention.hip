@@ -605,6 +605,310 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Grouped cross-attention (fusion towers: Sq = 30 text queries against Sk = 197 image tokens, xroberta.py:201-289 with
+// encoder_hidden_states).  Several query batch rows read the SAME key/value source (XFM's ITM negatives and MLM pass reuse
+// the batch's images, xfm.py:749-802), so a workgroup is one (source, head): K/V are staged once and stay LDS-resident
+// while the 8 waves walk every (row, 16-query tile) of the group; dK/dV are accumulated over the group's rows in
+// registers and written once per SOURCE (no per-row copies, no fold pass).  group g = rows grp_rows[grp_start[g] ..
+// grp_start[g+1]) and reads source g.  Sq <= 64, Sk <= 256, no additive bias, no causal mask.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void xattn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int rstart = a.grp_start[g], nrows = a.grp_start[g + 1] - rstart;
+  if (nrows <= 0) return;  // uniform: before any barrier
+  const int kvb = g;
+  const bf16* kb = a.k + (long)kvb * a.Sk * a.k_rs + h * 64;
+  const bf16* vb = a.v + (long)kvb * a.Sk * a.v_rs + h * 64;
+  const int nchunks = (a.Sk + 63) / 64;
+  for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, a.Sk, w, nw, lane);
+  stage_wait();
+  const int tq = (a.Sq + 15) / 16, rpp = nw / tq;  // waves per row, rows per pass
+  const int jr = w / tq, tile = w - jr * tq;
+  const bool has_mask = a.key_keep != nullptr;
+  if (jr >= rpp) return;  // no barriers below
+  for (int j = jr; j < nrows; j += rpp) {
+    const int b = a.grp_rows[rstart + j];
+    const int qi = tile * 16 + lr;
+    const int qc = qi < a.Sq ? qi : a.Sq - 1;
+    const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
+    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
+    const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
+    f32x4 oacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = EXCL_NEG, l_run = 0.f;
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const char* sK = lds + kc * ATTN_SLOT;
+      const char* sV = sK + ATTN_TILE;
+      f32x4 st[4];
+      int kk[4][4];
+      if (has_mask) load_keep(a, kvb, kc, lg, kk);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 0, lr, lg), qf0, st[t], 0, 0, 0);
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 1, lr, lg), qf1, st[t], 0, 0, 0);
+      }
+      float mx = EXCL_NEG;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[t][r] = score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, false, qi, kc * 64 + t * 16 + 4 * lg + r);
+          mx = fmaxf(mx, st[t][r]);
+        }
+      mx = group4_max(mx);
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __expf(m_run - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[t][r] = __expf(st[t][r] - m_new);
+          psum += st[t][r];
+        }
+      if (a.drop_thresh != 0u) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            st[t][r] = drop_keep(a, b, h, qi, kc * 64 + t * 16 + 4 * lg + r) ? st[t][r] * a.drop_scale : 0.f;
+      }
+      psum = group4_sum(psum);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = pack_pair(st[2 * s2], st[2 * s2 + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sV, 32 * s2, 32 * s2 + 16, dt * 16, lr, lg), pf, oacc[dt], 0, 0, 0);
+      }
+    }
+    if (qi < a.Sq) {
+      const float inv = 1.0f / l_run;
+      bf16* op = a.o + ((long)b * a.Sq + qi) * a.o_rs + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = f2bf(oacc[dt][r] * inv);
+        *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * lg) = ov;
+      }
+      if (lg == 0) a.lse[((long)b * a.H + h) * a.stat_ld + qi] = m_run + __logf(l_run);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void xattn_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int rstart = a.grp_start[g], nrows = a.grp_start[g + 1] - rstart;
+  if (nrows <= 0) return;
+  const int kvb = g;
+  const bf16* kb = a.k + (long)kvb * a.Sk * a.k_rs + h * 64;
+  const bf16* vb = a.v + (long)kvb * a.Sk * a.v_rs + h * 64;
+  const int nchunks = (a.Sk + 63) / 64;
+  for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, a.Sk, w, nw, lane);
+  stage_wait();
+  const int tq = (a.Sq + 15) / 16, rpp = nw / tq;
+  const int jr = w / tq, tile = w - jr * tq;
+  const bool has_mask = a.key_keep != nullptr;
+  if (jr >= rpp) return;
+  for (int j = jr; j < nrows; j += rpp) {
+    const int b = a.grp_rows[rstart + j];
+    const int qi = tile * 16 + lr;
+    const bool qvalid = qi < a.Sq;
+    const int qc = qvalid ? qi : a.Sq - 1;
+    const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
+    const bf16* dop = a.dout + ((long)b * a.Sq + qc) * a.do_rs + h * 64;
+    const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
+    const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
+    const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop + 8 * lg);
+    const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32 + 8 * lg);
+    const long stat_idx = ((long)b * a.H + h) * a.stat_ld + qc;
+    const float lse_q = qvalid ? a.lse[stat_idx] : 3.0e38f;
+    auto probs = [&](int kc, f32x4 (&st)[4], f32x4 (&dp)[4]) {
+      const char* sK = lds + kc * ATTN_SLOT;
+      const char* sV = sK + ATTN_TILE;
+      int kk[4][4];
+      if (has_mask) load_keep(a, kvb, kc, lg, kk);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 0, lr, lg), qf0, st[t], 0, 0, 0);
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 1, lr, lg), qf1, st[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 0, lr, lg), df0, dp[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 1, lr, lg), df1, dp[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          st[t][r] = __expf(score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, false, qi, kc * 64 + t * 16 + 4 * lg + r) - lse_q);
+      if (a.drop_thresh != 0u) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            dp[t][r] = drop_keep(a, b, h, qi, kc * 64 + t * 16 + 4 * lg + r) ? dp[t][r] * a.drop_scale : 0.f;
+      }
+    };
+    float delta = 0.f;
+    f32x4 st[4], dp[4];
+    for (int kc = 0; kc < nchunks; ++kc) {
+      probs(kc, st, dp);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) delta += st[t][r] * dp[t][r];
+    }
+    delta = group4_sum(delta);
+    if (qvalid && lg == 0) a.delta[stat_idx] = delta;
+    f32x4 dqacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < nchunks; ++kc) {
+      if (nchunks > 1) probs(kc, st, dp);
+      const char* sK = lds + kc * ATTN_SLOT;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[t][r] = st[t][r] * (dp[t][r] - delta);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = pack_pair(st[2 * s2], st[2 * s2 + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK, 32 * s2, 32 * s2 + 16, dt * 16, lr, lg), pf, dqacc[dt], 0, 0, 0);
+      }
+    }
+    if (qvalid) {
+      bf16* dqp = a.dq + ((long)b * a.Sq + qi) * a.dq_rs + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = f2bf(dqacc[dt][r] * a.scale);
+        *reinterpret_cast<bf16x4*>(dqp + dt * 16 + 4 * lg) = ov;
+      }
+    }
+  }
+}
+
+// dK/dV of one (source, head): wave w owns 16 keys; the group's rows go through LDS four at a time (one 64-slot query chunk
+// per row, Sq <= 64), gradients accumulate in registers across ALL rows and are written once, at the source's rows.
+__global__ __launch_bounds__(512) void xattn_dkv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int rstart = a.grp_start[g], nrows = a.grp_start[g + 1] - rstart;
+  const int kvb = g;
+  const int k0 = (blockIdx.x * nw + w) * 16;
+  const bool wave_active = k0 < a.Sk;
+  const int kj = k0 + lr;
+  const bool kvalid = kj < a.Sk;
+  const int kcl = kvalid ? kj : a.Sk - 1;
+  const bf16* kp = a.k + ((long)kvb * a.Sk + kcl) * a.k_rs + h * 64;
+  const bf16* vp = a.v + ((long)kvb * a.Sk + kcl) * a.v_rs + h * 64;
+  const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp + 8 * lg);
+  const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + 32 + 8 * lg);
+  const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vp + 8 * lg);
+  const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vp + 32 + 8 * lg);
+  const float key_add = (a.key_keep != nullptr && a.key_keep[(long)kvb * a.Sk + kcl] == 0) ? MASK_NEG : 0.f;
+  f32x4 dkacc[4], dvacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int j0 = 0; j0 < nrows; j0 += ATTN_RES_MAX) {  // nrows is workgroup-uniform: every wave takes the same barriers
+    const int nb = nrows - j0 < ATTN_RES_MAX ? nrows - j0 : ATTN_RES_MAX;
+    __syncthreads();  // readers of the previous batch are done
+    for (int jj = 0; jj < nb; ++jj) {
+      const int b = a.grp_rows[rstart + j0 + jj];
+      stage_slot(lds + jj * ATTN_SLOT, a.q + (long)b * a.Sq * a.q_rs + h * 64, a.q_rs, a.dout + (long)b * a.Sq * a.do_rs + h * 64, a.do_rs,
+                 0, a.Sq, w, nw, lane);
+    }
+    stage_wait();
+    if (!wave_active) continue;
+    for (int jj = 0; jj < nb; ++jj) {
+      const int b = a.grp_rows[rstart + j0 + jj];
+      const char* sQ = lds + jj * ATTN_SLOT;
+      const char* sD = sQ + ATTN_TILE;
+      const float* lse_b = a.lse + ((long)b * a.H + h) * a.stat_ld;
+      const float* del_b = a.delta + ((long)b * a.H + h) * a.stat_ld;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (s2 * 32 >= a.Sq) continue;  // uniform: no query in this half (Sq = 30 lives in the first)
+        f32x4 st[2], dp[2], pd[2], lsev[2], delv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int qi0 = (2 * s2 + u) * 16 + 4 * lg;
+          lsev[u] = delv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (qi0 < a.Sq) {
+            lsev[u] = *reinterpret_cast<const f32x4*>(lse_b + qi0);
+            delv[u] = *reinterpret_cast<const f32x4*>(del_b + qi0);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = 2 * s2 + u;
+          st[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 0, lr, lg), kf0, st[u], 0, 0, 0);
+          st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 1, lr, lg), kf1, st[u], 0, 0, 0);
+          dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 0, lr, lg), vf0, dp[u], 0, 0, 0);
+          dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 1, lr, lg), vf1, dp[u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = (2 * s2 + u) * 16 + 4 * lg + r;
+            const bool ok = qi < a.Sq && kvalid;
+            float pv = __expf(fmaf(st[u][r], a.scale, key_add) - lsev[u][r]);
+            pv = ok ? pv : 0.f;
+            const float dl = ok ? delv[u][r] : 0.f;
+            float keepf = 1.f;
+            if (a.drop_thresh != 0u) keepf = drop_keep(a, b, h, qi, kj) ? a.drop_scale : 0.f;
+            pd[u][r] = pv * keepf;
+            st[u][r] = pv * (dp[u][r] * keepf - dl);
+          }
+        const bf16x8 pf = pack_pair(pd[0], pd[1]);
+        const bf16x8 sf = pack_pair(st[0], st[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sD, 32 * s2, 32 * s2 + 16, dt * 16, lr, lg), pf, dvacc[dt], 0, 0, 0);
+          dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sQ, 32 * s2, 32 * s2 + 16, dt * 16, lr, lg), sf, dkacc[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!wave_active || !kvalid) return;
+  bf16* dkp = a.dk + ((long)kvb * a.Sk + kj) * a.dk_rs + h * 64;  // per SOURCE (zeros when the group is empty)
+  bf16* dvp = a.dv + ((long)kvb * a.Sk + kj) * a.dv_rs + h * 64;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    bf16x4 ok_, ov_;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ok_[r] = f2bf(dkacc[dt][r] * a.scale); ov_[r] = f2bf(dvacc[dt][r]); }
+    *reinterpret_cast<bf16x4*>(dkp + dt * 16 + 4 * lg) = ok_;
+    *reinterpret_cast<bf16x4*>(dvp + dt * 16 + 4 * lg) = ov_;
+  }
+}
+
 static int attn_check(const AttnArgs& a, bool bwd) {
   XFM_REQUIRE(a.B > 0 && a.H > 0 && a.Sq > 0 && a.Sk > 0, "attention: empty problem B=%d H=%d Sq=%d Sk=%d", a.B, a.H, a.Sq, a.Sk);
   XFM_REQUIRE(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.v_rs % 8 == 0 && a.o_rs % 4 == 0, "attention: row strides must be multiples of 8");
@@ -650,9 +954,35 @@ static void attn_geom(int S, int& nw, int& blocks, int max_nw = 8) {
   nw = cdiv(tiles, blocks);
 }
 
+static int attn_check_grouped(const AttnArgs& a) {
+  XFM_REQUIRE(a.grp_rows != nullptr && a.n_groups > 0 && a.n_groups <= 65535, "grouped attention: grp_rows / n_groups missing");
+  XFM_REQUIRE(a.Sq <= 64 && a.Sk <= 64 * ATTN_RES_MAX, "grouped attention needs Sq <= 64 and Sk <= %d (got %d, %d)", 64 * ATTN_RES_MAX, a.Sq, a.Sk);
+  XFM_REQUIRE(a.bias == nullptr && a.dbias == nullptr && a.causal == 0 && a.kv_index == nullptr,
+              "grouped attention: no bias / causal mask / kv_index (the group index IS the key/value source)");
+  return XFM_OK;
+}
+
+static void attn_grouped_lds() {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int mx = ATTN_RES_MAX * ATTN_SLOT;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    attr_set = true;
+  }
+}
+
 int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
   int rc = attn_check(a, false);
   if (rc != XFM_OK) return rc;
+  if (a.grp_start != nullptr) {
+    rc = attn_check_grouped(a);
+    if (rc != XFM_OK) return rc;
+    attn_grouped_lds();
+    hipLaunchKernelGGL(xattn_fwd_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)cdiv(a.Sk, 64) * ATTN_SLOT, st, a);
+    return xfm_check_launch("xattn_fwd");
+  }
   int nw, blocks;
   static const int fwd_nw = getenv("XFM_ATTN_FWD_NW") ? atoi(getenv("XFM_ATTN_FWD_NW")) : 8;  // tuning knob
   attn_geom(a.Sq, nw, blocks, fwd_nw);
@@ -671,6 +1001,18 @@ int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
 int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
   int rc = attn_check(a, true);
   if (rc != XFM_OK) return rc;
+  if (a.grp_start != nullptr) {
+    rc = attn_check_grouped(a);
+    if (rc != XFM_OK) return rc;
+    attn_grouped_lds();
+    hipLaunchKernelGGL(xattn_dq_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)cdiv(a.Sk, 64) * ATTN_SLOT, st, a);
+    rc = xfm_check_launch("xattn_dq");
+    if (rc != XFM_OK) return rc;
+    int knw, kblocks;
+    attn_geom(a.Sk, knw, kblocks);
+    hipLaunchKernelGGL(xattn_dkv_kernel, dim3(kblocks, a.H, a.n_groups), dim3(knw * 64), (size_t)ATTN_RES_MAX * ATTN_SLOT, st, a);
+    return xfm_check_launch("xattn_dkv");
+  }
   int nw, blocks;
   attn_geom(a.Sq, nw, blocks);
   const bool res = attn_resident(a.Sk, nw);

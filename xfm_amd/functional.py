@@ -194,38 +194,63 @@ def _stat_ld(Sq):
     return (Sq + 3) // 4 * 4
 
 
-def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t=None, kv_index=None):
+def kv_groups(kv_index, U):
+    """Group the query batch rows by key/value source (device-side, no host sync): returns (grp_start int32 [U+1],
+    grp_rows int32 [B], U) for the grouped attention mode -- group u = the rows r with kv_index[r] == u."""
+    idx = kv_index.long()
+    order = torch.sort(idx, stable=True).indices.to(torch.int32).contiguous()
+    counts = torch.zeros(U, dtype=torch.int64, device=idx.device).scatter_add_(0, idx, torch.ones_like(idx))
+    start = torch.zeros(U + 1, dtype=torch.int32, device=idx.device)
+    start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return start, order, U
+
+
+def attn_grouped_ok(Sq, Sk):
+    """Shapes the grouped (one workgroup per key/value source) kernels cover."""
+    return Sq <= 64 and Sk <= 256
+
+
+def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t=None, kv_index=None, groups=None):
     for t in (q, k, v, o):
         assert t.dtype == BF16 and t.stride(-1) == 1 and t.dim() == 2
     assert lse.shape[-1] == _stat_ld(Sq)
     if kv_index is not None:
         assert kv_index.dtype == torch.int32 and kv_index.numel() == B and kv_index.is_contiguous()
+    g_start = g_rows = None
+    n_groups = 0
+    if groups is not None:
+        g_start, g_rows, n_groups = groups
+        assert kv_index is None and bias is None and not causal and attn_grouped_ok(Sq, Sk)
+        assert g_start.dtype == torch.int32 and g_rows.dtype == torch.int32 and g_start.numel() == n_groups + 1 and g_rows.numel() == B
+        assert k.shape[0] == n_groups * Sk
     return AttnArgs(stat_ld=lse.shape[-1], bias_t=_ptr(bias_t), bias_t_ld=0 if bias_t is None else bias_t.stride(1),
-                    kv_index=_ptr(kv_index),
+                    kv_index=_ptr(kv_index), grp_start=_ptr(g_start), grp_rows=_ptr(g_rows), n_groups=n_groups,
                     q=q.data_ptr(), q_rs=q.stride(0), k=k.data_ptr(), k_rs=k.stride(0), v=v.data_ptr(), v_rs=v.stride(0),
                     o=o.data_ptr(), o_rs=o.stride(0), lse=lse.data_ptr(), bias=_ptr(bias),
                     bias_ld=0 if bias is None else bias.stride(1), key_keep=_ptr(key_keep), B=B, H=H, Sq=Sq, Sk=Sk,
                     scale=scale, causal=int(causal), drop_thresh=drop[0], drop_scale=drop[1], seed_lo=drop[2], seed_hi=drop[3])
 
 
-def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0), kv_index=None):
+def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0), kv_index=None, groups=None):
     """q [B*Sq, >=H*64] / k, v [B*Sk, ...] are 2-D (possibly strided column slices of fused projection buffers).
-    bias: dense fp32 [H,Sq,ld]; key_keep: int32 [B,Sk].  Returns (o [B*Sq, H*64] bf16, lse [B,H,Sq])."""
+    bias: dense fp32 [H,Sq,ld]; key_keep: int32 [B,Sk].  Returns (o [B*Sq, H*64] bf16, lse [B,H,Sq]).
+    groups = kv_groups(...): grouped mode, k / v / key_keep hold one entry per SOURCE."""
     _dev(q)
     o = torch.empty((B * Sq, H * 64), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, _stat_ld(Sq)), dtype=F32, device=q.device)
     if key_keep is not None:
         assert key_keep.dtype == torch.int32 and key_keep.is_contiguous()
-    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, kv_index=kv_index)
+    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, kv_index=kv_index, groups=groups)
     check(_lib.load().xfm_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
     return o, lse
 
 
 def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, dbias=None, key_keep=None, causal=False,
-             drop=(0, 1.0, 0, 0), bias_t=None, kv_index=None):
-    """Writes dq/dk/dv (2-D bf16 views with the same addressing convention as q/k/v); dbias (fp32 [H,Sq,ld]) += ."""
-    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t, kv_index)
-    delta = torch.zeros((B, H, lse.shape[-1]), dtype=F32, device=q.device)
+             drop=(0, 1.0, 0, 0), bias_t=None, kv_index=None, groups=None):
+    """Writes dq/dk/dv (2-D bf16 views with the same addressing convention as q/k/v); dbias (fp32 [H,Sq,ld]) += .
+    Grouped mode: dk/dv are per SOURCE ([n_groups*Sk] rows), summed over each group's rows."""
+    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t, kv_index, groups)
+    delta = torch.empty((B, H, lse.shape[-1]), dtype=F32, device=q.device)  # the kernels never use its padding entries
     assert dout.dtype == BF16 and dout.stride(-1) == 1
     a.dout, a.do_rs = dout.data_ptr(), dout.stride(0)
     a.dq, a.dq_rs = dq.data_ptr(), dq.stride(0)

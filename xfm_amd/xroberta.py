@@ -184,8 +184,11 @@ class _EncoderFn(torch.autograd.Function):
         need_dx, need_denc = x.requires_grad, (enc is not None and enc.requires_grad)
         saved = []
         x = x.contiguous()
+        groups = None
         if enc is not None:
             enc = enc.contiguous()
+            if enc_index is not None and Fx.attn_grouped_ok(T, Nenc):
+                groups = Fx.kv_groups(enc_index, enc.shape[0] // Nenc)
         for li in range(lo, hi):
             layer = model.encoder.layer[li]
             s = layer._s
@@ -204,7 +207,10 @@ class _EncoderFn(torch.autograd.Function):
                 d_att2, d_h2 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
                 q2 = Fx.gemm_nt(y1, s["q2"].wb, s["q2"].b)
                 kv = Fx.gemm_nt(enc, s["kv2"].wb, s["kv2"].b)
-                c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, kv_index=enc_index)
+                if groups is not None:  # one workgroup per (image, head): K/V staged once for every row that reads it
+                    c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, groups=groups)
+                else:
+                    c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, kv_index=enc_index)
                 h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
                 ln2 = co.output.LayerNorm
                 y2, z2, m2, r2 = Fx.ln_post_fwd(h2, y1, ln2.weight, ln2.bias, ln2.eps, d_h2)
@@ -218,7 +224,7 @@ class _EncoderFn(torch.autograd.Function):
             saved.append(rec)
             x = y3
         ctx.saved, ctx.model, ctx.enc = saved, model, enc
-        ctx.meta = (lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index)
+        ctx.meta = (lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index, groups)
         ctx.noted = need_dx or need_denc
         if ctx.noted:
             arena_note_use(model)
@@ -227,7 +233,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         model, enc = ctx.model, ctx.enc
-        lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index = ctx.meta
+        lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index, groups = ctx.meta
         cfg = model.config
         D, H = cfg.hidden_size, cfg.num_attention_heads
         g = grad_view
@@ -252,11 +258,16 @@ class _EncoderFn(torch.autograd.Function):
                 dc2 = Fx.gemm_nt(dh2, s["o2"].wt, n=s["o2"].K)
                 kv = r["kv"]
                 dq2 = torch.empty_like(r["q2"])
-                dkv = torch.empty((B * Nenc, 2 * D), dtype=BF16, device=dq2.device)  # per query row
-                Fx.attn_bwd(dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc,
-                            scale, key_keep=enc_keep, drop=r["d_att2"], kv_index=enc_index)
-                if enc_index is not None:  # fold onto the unique key/value sources
-                    dkv = Fx.rows_index_sum(dkv, enc_index, enc.shape[0] // Nenc, Nenc)
+                if groups is not None:  # dK/dV accumulated over each image's rows in registers, written once per image
+                    dkv = torch.empty((enc.shape[0], 2 * D), dtype=BF16, device=dq2.device)
+                    Fx.attn_bwd(dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc,
+                                scale, key_keep=enc_keep, drop=r["d_att2"], groups=groups)
+                else:
+                    dkv = torch.empty((B * Nenc, 2 * D), dtype=BF16, device=dq2.device)  # per query row
+                    Fx.attn_bwd(dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc,
+                                scale, key_keep=enc_keep, drop=r["d_att2"], kv_index=enc_index)
+                    if enc_index is not None:  # fold onto the unique key/value sources
+                        dkv = Fx.rows_index_sum(dkv, enc_index, enc.shape[0] // Nenc, Nenc)
                 Fx.gemm_tn(dq2, r["y1"], s["q2"].dw, dbias=s["q2"].db)
                 Fx.gemm_tn(dkv, enc, s["kv2"].dw, dbias=s["kv2"].db)
                 if need_denc:
