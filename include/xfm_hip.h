@@ -46,9 +46,10 @@ int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* 
 
 /* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]   (weight gradient, split over M).
  * dbias (optional, fp32 [N]) += column sums of dY: the bias gradient rides along in the same pass over dY.
- * Large edge-free shapes (M % 64 == 0; N, K % 256 == 0) run on a 256x256 pipelined kernel whose split partials go to
- * `workspace` (xfm_gemm_tn_workspace bytes, may be 0) and are summed in a fixed order; without a workspace, and for
- * every other shape, the splits are accumulated with fp32 atomics.  splits_hint: 0 = auto. */
+ * The split partials are written to `workspace` (xfm_gemm_tn_workspace bytes for splits_hint 0; may be 0) and summed
+ * in a fixed order by a reduce kernel; a single split updates dW in place; only splits without a workspace fall back to
+ * fp32 atomics.  Large edge-free shapes (M % 64 == 0; N, K % 256 == 0) run on a 256x256 pipelined kernel.
+ * splits_hint: 0 = auto, > 0 = that many splits of the 128x128 kernel. */
 long xfm_gemm_tn_workspace(int M, int N, int K);
 int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float* dW, long ldw, float* dbias, int M, int N,
                 int K, int splits_hint, float* workspace, long workspace_bytes, void* stream);

@@ -95,7 +95,7 @@ def test_gemm_nt_gelu_and_dgelu(M, N, K, hint):
 
 @pytest.mark.parametrize("M,N,K,splits", [(788, 200, 136, 0), (1920, 768, 768, 0), (1920, 768, 3072, 3), (64, 136, 64, 1),
                                            (960, 1000, 768, 0),
-                                           (4100, 768, 768, -2), (12608, 2304, 768, -2), (5003, 520, 136, -2), (12608, 768, 768, 0),
+                                           (4100, 768, 768, 2), (12608, 2304, 768, 5), (5003, 520, 136, 0), (12608, 768, 768, 0), (960, 1000, 136, 1),
                                            (1920, 768, 768, -3), (64, 256, 256, -3), (12608, 2304, 768, -3), (25216, 768, 3072, 0),
                                            (7680, 3072, 768, 0), (12608, 768, 768, -4)])
 def test_gemm_tn_wgrad_accumulates(M, N, K, splits):

@@ -841,7 +841,8 @@ struct GemmTN {
   float* dbias;  // optional: dbias[n] += sum_m dY[m,n] (bias gradient), folded into the k-tile-0 workgroups
   int M, N, K;
   int m_per_split;
-  float* ws;  // 256x256 kernel only: per-(split, tile) partial tiles in accumulator-register order (null = atomics into dW)
+  float* ws;  // per-(split, tile) partial tiles in accumulator-register order, summed by the reduce kernels (null: see direct)
+  int direct; // no workspace: 1 = single split, every dW element has one owner -> plain read-modify-write; 0 = fp32 atomics
 };
 
 __device__ __forceinline__ int swz_t(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }  // XOR on the 16-B chunk idx
@@ -966,6 +967,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
       atomicAdd(g.dbias + n0 + tid, t2);
     }
   }
+  if (g.ws != nullptr) {  // split partial in accumulator-register order (coalesced 16-B stores); tn_reduce128_kernel sums them
+    f32x4* wsp = reinterpret_cast<f32x4*>(g.ws) + ((((long)split * per_split + t) * 4 + w) * 16) * 64 + lane;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) wsp[(nt * 4 + kt) * 64] = acc[nt][kt];
+    return;
+  }
   // D[i = n slot][j = k col]: lane (lg, lr) holds k = ..+lr and n = ..+4*lg+reg
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
@@ -975,145 +984,34 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
 #pragma unroll
       for (int rgi = 0; rgi < 4; ++rgi) {
         const int n = n0 + wn * 64 + nt * 16 + 4 * lg + rgi;
-        if (n < g.N && k < g.K) atomicAdd(g.dW + (long)n * g.ldw + k, acc[nt][kt][rgi]);
+        if (n < g.N && k < g.K) {
+          float* dst = g.dW + (long)n * g.ldw + k;
+          if (g.direct) *dst += acc[nt][kt][rgi];  // single split: this workgroup is the element's only writer
+          else atomicAdd(dst, acc[nt][kt][rgi]);
+        }
       }
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Large-M wgrad: 256 (n) x 128 (k) output tile, 8 waves, one workgroup per CU, 3-slot LDS ring (dY 64 x 256 + X 64 x 128
-// per slot = 48 KiB) filled by direct-to-LDS loads that stay in flight across the per-step barrier (counted vmcnt(6)).
-// The bias gradient rides along as MFMAs against an all-ones B fragment (sum_m dY[m,n] = dY^T . 1) in the k-tile-0
-// workgroups -- no extra pass over dY and no LDS re-reads.
-// ---------------------------------------------------------------------------------------------
-template <int ROW_BYTES>
-__device__ __forceinline__ bf16x8 tr_read_pair_rs(const char* tile, int row0, int col0, int lr) {
-  const int r = row0 + (lr >> 2);
-  const int col = col0 + 4 * (lr & 3);
-  const int off0 = r * ROW_BYTES + ((((col >> 3)) ^ swz_t(r)) << 4) + (col & 7) * 2;
-  const int r2 = r + 4;
-  const int off1 = r2 * ROW_BYTES + ((((col >> 3)) ^ swz_t(r2)) << 4) + (col & 7) * 2;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + off0));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + off1));
-  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-  u.s.a = lo;
-  u.s.b = hi;
-  return u.v;
-}
-
-__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(GemmTN g) {
-  constexpr int Y_BYTES = 64 * 512, X_BYTES = 64 * 256, STAGE = Y_BYTES + X_BYTES;  // 48 KiB
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wn = w >> 1, wk = w & 1;
-  const int lr = lane & 15, lg = lane >> 4;
-  const int tiles_k = (g.K + 127) / 128, tiles_n = (g.N + 255) / 256;
-  const int per_split = tiles_k * tiles_n;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = wg / per_split, t = wg % per_split;
-  const int n0 = (t / tiles_k) * 256, k0 = (t % tiles_k) * 128;
-  const int mbeg = split * g.m_per_split;
-  int mend = mbeg + g.m_per_split;
-  mend = mend < g.M ? mend : g.M;
-  const int nsteps = (mend - mbeg + 63) / 64;
-  const bool do_bias = g.dbias != nullptr && k0 == 0 && wk == 0;
-
-  auto stage = [&](int slot, int step) {  // 32 wave-instructions for dY (2 rows each) + 16 for X (4 rows each): 6 per wave
-    char* sY = smem + slot * STAGE;
-    char* sX = sY + Y_BYTES;
-    const int mb = mbeg + step * 64;
+// dW += sum over splits of the 128 x 128 partial tiles (register order of gemm_tn_kernel), fixed summation order.
+__global__ __launch_bounds__(256) void tn_reduce128_kernel(const float* __restrict__ ws, float* __restrict__ dW, long ldw, int N, int K,
+                                                           int tiles_k, int per_split, int splits) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (tile t, wave w, quad q = nt*4+kt, lane)
+  const int lane = (int)(idx & 63), q = (int)((idx >> 6) & 15), w = (int)((idx >> 10) & 3);
+  const int t = (int)(idx >> 12);
+  if (t >= per_split) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(ws) + idx;
+  const long stride = (long)per_split * 4 * 16 * 64;
+  f32x4 sum = p[0];
+  for (int sp = 1; sp < splits; ++sp) sum += p[sp * stride];
+  const int n0 = (t / tiles_k) * 128, k0 = (t % tiles_k) * 128;
+  const int wn = w >> 1, wk = w & 1, lr = lane & 15, lg = lane >> 4, nt = q >> 2, kt = q & 3;
+  const int k = k0 + wk * 64 + kt * 16 + lr;
+  const int n = n0 + wn * 64 + nt * 16 + 4 * lg;
+  if (k >= K) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int blk = i * 8 + w;
-      const int r = blk * 2 + (lane >> 5);
-      const int c = (lane & 31) ^ swz_t(r);
-      int m = mb + r;
-      m = m < mend ? m : mend - 1;                 // tail rows are zeroed in LDS after they land (see below)
-      int nn = n0 + c * 8;
-      nn = nn < g.N ? nn : 0;                      // columns past N only feed masked outputs; keep the address in range
-      __builtin_amdgcn_global_load_lds(GLB_PTR(void, g.dY + (long)m * g.ldy + nn), LDS_PTR(void, sY + blk * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int blk = i * 8 + w;
-      const int r = blk * 4 + (lane >> 4);
-      const int c = (lane & 15) ^ swz_t(r);
-      int m = mb + r;
-      m = m < mend ? m : mend - 1;
-      int kk = k0 + c * 8;
-      kk = kk < g.K ? kk : 0;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(void, g.X + (long)m * g.ldx + kk), LDS_PTR(void, sX + blk * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[4][4], bacc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  bf16x8 ones;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ones[i] = f2bf(1.0f);
-
-  if (nsteps > 0) stage(0, 0);
-  if (nsteps > 1) stage(1, 1);
-  int slot = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (s + 2 < nsteps) stage(slot == 0 ? 2 : slot - 1, s + 2);
-    char* sY = smem + slot * STAGE;
-    char* sX = sY + Y_BYTES;
-    const int valid = mend - (mbeg + s * 64);  // rows of this step that exist
-    if (valid < 64) {                            // ragged last step: zero the duplicated rows of the dY tile
-      for (int q = tid; q < (64 - valid) * 32; q += 512) {
-        const int r = valid + (q >> 5), c = q & 31;
-        *reinterpret_cast<u32x4*>(sY + r * 512 + (c << 4)) = u32x4{0, 0, 0, 0};
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) af[nt] = tr_read_pair_rs<512>(sY, ks * 32 + 8 * lg, wn * 64 + nt * 16, lr);
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) bfr[kt] = tr_read_pair_rs<256>(sX, ks * 32 + 8 * lg, wk * 64 + kt * 16, lr);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-          acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
-      if (do_bias) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], ones, bacc[nt], 0, 0, 0);
-      }
-    }
-    slot = slot == 2 ? 0 : slot + 1;
-  }
-
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const int k = k0 + wk * 64 + kt * 16 + lr;
-#pragma unroll
-      for (int rgi = 0; rgi < 4; ++rgi) {
-        const int n = n0 + wn * 64 + nt * 16 + 4 * lg + rgi;
-        if (n < g.N && k < g.K) atomicAdd(g.dW + (long)n * g.ldw + k, acc[nt][kt][rgi]);
-      }
-    }
-    if (do_bias && lr == 0) {  // every column of the ones-product holds the row sum: take column 0
-#pragma unroll
-      for (int rgi = 0; rgi < 4; ++rgi) {
-        const int n = n0 + wn * 64 + nt * 16 + 4 * lg + rgi;
-        if (n < g.N) atomicAdd(g.dbias + n, bacc[nt][rgi]);
-      }
-    }
-  }
+  for (int i = 0; i < 4; ++i)
+    if (n + i < N) dW[(long)(n + i) * ldw + k] += sum[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1359,13 +1257,35 @@ static bool tn256_eligible(long ldy, long ldx, int M, int N, int K) {
          (unsigned long)M * (unsigned long)(ldy > ldx ? ldy : ldx) < (1ul << 32);
 }
 
-// Workspace (bytes) the 256x256 wgrad path wants for this shape; 0 when the shape runs on the atomic 128x128 kernel.
+// Below this many bytes of split partials the atomics' ~12 us/10 MB beat the extra reduce launch (measured, tools/tune_gemm.py).
+#define TN_WS_MIN_BYTES (16l << 20)
+
+static int tn128_plan(int M, int N, int K, int splits_hint, int& splits, int& mps) {  // -> number of 128x128 tiles
+  const int tiles = cdiv(N, 128) * cdiv(K, 128);
+  splits = splits_hint < 0 ? 0 : splits_hint;
+  if (splits <= 0) {
+    splits = (432 + tiles / 2) / tiles;        // measured optimum: ~432 workgroups in total (tools/tune_gemm.py)
+    const int max_splits = M / 480;            // ... while every split still walks >= ~8 K-steps
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+  }
+  mps = cdiv(cdiv(M, splits), 64) * 64;
+  splits = cdiv(M, mps);
+  return tiles;
+}
+
+// Workspace (bytes) xfm_gemm_tn wants for this shape with splits_hint = 0: the split partials of whichever kernel the
+// heuristic picks (0 when a single split writes dW directly).
 long xfm_gemm_tn_workspace_impl(int M, int N, int K) {
-  if (M <= 0 || N <= 0 || K <= 0 || !tn256_eligible(N, K, M, N, K)) return 0;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
   int splits, mps;
-  const int t256 = tn256_plan(M, N, K, splits, mps);
-  if (!(t256 >= 18 && M >= 4096)) return 0;
-  return (long)splits * N * K * 4;
+  if (tn256_eligible(N, K, M, N, K)) {
+    const int t256 = tn256_plan(M, N, K, splits, mps);
+    if (t256 >= 18 && M >= 4096) return (long)splits * N * K * 4;
+  }
+  const int tiles = tn128_plan(M, N, K, 0, splits, mps);
+  const long need = (long)splits * tiles * 128 * 128 * 4;
+  return (splits > 1 && need >= TN_WS_MIN_BYTES) ? need : 0;
 }
 
 int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, float* dbias, int M, int N, int K,
@@ -1373,33 +1293,10 @@ int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* d
   XFM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
   XFM_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "gemm_tn: K=%d ldx=%ld ldy=%ld must be multiples of 8", K, ldx, ldy);
   XFM_REQUIRE(((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0, "gemm_tn: operands must be 16-byte aligned");
-  // splits_hint == -2 selects the experimental 256 x 128 ring variant (one workgroup per CU).  Measured on MI355X it is
-  // 10-25 % SLOWER than two co-resident 128 x 128 workgroups per CU: with a single round of lock-stepped workgroups the fp32
-  // atomic epilogue (128 KiB per workgroup) is fully exposed instead of overlapping the neighbour's MFMA loop.  Kept for
-  // tuning; the default is the register-staged 128 x 128 kernel below.
-  const int rtiles = cdiv(N, 256) * cdiv(K, 128);
-  if (splits_hint == -2 && M >= 4096 && rtiles <= 128 && N >= 256) {
-    int splits = 256 / rtiles;
-    const int max_splits = M / 512;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int mps = cdiv(cdiv(M, splits), 64) * 64;
-    splits = cdiv(M, mps);
-    GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, dbias, M, N, K, mps, nullptr};
-    static bool ring_attr = false;
-    const size_t rsmem = 3 * 48 * 1024;
-    if (!ring_attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)rsmem);
-      ring_attr = true;
-    }
-    hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(rtiles * splits), dim3(512), rsmem, st, g);
-    return xfm_check_launch("gemm_tn_ring");
-  }
-  // 256 x 256 phase-pipelined kernel: shapes without edges and with enough output tiles.  Its split partials go to the
-  // caller's workspace with plain coalesced stores and are summed by tn_reduce_kernel -- fp32 atomics into dW run at
-  // ~0.8 TB/s on this part and would cost more than the MFMA loop.  Without a workspace it is only used when forced
-  // (splits_hint == -3, atomics; tests / tuning); splits_hint == -4 forbids it.
+  // Split partials go to the caller's workspace with plain coalesced stores and are summed by a reduce kernel: fp32 atomics
+  // into dW run at ~0.8 TB/s on this part (28 MB of them cost more than the MFMA loop of a mid-size wgrad).  A single
+  // split updates dW with plain read-modify-writes.  Atomics remain only when splits > 1 and no workspace was passed.
+  // 256 x 256 phase-pipelined kernel: shapes without edges and with enough output tiles (splits_hint -3 forces, -4 forbids).
   if (tn256_eligible(ldy, ldx, M, N, K) && splits_hint != -4) {
     int splits, mps;
     const int t256 = tn256_plan(M, N, K, splits, mps);
@@ -1407,7 +1304,7 @@ int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* d
     const bool have_ws = workspace != nullptr && workspace_bytes >= need;
     const bool want = splits_hint == -3 || (splits_hint == 0 && t256 >= 18 && M >= 4096 && have_ws);
     if (want) {
-      GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, dbias, M, N, K, mps, have_ws ? workspace : nullptr};
+      GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, dbias, M, N, K, mps, have_ws ? workspace : nullptr, 0};
       static bool attr256 = false;
       const size_t smem256 = 2 * 4 * 64 * 256;
       if (!attr256) {
@@ -1423,17 +1320,11 @@ int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* d
       return xfm_check_launch("gemm_tn_reduce");
     }
   }
-  const int tiles = cdiv(N, 128) * cdiv(K, 128);
-  int splits = splits_hint < 0 ? 0 : splits_hint;
-  if (splits <= 0) {
-    splits = (432 + tiles / 2) / tiles;        // measured optimum: ~432 workgroups in total (tools/tune_gemm.py)
-    const int max_splits = M / 480;            // ... while every split still walks >= ~8 K-steps
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-  }
-  int mps = cdiv(cdiv(M, splits), 64) * 64;
-  splits = cdiv(M, mps);
-  GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, dbias, M, N, K, mps, nullptr};
+  int splits, mps;
+  const int tiles = tn128_plan(M, N, K, splits_hint, splits, mps);
+  const long need = (long)splits * tiles * 128 * 128 * 4;
+  const bool use_ws = splits > 1 && workspace != nullptr && workspace_bytes >= need && (need >= TN_WS_MIN_BYTES || splits_hint > 0);
+  GemmTN g{(const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, dbias, M, N, K, mps, use_ws ? workspace : nullptr, splits == 1 ? 1 : 0};
   static bool attr_set = false;
   const size_t smem = 4 * 64 * 256;
   if (!attr_set) {
@@ -1442,7 +1333,12 @@ int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* d
     attr_set = true;
   }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), smem, st, g);
-  return xfm_check_launch("gemm_tn");
+  int rc = xfm_check_launch("gemm_tn");
+  if (rc != XFM_OK || !use_ws) return rc;
+  const long quads = (long)tiles * 4 * 16 * 64;
+  hipLaunchKernelGGL(tn_reduce128_kernel, dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, st, workspace, dW, ldw, N, K, cdiv(K, 128), tiles,
+                     splits);
+  return xfm_check_launch("gemm_tn_reduce128");
 }
 
 // ---------------------------------------------------------------------------------------------

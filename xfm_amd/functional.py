@@ -75,7 +75,7 @@ def gemm_tn(dy, x, dw, n=None, splits=0, dbias=None):
     N = dy.shape[1] if n is None else n
     assert dy.shape[0] == M and dw.shape[0] >= N and dw.shape[1] == K, (dy.shape, x.shape, dw.shape)
     lib = _lib.load()
-    need = lib.xfm_gemm_tn_workspace(M, N, K) if splits == 0 else 0
+    need = lib.xfm_gemm_tn_workspace(M, N, K) if splits == 0 else (splits * ((N + 127) // 128) * ((K + 127) // 128) * 65536 if splits > 1 else 0)
     ws = workspace(need, dy.device) if need > 0 else None
     check(lib.xfm_gemm_tn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0), _ptr(dbias), M, N, K,
                           splits, _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream()), "gemm_tn")
