@@ -801,9 +801,9 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
     // Tail split: one workgroup per CU, so T tiles of 256x256 cost ceil(T / 256) rounds.  When the last round would be
     // nearly empty (N = 768: 99 x 3 = 297 tiles = 1.16 rounds), the whole rounds run as 256x256 tiles and the remaining
     // rows go to the small-tile kernels, which fill every CU for a fraction of a big-tile time.
-    static const int split_env = getenv("XFM_GEMM_TAIL_SPLIT") ? atoi(getenv("XFM_GEMM_TAIL_SPLIT")) : 1;  // tuning knob
+    static const int split_env = getenv("XFM_GEMM_TAIL_SPLIT") ? atoi(getenv("XFM_GEMM_TAIL_SPLIT")) : 35;  // tuning knob: max tail % (35 measured best, tools/split_sweep.sh)
     const long tn256 = cdiv(N, 256), t256 = (long)cdiv(M, 256) * tn256;
-    if (split_env && tile_hint == 0 && M >= 2048 && t256 > 256 && t256 % 256 != 0 && (t256 % 256) * 100 < 35 * 256) {
+    if (split_env && tile_hint == 0 && M >= 2048 && t256 > 256 && t256 % 256 != 0 && (t256 % 256) * 100 < split_env * 256) {
       const int rows_a = (int)((t256 / 256) * 256 / tn256) * 256;  // row tiles that exactly fill the whole rounds
       if (rows_a > 0 && rows_a < M) {
         int rc = xfm_gemm_nt_impl(A, lda, B, ldb, C, ldc, bias, aux, ldaux, rows_a, N, K, epi, 5, st);
