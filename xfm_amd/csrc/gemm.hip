@@ -15,6 +15,16 @@
 
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_DGELU = 3, EPI_F32_ACC = 4 };
 
+// raw workgroup barrier fenced for the compiler only: direct-to-LDS loads stay in flight across it (no vmcnt(0) drain)
+#define XFM_FENCE() asm volatile("" ::: "memory")
+#define XFM_BAR()                    \
+  do {                               \
+    XFM_FENCE();                     \
+    __builtin_amdgcn_s_barrier();    \
+    XFM_FENCE();                     \
+  } while (0)
+
+
 struct GemmNT {
   const bf16* A; long lda;
   const bf16* B; long ldb;
@@ -116,9 +126,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNT& g, f32x4 (&acc)[MT][
 }
 
 
-template <int BM, int BN, int EPI>
+// NS = LDS stages: 2 = load K-tile kt+1 while computing kt (enough when several workgroups share a CU); 3 / 4 keep one / two
+// more K-tiles in flight behind a counted s_waitcnt -- for the small-M problems (text tower) where a CU holds one or two
+// workgroups and each K-step would otherwise expose the full L2 latency.
+template <int BM, int BN, int EPI, int NS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
   constexpr int MT = BM / 32, NT = BN / 32;
+  constexpr int LOADS = (BM + BN) / 32;  // direct-to-LDS loads per thread per stage
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -170,12 +184,29 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
   for (int nt = 0; nt < NT; ++nt) wrow[nt] = wn * (BN / 2) + (nt >> 1) * 32 + 8 * (lr >> 2) + 4 * (nt & 1) + (lr & 3);
 
   const int nk = g.K / 64;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (NS == 2) {
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+      if (s0 < nk) stage(s0, s0);
+  }
+  int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    if (NS == 2) {
+      if (kt + 1 < nk) stage((kt & 1) ^ 1, kt + 1);
+    } else {
+      // stage kt must have landed; the younger stages kt+1 .. kt+NS-2 (where they exist) stay in flight across the barrier
+      const int younger = nk - 1 - kt < NS - 2 ? nk - 1 - kt : NS - 2;
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      XFM_BAR();  // everyone's share of stage kt has landed; everyone is done reading the slot of stage kt-1
+      if (kt + NS - 1 < nk) stage(slot == 0 ? NS - 1 : slot - 1, kt + NS - 1);
+    }
+    const int cur = NS == 2 ? (kt & 1) : slot;
     const char* sA = smem + cur * STAGE;
     const char* sB = sA + A_BYTES;
 #pragma unroll
@@ -194,8 +225,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (NS == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    } else {
+      slot = slot == NS - 1 ? 0 : slot + 1;
+    }
   }
 
   gemm_epilogue<MT, NT, EPI>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), lr, lg);
@@ -345,13 +380,6 @@ __device__ __forceinline__ int unit_row(int u) {  // row of the X (J = 0, 3) or 
   return ((u >> 5) << 6) + 32 + (u & 31);
 }
 
-#define XFM_FENCE() asm volatile("" ::: "memory")
-#define XFM_BAR()                    \
-  do {                               \
-    XFM_FENCE();                     \
-    __builtin_amdgcn_s_barrier();    \
-    XFM_FENCE();                     \
-  } while (0)
 
 __device__ __forceinline__ void wait_younger(int y) {  // leave the y youngest units (2 loads each) in flight
   if (y >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -757,19 +785,19 @@ static int launch_nt_256(const GemmNT& g, int epi, hipStream_t st) {
   return xfm_check_launch("gemm_nt_256");
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NS>
 static int launch_nt(const GemmNT& g, int epi, hipStream_t st) {
   const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
-  const size_t smem = 2 * (BM + BN) * 128;
+  const size_t smem = NS * (BM + BN) * 128;
 #define XFM_NT_CASE(E)                                                                                         \
   case E: {                                                                                                    \
     static bool attr_set = false;                                                                              \
     if (!attr_set) {                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN, E>),                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN, E, NS>),                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
       attr_set = true;                                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, E>), dim3(tiles), dim3(256), smem, st, g);                      \
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, E, NS>), dim3(tiles), dim3(256), smem, st, g);                  \
     break;                                                                                                     \
   }
   switch (epi) {
@@ -817,15 +845,18 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
     else if ((long)cdiv(M, 256) * cdiv(N, 128) >= 768) cfg = 4;  // >= 3 rounds of 256x128 tiles: the 3-slot ring wins on cold operands
     else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 800) cfg = 1;
     else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 256) cfg = 2;
+    else if (K >= 1536) cfg = 7;  // under one workgroup per CU and a long K loop: keep two K-tiles in flight (3-stage 64x128)
     else cfg = 3;
   }
   switch (cfg) {
-    case 1: return launch_nt<128, 128>(g, epi, st);
-    case 2: return launch_nt<64, 128>(g, epi, st);
+    case 1: return launch_nt<128, 128, 2>(g, epi, st);
+    case 2: return launch_nt<64, 128, 2>(g, epi, st);
+    case 7: return launch_nt<64, 128, 3>(g, epi, st);
+    case 8: return launch_nt<64, 64, 4>(g, epi, st);
     case 4: return launch_nt_ring(g, epi, st);
     case 5: return launch_nt_256(g, epi, st);
     case 6: return launch_nt_256p(g, epi, st);
-    default: return launch_nt<64, 64>(g, epi, st);
+    default: return launch_nt<64, 64, 2>(g, epi, st);
   }
 }
 
