@@ -1,0 +1,52 @@
+"""Sum rocprofv3 FETCH_SIZE / WRITE_SIZE counter CSVs per kernel family (see tools/pmc_traffic.sh).
+
+usage: hbm_traffic.py <fetch_dir> <write_dir> <steps in the run>   -> JSON on stdout
+Correction per MI355X_MICROARCH.md (HBM): read bytes = 2 x FETCH_SIZE (gfx950 tallies the 128-B requests of wide
+coalesced reads at 64 B), write bytes = WRITE_SIZE; both counters are in KB."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def family(name):
+    if "gemm_nt" in name:
+        return "gemm_nt"
+    if "gemm_tn" in name or "tn_reduce" in name:
+        return "gemm_tn"
+    if "attn" in name:
+        return "attn"
+    return "other"
+
+
+def load(d, counter):
+    tot, calls = collections.defaultdict(float), collections.defaultdict(int)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            fam = family(r["Kernel_Name"])
+            tot[fam] += float(r["Counter_Value"])
+            calls[fam] += 1
+    return tot, calls
+
+
+def main():
+    fetch_dir, write_dir, steps = sys.argv[1], sys.argv[2], float(sys.argv[3])
+    fetch, calls = load(fetch_dir, "FETCH_SIZE")
+    write, _ = load(write_dir, "WRITE_SIZE")
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_traffic.sh) -- python3 bench.py --steps 2 "
+                     "--warmup 1 --no-cpu-baseline; averaged over the steps of the run (warm-up + timed + instrumented)",
+           "correction": "read bytes = 2 x FETCH_SIZE (gfx950 counts 128-B requests of wide coalesced reads as 64 B), write bytes = "
+                         "WRITE_SIZE; KB -> bytes x1024 (MI355X_MICROARCH.md, HBM)",
+           "families": {}}
+    for fam in sorted(set(fetch) | set(write)):
+        out["families"][fam] = {"launches_per_step": calls[fam] / steps, "FETCH_SIZE_KB_per_step": fetch[fam] / steps,
+                                "WRITE_SIZE_KB_per_step": write[fam] / steps,
+                                "hbm_bytes_per_step_corrected": (2.0 * fetch[fam] + write[fam]) * 1024.0 / steps}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
