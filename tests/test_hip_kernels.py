@@ -33,7 +33,7 @@ def gelu_grad(u):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 200, 128), (1920, 768, 768), (788, 2304, 768), (64, 50265, 64), (5, 3, 64)])
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 7, 8])
 def test_gemm_nt_bias_bf16_and_f32(M, N, K, hint):
     Fx = _fx()
     a, b = _rand((M, K), seed=1), _rand((N, K), 0.05, seed=2)
@@ -58,7 +58,7 @@ def test_gemm_nt_tile_configs_agree_bitwise(M, N, K):
     a, b = _rand((M, K), seed=11), _rand((N, K), 0.05, seed=12)
     ref = Fx.gemm_nt(a, b, tile_hint=1)
     for rep in range(3):
-        for hint in (0, 4, 5, 6, 7, 8):  # 0 = auto, incl. the tail split of the N = 768 shapes
+        for hint in (0, 4, 5, 7, 8):  # 0 = auto, incl. the tail split of the N = 768 shapes
             out = Fx.gemm_nt(a, b, tile_hint=hint)
             assert torch.equal(out, ref), f"tile config {hint} rep {rep}: {int((out != ref).sum())} elements differ"
 
@@ -69,12 +69,12 @@ def test_gemm_nt_identity_catches_transposed_maps():
     K = 128
     a = torch.eye(K, dtype=BF16, device="cuda")
     b = (torch.arange(200 * K, device="cuda").reshape(200, K) % 251).to(BF16)  # exact small integers
-    for hint in (1, 2, 3, 4, 5, 6, 7, 8):
+    for hint in (1, 2, 3, 4, 5, 7, 8):
         out = Fx.gemm_nt(a, b, tile_hint=hint)
         assert torch.equal(out.float(), b.float().t().contiguous()), f"tile config {hint}"
 
 
-@pytest.mark.parametrize("hint", [0, 4, 5, 6])
+@pytest.mark.parametrize("hint", [0, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1920, 3072, 768)])
 def test_gemm_nt_gelu_and_dgelu(M, N, K, hint):
     Fx = _fx()

@@ -24,7 +24,7 @@ def main():
                  (B * 30, 2304, 768), (B * 30, 768, 768), (B * 30, 3072, 768), (B * 30, 768, 3072),
                  (3 * B * 30, 2304, 768), (3 * B * 30, 768, 768), (3 * B * 30, 3072, 768), (3 * B * 30, 768, 3072),
                  (3 * B * 197, 1536, 768), (B * 197, 1536, 768), (3 * B * 197, 768, 1536), (B * 15, 50265, 768), (B * 15, 768, 50304)]
-    print("== gemm_nt  (M,N,K): us / TFLOP/s per tile config [auto,128x128,ring256x128,256x256,256x256 persistent]")
+    print("== gemm_nt  (M,N,K): us / TFLOP/s per tile config [auto,128x128,ring256x128,256x256]")
     if os.environ.get('XFM_TUNE_NT_SHAPES'):
         shapes_nt = [(1920, 768, 768), (1920, 2304, 768), (1920, 3072, 768), (1920, 768, 3072), (1920, 768, 2304), (7680, 768, 768), (7680, 2304, 768), (7680, 768, 3072), (960, 768, 768)]
     for M, N, K in shapes_nt:
@@ -35,7 +35,7 @@ def main():
         Bs = [(torch.randn(N, K, device="cuda") * 0.05).bfloat16() for _ in range(nbuf)]
         Os = [torch.empty(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(nbuf)]
         res = []
-        for hint in ((0, 2, 3, 7, 8) if os.environ.get('XFM_TUNE_NT_SHAPES') else (0, 1, 4, 5, 6)):
+        for hint in ((0, 2, 3, 7, 8) if os.environ.get('XFM_TUNE_NT_SHAPES') else (0, 1, 4, 5)):
             cnt = [0]
 
             def run():
@@ -86,7 +86,7 @@ def epilogues():
     bias = torch.randn(N, device="cuda")
     for name, epi in (("plain", Fx.EPI_BF16), ("gelu", Fx.EPI_GELU), ("dgelu", Fx.EPI_DGELU)):
         res = []
-        for hint in (1, 4, 5, 6):
+        for hint in (1, 4, 5):
             cnt = [0]
 
             def run():

@@ -535,224 +535,6 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g) {
   gemm_epilogue<MT, NT, EPI>(g, acc, m0 + wr * 128, n0 + wc * 64, lr, lg);
 }
 
-// Persistent form of the 256 x 256 kernel: one workgroup per CU walks tiles blockIdx, blockIdx + grid, ... and the
-// staging-unit stream simply continues across tile boundaries (unit index = 4 * global K-tile + part), so the next
-// tile's first loads are in flight during the current tile's last phases and its MFMAs start while the epilogue's
-// stores are still draining -- no per-tile prologue bubble, and the C write burst overlaps compute.
-// Stores share the in-order vmcnt queue with the direct-to-LDS loads; they only make the counted waits conservative.
-template <int V>
-struct JTag { static constexpr int value = V; };
-
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_256p_kernel(GemmNT g, int ntiles) {
-  constexpr int BM = 256, BN = 256, MT = 8, NT = 4;
-  constexpr int XBYTES = 256 * 128, BUF = 2 * XBYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wr = w >> 2, wc = w & 3;
-  const int lr = lane & 15, lg = lane >> 4;
-  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-  const int G = gridDim.x;
-  const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
-  const int nk = g.K / 64;
-  const int total = 4 * nk * my_tiles;  // staging units of this workgroup
-
-  unsigned soff[4][2];
-  int doff[4][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int u = (i * 8 + w) * 8 + (lane >> 3);
-    doff[0][i] = (unit_row<0>(u) >> 3) * 1024;
-    doff[3][i] = (unit_row<3>(u) >> 3) * 1024;
-    doff[1][i] = XBYTES + (unit_row<1>(u) >> 3) * 1024;
-    doff[2][i] = XBYTES + (unit_row<2>(u) >> 3) * 1024;
-  }
-  auto tile_origin = [&](int ti, int& m0, int& n0) {
-    const int wg = xcd_remap((int)blockIdx.x + ti * G, ntiles);
-    int tm, tn;
-    grouped_tile(wg, tiles_m, tiles_n, g.group_m, tm, tn);
-    m0 = tm * BM;
-    n0 = tn * BN;
-  };
-  auto set_tile_offsets = [&](int ti) {
-    int m0, n0;
-    tile_origin(ti, m0, n0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int u = (i * 8 + w) * 8 + (lane >> 3);
-      int r = unit_row<0>(u), gr = m0 + r;
-      gr = gr < g.M ? gr : g.M - 1;
-      soff[0][i] = (unsigned)gr * (unsigned)g.lda + (((lane & 7) ^ swz_x(r)) << 3);
-      r = unit_row<3>(u); gr = m0 + r;
-      gr = gr < g.M ? gr : g.M - 1;
-      soff[3][i] = (unsigned)gr * (unsigned)g.lda + (((lane & 7) ^ swz_x(r)) << 3);
-      r = unit_row<1>(u); gr = n0 + r;
-      gr = gr < g.N ? gr : g.N - 1;
-      soff[1][i] = (unsigned)gr * (unsigned)g.ldb + (((lane & 7) ^ swz_w(r)) << 3);
-      r = unit_row<2>(u); gr = n0 + r;
-      gr = gr < g.N ? gr : g.N - 1;
-      soff[2][i] = (unsigned)gr * (unsigned)g.ldb + (((lane & 7) ^ swz_w(r)) << 3);
-    }
-  };
-  // issue side of the unit stream (all wave-uniform scalars)
-  int issued = 0, i_kt = 0, i_gk = 0, i_tile = 0;
-  auto issue = [&](auto jtag) {
-    constexpr int J = decltype(jtag)::value;
-    if (issued >= total) return;
-    char* base = smem + (i_gk & 1) * BUF;
-    const bf16* src = ((J == 0 || J == 3) ? g.A : g.B) + i_kt * 64;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(void, src + (size_t)soff[J][i]),
-                                       LDS_PTR(void, base + __builtin_amdgcn_readfirstlane(doff[J][i])), 16, 0, 0);
-    ++issued;
-    if (J == 3) {
-      ++i_gk;
-      if (++i_kt == nk) {
-        i_kt = 0;
-        if (++i_tile < my_tiles) set_tile_offsets(i_tile);
-      }
-    }
-  };
-  auto wait_for = [&](int needed) {  // units up to index `needed` must have landed; younger ones may stay in flight
-    const int y = issued - 1 - needed;
-    if (y >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else wait_younger(y < 0 ? 0 : y);
-  };
-  using J0 = JTag<0>; using J1 = JTag<1>; using J2 = JTag<2>; using J3 = JTag<3>;
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int xr0 = wr * 128 + lr;
-  const int xs = swz_x(xr0);
-  const int wr0 = wc * 64 + 8 * (lr >> 2) + (lr & 3);
-  const int ws = swz_w(wr0);
-  const int xbase0 = xr0 * 128 + (((0 + lg) ^ xs) << 4), xbase1 = xr0 * 128 + (((4 + lg) ^ xs) << 4);
-  const int wbase0 = XBYTES + wr0 * 128 + (((0 + lg) ^ ws) << 4), wbase1 = XBYTES + wr0 * 128 + (((4 + lg) ^ ws) << 4);
-
-  bf16x8 xa[4][2], wb0[2][2], wb1[2][2];
-  auto read_x = [&](const char* buf, int half) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      xa[m][0] = *reinterpret_cast<const bf16x8*>(buf + xbase0 + (half * 4 + m) * 2048);
-      xa[m][1] = *reinterpret_cast<const bf16x8*>(buf + xbase1 + (half * 4 + m) * 2048);
-    }
-  };
-  auto read_w = [&](const char* buf, int half, bf16x8 (&wb)[2][2]) {
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      wb[n][0] = *reinterpret_cast<const bf16x8*>(buf + wbase0 + half * 4096 + n * 512);
-      wb[n][1] = *reinterpret_cast<const bf16x8*>(buf + wbase1 + half * 4096 + n * 512);
-    }
-  };
-#define XFM_QUAD(MH, NH, WB)                                                                                     \
-  do {                                                                                                           \
-    __builtin_amdgcn_s_setprio(1);                                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
-    _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                                \
-    _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                                \
-      acc[MH * 4 + m][NH * 2 + n] =                                                                              \
-          __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[n][ks], xa[m][ks], acc[MH * 4 + m][NH * 2 + n], 0, 0, 0);  \
-    __builtin_amdgcn_s_setprio(0);                                                                               \
-  } while (0)
-
-  set_tile_offsets(0);
-  issue(J0{}); issue(J1{}); issue(J2{}); issue(J3{}); issue(J0{});
-  wait_for(1);
-  XFM_BAR();
-  if (wr == 1) XFM_BAR();  // stagger the second M-wave group by one barrier
-
-  const int total_k = nk * my_tiles;
-  int c_kt = 0, c_tile = 0;
-  for (int gk = 0; gk < total_k; ++gk) {
-    const char* buf = smem + (gk & 1) * BUF;
-    const int ph = 4 * gk;
-    // ---- P0: (a0, b0)
-    issue(J1{});
-    read_x(buf, 0);
-    read_w(buf, 0, wb0);
-    wait_for(ph + 2);
-    XFM_BAR();
-    XFM_QUAD(0, 0, wb0);
-    XFM_BAR();
-    // ---- P1: (a0, b1)
-    issue(J2{});
-    read_w(buf, 1, wb1);
-    wait_for(ph + 3);
-    XFM_BAR();
-    XFM_QUAD(0, 1, wb1);
-    XFM_BAR();
-    // ---- P2: (a1, b1)
-    issue(J3{});
-    read_x(buf, 1);
-    XFM_BAR();
-    XFM_QUAD(1, 1, wb1);
-    XFM_BAR();
-    // ---- P3: (a1, b0); retire a0, b0 of the next K-tile
-    issue(J0{});
-    wait_for(ph + 5);
-    XFM_BAR();
-    XFM_QUAD(1, 0, wb0);
-    XFM_BAR();
-    if (++c_kt == nk) {  // tile finished: write it out (stores drain behind the next tile's MFMAs) and restart the accumulators
-      c_kt = 0;
-      int m0, n0;
-      tile_origin(c_tile, m0, n0);
-      ++c_tile;
-      gemm_epilogue<MT, NT, EPI>(g, acc, m0 + wr * 128, n0 + wc * 64, lr, lg);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  if (wr == 0) XFM_BAR();
-#undef XFM_QUAD
-}
-
-static int launch_nt_256p(const GemmNT& g, int epi, hipStream_t st) {
-  const int tiles = cdiv(g.M, 256) * cdiv(g.N, 256);
-  const size_t smem = 4 * 256 * 128;
-  if ((unsigned long)g.M * (unsigned long)g.lda >= (1ul << 32) || (unsigned long)g.N * (unsigned long)g.ldb >= (1ul << 32)) {
-    xfm_set_error("gemm_nt: operand too large for the 256x256 kernel's 32-bit element offsets");
-    return XFM_E_ARG;
-  }
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    num_cu = n;
-  }
-  const int grid = tiles < num_cu ? tiles : num_cu;
-#define XFM_256P_CASE(E)                                                                                       \
-  case E: {                                                                                                    \
-    static bool attr_set = false;                                                                              \
-    if (!attr_set) {                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256p_kernel<E>),                         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
-      attr_set = true;                                                                                         \
-    }                                                                                                          \
-    hipLaunchKernelGGL((gemm_nt_256p_kernel<E>), dim3(grid), dim3(512), smem, st, g, tiles);                   \
-    break;                                                                                                     \
-  }
-  switch (epi) {
-    XFM_256P_CASE(EPI_BF16)
-    XFM_256P_CASE(EPI_F32)
-    XFM_256P_CASE(EPI_GELU)
-    XFM_256P_CASE(EPI_DGELU)
-    XFM_256P_CASE(EPI_F32_ACC)
-    default:
-      xfm_set_error("gemm_nt: bad epilogue %d", epi);
-      return XFM_E_ARG;
-  }
-#undef XFM_256P_CASE
-  return xfm_check_launch("gemm_nt_256p");
-}
-
 static int launch_nt_256(const GemmNT& g, int epi, hipStream_t st) {
   const int tiles = cdiv(g.M, 256) * cdiv(g.N, 256);
   const size_t smem = 4 * 256 * 128;
@@ -855,7 +637,6 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
     case 8: return launch_nt<64, 64, 4>(g, epi, st);
     case 4: return launch_nt_ring(g, epi, st);
     case 5: return launch_nt_256(g, epi, st);
-    case 6: return launch_nt_256p(g, epi, st);
     default: return launch_nt<64, 64, 2>(g, epi, st);
   }
 }
