@@ -277,31 +277,43 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
 }
 
 // out[s][c] += sum_b partial[s][b][c]   (each set s has its own destination pointer; null = skip)
-// 64 columns x 4 row-slices per block: every thread keeps nblocks/4 independent loads in flight, LDS folds the slices.
+// grid (D/64, sets, row groups): a block folds its group's partial rows (64 columns x 4 row-slices, LDS folds the slices) and
+// adds the 64 sums with fp32 atomics -- a few thousand atomics per call, but every CU takes part (a (D/64) x sets grid alone
+// leaves 200 of the 256 CUs idle while ~48 blocks crawl through up to 9 MB of partials).
+#define REDUCE_SETS_GROUPS 8
 struct ReduceSets { const float* partial; float* out[4]; int nblocks; int D; };
 __global__ __launch_bounds__(256) void reduce_sets_kernel(ReduceSets r) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   const int s = blockIdx.y;
+  const int per = (r.nblocks + gridDim.z - 1) / gridDim.z;
+  const int b0 = blockIdx.z * per;
+  int b1 = b0 + per;
+  b1 = b1 < r.nblocks ? b1 : r.nblocks;
   float t = 0.f;
   if (c < r.D && r.out[s] != nullptr) {
     const float* src = r.partial + (long)s * r.nblocks * r.D + c;
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    int b = sl;
-    for (; b + 12 < r.nblocks; b += 16) {
+    int b = b0 + sl;
+    for (; b + 12 < b1; b += 16) {
       t0 += src[(long)b * r.D];
       t1 += src[(long)(b + 4) * r.D];
       t2 += src[(long)(b + 8) * r.D];
       t3 += src[(long)(b + 12) * r.D];
     }
-    for (; b < r.nblocks; b += 4) t0 += src[(long)b * r.D];
+    for (; b < b1; b += 4) t0 += src[(long)b * r.D];
     t = (t0 + t1) + (t2 + t3);
   }
   red[sl][cl] = t;
   __syncthreads();
-  if (sl == 0 && c < r.D && r.out[s] != nullptr) r.out[s][c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  if (sl == 0 && c < r.D && r.out[s] != nullptr && b0 < b1) {
+    const float v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (gridDim.z == 1) r.out[s][c] += v;
+    else atomicAdd(r.out[s] + c, v);
+  }
 }
+static int reduce_sets_groups(int nblocks) { return nblocks >= 64 * REDUCE_SETS_GROUPS ? REDUCE_SETS_GROUPS : 1; }
 
 int xfm_ln_bwd_grid(int rows) {
   int blocks = cdiv(rows, 16);  // >= 4 rows per wave so the column sums amortise
@@ -339,7 +351,7 @@ int xfm_ln_bwd_impl(LnBwd p, int D, int mode, float* dgamma, float* dbeta, float
   int rc = xfm_check_launch("ln_bwd");
   if (rc != XFM_OK) return rc;
   ReduceSets r{workspace, {dgamma, dbeta, dbias, dls}, grid, D};
-  hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(D, 64), nset), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(D, 64), nset, reduce_sets_groups(grid)), dim3(256), 0, st, r);
   return xfm_check_launch("ln_bwd_reduce");
 }
 
@@ -384,6 +396,6 @@ int xfm_colsum_impl(const void* y, long ldy, int M, int N, float* out, float* wo
   int rc = xfm_check_launch("colsum");
   if (rc != XFM_OK) return rc;
   ReduceSets r{workspace, {out, nullptr, nullptr, nullptr}, by, N};
-  hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(N, 64), 1), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(N, 64), 1, reduce_sets_groups(by)), dim3(256), 0, st, r);
   return xfm_check_launch("colsum_reduce");
 }
