@@ -140,6 +140,9 @@ int xfm_rows_index_sum(const xfm_bf16* src, const int* index, int R, int U, long
 int xfm_relpos_gather(const float* table, const int* index, int H, int N, long ld, float* dense, float* dense_t,
                       void* stream);
 int xfm_relpos_scatter(const float* ddense, const int* index, int H, int N, long ld, float* dtable, void* stream);
+/* the same gradient without atomics: order = positions i*N+j sorted by index[i*N+j], start = [entries+1] offsets into order */
+int xfm_relpos_scatter_sorted(const float* ddense, const int* order, const int* start, int entries, int H, int N, long ld,
+                              float* dtable, void* stream);
 
 /* ---- Patch gather for the patch-embed GEMM (beit2.py:224-230) --------------------------------------------------- */
 int xfm_patchify(const float* image, int B, int C, int H, int W, int P, xfm_bf16* out, void* stream);

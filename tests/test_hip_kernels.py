@@ -363,6 +363,11 @@ def test_relpos_gather_scatter():
     tr = table.clone().requires_grad_(True)
     (tr[idx.view(-1)].view(N, N, H).permute(2, 0, 1) * dd[:, :, :N]).sum().backward()
     _close(dt, tr.grad, 1e-5, "relpos table grad")
+    # atomic-free form: positions pre-sorted by table entry, accumulates (+=) into the gradient
+    order, start = Fx.relpos_sorted_index(idx.to(torch.int32).contiguous(), table.shape[0])
+    dt2 = torch.ones_like(table)
+    Fx.relpos_scatter_sorted(dd, order, start, H, N, ld, dt2)
+    _close(dt2 - 1.0, tr.grad, 1e-5, "relpos table grad (sorted gather)")
 
 
 def test_patchify_matches_conv_unfold():

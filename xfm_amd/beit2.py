@@ -214,7 +214,7 @@ class _TrunkFn(torch.autograd.Function):
             ddense = torch.zeros_like(dense)
             Fx.attn_bwd(dctx, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ctxv, lse, dqkv[:, :D], dqkv[:, D:2 * D],
                         dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense, bias_t=dense_t)
-            Fx.relpos_scatter(ddense, vit._index32, H, N, ld, g(blk.attn.relative_position_bias_table))
+            Fx.relpos_scatter_sorted(ddense, vit._relpos_order, vit._relpos_start, H, N, ld, g(blk.attn.relative_position_bias_table))
             Fx.gemm_tn(dqkv, y, s["qkv"].dw, dbias=s["qkv"].db)
             dy = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K)
             ctx.saved[i] = None
@@ -309,6 +309,8 @@ class VisionTransformer(nn.Module):
         N = self.patch_embed.num_patches + 1
         self._bias_ld = (N + 15) // 16 * 16
         self._index32 = self.blocks[0].attn.relative_position_index.to(device=arena.device, dtype=torch.int32).contiguous()
+        self._relpos_order, self._relpos_start = Fx.relpos_sorted_index(
+            self._index32, self.blocks[0].attn.relative_position_bias_table.shape[0])
 
     def finalize(self, device=None):
         """Stand-alone use (the XFM wrapper builds one arena for all towers instead)."""

@@ -363,3 +363,19 @@ def adamw(p, g, m, v, group, lrs, wds, beta1, beta2, eps, step, clip_coef=None):
         a.lr[i] = lrs[i] if i < len(lrs) else 0.0
         a.wd[i] = wds[i] if i < len(wds) else 0.0
     check(_lib.load().xfm_adamw(ctypes.byref(a), _stream()), "adamw")
+
+
+def relpos_sorted_index(index32, entries):
+    """(order, start) for relpos_scatter_sorted: positions sorted by table entry and the per-entry offsets (built once)."""
+    flat = index32.reshape(-1).long()
+    order = torch.sort(flat, stable=True).indices.to(torch.int32).contiguous()
+    counts = torch.zeros(entries, dtype=torch.int64, device=flat.device).scatter_add_(0, flat, torch.ones_like(flat))
+    start = torch.zeros(entries + 1, dtype=torch.int32, device=flat.device)
+    start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return order, start
+
+
+def relpos_scatter_sorted(ddense, order, start, H, N, ld, dtable):
+    check(_lib.load().xfm_relpos_scatter_sorted(ddense.data_ptr(), order.data_ptr(), start.data_ptr(), start.numel() - 1, H, N, ld,
+                                                dtable.data_ptr(), _stream()), "relpos_scatter_sorted")
+
