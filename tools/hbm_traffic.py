@@ -26,9 +26,13 @@ def load(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            fam = family(r["Kernel_Name"])
-            tot[fam] += float(r["Counter_Value"])
-            calls[fam] += 1
+            name = r["Kernel_Name"]
+            keys = [family(name)]
+            if "gemm" in name:  # the GEMM kernels also individually, keyed by their symbol up to the argument list
+                keys.append("kernel:" + name.replace("void ", "").split("(")[0])
+            for k in keys:
+                tot[k] += float(r["Counter_Value"])
+                calls[k] += 1
     return tot, calls
 
 

@@ -132,10 +132,12 @@ __device__ __forceinline__ float score_masked(const AttnArgs& a, float raw, floa
   return kj >= a.Sk ? EXCL_NEG : s;
 }
 
-__device__ __forceinline__ bool drop_keep(const AttnArgs& a, int b, int h, int qi, int kj) {
-  const uint64_t idx = (((uint64_t)(b * a.H + h)) * a.Sq + qi) * a.Sk + kj;
-  return rng_keep(rng_u32(a.seed_lo, a.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32)), a.drop_thresh);
+// dropout decision of score (b, h, qi, kj): row = the query row, column = the key.  `drop_key` is loop-invariant wherever a
+// lane keeps its query row (forward, dQ); dK/dV walks query rows and pays the key per element.
+__device__ __forceinline__ uint32_t drop_key(const AttnArgs& a, int b, int h, int qi) {
+  return rng_row_key(a.seed_lo, a.seed_hi, (uint32_t)((b * a.H + h) * a.Sq + qi));
 }
+__device__ __forceinline__ bool drop_keep(const AttnArgs& a, uint32_t key, int kj) { return rng_keep(rng_u32(key, (uint32_t)kj), a.drop_thresh); }
 
 // ---------------------------------------------------------------------------------------------
 // forward: grid (q blocks, H, B); block = NW waves, wave w owns query rows [qblk*16*NW + 16*w, +16)
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnArgs a) {
   const bool wave_active = q0 < a.Sq;
   const int qi = q0 + lr;
   const int qc = qi < a.Sq ? qi : a.Sq - 1;
+  const uint32_t dkey = drop_key(a, b, h, qi);
   const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
   const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
   const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnArgs a) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          st[t][r] = drop_keep(a, b, h, qi, kc * 64 + t * 16 + 4 * lg + r) ? st[t][r] * a.drop_scale : 0.f;
+          st[t][r] = drop_keep(a, dkey, kc * 64 + t * 16 + 4 * lg + r) ? st[t][r] * a.drop_scale : 0.f;
     }
     psum = group4_sum(psum);
     l_run = l_run * alpha + psum;
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
   for (int bi = 0; bi < nb_per_block; ++bi) {
     const int b = blockIdx.z * nb_per_block + bi;
     if (b >= a.B) break;
+    const uint32_t dkey = drop_key(a, b, h, qi);
     const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
     const bf16* dop = a.dout + ((long)b * a.Sq + qc) * a.do_rs + h * 64;
     const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            dp[t][r] = drop_keep(a, b, h, qi, kc * 64 + t * 16 + 4 * lg + r) ? dp[t][r] * a.drop_scale : 0.f;
+            dp[t][r] = drop_keep(a, dkey, kc * 64 + t * 16 + 4 * lg + r) ? dp[t][r] * a.drop_scale : 0.f;
       }
     };
 
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int qi = qc * 64 + (2 * s2 + u) * 16 + 4 * lg + r;
-            const float keepf = drop_keep(a, b, h, qi, kj) ? a.drop_scale : 0.f;
+            const float keepf = drop_keep(a, drop_key(a, b, h, qi), kj) ? a.drop_scale : 0.f;
             st[u][r] = pd[u][r] * (dp[u][r] * keepf - delv[u][r]);
             pd[u][r] *= keepf;
           }
@@ -634,6 +638,7 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(AttnArgs a) {
     const int b = a.grp_rows[rstart + j];
     const int qi = tile * 16 + lr;
     const int qc = qi < a.Sq ? qi : a.Sq - 1;
+    const uint32_t dkey = drop_key(a, b, h, qi);
     const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
     const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
     const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(AttnArgs a) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            st[t][r] = drop_keep(a, b, h, qi, kc * 64 + t * 16 + 4 * lg + r) ? st[t][r] * a.drop_scale : 0.f;
+            st[t][r] = drop_keep(a, dkey, kc * 64 + t * 16 + 4 * lg + r) ? st[t][r] * a.drop_scale : 0.f;
       }
       psum = group4_sum(psum);
       l_run = l_run * alpha + psum;
@@ -731,6 +736,7 @@ __global__ __launch_bounds__(512) void xattn_dq_kernel(AttnArgs a) {
     const int qi = tile * 16 + lr;
     const bool qvalid = qi < a.Sq;
     const int qc = qvalid ? qi : a.Sq - 1;
+    const uint32_t dkey = drop_key(a, b, h, qi);
     const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
     const bf16* dop = a.dout + ((long)b * a.Sq + qc) * a.do_rs + h * 64;
     const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
@@ -763,7 +769,7 @@ __global__ __launch_bounds__(512) void xattn_dq_kernel(AttnArgs a) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            dp[t][r] = drop_keep(a, b, h, qi, kc * 64 + t * 16 + 4 * lg + r) ? dp[t][r] * a.drop_scale : 0.f;
+            dp[t][r] = drop_keep(a, dkey, kc * 64 + t * 16 + 4 * lg + r) ? dp[t][r] * a.drop_scale : 0.f;
       }
     };
     float delta = 0.f;
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(512) void xattn_dkv_kernel(AttnArgs a) {
             pv = ok ? pv : 0.f;
             const float dl = ok ? delv[u][r] : 0.f;
             float keepf = 1.f;
-            if (a.drop_thresh != 0u) keepf = drop_keep(a, b, h, qi, kj) ? a.drop_scale : 0.f;
+            if (a.drop_thresh != 0u) keepf = drop_keep(a, drop_key(a, b, h, qi), kj) ? a.drop_scale : 0.f;
             pd[u][r] = pv * keepf;
             st[u][r] = pv * (dp[u][r] * keepf - dl);
           }

@@ -68,9 +68,14 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ uint32_t rng_u32(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx_lo, uint32_t idx_hi) {
-  return mix32(mix32(idx_lo ^ seed_lo) + 0x9E3779B9U * (idx_hi ^ seed_hi) + 0x85EBCA6BU);
+// Counter-based dropout stream over (row, column): a per-row key (two lowbias32 rounds over the row id and the 64-bit seed,
+// computed once per row) and ONE round per element, mix32(column + key) -- 2 integer multiplies, which are quarter-rate on
+// CDNA.  (A single 64-bit linear index made the key depend on the index's high word, which the compiler must recompute per
+// element: 5 multiplies per attention score, two thirds of the VALU time of the text-side attention kernels.)
+__device__ __forceinline__ uint32_t rng_row_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t row) {
+  return mix32(mix32(row ^ seed_lo) + 0x9E3779B9U * seed_hi + 0x85EBCA6BU);
 }
+__device__ __forceinline__ uint32_t rng_u32(uint32_t row_key, uint32_t col) { return mix32(col + row_key); }
 // keep with probability (1-p): thresh = p * 2^32
 __device__ __forceinline__ bool rng_keep(uint32_t r, uint32_t thresh) { return r >= thresh; }
 

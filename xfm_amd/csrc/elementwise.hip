@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs p) {
   const int rows = p.B * p.T;
   for (int row = wave; row < rows; row += nwaves) {
     const int b = row / p.T, t = row % p.T;
+    const uint32_t rkey = rng_row_key(p.seed_lo, p.seed_hi, (uint32_t)row);
     const int64_t* ids_row = p.ids + (long)b * p.T;
     const int pid = p.pos_mode ? t : roberta_pos(ids_row, t, p.pad_id, lane);
     const long wid = ids_row[t];
@@ -95,8 +96,7 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs p) {
       for (int j = 0; j < 4; ++j) {
         float yv = (v[i][j] - mu) * rstd * wv[j] + bv[j];
         if (p.drop_thresh != 0u) {
-          const uint64_t idx = (uint64_t)row * D + e + j;
-          yv = rng_keep(rng_u32(p.seed_lo, p.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32)), p.drop_thresh) ? yv * p.drop_scale : 0.f;
+          yv = rng_keep(rng_u32(rkey, (uint32_t)(e + j)), p.drop_thresh) ? yv * p.drop_scale : 0.f;
         }
         o[j] = f2bf(yv);
       }
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void emb_bwd_kernel(EmbArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[s][i][j] = 0.f;
   for (int row = wave; row < rows; row += nwaves) {
+    const uint32_t rkey = rng_row_key(p.seed_lo, p.seed_hi, (uint32_t)row);
     const long wid = p.ids[row];
     const int pid = p.pos_ids[row];
     const float mu = p.mean[row], rstd = p.rstd[row];
@@ -138,8 +139,7 @@ __global__ __launch_bounds__(256) void emb_bwd_kernel(EmbArgs p) {
       for (int j = 0; j < 4; ++j) {
         float gv = bf2f(g[j]);
         if (p.drop_thresh != 0u) {
-          const uint64_t idx = (uint64_t)row * D + e + j;
-          gv = rng_keep(rng_u32(p.seed_lo, p.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32)), p.drop_thresh) ? gv * p.drop_scale : 0.f;
+          gv = rng_keep(rng_u32(rkey, (uint32_t)(e + j)), p.drop_thresh) ? gv * p.drop_scale : 0.f;
         }
         dy[i][j] = gv;
         wv[i][j] = w4[j];

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
   }
   for (int row = wave; row < p.rows; row += nwaves) {
     const long base = (long)row * D;
+    const uint32_t rkey = rng_row_key(p.seed_lo, p.seed_hi, (uint32_t)row);  // dropout stream of this row
     float v[NCH][4];
     float s = 0.f;
     float rs = 1.f;
@@ -59,8 +60,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
         for (int j = 0; j < 4; ++j) {
           float hv = bf2f(hh[j]);
           if (p.drop_thresh != 0u) {
-            const uint64_t idx = (uint64_t)base + e + j;
-            const uint32_t r = rng_u32(p.seed_lo, p.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32));
+            const uint32_t r = rng_u32(rkey, (uint32_t)(e + j));
             hv = rng_keep(r, p.drop_thresh) ? hv * p.drop_scale : 0.f;
           }
           v[i][j] = hv + bf2f(rr[j]);
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
   }
   for (int row = wave; row < p.rows; row += nwaves) {
     const long base = (long)row * D;
+    const uint32_t rkey = rng_row_key(p.seed_lo, p.seed_hi, (uint32_t)row);  // dropout stream of this row
     const float mu = p.mean[row], rstd = p.rstd[row];
     float dy[NCH][4], xh[NCH][4];
     float c1 = 0.f, c2 = 0.f;
@@ -234,8 +235,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
         for (int j = 0; j < 4; ++j) {
           float dhv = dz[j];
           if (p.drop_thresh != 0u) {
-            const uint64_t idx = (uint64_t)base + e + j;
-            const uint32_t r = rng_u32(p.seed_lo, p.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32));
+            const uint32_t r = rng_u32(rkey, (uint32_t)(e + j));
             dhv = rng_keep(r, p.drop_thresh) ? dhv * p.drop_scale : 0.f;
           }
           orr[j] = f2bf(dz[j]);
