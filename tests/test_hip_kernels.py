@@ -531,3 +531,15 @@ def test_attention_grouped_by_kv_source(B, U, Sq, Sk, p):
     _close(dkv, ref, 1e-2, "grouped dK/dV (summed per source)")
     if U > 1:
         assert float(dkv.view(U, -1)[U - 1].float().abs().max()) == 0.0, "unused source must get zero gradients"
+
+
+def test_gemm_nt_split_k_accumulate():
+    """Few output tiles, very long K, fp32-accumulate epilogue: the launcher slices K over gridDim.y (atomics into C)."""
+    Fx = _fx()
+    M, N, K = 960, 768, 50304
+    a, b = _rand((M, K), 0.05, seed=31), _rand((N, K), 0.05, seed=32)
+    bias = _rand((N,), 0.5, F32, seed=33)
+    c = torch.full((M, N), 2.0, dtype=F32, device="cuda")
+    Fx.gemm_nt(a, b, bias, epi=Fx.EPI_F32_ACC, out=c)
+    ref = a.float() @ b.float().t() + bias + 2.0
+    _close(c, ref, 1e-4, "split-K fp32 accumulate")

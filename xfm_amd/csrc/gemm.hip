@@ -33,6 +33,7 @@ struct GemmNT {
   bf16* aux; long ldaux;
   int M, N, K;
   int group_m;  // row-panels per tile group (L2 locality of the block order)
+  int k_splits; // small-tile kernels, EPI_F32_ACC only: gridDim.y K-slices, fp32 atomics into C (1 = off)
 };
 
 // LDS swizzles (16-B chunk index XOR) for 128-B tile rows read with ds_read_b128.
@@ -77,6 +78,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNT& g, f32x4 (&acc)[MT][
       const bool full = (nb + 8 <= g.N) && vec_c;
       if (EPI == EPI_F32 || EPI == EPI_F32_ACC) {
         float* cp = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + nb;
+        if (EPI == EPI_F32_ACC && g.k_splits > 1) {  // K-slices meet in C through fp32 atomics; slice 0 carried the bias
+          for (int i = 0; i < 8; ++i)
+            if (nb + i < g.N) atomicAdd(cp + i, v[i] - (blockIdx.y == 0 ? 0.f : bv[i]));
+          continue;
+        }
         if (EPI == EPI_F32_ACC) {
           for (int i = 0; i < 8; ++i)
             if (nb + i < g.N) v[i] += cp[i];
@@ -144,10 +150,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
   grouped_tile(wg, tiles_m, tiles_n, g.group_m, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
+  // K-slice of this workgroup (k_splits > 1: the LM-head dgrad, K = 50304 against 90 output tiles)
+  const int nk_all = g.K / 64;
+  const int nk_per = (nk_all + g.k_splits - 1) / g.k_splits;
+  const int kt0 = blockIdx.y * nk_per;
+  const int nk = nk_all - kt0 < nk_per ? nk_all - kt0 : nk_per;
+  if (nk <= 0) return;  // workgroup-uniform, before any barrier
   auto stage = [&](int buf, int kt) {
     char* sA = smem + buf * STAGE;
     char* sB = sA + A_BYTES;
-    const int k0 = kt * 64;
+    const int k0 = (kt0 + kt) * 64;
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) {
       const int blk = i * 4 + w;  // one wave-instruction fills 1 KiB = 8 rows x 128 B, lane-linear
@@ -183,7 +195,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) wrow[nt] = wn * (BN / 2) + (nt >> 1) * 32 + 8 * (lr >> 2) + 4 * (nt & 1) + (lr & 3);
 
-  const int nk = g.K / 64;
   if (NS == 2) {
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -579,7 +590,7 @@ static int launch_nt(const GemmNT& g, int epi, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
       attr_set = true;                                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, E, NS>), dim3(tiles), dim3(256), smem, st, g);                  \
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, E, NS>), dim3(tiles, g.k_splits), dim3(256), smem, st, g);      \
     break;                                                                                                     \
   }
   switch (epi) {
@@ -605,7 +616,7 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
               "gemm_nt: operands must be 16-byte aligned");
   XFM_REQUIRE((epi != EPI_GELU && epi != EPI_DGELU) || aux != nullptr, "gemm_nt: epilogue %d needs aux", epi);
   static const int gm_env = getenv("XFM_GEMM_GROUP_M") ? atoi(getenv("XFM_GEMM_GROUP_M")) : 0;  // tuning knob
-  GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K, gm_env > 0 ? gm_env : 8};
+  GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K, gm_env > 0 ? gm_env : 8, 1};
   int cfg = tile_hint;
   if (cfg <= 0) {  // measured on MI355X (tools/tune_gemm.py): 128x128 pays from ~3 workgroups per CU, else go smaller
     // Tail split: one workgroup per CU, so T tiles of 256x256 cost ceil(T / 256) rounds.  When the last round would be
@@ -627,7 +638,17 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
     else if ((long)cdiv(M, 256) * cdiv(N, 128) >= 768) cfg = 4;  // >= 3 rounds of 256x128 tiles: the 3-slot ring wins on cold operands
     else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 800) cfg = 1;
     else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 256) cfg = 2;
-    else if (K >= 1536) cfg = 7;  // under one workgroup per CU and a long K loop: keep two K-tiles in flight (3-stage 64x128)
+    else if (K >= 1536) {  // under one workgroup per CU and a long K loop: keep two K-tiles in flight (3-stage 64x128)
+      cfg = 7;
+      // ... and when the loop is VERY long against very few tiles (LM-head dgrad: K = 50304, 90 tiles) slice K over gridDim.y;
+      // only the fp32-accumulate epilogue can merge slices (atomics), so callers ask for it with a zeroed fp32 C
+      const long t = (long)cdiv(M, 64) * cdiv(N, 128);
+      if (epi == EPI_F32_ACC && K >= 8192 && t < 192) {
+        int sp = (int)(512 / t);
+        if (sp > K / 1024) sp = K / 1024;
+        g.k_splits = sp < 1 ? 1 : sp;
+      }
+    }
     else cfg = 3;
   }
   switch (cfg) {
