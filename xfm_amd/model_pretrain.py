@@ -42,8 +42,12 @@ class XFM(XFMBase):
             image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
         else:
             image_embeds, image_atts = self.get_vision_embeds(image)
+        mlm_embeds = None
         if data_source != 'imagenet':
-            text_embeds = self.get_text_embeds(text_ids, text_atts)
+            if self.batch_passes and ret_match_loss and ret_mlm_loss and self.detach_text_forMLM and text_ids_masked is not None:
+                text_embeds, mlm_embeds = self.get_text_embeds_with_masked(text_ids, text_atts, text_ids_masked)
+            else:
+                text_embeds = self.get_text_embeds(text_ids, text_atts)
             image_feat, text_feat = self.get_features(image_embeds, text_embeds)
         loss_itc = loss_itm = loss_mlm = loss_mim = zero
         if ret_itc_loss and data_source != 'imagenet':
@@ -53,7 +57,7 @@ class XFM(XFMBase):
         if self.batch_passes and ret_match_loss and ret_mlm_loss and data_source != 'imagenet':
             loss_itm, loss_mlm = self.get_matching_and_fuse_mlm_loss(image_embeds, image_atts, image_feat, text_ids, text_atts,
                                                                      text_feat, text_embeds, text_ids_masked, masked_pos,
-                                                                     masked_ids, neg_idx=neg_idx)
+                                                                     masked_ids, neg_idx=neg_idx, mlm_embeds=mlm_embeds)
             if w is not None:
                 loss_itm, loss_mlm = loss_itm * w, loss_mlm * w
         else:

@@ -221,6 +221,18 @@ class XFMBase(nn.Module):
         return self.text_encoder.bert(text_ids, attention_mask=text_atts, encoder_hidden_states=None,
                                       encoder_attention_mask=None, return_dict=True).last_hidden_state
 
+    def get_text_embeds_with_masked(self, text_ids, text_atts, text_ids_masked):
+        """get_text_embeds(text_ids) and the DETACHED get_text_embeds(text_ids_masked) of get_fuse_mlm_loss (xfm.py:648-649) as one
+        2B-row pass through the text tower: same arithmetic per row, GEMMs twice as tall; the backward only walks the first B
+        sequences (`grad_batch`).  Returns (text_embeds, mlm_embeds.detach())."""
+        assert self.detach_text_forMLM
+        self._ready()
+        bs = text_ids.shape[0]
+        both = self.text_encoder.bert(torch.cat([text_ids, text_ids_masked], dim=0), attention_mask=torch.cat([text_atts, text_atts], dim=0),
+                                      encoder_hidden_states=None, encoder_attention_mask=None, return_dict=True,
+                                      grad_batch=bs).last_hidden_state
+        return both[:bs], both[bs:].detach()
+
     def get_features(self, image_embeds=None, text_embeds=None):
         out = []
         if image_embeds is not None:
@@ -301,7 +313,8 @@ class XFMBase(nn.Module):
         return loss
 
     def get_matching_and_fuse_mlm_loss(self, image_embeds, image_atts, image_feat, text_ids, text_atts, text_feat, text_embeds,
-                                       text_ids_masked, masked_pos, masked_ids, idx=None, is_pretrain=True, neg_idx=None):
+                                       text_ids_masked, masked_pos, masked_ids, idx=None, is_pretrain=True, neg_idx=None,
+                                       mlm_embeds=None):
         """get_matching_loss (xfm.py:749-802) and get_fuse_mlm_loss (xfm.py:638-656) through ONE 4B-row fusion pass:
         rows [0,3B) are the ITM positives / negatives, rows [3B,4B) the masked-text MLM inputs.  Same arithmetic per
         row as the two separate calls (no op couples rows); larger GEMMs and a third fewer launches."""
@@ -311,10 +324,11 @@ class XFMBase(nn.Module):
             image_neg_idx = torch.as_tensor(neg_idx[0], dtype=torch.long, device=image_embeds.device)
             text_neg_idx = torch.as_tensor(neg_idx[1], dtype=torch.long, device=image_embeds.device)
         bs = image_feat.size(0)
-        with torch.set_grad_enabled(torch.is_grad_enabled() and not self.detach_text_forMLM):
-            mlm_embeds = self.get_text_embeds(text_ids_masked, text_atts)
-        if self.detach_text_forMLM:
-            mlm_embeds = mlm_embeds.detach()
+        if mlm_embeds is None:  # (else: already computed, detached, by get_text_embeds_with_masked)
+            with torch.set_grad_enabled(torch.is_grad_enabled() and not self.detach_text_forMLM):
+                mlm_embeds = self.get_text_embeds(text_ids_masked, text_atts)
+            if self.detach_text_forMLM:
+                mlm_embeds = mlm_embeds.detach()
         itm_text = text_embeds.detach() if is_pretrain else text_embeds
         # every fusion row attends to one of the B unique images: project K/V once per image and layer and let the
         # attention kernels gather them by index (the reference re-projects the duplicated image rows 4x, xfm.py:781-793)

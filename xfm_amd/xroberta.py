@@ -175,7 +175,7 @@ class _EncoderFn(torch.autograd.Function):
     """Layers [lo, hi) of a RobertaEncoder.  x: bf16 [B*T, D]; enc: bf16 [B*N, D] or None."""
 
     @staticmethod
-    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index):
+    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index, grad_batch=None):
         cfg = model.config
         D, H = cfg.hidden_size, cfg.num_attention_heads
         scale = 1.0 / math.sqrt(D // H)
@@ -224,7 +224,9 @@ class _EncoderFn(torch.autograd.Function):
             saved.append(rec)
             x = y3
         ctx.saved, ctx.model, ctx.enc = saved, model, enc
-        ctx.meta = (lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index, groups)
+        if grad_batch is not None and (enc is not None or not 0 < grad_batch <= B):
+            raise ValueError("grad_batch is for self-attention-only passes: 0 < grad_batch <= batch")
+        ctx.meta = (lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index, groups, grad_batch)
         ctx.noted = need_dx or need_denc
         if ctx.noted:
             arena_note_use(model)
@@ -233,11 +235,23 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         model, enc = ctx.model, ctx.enc
-        lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index, groups = ctx.meta
+        lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index, groups, grad_batch = ctx.meta
         cfg = model.config
         D, H = cfg.hidden_size, cfg.num_attention_heads
         g = grad_view
         dy_a, dy_b = dy.contiguous(), None
+        B_full = B
+        if grad_batch is not None and grad_batch < B:
+            # only the first `grad_batch` sequences carry gradient (the rest of the pass was a detached forward that shared the
+            # GEMMs): every op is per token / per sequence, so the backward runs on the row prefix of the saved activations
+            B = grad_batch
+            G = B * T
+            dy_a = dy_a[:G]
+            key_keep = None if key_keep is None else key_keep[:B]
+            for rec in ctx.saved:
+                for k, v in list(rec.items()):
+                    if torch.is_tensor(v):
+                        rec[k] = v[:B] if k.startswith("lse") else v[:G]
         denc32 = torch.zeros((enc.shape[0], D), dtype=F32, device=dy.device) if need_denc else None
         for li in reversed(range(lo, hi)):
             layer = model.encoder.layer[li]
@@ -287,10 +301,12 @@ class _EncoderFn(torch.autograd.Function):
                 dy_a, dy_b = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K), dres1
             ctx.saved[li - lo] = None
         dx = (dy_a.float() + dy_b.float()).to(BF16) if need_dx else None
+        if dx is not None and B < B_full:
+            dx = torch.cat([dx, torch.zeros(((B_full - B) * T, dx.shape[1]), dtype=dx.dtype, device=dx.device)], dim=0)
         denc = denc32.to(BF16) if need_denc else None
         if ctx.noted:
             arena_note_grad(model)
-        return (dx, denc) + (None,) * 11
+        return (dx, denc) + (None,) * 12
 
 
 class RobertaModel(nn.Module):
@@ -320,9 +336,11 @@ class RobertaModel(nn.Module):
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
                 inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
-                is_decoder=False, mode='multi_modal', encoder_batch_index=None):
+                is_decoder=False, mode='multi_modal', encoder_batch_index=None, grad_batch=None):
         """`encoder_batch_index` (extension, default None = reference behaviour): int tensor [B] mapping every text row to the
-        row of `encoder_hidden_states` it attends to, so duplicated images are projected to K/V once per layer."""
+        row of `encoder_hidden_states` it attends to, so duplicated images are projected to K/V once per layer.
+        `grad_batch` (extension): only the first grad_batch sequences of the batch propagate gradient through the layer stack
+        (a detached pass batched behind a differentiable one, e.g. the masked-text pass of get_fuse_mlm_loss)."""
         if any(v is not None for v in (token_type_ids, position_ids, head_mask, inputs_embeds, past_key_values)):
             raise NotImplementedError("token_type_ids/position_ids/head_mask/inputs_embeds/past_key_values are not used on the XFM path")
         if isinstance(encoder_hidden_states, (list, tuple)):
@@ -363,7 +381,7 @@ class RobertaModel(nn.Module):
         y = x.reshape(B * T, -1)
         if hi > lo:
             y = _EncoderFn.apply(y, enc, self, key_keep, enc_keep, lo, hi, bool(is_decoder), B, T, Nenc, self.training,
-                                 encoder_batch_index if enc is not None else None)
+                                 encoder_batch_index if enc is not None else None, grad_batch)
         return SimpleNamespace(last_hidden_state=y.view(B, T, -1), pooler_output=None, past_key_values=None,
                                hidden_states=None, attentions=None, cross_attentions=None)
 
