@@ -252,7 +252,15 @@ class _EncoderFn(torch.autograd.Function):
                 for k, v in list(rec.items()):
                     if torch.is_tensor(v):
                         rec[k] = v[:B] if k.startswith("lse") else v[:G]
-        denc32 = torch.zeros((enc.shape[0], D), dtype=F32, device=dy.device) if need_denc else None
+        denc32 = None
+        # gradient w.r.t. the shared image states = sum over the cross-attention layers of dKV_l @ Wkv_l: with the grouped
+        # kernels every layer's dKV is [images*Nenc, 2D], so the layers write column blocks of ONE buffer and a single GEMM
+        # with K = layers*2D (against the column-concatenated transposed weights) replaces one fp32 read-modify-write GEMM per layer
+        cross_layers = [li for li in range(lo, hi) if model.encoder.layer[li].has_cross_attention] if enc is not None else []
+        concat_k = need_denc and groups is not None and len(cross_layers) > 1
+        dkv_all = torch.empty((enc.shape[0], len(cross_layers) * 2 * D), dtype=BF16, device=dy.device) if concat_k else None
+        if need_denc and not concat_k:
+            denc32 = torch.zeros((enc.shape[0], D), dtype=F32, device=dy.device)
         for li in reversed(range(lo, hi)):
             layer = model.encoder.layer[li]
             s, r = layer._s, ctx.saved[li - lo]
@@ -273,7 +281,11 @@ class _EncoderFn(torch.autograd.Function):
                 kv = r["kv"]
                 dq2 = torch.empty_like(r["q2"])
                 if groups is not None:  # dK/dV accumulated over each image's rows in registers, written once per image
-                    dkv = torch.empty((enc.shape[0], 2 * D), dtype=BF16, device=dq2.device)
+                    if concat_k:
+                        j = cross_layers.index(li)
+                        dkv = dkv_all[:, j * 2 * D:(j + 1) * 2 * D]
+                    else:
+                        dkv = torch.empty((enc.shape[0], 2 * D), dtype=BF16, device=dq2.device)
                     Fx.attn_bwd(dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc,
                                 scale, key_keep=enc_keep, drop=r["d_att2"], groups=groups)
                 else:
@@ -284,7 +296,7 @@ class _EncoderFn(torch.autograd.Function):
                         dkv = Fx.rows_index_sum(dkv, enc_index, enc.shape[0] // Nenc, Nenc)
                 Fx.gemm_tn(dq2, r["y1"], s["q2"].dw, dbias=s["q2"].db)
                 Fx.gemm_tn(dkv, enc, s["kv2"].dw, dbias=s["kv2"].db)
-                if need_denc:
+                if need_denc and not concat_k:
                     Fx.gemm_nt(dkv, s["kv2"].wt, epi=Fx.EPI_F32_ACC, out=denc32, n=s["kv2"].K)
                 d1a, d1b = Fx.gemm_nt(dq2, s["q2"].wt, n=s["q2"].K), dres2
             ln1 = layer.attention.output.LayerNorm
@@ -303,7 +315,12 @@ class _EncoderFn(torch.autograd.Function):
         dx = (dy_a.float() + dy_b.float()).to(BF16) if need_dx else None
         if dx is not None and B < B_full:
             dx = torch.cat([dx, torch.zeros(((B_full - B) * T, dx.shape[1]), dtype=dx.dtype, device=dx.device)], dim=0)
-        denc = denc32.to(BF16) if need_denc else None
+        denc = None
+        if concat_k:
+            wt_cat = torch.cat([model.encoder.layer[li]._s["kv2"].wt[:, :2 * D] for li in cross_layers], dim=1)  # [D_enc, layers*2D]
+            denc = Fx.gemm_nt(dkv_all, wt_cat)
+        elif need_denc:
+            denc = denc32.to(BF16)
         if ctx.noted:
             arena_note_grad(model)
         return (dx, denc) + (None,) * 12
