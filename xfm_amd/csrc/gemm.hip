@@ -637,8 +637,10 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
     if (M >= 2048 && t256 >= 120) cfg = 5;  // ~half a round of 256x256 tiles already beats the rest
     else if ((long)cdiv(M, 256) * cdiv(N, 128) >= 768) cfg = 4;  // >= 3 rounds of 256x128 tiles: the 3-slot ring wins on cold operands
     else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 800) cfg = 1;
-    else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 256) cfg = 2;
-    else if (K >= 1536) {  // under one workgroup per CU and a long K loop: keep two K-tiles in flight (3-stage 64x128)
+    else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 512) cfg = 2;
+    else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 128 || K >= 1536) {  // under two workgroups per CU (tail-split row blocks, text
+      // tower) the 2-stage loop exposes the load latency of every K-step: keep two K-tiles in flight (3-stage 64x128; measured
+      // 45.9 -> 31.7 us on 3456x768x3072, 18.9 -> 20.6 us on the 720-tile 7680x768x768 which therefore stays 2-stage)
       cfg = 7;
       // ... and when the loop is VERY long against very few tiles (LM-head dgrad: K = 50304, 90 tiles) slice K over gridDim.y;
       // only the fp32-accumulate epilogue can merge slices (atomics), so callers ask for it with a zeroed fp32 C
