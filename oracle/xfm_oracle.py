@@ -127,6 +127,32 @@ def beit_forward(P, pre, image, depth=12, heads=12, ids_mask=None, drop_path=Non
 
 
 # --------------------------------------------------------------------------------------
+# Plain ViT  (models/vit.py; SURVEY row V0, unused by the shipped configs)
+# --------------------------------------------------------------------------------------
+def vit_attention(P, pre, x, heads):
+    """vit.py:60-83: qkv Linear WITH bias, (q @ k^T) * scale AFTER the product, softmax, @ v, proj."""
+    B, N, C = x.shape
+    d = C // heads
+    qkv = _lin(P, pre + "qkv", x).reshape(B, N, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    p = ((q @ k.transpose(-2, -1)) * (d ** -0.5)).softmax(dim=-1)
+    return _lin(P, pre + "proj", (p @ v).transpose(1, 2).reshape(B, N, C))
+
+
+def vit_forward(P, pre, image, depth=12, heads=12, eps=1e-6):
+    """vit.py:177-219 (eval mode: drop-path off): patch-embed, cls token, + pos_embed, pre-LN blocks :100-103, final norm."""
+    x = beit_patch_embed(P, pre, image)
+    B = x.shape[0]
+    x = torch.cat([P[pre + "cls_token"].expand(B, -1, -1), x], dim=1)
+    x = x + P[pre + "pos_embed"][:, :x.shape[1], :]
+    for i in range(depth):
+        b = f"{pre}blocks.{i}."
+        x = x + vit_attention(P, b + "attn.", _ln(P, b + "norm1", x, eps), heads)
+        x = x + _lin(P, b + "mlp.fc2", F.gelu(_lin(P, b + "mlp.fc1", _ln(P, b + "norm2", x, eps))))
+    return _ln(P, pre + "norm", x, eps)
+
+
+# --------------------------------------------------------------------------------------
 # RoBERTa text / fusion tower  (models/xroberta.py; xbert.py differs where flagged)
 # --------------------------------------------------------------------------------------
 def roberta_position_ids(input_ids, padding_idx=1):

@@ -240,6 +240,25 @@ def test_xbert_variant_vs_golden():
     assert err <= GRAD_TOL and cos >= COS_TOL, (err, cos)
 
 
+def test_plain_vit_tower_vs_golden():
+    """models/vit.py (row V0): the fused trunk with a constant-ones layer scale, no relative-position bias, qkv bias as one
+    parameter, absolute position embedding and the final LayerNorm over every token."""
+    from xfm_amd.vit import VisionTransformer
+    z, meta = load("vit_2blk")
+    m = VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=meta["depth"], num_heads=12, mlp_ratio=4, qkv_bias=True,
+                          drop_path_rate=0.1)
+    ours = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+    assert ours == meta["spec"]
+    _load_into(m, meta["spec"])
+    m.cuda().finalize().eval()
+    image = syn.gaussian("vit.image", (meta["B"], 3, 224, 224)).cuda()
+    y = m(image)
+    _check_out(z, "out", y)
+    cot = syn.symmetric("vit.cot", tuple(y.shape), 1.0).cuda()
+    (y.float() * cot).sum().backward()
+    _check_grads(z, "grad", m)
+
+
 def _pretrain_cfg(meta):
     return {"use_beit_v2": True, "image_res": 224, "patch_size": 16, "local_attn_depth": -1, "text_encoder": "roberta-base",
             "text_num_hidden_layers": meta["text_layers"], "text_fusion_start_at": meta["text_layers"],

@@ -157,6 +157,17 @@ def test_xbert_variant():
     check(z, "grad_mlm_in/image_embeds", img.grad, ATOL, RTOL)
 
 
+def test_plain_vit_tower():
+    z, meta = load("vit_2blk")
+    P = _params(meta["spec"])
+    image = syn.gaussian("vit.image", (meta["B"], 3, 224, 224))
+    y = O.vit_forward(P, "", image, depth=meta["depth"])
+    check(z, "out", y, ATOL, RTOL)
+    cot = syn.symmetric("vit.cot", tuple(y.shape), 1.0)
+    (y * cot).sum().backward()
+    _check_grads(z, "grad", P)
+
+
 def _pretrain(name):
     z, meta = load(name)
     B = meta["B"]

@@ -110,6 +110,24 @@ def gen_beit(depth=2, B=4):
     save(f"beit_{depth}blk", out, {"spec": spec_of(m), "B": B, "depth": depth})
 
 
+def gen_vit(depth=2, B=3):
+    """models/vit.py (unused by the shipped configs): plain pre-LN ViT-B/16, absolute position embedding."""
+    from models.vit import VisionTransformer
+    torch.manual_seed(0)
+    m = VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=depth, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                          drop_path_rate=0.1)
+    load_formula(m)
+    m.eval()
+    image = syn.gaussian("vit.image", (B, 3, 224, 224))
+    cot = syn.symmetric("vit.cot", (B, 197, 768), 1.0)
+    out = {}
+    y = m(image)
+    pack("out", y, out)
+    (y * cot).sum().backward()
+    grads_of(m, out)
+    save(f"vit_{depth}blk", out, {"spec": spec_of(m), "B": B, "depth": depth})
+
+
 def roberta_cfg(layers, fusion_layer):
     from models.xroberta import RobertaConfig
     cfg = RobertaConfig(**ref_shim.ROBERTA_BASE_CONFIG)
@@ -299,7 +317,7 @@ def main():
     torch.set_num_threads(8)
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2)}
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2)}
     if a.full:
         jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
     for k, fn in jobs.items():

@@ -124,7 +124,20 @@ def install():
     _stub("timm.models.layers", drop_path=drop_path, to_2tuple=to_2tuple, trunc_normal_=trunc_normal_,
           DropPath=DropPath)
     _stub("timm.models.registry", register_model=register_model)
-    _stub("timm.models.vision_transformer", _cfg=_cfg, PatchEmbed=None)
+    class PatchEmbed(nn.Module):
+        """timm.models.vision_transformer.PatchEmbed (third-party, absent here; reference pins timm in requirements.txt):
+        Conv2d(in_chans, embed_dim, kernel=stride=patch) -> flatten(2).transpose(1, 2); used by models/vit.py:8,147."""
+
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+            super().__init__()
+            self.img_size, self.patch_size = (img_size, img_size), (patch_size, patch_size)
+            self.num_patches = (img_size // patch_size) ** 2
+            self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+        def forward(self, x):
+            return self.proj(x).flatten(2).transpose(1, 2)
+
+    _stub("timm.models.vision_transformer", _cfg=_cfg, PatchEmbed=PatchEmbed)
     _stub("timm.models.helpers", load_pretrained=None)
     _stub("timm.data")
     _stub("timm.data.constants", IMAGENET_DEFAULT_MEAN=(0.485, 0.456, 0.406), IMAGENET_DEFAULT_STD=(0.229, 0.224, 0.225),

@@ -166,19 +166,25 @@ class _TrunkFn(torch.autograd.Function):
         n0 = blocks[0].norm1
         y, mean, rstd = Fx.ln_fwd(x, n0.weight, n0.bias, n0.eps)
         ctx.first = (x, mean, rstd)
+        rel_pos = getattr(vit, "_rel_pos", True)      # models/vit.py (plain ViT): no relative-position bias,
+        final_norm = vit._final_norm if hasattr(vit, "_final_norm") else vit.fc_norm
         for i, blk in enumerate(blocks):
             s = vit._slots[i]
-            dense, dense_t = Fx.relpos_gather(blk.attn.relative_position_bias_table, vit._index32, H, N, ld, transposed=True)
+            g1 = blk.gamma_1 if blk.gamma_1 is not None else vit._ones   # ... and no layer scale (gamma = 1, no gradient)
+            g2 = blk.gamma_2 if blk.gamma_2 is not None else vit._ones
+            dense = dense_t = None
+            if rel_pos:
+                dense, dense_t = Fx.relpos_gather(blk.attn.relative_position_bias_table, vit._index32, H, N, ld, transposed=True)
             qkv = Fx.gemm_nt(y, s["qkv"].wb, s["qkv"].b)
             ctxv, lse = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense)
             h1 = Fx.gemm_nt(ctxv, s["proj"].wb, s["proj"].b)
             dp1 = None if dp is None else dp[i, 0]
             dp2 = None if dp is None else dp[i, 1]
-            x1, y2, mean2, rstd2 = Fx.ln_ls_fwd(x, h1, blk.gamma_1, dp1, N, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            x1, y2, mean2, rstd2 = Fx.ln_ls_fwd(x, h1, g1, dp1, N, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             hact, u = Fx.gemm_nt(y2, s["fc1"].wb, s["fc1"].b, epi=Fx.EPI_GELU)
             h2 = Fx.gemm_nt(hact, s["fc2"].wb, s["fc2"].b)
-            nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else vit.fc_norm
-            x2, yn, meann, rstdn = Fx.ln_ls_fwd(x1, h2, blk.gamma_2, dp2, N, nxt.weight, nxt.bias, nxt.eps)
+            nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else final_norm
+            x2, yn, meann, rstdn = Fx.ln_ls_fwd(x1, h2, g2, dp2, N, nxt.weight, nxt.bias, nxt.eps)
             saved.append((y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t))
             x, y = x2, yn
         ctx.saved, ctx.vit, ctx.shape = saved, vit, (B, N, D)
@@ -198,23 +204,29 @@ class _TrunkFn(torch.autograd.Function):
         for i in reversed(range(len(blocks))):
             blk, s = blocks[i], vit._slots[i]
             (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t) = ctx.saved[i]
-            nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else vit.fc_norm
+            final_norm = vit._final_norm if hasattr(vit, "_final_norm") else vit.fc_norm
+            nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else final_norm
             g = _g
-            dh2 = Fx.ln_ls_bwd(dy, dstream, x2, meann, rstdn, nxt.weight, h2, blk.gamma_2, dp2, N, g(nxt.weight), g(nxt.bias),
-                               s["fc2"].db, g(blk.gamma_2))
+            g1 = blk.gamma_1 if blk.gamma_1 is not None else vit._ones
+            g2 = blk.gamma_2 if blk.gamma_2 is not None else vit._ones
+            dg1 = g(blk.gamma_1) if blk.gamma_1 is not None else None
+            dg2 = g(blk.gamma_2) if blk.gamma_2 is not None else None
+            dh2 = Fx.ln_ls_bwd(dy, dstream, x2, meann, rstdn, nxt.weight, h2, g2, dp2, N, g(nxt.weight), g(nxt.bias),
+                               s["fc2"].db, dg2)
             Fx.gemm_tn(dh2, hact, s["fc2"].dw)
             du = Fx.gemm_nt(dh2, s["fc2"].wt, epi=Fx.EPI_DGELU, aux=u, n=s["fc2"].K)
             Fx.gemm_tn(du, y2, s["fc1"].dw, dbias=s["fc1"].db)
             dy2 = Fx.gemm_nt(du, s["fc1"].wt, n=s["fc1"].K)
-            dh1 = Fx.ln_ls_bwd(dy2, dstream, x1, mean2, rstd2, blk.norm2.weight, h1, blk.gamma_1, dp1, N, g(blk.norm2.weight),
-                               g(blk.norm2.bias), s["proj"].db, g(blk.gamma_1))
+            dh1 = Fx.ln_ls_bwd(dy2, dstream, x1, mean2, rstd2, blk.norm2.weight, h1, g1, dp1, N, g(blk.norm2.weight),
+                               g(blk.norm2.bias), s["proj"].db, dg1)
             Fx.gemm_tn(dh1, ctxv, s["proj"].dw)
             dctx = Fx.gemm_nt(dh1, s["proj"].wt, n=s["proj"].K)
             dqkv = torch.empty_like(qkv)
-            ddense = torch.zeros_like(dense)
+            ddense = torch.zeros_like(dense) if dense is not None else None
             Fx.attn_bwd(dctx, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ctxv, lse, dqkv[:, :D], dqkv[:, D:2 * D],
                         dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense, bias_t=dense_t)
-            Fx.relpos_scatter_sorted(ddense, vit._relpos_order, vit._relpos_start, H, N, ld, g(blk.attn.relative_position_bias_table))
+            if dense is not None:
+                Fx.relpos_scatter_sorted(ddense, vit._relpos_order, vit._relpos_start, H, N, ld, g(blk.attn.relative_position_bias_table))
             Fx.gemm_tn(dqkv, y, s["qkv"].dw, dbias=s["qkv"].db)
             dy = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K)
             ctx.saved[i] = None
