@@ -419,3 +419,19 @@ def pretrain_forward(P, cfg, batch, image_neg_idx=None, text_neg_idx=None, ids_m
     return {"loss_itc": loss_itc, "loss_itm": loss_itm, "loss_mlm": loss_mlm, "loss_mim": loss_mim,
             "image_embeds": image_embeds, "text_embeds": text_embeds,
             "image_neg_idx": list(image_neg_idx), "text_neg_idx": list(text_neg_idx)}
+
+
+def retrieval_forward(P, cfg, batch, idx, image_neg_idx, text_neg_idx, text_prefix="text_encoder."):
+    """model_retrieval.py:25-36 XFMForRetrieval.forward given the sampled negatives: ITC with idx soft labels, ITM with the
+    text tower attached (is_pretrain=False)."""
+    image_embeds = beit_forward(P, "vision_encoder.", batch["image"], depth=cfg["vit_depth"])
+    image_atts = torch.ones(image_embeds.shape[:2], dtype=torch.long)
+    # without the MLM loss the text tower is a bare RobertaModel: keys `text_encoder.embeddings...` (xfm.py:398-403)
+    text_embeds = roberta_model(P, text_prefix, input_ids=batch["text_ids"], att=batch["text_atts"],
+                                num_layers=cfg["text_layers"], fusion_layer=cfg["text_layers"])
+    image_feat, text_feat = get_features(P, image_embeds, text_embeds)
+    loss_itc = contrastive_loss(image_feat, text_feat, P["temp"], idx_all=idx)
+    loss_itm = matching_loss(P, cfg, image_embeds, image_atts, text_embeds, batch["text_atts"], image_neg_idx, text_neg_idx,
+                             is_pretrain=False)
+    return loss_itc, loss_itm
+

@@ -259,6 +259,34 @@ def test_plain_vit_tower_vs_golden():
     _check_grads(z, "grad", m)
 
 
+def test_retrieval_model_vs_golden():
+    """model_retrieval.XFMForRetrieval: bare RobertaModel text tower (no LM heads), ITC with duplicated idx (soft labels), ITM with
+    is_pretrain=False (the text tower also gets the matching gradient)."""
+    from xfm_amd.model_retrieval import XFMForRetrieval
+    z, meta = load("retrieval_small")
+    m = XFMForRetrieval(_pretrain_cfg(meta))
+    ours = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+    assert ours == meta["spec"]
+    _load_into(m, meta["spec"])
+    m.cuda().finalize().eval()
+    b = {k: v.cuda() for k, v in syn.pretrain_batch(meta["B"], seed=77).items()}
+    idx = torch.tensor(meta["idx"]).cuda()
+    itc, itm = m(b["image"], b["text_ids"], b["text_atts"], idx=idx, neg_idx=(meta["image_neg_idx"], meta["text_neg_idx"]))
+    ri, rm = float(z["loss_itc"]), float(z["loss_itm"])
+    assert abs(float(itc) - ri) <= 3e-3 * max(abs(ri), 1.0) and abs(float(itm) - rm) <= 3e-2 * max(abs(rm), 1.0), (float(itc), ri, float(itm), rm)
+    assert abs(float(itc + itm) - (ri + rm)) <= 2e-3 * (ri + rm)
+    (itc + itm).backward()
+    _check_grads(z, "grad", m, min_rms=1e-6)
+    # the sampler itself: device-side draws must respect the same-idx exclusion (xfm.py:731-734)
+    with torch.no_grad():
+        img, _ = m.get_vision_embeds(b["image"])
+        txt = m.get_text_embeds(b["text_ids"], b["text_atts"])
+        fi, ft = m.get_features(img, txt)
+        ini, tni = m.get_hard_negatives(fi, ft, idx=idx)
+    for r in range(meta["B"]):
+        assert meta["idx"][int(ini[r])] != meta["idx"][r] and meta["idx"][int(tni[r])] != meta["idx"][r]
+
+
 def _pretrain_cfg(meta):
     return {"use_beit_v2": True, "image_res": 224, "patch_size": 16, "local_attn_depth": -1, "text_encoder": "roberta-base",
             "text_num_hidden_layers": meta["text_layers"], "text_fusion_start_at": meta["text_layers"],

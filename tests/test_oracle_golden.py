@@ -168,6 +168,21 @@ def test_plain_vit_tower():
     _check_grads(z, "grad", P)
 
 
+def test_retrieval_model():
+    z, meta = load("retrieval_small")
+    P = _params(meta["spec"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    b = syn.pretrain_batch(meta["B"], seed=77)
+    idx = torch.tensor(meta["idx"])
+    itc, itm = O.retrieval_forward(P, cfg, b, idx, meta["image_neg_idx"], meta["text_neg_idx"], text_prefix="text_encoder.")
+    assert abs(float(itc) - float(z["loss_itc"])) < 2e-4 and abs(float(itm) - float(z["loss_itm"])) < 2e-4
+    # the captured negatives respect the idx rule: never a pair with the same idx (xfm.py:731-734)
+    for r, (i, t) in enumerate(zip(meta["image_neg_idx"], meta["text_neg_idx"])):
+        assert meta["idx"][i] != meta["idx"][r] and meta["idx"][t] != meta["idx"][r]
+    (itc + itm).backward()
+    _check_grads(z, "grad", P)
+
+
 def _pretrain(name):
     z, meta = load(name)
     B = meta["B"]

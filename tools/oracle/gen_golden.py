@@ -309,6 +309,38 @@ def gen_pretrain(name, text_layers, fusion_layers, B=4):
                      "text_neg_idx": [int(i) for i in captured["text_neg_idx"]], "unused": unused})
 
 
+def gen_retrieval(B=4):
+    """models/model_retrieval.py XFMForRetrieval: ITC with duplicated `idx` (soft labels, xfm.py:705-713), hard negatives that
+    avoid same-idx pairs (:731-734), ITM with the text gradient kept (is_pretrain=False)."""
+    from models.model_retrieval import XFMForRetrieval
+    ref_shim.init_single_process_group()
+    torch.manual_seed(0)
+    cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2)
+    m = XFMForRetrieval(cfg)
+    load_formula(m)
+    m.eval()
+    b = syn.pretrain_batch(B, seed=77)
+    idx = torch.tensor([5, 9, 5, 2][:B])
+    captured = {}
+    orig = m.get_hard_negatives
+
+    def capture(*a, **kw):
+        torch.manual_seed(4321)
+        r = orig(*a, **kw)
+        captured["image_neg_idx"], captured["text_neg_idx"] = list(r[0]), list(r[1])
+        return r
+
+    m.get_hard_negatives = capture
+    loss_itc, loss_itm = m(b["image"], b["text_ids"], b["text_atts"], idx=idx)
+    out = {"loss_itc": np.asarray(float(loss_itc)), "loss_itm": np.asarray(float(loss_itm))}
+    (loss_itc + loss_itm).backward()
+    grads_of(m, out)
+    unused = [n for n, p in m.named_parameters() if p.grad is None]
+    save("retrieval_small", out, {"spec": spec_of(m), "B": B, "text_layers": 2, "fusion_layers": 2, "idx": idx.tolist(),
+                                  "image_neg_idx": [int(i) for i in captured["image_neg_idx"]],
+                                  "text_neg_idx": [int(i) for i in captured["text_neg_idx"]], "unused": unused})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -317,7 +349,7 @@ def main():
     torch.set_num_threads(8)
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2)}
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval()}
     if a.full:
         jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
     for k, fn in jobs.items():

@@ -1,0 +1,25 @@
+"""Drop-in for models/model_retrieval.py (image-text retrieval fine-tuning): ITC with `idx` soft labels + ITM with the text
+tower's gradient kept (`is_pretrain=False`), on the HIP towers."""
+from .xfm import XFMBase
+
+
+class XFMForRetrieval(XFMBase):
+    """model_retrieval.py:11-36."""
+
+    def __init__(self, config):
+        super().__init__(config, load_vision_params=False, load_text_params=False, use_contrastive_loss=True,
+                         use_matching_loss=True, use_mlm_loss=False, use_bbox_loss=False)
+        self.num_attention_heads = self.text_encoder.config.num_attention_heads
+        self.init_params = []
+
+    def load_pretrained(self, ckpt_rpath, config, is_eval=False):
+        raise NotImplementedError("checkpoint key surgery (xfm.py:408-468) is outside the hot-path scope; load a state_dict instead")
+
+    def forward(self, image, text_ids, text_atts, idx=None, neg_idx=None):
+        image_embeds, image_atts = self.get_vision_embeds(image)
+        text_embeds = self.get_text_embeds(text_ids, text_atts)
+        image_feat, text_feat = self.get_features(image_embeds, text_embeds)
+        loss_itc = self.get_contrastive_loss(image_feat, text_feat, idx=idx)
+        loss_itm = self.get_matching_loss(image_embeds, image_atts, image_feat, text_ids, text_atts, text_feat, idx=idx,
+                                          text_embeds=text_embeds, is_pretrain=False, neg_idx=neg_idx)
+        return loss_itc, loss_itm

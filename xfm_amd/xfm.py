@@ -105,11 +105,14 @@ def _text_config(config, cls=RobertaConfig):
 def build_text_encoder(config, vision_width, load_text_params=False, use_mlm_loss=False, config_text=None):
     """xfm.py:258-405: 'roberta' in config['text_encoder'] -> xroberta towers, 'bert' -> xbert towers."""
     name = config.get('text_encoder', 'roberta-base')
+    # with the MLM loss the text tower carries its LM heads (`.bert` reaches the encoder); fine-tuning models build the bare
+    # encoder (xfm.py:345-352, :398-403)
     if 'roberta' in name:
-        cfg_cls, model_cls = RobertaConfig, RobertaForMaskedLM
+        from .xroberta import RobertaModel
+        cfg_cls, model_cls = RobertaConfig, (RobertaForMaskedLM if use_mlm_loss else RobertaModel)
     elif 'bert' in name:
-        from .xbert import BertConfig, BertForMaskedLM
-        cfg_cls, model_cls = BertConfig, BertForMaskedLM
+        from .xbert import BertConfig, BertForMaskedLM, BertModel
+        cfg_cls, model_cls = BertConfig, (BertForMaskedLM if use_mlm_loss else BertModel)
     else:
         raise ValueError(name)
     if load_text_params:
@@ -218,8 +221,9 @@ class XFMBase(nn.Module):
     def get_text_embeds(self, text_ids, text_atts):
         assert text_atts is not None
         self._ready()
-        return self.text_encoder.bert(text_ids, attention_mask=text_atts, encoder_hidden_states=None,
-                                      encoder_attention_mask=None, return_dict=True).last_hidden_state
+        encoder = self.text_encoder.bert if hasattr(self.text_encoder, 'bert') else self.text_encoder  # xfm.py:605
+        return encoder(text_ids, attention_mask=text_atts, encoder_hidden_states=None, encoder_attention_mask=None,
+                       return_dict=True).last_hidden_state
 
     def get_text_embeds_with_masked(self, text_ids, text_atts, text_ids_masked):
         """get_text_embeds(text_ids) and the DETACHED get_text_embeds(text_ids_masked) of get_fuse_mlm_loss (xfm.py:648-649) as one
