@@ -341,6 +341,29 @@ def gen_retrieval(B=4):
                                   "text_neg_idx": [int(i) for i in captured["text_neg_idx"]], "unused": unused})
 
 
+def gen_checkpoint():
+    """Checkpoint key surgery (xfm.py:408-468) at equal resolution: a pre-training checkpoint ({'model': state_dict}, text tower with
+    LM heads) loaded into the fine-tuning XFMForRetrieval (bare text encoder) by the reference's own load_pretrained."""
+    import tempfile
+    from models import load_pretrained
+    from models.model_pretrain import XFM
+    from models.model_retrieval import XFMForRetrieval
+    ref_shim.init_single_process_group()
+    torch.manual_seed(0)
+    cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2)
+    pre = XFM(cfg, load_vision_params=False, load_text_params=False)
+    sd = syn.formula_state_dict(pre.state_dict())
+    path = os.path.join(tempfile.mkdtemp(), "ckpt.th")
+    torch.save({"model": sd, "epoch": 3}, path)
+    m = XFMForRetrieval(cfg)
+    state_dict = load_pretrained(m, path, cfg, is_eval=False, load_text=True)
+    msg = m.load_state_dict(state_dict, strict=False)
+    # every surviving tensor is the checkpoint tensor of its (renamed) source key: record a checksum per key
+    sums = {k: float(v.double().sum()) for k, v in state_dict.items()}
+    save("checkpoint_surgery", {}, {"pretrain_spec": spec_of(pre), "keys": sorted(state_dict.keys()), "missing": sorted(msg.missing_keys),
+                                    "unexpected": sorted(msg.unexpected_keys), "sums": sums})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -349,7 +372,7 @@ def main():
     torch.set_num_threads(8)
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval()}
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint()}
     if a.full:
         jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
     for k, fn in jobs.items():

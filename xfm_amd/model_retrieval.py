@@ -13,7 +13,13 @@ class XFMForRetrieval(XFMBase):
         self.init_params = []
 
     def load_pretrained(self, ckpt_rpath, config, is_eval=False):
-        raise NotImplementedError("checkpoint key surgery (xfm.py:408-468) is outside the hot-path scope; load a state_dict instead")
+        """model_retrieval.py:19-24: a pre-training checkpoint into the bare-encoder fine-tuning model."""
+        from .xfm import load_pretrained
+        state_dict = load_pretrained(self, ckpt_rpath, config, is_eval=is_eval, load_text=True)
+        msg = self.load_state_dict(state_dict, strict=False)
+        if self._arena is not None:
+            self._arena.bump()
+        return msg
 
     def forward(self, image, text_ids, text_atts, idx=None, neg_idx=None):
         image_embeds, image_atts = self.get_vision_embeds(image)

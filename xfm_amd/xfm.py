@@ -125,6 +125,36 @@ def build_text_encoder(config, vision_width, load_text_params=False, use_mlm_los
     return model_cls(config_text), []
 
 
+def load_pretrained(model, ckpt_rpath, config, is_eval=False, load_text=False):
+    """Checkpoint key surgery of the reference (xfm.py:408-468) for the BEiT-v2 configuration: unwrap `{'model': state_dict}`,
+    drop the `relative_position_index` buffers (rebuilt by the model), and -- with `load_text` -- strip the `roberta.` / `bert.`
+    level from `text_encoder.*` keys so that a pre-training checkpoint (text tower with LM heads) loads into a fine-tuning model
+    (bare encoder).  Returns the state_dict to pass to `load_state_dict(strict=False)`.
+    Resolution changes are NOT handled: the reference interpolates the relative-position tables with
+    `scipy.interpolate.interp2d` (beit2.py:753-821), which SciPy >= 1.14 removed, so that arithmetic cannot be pinned here."""
+    checkpoint = torch.load(ckpt_rpath, map_location='cpu')
+    state_dict = checkpoint['model'] if 'model' in checkpoint.keys() else checkpoint
+    if is_eval:
+        return state_dict
+    if not config.get('use_beit_v2', False):
+        raise NotImplementedError("only the use_beit_v2 branch of load_pretrained (xfm.py:438-449) is built")
+    own = model.vision_encoder.state_dict()
+    for k in list(state_dict.keys()):
+        if k.startswith('vision_encoder.'):
+            if 'relative_position_index' in k:
+                del state_dict[k]
+            elif 'relative_position_bias_table' in k and k[15:] in own and own[k[15:]].shape != state_dict[k].shape:
+                raise NotImplementedError(f"{k}: {tuple(state_dict[k].shape)} -> {tuple(own[k[15:]].shape)} needs the reference's "
+                                          "interp2d-based table interpolation (beit2.py:775-821), unavailable with SciPy >= 1.14")
+    if load_text:
+        name_to_replace = 'roberta.' if 'roberta' in config['text_encoder'] else 'bert.'
+        for key in list(state_dict.keys()):
+            if key.startswith('text_encoder.') and name_to_replace in key:
+                state_dict[key.replace(name_to_replace, '')] = state_dict[key]
+                del state_dict[key]
+    return state_dict
+
+
 class XFMBase(nn.Module):
     def __init__(self, config=None, load_vision_params=False, load_text_params=False, use_contrastive_loss=False,
                  use_matching_loss=False, use_mlm_loss=False, use_bbox_loss=False, config_text=None):
@@ -172,6 +202,22 @@ class XFMBase(nn.Module):
         if self.vision_width != self.text_width:
             raise NotImplementedError("fusion_proj (vision_width != text_width) is not on the base-model path")
         self._arena = None
+
+    def load_pretrained(self, ckpt_rpath, config, is_eval=False, is_domain_pretrain=False):
+        """xfm.py:540-557."""
+        if is_domain_pretrain:
+            checkpoint = torch.load(ckpt_rpath, map_location='cpu')
+            state_dict = checkpoint['model'] if 'model' in checkpoint.keys() else checkpoint
+            for key in list(state_dict.keys()):
+                if 'visual_encoder' in key:
+                    state_dict[key.replace('visual_encoder', 'vision_encoder')] = state_dict[key]
+                    del state_dict[key]
+        else:
+            state_dict = load_pretrained(self, ckpt_rpath, config, is_eval=is_eval, load_text=True)
+        msg = self.load_state_dict(state_dict, strict=False)
+        if self._arena is not None:
+            self._arena.bump()
+        return msg
 
     # ---- arena ----------------------------------------------------------------------------------
     def finalize(self, device=None):
