@@ -435,3 +435,30 @@ def retrieval_forward(P, cfg, batch, idx, image_neg_idx, text_neg_idx, text_pref
                              is_pretrain=False)
     return loss_itc, loss_itm
 
+
+def deep_mlp_forward(P, pre, x, eps=1e-5):
+    """XFMForClassification.build_mlp model_classification.py:33-48: (Linear, LayerNorm, GELU) x 4 then Linear; keys 0,1 / 3,4 / 6,7 /
+    9,10 / 12."""
+    for j in range(4):
+        x = gelu_erf(_ln(P, f"{pre}{3 * j + 1}", _lin(P, f"{pre}{3 * j}", x), eps))
+    return _lin(P, pre + "12", x)
+
+
+def classification_forward(P, cfg, image, text_ids, text_atts, deep_head):
+    """XFMForClassification.forward model_classification.py:50-93 -> prediction logits.  Branches: image only (cls + mean of the
+    patch tokens, :67-70), text only (:52-55), multimodal (fusion [CLS], is_pretrain=False, :72-78)."""
+    if image is None:
+        feat = roberta_model(P, "text_encoder.", input_ids=text_ids, att=text_atts, num_layers=cfg["text_layers"],
+                             fusion_layer=cfg["text_layers"])[:, 0, :]
+    elif text_ids is None:
+        emb = beit_forward(P, "vision_encoder.", image, depth=cfg["vit_depth"])
+        feat = torch.cat([emb[:, 0, :], emb[:, 1:, :].mean(dim=1)], dim=-1)
+    else:
+        emb = beit_forward(P, "vision_encoder.", image, depth=cfg["vit_depth"])
+        atts = torch.ones(emb.shape[:2], dtype=torch.long)
+        txt = roberta_model(P, "text_encoder.", input_ids=text_ids, att=text_atts, num_layers=cfg["text_layers"],
+                            fusion_layer=cfg["text_layers"])
+        feat = roberta_model(P, "fusion_encoder.roberta.", att=text_atts, encoder_embeds=txt, enc=emb, enc_att=atts,
+                             num_layers=cfg["fusion_layers"], fusion_layer=cfg["fusion_start"])[:, 0, :]
+    return deep_mlp_forward(P, "cls_head.", feat) if deep_head else build_mlp_forward(P, "cls_head.", feat)
+

@@ -147,7 +147,7 @@ def _ln_ref(x, w, b, eps):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
-@pytest.mark.parametrize("D", [768, 1536])
+@pytest.mark.parametrize("D", [768, 1536, 3072, 6144])  # 3072 / 6144: the wide-row kernels of the classification head
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_layernorm_plain_fwd_bwd(D, dtype):
     Fx = _fx()

@@ -10,6 +10,7 @@ Stated tolerances (bf16 MFMA compute, fp32 accumulate/statistics, vs an fp32 ref
   losses         total loss within 1e-3 rel (north-star bound); ITC/MLM/MIM within 3e-3 each, ITM (12-row 2-way CE) 3e-2.
 """
 import json
+import os
 
 import pytest
 import torch
@@ -285,6 +286,75 @@ def test_retrieval_model_vs_golden():
         ini, tni = m.get_hard_negatives(fi, ft, idx=idx)
     for r in range(meta["B"]):
         assert meta["idx"][int(ini[r])] != meta["idx"][r] and meta["idx"][int(tni[r])] != meta["idx"][r]
+
+
+def _cls_cfg(meta, **kw):
+    cfg = dict(_pretrain_cfg(meta))
+    cfg.update(kw)
+    return cfg
+
+
+def test_classification_imagenet_branch_vs_golden(tmp_path):
+    """BASELINE configs[1] (ImageNet fine-tune, ViT-only path): XFMForClassification built the reference's way -- vision tower loaded
+    by load_pretrained_beit2 from a checkpoint file -- then cls + mean-patch features through the deep MLP head."""
+    from xfm_amd.model_classification import XFMForClassification
+    z, meta = load("classification_imagenet")
+    spec = meta["spec"]
+    vis = {k[len("vision_encoder."):]: v for k, v in state_from_spec(spec).items() if k.startswith("vision_encoder.")}
+    vis["head.weight"], vis["head.bias"] = torch.zeros(1000, 768), torch.zeros(1000)
+    ckpt = os.path.join(tmp_path, "beit.pth")
+    torch.save({"model": vis}, ckpt)
+    vcfg = os.path.join(tmp_path, "config_beit2_base.json")
+    with open(vcfg, "w") as f:
+        json.dump({"ckpt": ckpt, "vision_width": 768, "patch_size": 16}, f)
+    m = XFMForClassification(_cls_cfg(meta, vision_config=vcfg, task_name="imagenet", num_labels=1000))
+    ours = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+    assert ours == spec
+    ref_vis = state_from_spec(spec)
+    for k, v in m.vision_encoder.state_dict().items():  # the checkpoint file reached the tower (load_vision_params=True)
+        if v.dtype.is_floating_point:
+            assert torch.equal(v, ref_vis["vision_encoder." + k]), k
+    _load_into(m, spec)
+    m.cuda().finalize().eval()
+    b = {k: v.cuda() for k, v in syn.pretrain_batch(meta["B"], seed=55).items()}
+    targets = torch.tensor(meta["targets"]).cuda()
+    pred = m(b["image"], None, None, targets, train=False)
+    _check_out(z, "pred_imagenet", pred)
+    loss = m(b["image"], None, None, targets, train=True)
+    ref = float(z["loss_imagenet"])
+    assert abs(float(loss) - ref) <= 2e-3 * abs(ref), (float(loss), ref)
+    loss.backward()
+    _check_grads(z, "grad_imagenet", m, min_rms=1e-6, tol=1.5e-1, cos_tol=0.985)  # 12-block ViT: full-depth tolerance
+
+
+def test_classification_multimodal_and_text_branches_vs_golden(tmp_path):
+    from xfm_amd.model_classification import XFMForClassification
+    z, meta = load("classification_mm")
+    spec = meta["spec"]
+    vis = {k[len("vision_encoder."):]: v for k, v in state_from_spec(spec).items() if k.startswith("vision_encoder.")}
+    ckpt = os.path.join(tmp_path, "beit.pth")
+    torch.save({"module": vis}, ckpt)
+    vcfg = os.path.join(tmp_path, "config_beit2_base.json")
+    with open(vcfg, "w") as f:
+        json.dump({"ckpt": ckpt, "vision_width": 768, "patch_size": 16}, f)
+    m = XFMForClassification(_cls_cfg(meta, vision_config=vcfg, task_name="ve", num_labels=3))
+    ours = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+    assert ours == spec
+    _load_into(m, spec)
+    m.cuda().finalize().eval()
+    b = {k: v.cuda() for k, v in syn.pretrain_batch(meta["B"], seed=55).items()}
+    t = torch.tensor(meta["targets"]).cuda()
+    loss = m(b["image"], b["text_ids"], b["text_atts"], t, train=True)
+    ref = float(z["loss_mm"])
+    assert abs(float(loss) - ref) <= 5e-3 * abs(ref), (float(loss), ref)  # 3-way CE over 4 rows fed by bf16 towers
+    loss.backward()
+    _check_grads(z, "grad_mm", m, min_rms=1e-6, tol=1.5e-1, cos_tol=0.985)
+    m._arena.zero_grad()
+    loss = m(None, b["text_ids"], b["text_atts"], t, train=True)
+    ref = float(z["loss_text"])
+    assert abs(float(loss) - ref) <= 5e-3 * abs(ref), (float(loss), ref)
+    loss.backward()
+    _check_grads(z, "grad_text", m, min_rms=1e-6)
 
 
 def _pretrain_cfg(meta):

@@ -183,6 +183,34 @@ def test_retrieval_model():
     _check_grads(z, "grad", P)
 
 
+def test_classification_models():
+    z, meta = load("classification_imagenet")
+    P = _params(meta["spec"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    b = syn.pretrain_batch(meta["B"], seed=55)
+    pred = O.classification_forward(P, cfg, b["image"], None, None, deep_head=True)
+    check(z, "pred_imagenet", pred, 1e-4, RTOL)
+    loss = torch.nn.functional.cross_entropy(pred, torch.tensor(meta["targets"]))
+    assert abs(float(loss) - float(z["loss_imagenet"])) < 2e-4
+    loss.backward()
+    _check_grads(z, "grad_imagenet", P)
+    unused = set(meta["unused"])
+    assert all(P[k].grad is None or float(P[k].grad.abs().max()) == 0.0 for k in unused if k in P and P[k].dtype.is_floating_point)
+    z, meta = load("classification_mm")
+    P = _params(meta["spec"])
+    t = torch.tensor(meta["targets"])
+    loss = torch.nn.functional.cross_entropy(O.classification_forward(P, cfg, b["image"], b["text_ids"], b["text_atts"], False), t)
+    assert abs(float(loss) - float(z["loss_mm"])) < 2e-4
+    loss.backward()
+    _check_grads(z, "grad_mm", P)
+    for v in P.values():
+        v.grad = None
+    loss = torch.nn.functional.cross_entropy(O.classification_forward(P, cfg, None, b["text_ids"], b["text_atts"], False), t)
+    assert abs(float(loss) - float(z["loss_text"])) < 2e-4
+    loss.backward()
+    _check_grads(z, "grad_text", P)
+
+
 def _pretrain(name):
     z, meta = load(name)
     B = meta["B"]

@@ -364,6 +364,66 @@ def gen_checkpoint():
                                     "unexpected": sorted(msg.unexpected_keys), "sums": sums})
 
 
+def _beit_ckpt_config(depth_spec_model):
+    """A synthetic BEiT-v2 checkpoint + vision_config json for models that are built with load_vision_params=True."""
+    import tempfile
+    d = tempfile.mkdtemp()
+    sd = syn.formula_state_dict(depth_spec_model.state_dict())
+    sd["head.weight"], sd["head.bias"] = torch.zeros(1000, 768), torch.zeros(1000)  # dropped by load_pretrained_beit2
+    torch.save({"model": sd}, os.path.join(d, "beit.pth"))
+    with open(os.path.join(d, "config_beit2_base.json"), "w") as f:
+        json.dump({"ckpt": os.path.join(d, "beit.pth"), "vision_width": 768, "patch_size": 16}, f)
+    return os.path.join(d, "config_beit2_base.json")
+
+
+def gen_classification(B=4):
+    """models/model_classification.py XFMForClassification, ImageNet branch (BASELINE configs[1]: ViT-only path): vision tower loaded
+    through load_pretrained_beit2 from a synthetic checkpoint, cls + mean-patch features, deep MLP head, CE; and the multimodal
+    branch (fusion tower, plain head) on the same weights."""
+    from models.beit2 import beit_base_patch16
+    from models.model_classification import XFMForClassification
+    ref_shim.init_single_process_group()
+    torch.manual_seed(0)
+    probe = beit_base_patch16(img_size=224, drop_rate=0.0, drop_path_rate=0.1, attn_drop_rate=0.0, use_mean_pooling=True,
+                              init_scale=0.001, use_rel_pos_bias=True, use_abs_pos_emb=False, init_values=0.1, qkv_bias=True,
+                              local_attn_depth=-1)
+    vcfg = _beit_ckpt_config(probe)
+    cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2, overrides={"vision_config": vcfg, "task_name": "imagenet",
+                                                                             "num_labels": 1000})
+    m = XFMForClassification(cfg)
+    load_formula(m)
+    m.eval()
+    b = syn.pretrain_batch(B, seed=55)
+    targets = torch.tensor([3, 999, 0, 512][:B])
+    out = {}
+    loss = m(b["image"], None, None, targets, train=True)
+    out["loss_imagenet"] = np.asarray(float(loss.detach()))
+    pack("pred_imagenet", m(b["image"], None, None, targets, train=False), out)
+    loss.backward()
+    grads_of(m, out, "grad_imagenet")
+    unused = [n for n, p in m.named_parameters() if p.grad is None]
+    save("classification_imagenet", out, {"spec": spec_of(m), "B": B, "targets": targets.tolist(), "unused": unused,
+                                          "text_layers": 2, "fusion_layers": 2})
+    # multimodal branch (e.g. NLVR / VE style heads): plain 2-layer head on the fused [CLS]
+    cfg2 = ref_shim.pretrain_config(text_layers=2, fusion_layers=2, overrides={"vision_config": vcfg, "task_name": "ve", "num_labels": 3})
+    m2 = XFMForClassification(cfg2)
+    load_formula(m2)
+    m2.eval()
+    t2 = torch.tensor([2, 0, 1, 1][:B])
+    out2 = {}
+    loss2 = m2(b["image"], b["text_ids"], b["text_atts"], t2, train=True)
+    out2["loss_mm"] = np.asarray(float(loss2.detach()))
+    loss2.backward()
+    grads_of(m2, out2, "grad_mm")
+    # text-only branch on the same model
+    m2.zero_grad()
+    loss3 = m2(None, b["text_ids"], b["text_atts"], t2, train=True)
+    out2["loss_text"] = np.asarray(float(loss3.detach()))
+    loss3.backward()
+    grads_of(m2, out2, "grad_text")
+    save("classification_mm", out2, {"spec": spec_of(m2), "B": B, "targets": t2.tolist(), "text_layers": 2, "fusion_layers": 2})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -372,7 +432,7 @@ def main():
     torch.set_num_threads(8)
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint()}
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification()}
     if a.full:
         jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
     for k, fn in jobs.items():

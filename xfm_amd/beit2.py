@@ -369,6 +369,38 @@ class VisionTransformer(nn.Module):
         return (out, ids_mask) if do_mask else out
 
 
+def load_pretrained_beit2(model, ckpt_rpath):
+    """beit2.py:572-660 at equal resolution: unwrap `model` / `module`, drop the classification head and the
+    `relative_position_index` buffers, expand a shared relative-position table to every block, load with strict=False.
+    A table of another grid size would need the reference's `scipy.interpolate.interp2d` call (:640-655), which SciPy >= 1.14
+    removed -- refused, not approximated."""
+    checkpoint = torch.load(ckpt_rpath, map_location='cpu')
+    checkpoint_model = None
+    for model_key in ('model', 'module'):
+        if model_key in checkpoint:
+            checkpoint_model = checkpoint[model_key]
+            break
+    if checkpoint_model is None:
+        checkpoint_model = checkpoint
+    for k in ('head.weight', 'head.bias'):
+        checkpoint_model.pop(k, None)
+    if "rel_pos_bias.relative_position_bias_table" in checkpoint_model:
+        shared = checkpoint_model.pop("rel_pos_bias.relative_position_bias_table")
+        for i in range(len(model.blocks)):
+            checkpoint_model["blocks.%d.attn.relative_position_bias_table" % i] = shared.clone()
+    own = model.state_dict()
+    for key in list(checkpoint_model.keys()):
+        if "relative_position_index" in key:
+            checkpoint_model.pop(key)
+        elif "relative_position_bias_table" in key and key in own and own[key].shape != checkpoint_model[key].shape:
+            raise NotImplementedError(f"{key}: {tuple(checkpoint_model[key].shape)} -> {tuple(own[key].shape)} needs the reference's "
+                                      "interp2d-based interpolation (beit2.py:626-655), unavailable with SciPy >= 1.14")
+    msg = model.load_state_dict(checkpoint_model, strict=False)
+    if getattr(model, "_arena", None) is not None:
+        model._arena.bump()
+    return msg
+
+
 def beit_base_patch16(img_size, depth=12, **kwargs):
     return VisionTransformer(img_size=img_size, patch_size=16, embed_dim=768, depth=depth, num_heads=12, mlp_ratio=4,
                              layer_norm_eps=1e-6, **kwargs)

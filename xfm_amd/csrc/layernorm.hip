@@ -105,8 +105,59 @@ static int ln_grid(int rows) {
   return blocks;
 }
 
+// Wide rows (D a multiple of 1024 up to 8192, PLAIN mode): the 3072 / 6144-wide LayerNorms of the classification head
+// (model_classification.py:33-48).  One 256-thread workgroup per row, the row stays in registers (<= 8 x 4 values per thread),
+// block reductions through LDS.  Few rows (one per sample), so no attempt at the multi-row tiling of the main kernels.
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void ln_wide_fwd_kernel(LnFwd p, int D) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, nv = D / 1024;
+  const long base = (long)row * D;
+  float v[8][4];
+  float s = 0.f;
+  for (int i = 0; i < nv; ++i) {
+    const int e = (i * 256 + threadIdx.x) * 4;
+    if (p.x32 != nullptr) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p.x32 + base + e);
+      for (int j = 0; j < 4; ++j) v[i][j] = a[j];
+    } else {
+      const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.x16 + base + e);
+      for (int j = 0; j < 4; ++j) v[i][j] = bf2f(a[j]);
+    }
+    for (int j = 0; j < 4; ++j) s += v[i][j];
+  }
+  const float mu = block_sum256(s, red) / D;
+  float q = 0.f;
+  for (int i = 0; i < nv; ++i)
+    for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mu; q += d * d; }
+  const float rstd = rsqrtf(block_sum256(q, red) / D + p.eps);
+  if (threadIdx.x == 0) { p.mean[row] = mu; p.rstd[row] = rstd; }
+  for (int i = 0; i < nv; ++i) {
+    const int e = (i * 256 + threadIdx.x) * 4;
+    const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + e), b = *reinterpret_cast<const f32x4*>(p.b + e);
+    bf16x4 o;
+    f32x4 o32;
+    for (int j = 0; j < 4; ++j) { o32[j] = (v[i][j] - mu) * rstd * w[j] + b[j]; o[j] = f2bf(o32[j]); }
+    if (p.y != nullptr) *reinterpret_cast<bf16x4*>(p.y + base + e) = o;
+    if (p.y32 != nullptr) *reinterpret_cast<f32x4*>(p.y32 + base + e) = o32;
+  }
+}
+
+static bool ln_wide(int D, int mode) { return mode == LN_PLAIN && D > 1536 && D % 1024 == 0 && D <= 8192; }
+
 int xfm_ln_fwd_impl(const LnFwd& p, int D, int mode, hipStream_t st) {
   XFM_REQUIRE(p.rows > 0, "ln_fwd: no rows");
+  if (ln_wide(D, mode)) {
+    hipLaunchKernelGGL(ln_wide_fwd_kernel, dim3(p.rows), dim3(256), 0, st, p, D);
+    return xfm_check_launch("ln_fwd_wide");
+  }
   XFM_REQUIRE(D == 768 || D == 1536 || D == 1024 || D == 256 || D == 512, "ln_fwd: unsupported width %d", D);
   const int grid = ln_grid(p.rows);
 #define LN_CASE(NCH, MD) hipLaunchKernelGGL((ln_fwd_kernel<NCH, MD>), dim3(grid), dim3(256), 0, st, p); break;
@@ -322,9 +373,73 @@ int xfm_ln_bwd_grid(int rows) {
   return blocks;
 }
 
+// backward of the wide-row form: dx = rstd (dy w - mean(dy w) - xhat mean(dy w xhat)); dgamma / dbeta by fp32 atomics per column
+// (rows are few: one per sample of a classification batch)
+__global__ __launch_bounds__(256) void ln_wide_bwd_kernel(LnBwd p, int D, float* dgamma, float* dbeta) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, nv = D / 1024;
+  const long base = (long)row * D;
+  const float mu = p.mean[row], rstd = p.rstd[row];
+  float dy[8][4], xh[8][4];
+  float c1 = 0.f, c2 = 0.f;
+  for (int i = 0; i < nv; ++i) {
+    const int e = (i * 256 + threadIdx.x) * 4;
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.dy1 + base + e);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + e);
+    for (int j = 0; j < 4; ++j) dy[i][j] = bf2f(a[j]);
+    if (p.dy2 != nullptr) {
+      const bf16x4 b2 = *reinterpret_cast<const bf16x4*>(p.dy2 + base + e);
+      for (int j = 0; j < 4; ++j) dy[i][j] += bf2f(b2[j]);
+    }
+    if (p.dy32 != nullptr) {
+      const f32x4 b3 = *reinterpret_cast<const f32x4*>(p.dy32 + base + e);
+      for (int j = 0; j < 4; ++j) dy[i][j] += b3[j];
+    }
+    if (p.x32 != nullptr) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(p.x32 + base + e);
+      for (int j = 0; j < 4; ++j) xh[i][j] = (x[j] - mu) * rstd;
+    } else {
+      const bf16x4 x = *reinterpret_cast<const bf16x4*>(p.x16 + base + e);
+      for (int j = 0; j < 4; ++j) xh[i][j] = (bf2f(x[j]) - mu) * rstd;
+    }
+    for (int j = 0; j < 4; ++j) {
+      const float gw = dy[i][j] * w[j];
+      c1 += gw;
+      c2 += gw * xh[i][j];
+      if (dgamma != nullptr) atomicAdd(dgamma + e + j, dy[i][j] * xh[i][j]);
+      if (dbeta != nullptr) atomicAdd(dbeta + e + j, dy[i][j]);
+    }
+  }
+  c1 = block_sum256(c1, red) / D;
+  c2 = block_sum256(c2, red) / D;
+  for (int i = 0; i < nv; ++i) {
+    const int e = (i * 256 + threadIdx.x) * 4;
+    const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + e);
+    f32x4 dz;
+    for (int j = 0; j < 4; ++j) dz[j] = rstd * (dy[i][j] * w[j] - c1 - xh[i][j] * c2);
+    if (p.dx32 != nullptr) {
+      f32x4 o = dz;
+      if (p.dx_accum) {
+        const f32x4 old = *reinterpret_cast<const f32x4*>(p.dx32 + base + e);
+        for (int j = 0; j < 4; ++j) o[j] += old[j];
+      }
+      *reinterpret_cast<f32x4*>(p.dx32 + base + e) = o;
+    }
+    if (p.dx16 != nullptr) {
+      bf16x4 o;
+      for (int j = 0; j < 4; ++j) o[j] = f2bf(dz[j]);
+      *reinterpret_cast<bf16x4*>(p.dx16 + base + e) = o;
+    }
+  }
+}
+
 int xfm_ln_bwd_impl(LnBwd p, int D, int mode, float* dgamma, float* dbeta, float* dbias, float* dls, float* workspace,
                     long workspace_bytes, hipStream_t st) {
   XFM_REQUIRE(p.rows > 0, "ln_bwd: no rows");
+  if (ln_wide(D, mode)) {
+    hipLaunchKernelGGL(ln_wide_bwd_kernel, dim3(p.rows), dim3(256), 0, st, p, D, dgamma, dbeta);
+    return xfm_check_launch("ln_bwd_wide");
+  }
   XFM_REQUIRE(D == 768 || D == 1536 || D == 1024 || D == 256 || D == 512, "ln_bwd: unsupported width %d", D);
   const int grid = xfm_ln_bwd_grid(p.rows);
   const int nset = mode == LN_PLAIN ? 2 : (mode == LN_POST ? 3 : 4);

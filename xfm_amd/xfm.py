@@ -70,6 +70,32 @@ def build_mlp(input_dim, output_dim):
     return _Mlp(input_dim, output_dim)
 
 
+class _DeepMlp(nn.Module):
+    """XFMForClassification.build_mlp (model_classification.py:33-48): four Linear-LayerNorm-GELU stages (widths 2x, 4x, 2x, 1x the
+    input) and a final Linear, with the reference's nn.Sequential key names 0,1 / 3,4 / 6,7 / 9,10 / 12."""
+
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        widths = [input_dim, input_dim * 2, input_dim * 4, input_dim * 2, input_dim]
+        for j in range(4):
+            setattr(self, str(3 * j), _Lin(widths[j], widths[j + 1], 0.02))
+            setattr(self, str(3 * j + 1), _Affine(widths[j + 1], 1e-5))
+        setattr(self, "12", _Lin(input_dim, output_dim, 0.02))
+
+    def linear_slots(self, prefix):
+        self._slots = []
+        for name in ("0", "3", "6", "9", "12"):
+            lin = getattr(self, name)
+            self._slots.append(LinearSlot(prefix + name, [lin.weight], [lin.bias]))
+        return list(self._slots)
+
+    def forward(self, x):
+        for j in range(4):
+            h = layer_norm(linear_slot(x, self._slots[j]), getattr(self, str(3 * j + 1)))
+            x = F.gelu(h.float()).to(BF16)
+        return linear_slot(x, self._slots[4], out_fp32=True)
+
+
 def _read_json(path, default):
     if path and os.path.exists(path):
         with open(path) as f:
@@ -81,8 +107,6 @@ def build_vision_encoder(config, load_params=False):
     """xfm.py:124-255, BEiT-v2 branch (the only one a shipped config selects)."""
     if not config.get('use_beit_v2', False):
         raise ValueError("only use_beit_v2 vision encoders are implemented (xfm.py:206-234)")
-    if load_params:
-        raise NotImplementedError("checkpoint loading (beit2.py:572-849) is outside the hot-path scope; load a state_dict instead")
     vision_config = _read_json(config.get('vision_config'), {"vision_width": 768, "patch_size": 16})
     assert config['patch_size'] == vision_config['patch_size']
     enc = beit_base_patch16(img_size=config['image_res'], drop_rate=0.0, drop_path_rate=0.1, attn_drop_rate=0.0,
@@ -90,6 +114,9 @@ def build_vision_encoder(config, load_params=False):
                             init_values=0.1, qkv_bias=True, local_attn_depth=config.get('local_attn_depth', -1),
                             num_masking_patches=config.get('num_masking_patches', 75),
                             min_num_patches=config.get('min_num_patches', 16), depth=config.get('vision_depth', 12))
+    if load_params:  # xfm.py:230-232
+        from .beit2 import load_pretrained_beit2
+        load_pretrained_beit2(enc, vision_config['ckpt'])
     return enc, vision_config['vision_width']
 
 
@@ -234,6 +261,8 @@ class XFMBase(nn.Module):
             slots += self.itm_head.linear_slots("itm_head.")
         if hasattr(self, "bbox_head"):
             slots += self.bbox_head.linear_slots("bbox_head.")
+        if hasattr(self, "cls_head"):  # task models (model_classification.py)
+            slots += self.cls_head.linear_slots("cls_head.")
         self._arena = ParamArena(self, slots, device)
         self.vision_encoder.attach(self._arena)
         self.text_encoder.attach(self._arena)
