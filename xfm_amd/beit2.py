@@ -287,7 +287,7 @@ class VisionTransformer(nn.Module):
         self.mask_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.pos_embed = None
         self.generator = BlockMaskGenerator(img_size // patch_size, num_masking_patches, min_num_patches)
-        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth, device="cpu")]
         self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, init_values, self.patch_embed.patch_shape,
                                            dpr[i], layer_norm_eps) for i in range(depth)])
         self.fc_norm = _Affine(embed_dim, layer_norm_eps)

@@ -72,7 +72,7 @@ class VisionTransformer(nn.Module):
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.num_pos_embed = self.num_patch_embed + 1
         self.pos_embed = nn.Parameter(torch.zeros(1, self.num_pos_embed, embed_dim))
-        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth, device="cpu")]
         self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qk_scale, dpr[i], layer_norm_eps) for i in range(depth)])
         self.norm = _Affine(embed_dim, layer_norm_eps)
         nn.init.trunc_normal_(self.pos_embed, std=.02)
