@@ -154,6 +154,42 @@ class GemmTimer:
         return n, ms, fl, by
 
 
+FUSION_PASS_GFLOP = 35.32    # fusion encoder fwd+bwd per (image, text) sample-pass as the reference executes it
+
+
+def fusion_probe(model, B, iters=5):
+    """The north-star's named sub-target: the fusion encoder's forward + backward alone, on the step's 4B-row shape (B positives,
+    2B ITM negatives, B MLM rows; every row cross-attends one of the B images).  HIP events on the launch stream, outside the timed
+    region; gradients land in the arena and are zeroed afterwards."""
+    dev = next(model.parameters()).device
+    g = torch.Generator(device="cpu").manual_seed(7)
+    text = (torch.randn(4 * B, 30, 768, generator=g) * 0.7).to(dev, torch.bfloat16).requires_grad_(True)
+    img = (torch.randn(B, 197, 768, generator=g) * 0.7).to(dev, torch.bfloat16).requires_grad_(True)
+    atts = torch.ones(4 * B, 30, dtype=torch.long, device=dev)
+    iatts = torch.ones(B, 197, dtype=torch.long, device=dev)
+    ar = torch.arange(B, device=dev)
+    index = torch.cat([ar, torch.randperm(B, generator=g).to(dev), ar, ar]).to(torch.int32)
+
+    def once():
+        seq = model.fusion_encoder.bert(encoder_embeds=text, attention_mask=atts, encoder_hidden_states=img, encoder_attention_mask=iatts,
+                                        return_dict=True, encoder_batch_index=index).last_hidden_state
+        seq.float().square().mean().backward()
+
+    once()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        once()
+    e.record()
+    torch.cuda.synchronize()
+    model.zero_grad()
+    ms = s.elapsed_time(e) / iters
+    tf = 4 * B * FUSION_PASS_GFLOP / ms
+    return {"ms": round(ms, 3), "achieved": round(tf, 1), "unit": "TFLOP/s", "frac_of_mfma_peak": round(tf / BF16_DENSE_PEAK_TFLOPS, 4),
+            "flop_accounting": f"4B = {4 * B} sample-passes x {FUSION_PASS_GFLOP} GFLOP (reference arithmetic, incl. the per-row K/V projections "
+                               "of the image tokens that this build performs once per image)"}
+
+
 def cpu_baseline(model, batch_size):
     """The CPU oracle on the same architecture, same synthetic batch generator; bounded sample."""
     from oracle import xfm_oracle as O
@@ -297,6 +333,7 @@ def main():
                          "family_gemm_nt": {"achieved": round(achieved, 2), "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4),
                                             "calls": nlaunch, "kernel_ms_per_step": round(gemm_ms, 3), "flop_per_step": gemm_flop}},
         }
+        out["fusion_encoder_fwd_bwd"] = fusion_probe(model, B)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_batch)
         print(json.dumps(out), flush=True)
