@@ -9,6 +9,7 @@ dropout+residual+LayerNorm, (cross-attention with a fused K/V GEMM over the imag
 """
 import json
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -171,6 +172,42 @@ class RobertaEncoder(nn.Module):
         self.layer = nn.ModuleList([RobertaLayer(config, i) for i in range(config.num_hidden_layers)])
 
 
+class _WgradStream:
+    """Weight-gradient GEMMs of a tower's backward on a second HIP stream.  dW only feeds the optimizer / all-reduce, so the
+    dY^T X products need not sit on the activation-gradient critical path: at the fusion / text towers' sizes (M = 7680 / 1920 rows)
+    neither the dgrad nor the wgrad kernels fill the 256 CUs on their own, and the two chains overlap.  Every launch waits for an
+    event recorded on the main stream after its dY was produced; the tensors it reads are kept alive until the main stream has
+    re-joined (the caching allocator reuses freed blocks in main-stream order only)."""
+    _streams = {}
+    enabled = os.environ.get("XFM_WGRAD_STREAM", "1") != "0"
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        self.on = _WgradStream.enabled
+        if self.on:
+            key = device.index if device.index is not None else torch.cuda.current_device()
+            if key not in _WgradStream._streams:
+                _WgradStream._streams[key] = torch.cuda.Stream(device=device)
+            self.side = _WgradStream._streams[key]
+            self.side.wait_stream(self.main)  # arena state (zeroed grads, earlier kernels) is visible to the side stream
+        self.keep = []
+
+    def gemm_tn(self, dy, x, dw, **kw):
+        if not self.on:
+            return Fx.gemm_tn(dy, x, dw, **kw)
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        self.keep.append((dy, x))
+        with torch.cuda.stream(self.side):
+            Fx.gemm_tn(dy, x, dw, **kw)
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+        self.keep.clear()
+
+
 class _EncoderFn(torch.autograd.Function):
     """Layers [lo, hi) of a RobertaEncoder.  x: bf16 [B*T, D]; enc: bf16 [B*N, D] or None."""
 
@@ -240,6 +277,7 @@ class _EncoderFn(torch.autograd.Function):
         D, H = cfg.hidden_size, cfg.num_attention_heads
         g = grad_view
         dy_a, dy_b = dy.contiguous(), None
+        wg = _WgradStream(dy.device)
         B_full = B
         if grad_batch is not None and grad_batch < B:
             # only the first `grad_batch` sequences carry gradient (the rest of the pass was a detached forward that shared the
@@ -267,16 +305,16 @@ class _EncoderFn(torch.autograd.Function):
             ln3 = layer.output.LayerNorm
             dh3, dres3 = Fx.ln_post_bwd(dy_a, r["z3"], r["m3"], r["r3"], ln3.weight, g(ln3.weight), g(ln3.bias), s["out"].db,
                                         dy2=dy_b, drop=r["d_h3"])
-            Fx.gemm_tn(dh3, r["hact"], s["out"].dw)
+            wg.gemm_tn(dh3, r["hact"], s["out"].dw)
             du = Fx.gemm_nt(dh3, s["out"].wt, epi=Fx.EPI_DGELU, aux=r["u"], n=s["out"].K)
             y2 = r["y2"] if r["cross"] else r["y1"]
-            Fx.gemm_tn(du, y2, s["i"].dw, dbias=s["i"].db)
+            wg.gemm_tn(du, y2, s["i"].dw, dbias=s["i"].db)
             d1a, d1b = Fx.gemm_nt(du, s["i"].wt, n=s["i"].K), dres3
             if r["cross"]:
                 ln2 = layer.crossattention.output.LayerNorm
                 dh2, dres2 = Fx.ln_post_bwd(d1a, r["z2"], r["m2"], r["r2"], ln2.weight, g(ln2.weight), g(ln2.bias), s["o2"].db,
                                             dy2=d1b, drop=r["d_h2"])
-                Fx.gemm_tn(dh2, r["c2"], s["o2"].dw)
+                wg.gemm_tn(dh2, r["c2"], s["o2"].dw)
                 dc2 = Fx.gemm_nt(dh2, s["o2"].wt, n=s["o2"].K)
                 kv = r["kv"]
                 dq2 = torch.empty_like(r["q2"])
@@ -294,21 +332,21 @@ class _EncoderFn(torch.autograd.Function):
                                 scale, key_keep=enc_keep, drop=r["d_att2"], kv_index=enc_index)
                     if enc_index is not None:  # fold onto the unique key/value sources
                         dkv = Fx.rows_index_sum(dkv, enc_index, enc.shape[0] // Nenc, Nenc)
-                Fx.gemm_tn(dq2, r["y1"], s["q2"].dw, dbias=s["q2"].db)
-                Fx.gemm_tn(dkv, enc, s["kv2"].dw, dbias=s["kv2"].db)
+                wg.gemm_tn(dq2, r["y1"], s["q2"].dw, dbias=s["q2"].db)
+                wg.gemm_tn(dkv, enc, s["kv2"].dw, dbias=s["kv2"].db)
                 if need_denc and not concat_k:
                     Fx.gemm_nt(dkv, s["kv2"].wt, epi=Fx.EPI_F32_ACC, out=denc32, n=s["kv2"].K)
                 d1a, d1b = Fx.gemm_nt(dq2, s["q2"].wt, n=s["q2"].K), dres2
             ln1 = layer.attention.output.LayerNorm
             dh1, dres1 = Fx.ln_post_bwd(d1a, r["z1"], r["m1"], r["r1"], ln1.weight, g(ln1.weight), g(ln1.bias), s["o"].db,
                                         dy2=d1b, drop=r["d_h1"])
-            Fx.gemm_tn(dh1, r["c1"], s["o"].dw)
+            wg.gemm_tn(dh1, r["c1"], s["o"].dw)
             dc1 = Fx.gemm_nt(dh1, s["o"].wt, n=s["o"].K)
             qkv = r["qkv"]
             dqkv = torch.empty_like(qkv)
             Fx.attn_bwd(dc1, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], r["c1"], r["lse1"], dqkv[:, :D], dqkv[:, D:2 * D],
                         dqkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep, causal=causal, drop=r["d_att"])
-            Fx.gemm_tn(dqkv, r["x"], s["qkv"].dw, dbias=s["qkv"].db)
+            wg.gemm_tn(dqkv, r["x"], s["qkv"].dw, dbias=s["qkv"].db)
             if li > lo or need_dx:
                 dy_a, dy_b = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K), dres1
             ctx.saved[li - lo] = None
@@ -321,6 +359,7 @@ class _EncoderFn(torch.autograd.Function):
             denc = Fx.gemm_nt(dkv_all, wt_cat)
         elif need_denc:
             denc = denc32.to(BF16)
+        wg.join()  # the weight gradients are complete in main-stream order before the tower's all-reduce / the optimizer
         if ctx.noted:
             arena_note_grad(model)
         return (dx, denc) + (None,) * 12
