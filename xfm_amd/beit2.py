@@ -201,6 +201,8 @@ class _TrunkFn(torch.autograd.Function):
         ld = vit._bias_ld
         dy = dy_out.reshape(M, D).contiguous()
         dstream = torch.zeros((M, D), dtype=torch.float32, device=dy.device)
+        from .xroberta import _WgradStream
+        wg = _WgradStream(dy.device)
         for i in reversed(range(len(blocks))):
             blk, s = blocks[i], vit._slots[i]
             (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t) = ctx.saved[i]
@@ -213,13 +215,13 @@ class _TrunkFn(torch.autograd.Function):
             dg2 = g(blk.gamma_2) if blk.gamma_2 is not None else None
             dh2 = Fx.ln_ls_bwd(dy, dstream, x2, meann, rstdn, nxt.weight, h2, g2, dp2, N, g(nxt.weight), g(nxt.bias),
                                s["fc2"].db, dg2)
-            Fx.gemm_tn(dh2, hact, s["fc2"].dw)
+            wg.gemm_tn(dh2, hact, s["fc2"].dw)
             du = Fx.gemm_nt(dh2, s["fc2"].wt, epi=Fx.EPI_DGELU, aux=u, n=s["fc2"].K)
-            Fx.gemm_tn(du, y2, s["fc1"].dw, dbias=s["fc1"].db)
+            wg.gemm_tn(du, y2, s["fc1"].dw, dbias=s["fc1"].db)
             dy2 = Fx.gemm_nt(du, s["fc1"].wt, n=s["fc1"].K)
             dh1 = Fx.ln_ls_bwd(dy2, dstream, x1, mean2, rstd2, blk.norm2.weight, h1, g1, dp1, N, g(blk.norm2.weight),
                                g(blk.norm2.bias), s["proj"].db, dg1)
-            Fx.gemm_tn(dh1, ctxv, s["proj"].dw)
+            wg.gemm_tn(dh1, ctxv, s["proj"].dw)
             dctx = Fx.gemm_nt(dh1, s["proj"].wt, n=s["proj"].K)
             dqkv = torch.empty_like(qkv)
             ddense = torch.zeros_like(dense) if dense is not None else None
@@ -227,12 +229,13 @@ class _TrunkFn(torch.autograd.Function):
                         dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense, bias_t=dense_t)
             if dense is not None:
                 Fx.relpos_scatter_sorted(ddense, vit._relpos_order, vit._relpos_start, H, N, ld, g(blk.attn.relative_position_bias_table))
-            Fx.gemm_tn(dqkv, y, s["qkv"].dw, dbias=s["qkv"].db)
+            wg.gemm_tn(dqkv, y, s["qkv"].dw, dbias=s["qkv"].db)
             dy = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K)
             ctx.saved[i] = None
         x0, mean0, rstd0 = ctx.first
         n0 = blocks[0].norm1
         Fx.ln_bwd(dy, x0, mean0, rstd0, n0.weight, _g(n0.weight), _g(n0.bias), dx32=dstream, dx_accum=True)
+        wg.join()
         if ctx.noted:
             arena_note_grad(vit)
         return dstream.view(B, N, D), None, None
