@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU (north-star: 64)")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward(+all-reduce) only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fusion-probe", action="store_true", help="skip the stand-alone fusion-encoder fwd+bwd measurement (profiling runs)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--eval-mode", action="store_true", help="disable dropout / drop-path (not the headline setting)")
     return ap.parse_args()
@@ -276,8 +277,13 @@ def main():
     loss_vals = {k: round(float(v.detach()), 4) for k, v in losses.items() if k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim")}
 
     # one instrumented step (outside the timed region): HIP events around every gemm_nt launch on the launch stream
+    # (weight-gradient GEMMs normally run on a second stream; for this step they stay on the launch stream so that an event pair
+    # brackets exactly one kernel's execution instead of a stretch of two overlapping chains)
+    from xfm_amd.xroberta import _WgradStream
+    _WgradStream.enabled = False
     with GemmTimer() as gt:
         step()
+    _WgradStream.enabled = os.environ.get("XFM_WGRAD_STREAM", "1") != "0"
     nlaunch, gemm_ms, gemm_flop = gt.summary()
     dom_n, dom_ms, dom_fl, dom_bytes = gt.dominant()
     dom_tf = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -333,7 +339,8 @@ def main():
                          "family_gemm_nt": {"achieved": round(achieved, 2), "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4),
                                             "calls": nlaunch, "kernel_ms_per_step": round(gemm_ms, 3), "flop_per_step": gemm_flop}},
         }
-        out["fusion_encoder_fwd_bwd"] = fusion_probe(model, B)
+        if not args.no_fusion_probe:
+            out["fusion_encoder_fwd_bwd"] = fusion_probe(model, B)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_batch)
         print(json.dumps(out), flush=True)
