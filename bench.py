@@ -339,9 +339,10 @@ def main():
                          "family_gemm_nt": {"achieved": round(achieved, 2), "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4),
                                             "calls": nlaunch, "kernel_ms_per_step": round(gemm_ms, 3), "flop_per_step": gemm_flop}},
         }
-        if not args.no_fusion_probe:
+        if not args.no_fusion_probe and world == 1:  # single-rank only: its backward would launch unmatched gradient collectives
             out["fusion_encoder_fwd_bwd"] = fusion_probe(model, B)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
+
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_batch)
         print(json.dumps(out), flush=True)
     if world > 1:
