@@ -10,15 +10,11 @@ model = bench.build_model(device)
 model.finalize()
 model.train(True)
 bench.fusion_probe(model, 64, iters=1)
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     bench.fusion_probe(model, 64, iters=1)
     torch.cuda.synchronize()
-rows = prof.key_averages(group_by_stack_n=12)
-sel = [r for r in rows if r.key in ("aten::copy_", "aten::fill_", "aten::cat", "aten::add", "aten::mul", "aten::_to_copy")]
-sel.sort(key=lambda r: -r.count)
-for r in sel[:25]:
-    print(r.key, r.count, f"{r.device_time_total:.0f}us")
-    for fr in r.stack[:12]:
-        if "xfm_amd" in fr or "bench.py" in fr:
-            print("     ", fr[-110:])
-            break
+rows = prof.key_averages(group_by_input_shape=True)
+sel = [r for r in rows if r.key in ("aten::copy_", "aten::fill_", "aten::cat", "aten::add", "aten::mul", "aten::_to_copy", "aten::zeros", "aten::add_")]
+sel.sort(key=lambda r: -r.device_time_total)
+for r in sel[:30]:
+    print(f"{r.key:16s} calls {r.count:4d}  device {r.device_time_total:8.0f} us  shapes {r.input_shapes}")

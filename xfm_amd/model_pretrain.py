@@ -1,7 +1,37 @@
 """Pre-training model: which losses run and how they are weighted (mirrors models/model_pretrain.py:13-116)."""
+import os
+
 import torch
 
 from .xfm import XFMBase
+
+_TEXT_STREAM_ON = os.environ.get("XFM_TEXT_STREAM", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+
+class _JoinAfterBackward(torch.autograd.Function):
+    """Identity on the forward; in the backward it queues an end-of-backward callback that makes `main` wait for `side`.  The text
+    tower's backward runs on the side stream (autograd replays nodes on their forward stream) and writes its weight gradients
+    straight into the arena -- no AccumulateGrad node, so the engine's own end-of-backward stream sync does not cover it."""
+
+    @staticmethod
+    def forward(ctx, x, main, side):
+        ctx.main, ctx.side = main, side
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        main, side = ctx.main, ctx.side
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
+        return g, None, None
 
 
 class XFM(XFMBase):
@@ -31,6 +61,20 @@ class XFM(XFMBase):
         zero = torch.zeros((), device=image.device)
         do_mim = ret_mim_loss and (data_source == 'imagenet' or self.use_mm_mim_loss)
         image_embeds_masked = None
+        # The text tower (small, latency-bound kernels) is independent of the vision tower until the ITC loss: with batch_passes
+        # its forward is enqueued on a second HIP stream first and runs under the ViT's full-chip GEMMs; autograd replays each
+        # node's backward on the stream of its forward, so the two backward chains overlap the same way.
+        text_stream = None
+        mlm_embeds = text_embeds = None
+        if data_source != 'imagenet' and self.batch_passes and image.is_cuda and _TEXT_STREAM_ON:
+            main = torch.cuda.current_stream(image.device)
+            text_stream = _side_stream(image.device)
+            text_stream.wait_stream(main)
+            with torch.cuda.stream(text_stream):
+                if ret_match_loss and ret_mlm_loss and self.detach_text_forMLM and text_ids_masked is not None:
+                    text_embeds, mlm_embeds = self.get_text_embeds_with_masked(text_ids, text_atts, text_ids_masked)
+                else:
+                    text_embeds = self.get_text_embeds(text_ids, text_atts)
         if self.batch_passes and do_mim and self.do_image_mask:
             B = image.shape[0]
             if ids_mask is None:
@@ -42,9 +86,15 @@ class XFM(XFMBase):
             image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
         else:
             image_embeds, image_atts = self.get_vision_embeds(image)
-        mlm_embeds = None
         if data_source != 'imagenet':
-            if self.batch_passes and ret_match_loss and ret_mlm_loss and self.detach_text_forMLM and text_ids_masked is not None:
+            if text_stream is not None:  # re-join: the text features are consumed on the main stream from here on
+                main.wait_stream(text_stream)
+                for t in (text_embeds, mlm_embeds):
+                    if t is not None:
+                        t.record_stream(main)
+                if text_embeds.requires_grad:
+                    text_embeds = _JoinAfterBackward.apply(text_embeds, main, text_stream)
+            elif self.batch_passes and ret_match_loss and ret_mlm_loss and self.detach_text_forMLM and text_ids_masked is not None:
                 text_embeds, mlm_embeds = self.get_text_embeds_with_masked(text_ids, text_atts, text_ids_masked)
             else:
                 text_embeds = self.get_text_embeds(text_ids, text_atts)
