@@ -617,7 +617,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
 // registers and written once per SOURCE (no per-row copies, no fold pass).  group g = rows grp_rows[grp_start[g] ..
 // grp_start[g+1]) and reads source g.  Sq <= 64, Sk <= 256, no additive bias, no causal mask.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void xattn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(AttnArgs a) {
   }
 }
 
-__global__ __launch_bounds__(512) void xattn_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(512) void xattn_dq_kernel(AttnArgs a) {
 
 // dK/dV of one (source, head): wave w owns 16 keys; the group's rows go through LDS four at a time (one 64-slot query chunk
 // per row, Sq <= 64), gradients accumulate in registers across ALL rows and are written once, at the source's rows.
-__global__ __launch_bounds__(512) void xattn_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512, 4) void xattn_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
