@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from xfm_amd import functional as Fx
 
-B, H, N, D = 128, 12, 197, 768
+B, H, N, D = int(os.environ.get("B", 128)), 12, 197, 768
+torch.manual_seed(0)
 qkv = torch.randn(B * N, 3 * D, device="cuda").bfloat16()
 bias = torch.randn(H, N, 208, device="cuda")
 dout = torch.randn(B * N, D, device="cuda").bfloat16()
@@ -30,3 +31,4 @@ for it in range(iters):
 e.record()
 torch.cuda.synchronize()
 print("bwd (dq + dkv) us", s.elapsed_time(e) / iters * 1e3)
+print("checksum", float(o.float().abs().sum()), float(dqkv.float().abs().sum()), float(dbias.abs().sum()))

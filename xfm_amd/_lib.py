@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxfm_hip.so")
+# XFM_HIP_LIB: A/B a differently built library (kernel experiments); the default is the in-tree build.
+LIB_PATH = os.environ.get("XFM_HIP_LIB") or os.path.join(_HERE, "libxfm_hip.so")
 ABI_VERSION = 1
 
 c_void_p, c_int, c_long, c_float, c_u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint32

@@ -139,6 +139,16 @@ __device__ __forceinline__ uint32_t drop_key(const AttnArgs& a, int b, int h, in
 }
 __device__ __forceinline__ bool drop_keep(const AttnArgs& a, uint32_t key, int kj) { return rng_keep(rng_u32(key, (uint32_t)kj), a.drop_thresh); }
 
+// additive bias row segment of chunk kc for this lane's query row: keys kc*64 + t*16 + 4*lg .. +3, t = 0..3 (zeros past Sk)
+__device__ __forceinline__ void load_bias(const AttnArgs& a, int h, int qc, int kc, int lg, f32x4 (&bv)[4]) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int kj0 = kc * 64 + t * 16 + 4 * lg;
+    bv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr && kj0 < a.Sk) bv[t] = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: grid (q blocks, H, B); block = NW waves, wave w owns query rows [qblk*16*NW + 16*w, +16)
 // ---------------------------------------------------------------------------------------------
@@ -188,12 +198,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnArgs a) {
     const bool has_mask = !PLAIN && a.key_keep != nullptr;
     const bool causal = !PLAIN && a.causal != 0;
     const bool plain = !has_mask && !causal && kc * 64 + 64 <= a.Sk;  // wave-uniform: nothing to mask in this chunk
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {  // bias (and key-keep) loads first: their L2 latency hides under the QK^T MFMAs
-      const int kj0 = kc * 64 + t * 16 + 4 * lg;
-      bvs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a.bias != nullptr && kj0 < a.Sk) bvs[t] = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
-    }
+    load_bias(a, h, qc, kc, lg, bvs);  // bias (and key-keep) loads first: their L2 latency hides under the QK^T MFMAs
     if constexpr (!PLAIN) {
       if (has_mask) load_keep(a, kvb, kc, lg, kk);
     }
@@ -336,12 +341,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
       const bool has_mask = !PLAIN && a.key_keep != nullptr;
       const bool causal = !PLAIN && a.causal != 0;
       const bool plain = !has_mask && !causal && kc * 64 + 64 <= a.Sk;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int kj0 = kc * 64 + t * 16 + 4 * lg;
-        bvs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.bias != nullptr && kj0 < a.Sk) bvs[t] = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * a.Sq + qc) * a.bias_ld + kj0);
-      }
+      load_bias(a, h, qc, kc, lg, bvs);
       if constexpr (!PLAIN) {
         if (has_mask) load_keep(a, kvb, kc, lg, kk);
       }
@@ -505,6 +505,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int nchunks = (a.Sq + 63) / 64;
   constexpr bool resident = RES;
   const int nw = nthreads >> 6;
+  // row statistics / transposed bias of this lane's 4 consecutive queries in 32-query step `step`: 16-B loads
+  auto load_stats = [&](int step, f32x4 (&l)[2], f32x4 (&d)[2], f32x4 (&bt)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int qi0 = step * 32 + u * 16 + 4 * lg;
+      l[u] = d[u] = bt[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (qi0 < a.Sq) {
+        l[u] = *reinterpret_cast<const f32x4*>(lse_b + qi0);
+        d[u] = *reinterpret_cast<const f32x4*>(del_b + qi0);
+        if (a.bias_t != nullptr && kvalid) bt[u] = *reinterpret_cast<const f32x4*>(a.bias_t + ((long)h * a.Sk + kj) * a.bias_t_ld + qi0);
+      }
+    }
+  };
   if (resident) {
     for (int qc = 0; qc < nchunks; ++qc) stage_slot(lds + qc * ATTN_SLOT, qb, a.q_rs, db, a.do_rs, qc * 64, a.Sq, w, nw, lane);
     stage_wait();
@@ -524,16 +537,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       f32x4 st[2], dp[2], pd[2], lsev[2], delv[2], bvt[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {  // row statistics / bias of this lane's 4 consecutive queries: 16-B loads, issued early
-        const int qi0 = qc * 64 + (2 * s2 + u) * 16 + 4 * lg;
-        lsev[u] = delv[u] = bvt[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (qi0 < a.Sq) {
-          lsev[u] = *reinterpret_cast<const f32x4*>(lse_b + qi0);
-          delv[u] = *reinterpret_cast<const f32x4*>(del_b + qi0);
-          if (a.bias_t != nullptr && kvalid) bvt[u] = *reinterpret_cast<const f32x4*>(a.bias_t + ((long)h * a.Sk + kj) * a.bias_t_ld + qi0);
-        }
-      }
+      load_stats(qc * 2 + s2, lsev, delv, bvt);  // issued early: their latency hides under the MFMAs below
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int t = 2 * s2 + u;
@@ -617,25 +621,44 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
 // registers and written once per SOURCE (no per-row copies, no fold pass).  group g = rows grp_rows[grp_start[g] ..
 // grp_start[g+1]) and reads source g.  Sq <= 64, Sk <= 256, no additive bias, no causal mask.
 // ---------------------------------------------------------------------------------------------
+// PACK: the same wave layout serves small self-attention (Sq, Sk <= 64, e.g. the 30-token text rows): a workgroup takes nw/tq
+// CONSECUTIVE batch rows, each with its own key/value source in its own LDS slot -- 8 waves per workgroup instead of 2.
+template <bool PACK>
 __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int g = blockIdx.z, h = blockIdx.y;
-  const int rstart = a.grp_start[g], nrows = a.grp_start[g + 1] - rstart;
-  if (nrows <= 0) return;  // uniform: before any barrier
-  const int kvb = g;
-  const bf16* kb = a.k + (long)kvb * a.Sk * a.k_rs + h * 64;
-  const bf16* vb = a.v + (long)kvb * a.Sk * a.v_rs + h * 64;
-  const int nchunks = (a.Sk + 63) / 64;
-  for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, a.Sk, w, nw, lane);
-  stage_wait();
   const int tq = (a.Sq + 15) / 16, rpp = nw / tq;  // waves per row, rows per pass
+  int rstart, nrows;
+  if (PACK) {
+    rstart = g * rpp;
+    nrows = a.B - rstart < rpp ? a.B - rstart : rpp;
+  } else {
+    rstart = a.grp_start[g];
+    nrows = a.grp_start[g + 1] - rstart;
+  }
+  if (nrows <= 0) return;  // uniform: before any barrier
+  const int nchunks = PACK ? 1 : (a.Sk + 63) / 64;
+  if (PACK) {
+    for (int jj = 0; jj < nrows; ++jj) {
+      const int src = a.kv_index ? a.kv_index[rstart + jj] : rstart + jj;
+      stage_slot(lds + jj * ATTN_SLOT, a.k + (long)src * a.Sk * a.k_rs + h * 64, a.k_rs, a.v + (long)src * a.Sk * a.v_rs + h * 64, a.v_rs,
+                 0, a.Sk, w, nw, lane);
+    }
+  } else {
+    const bf16* kb = a.k + (long)g * a.Sk * a.k_rs + h * 64;
+    const bf16* vb = a.v + (long)g * a.Sk * a.v_rs + h * 64;
+    for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, a.Sk, w, nw, lane);
+  }
+  stage_wait();
   const int jr = w / tq, tile = w - jr * tq;
   const bool has_mask = a.key_keep != nullptr;
+  const bool causal = PACK && a.causal != 0;
   if (jr >= rpp) return;  // no barriers below
   for (int j = jr; j < nrows; j += rpp) {
-    const int b = a.grp_rows[rstart + j];
+    const int b = PACK ? rstart + j : a.grp_rows[rstart + j];
+    const int kvb = PACK ? (a.kv_index ? a.kv_index[b] : b) : g;
     const int qi = tile * 16 + lr;
     const int qc = qi < a.Sq ? qi : a.Sq - 1;
     const uint32_t dkey = drop_key(a, b, h, qi);
@@ -647,7 +670,7 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
     for (int i = 0; i < 4; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = EXCL_NEG, l_run = 0.f;
     for (int kc = 0; kc < nchunks; ++kc) {
-      const char* sK = lds + kc * ATTN_SLOT;
+      const char* sK = lds + (PACK ? j : kc) * ATTN_SLOT;
       const char* sV = sK + ATTN_TILE;
       f32x4 st[4];
       int kk[4][4];
@@ -663,7 +686,7 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          st[t][r] = score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, false, qi, kc * 64 + t * 16 + 4 * lg + r);
+          st[t][r] = score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, causal, qi, kc * 64 + t * 16 + 4 * lg + r);
           mx = fmaxf(mx, st[t][r]);
         }
       mx = group4_max(mx);
@@ -960,6 +983,15 @@ static void attn_geom(int S, int& nw, int& blocks, int max_nw = 8) {
   nw = cdiv(tiles, blocks);
 }
 
+// Small self-attention forward (both sequence lengths within one 64-row chunk, no additive bias): the packed kernel puts up to
+// four batch rows in one 8-wave workgroup (15 us instead of 18 us at B=256, S=30).  The backward kernels measured the same
+// packed or not (they are bound by each wave's dependent load -> MFMA -> exp -> MFMA chain, not by occupancy) and stay
+// one row per workgroup.  XFM_ATTN_PACK=0 is the A/B knob.
+static bool attn_packable(const AttnArgs& a) {
+  static const bool on = getenv("XFM_ATTN_PACK") ? atoi(getenv("XFM_ATTN_PACK")) != 0 : true;
+  return on && a.Sq <= 64 && a.Sk <= 64 && a.bias == nullptr && a.bias_t == nullptr && a.B >= 2;
+}
+
 static int attn_check_grouped(const AttnArgs& a) {
   XFM_REQUIRE(a.grp_rows != nullptr && a.n_groups > 0 && a.n_groups <= 65535, "grouped attention: grp_rows / n_groups missing");
   XFM_REQUIRE(a.Sq <= 64 && a.Sk <= 64 * ATTN_RES_MAX, "grouped attention needs Sq <= 64 and Sk <= %d (got %d, %d)", 64 * ATTN_RES_MAX, a.Sq, a.Sk);
@@ -972,7 +1004,8 @@ static void attn_grouped_lds() {
   static bool attr_set = false;
   if (!attr_set) {
     const int mx = ATTN_RES_MAX * ATTN_SLOT;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
     attr_set = true;
@@ -986,8 +1019,16 @@ int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
     rc = attn_check_grouped(a);
     if (rc != XFM_OK) return rc;
     attn_grouped_lds();
-    hipLaunchKernelGGL(xattn_fwd_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)cdiv(a.Sk, 64) * ATTN_SLOT, st, a);
+    hipLaunchKernelGGL(xattn_fwd_kernel<false>, dim3(1, a.H, a.n_groups), dim3(512), (size_t)cdiv(a.Sk, 64) * ATTN_SLOT, st, a);
     return xfm_check_launch("xattn_fwd");
+  }
+  if (attn_packable(a)) {
+    const int tq = cdiv(a.Sq, 16);
+    int rpb = 8 / tq < ATTN_RES_MAX ? 8 / tq : ATTN_RES_MAX;
+    if (rpb > a.B) rpb = a.B;
+    attn_grouped_lds();
+    hipLaunchKernelGGL(xattn_fwd_kernel<true>, dim3(1, a.H, cdiv(a.B, rpb)), dim3(rpb * tq * 64), (size_t)rpb * ATTN_SLOT, st, a);
+    return xfm_check_launch("xattn_fwd<pack>");
   }
   int nw, blocks;
   static const int fwd_nw = getenv("XFM_ATTN_FWD_NW") ? atoi(getenv("XFM_ATTN_FWD_NW")) : 8;  // tuning knob
@@ -1024,7 +1065,16 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
   const bool res = attn_resident(a.Sk, nw);
   const bool plain = attn_plain(a);
   if (a.dbias != nullptr && res && plain) {
-    int nb = a.B >= 32 ? 4 : (a.B >= 8 ? 2 : 1);  // batch entries whose dS one workgroup sums before touching HBM
+    // batch entries whose dS one workgroup sums before touching HBM.  The kernel holds 230+ VGPRs (sum_b dS of four chunks), i.e.
+    // one workgroup per CU: of 4 and 8 entries take the one with fewer (rounds of 256 workgroups) x entries, ties to 8
+    // (half the atomics) -- B = 64: 192 workgroups x 8 entries beats 384 x 4 (1.5 rounds) by 6 %.
+    int nb = a.B >= 8 ? 2 : 1;
+    if (a.B >= 32) {
+      const long c4 = (long)cdiv(blocks * a.H * cdiv(a.B, 4), 256) * 4, c8 = (long)cdiv(blocks * a.H * cdiv(a.B, 8), 256) * 8;
+      nb = c8 <= c4 ? 8 : 4;
+    }
+    static const int nb_env = getenv("XFM_ATTN_DBIAS_NB") ? atoi(getenv("XFM_ATTN_DBIAS_NB")) : 0;  // tuning knob
+    if (nb_env > 0) nb = nb_env;
     hipLaunchKernelGGL((attn_bwd_dq_kernel<4, true, true>), dim3(blocks, a.H, cdiv(a.B, nb)), dim3(nw * 64),
                        attn_lds_bytes(a.Sk, nw, 8 * 4096), st, a, nb);
   } else if (res) {  // (a masked / causal / dropped problem with a bias gradient falls back to per-element atomics here)
