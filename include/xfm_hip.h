@@ -57,6 +57,20 @@ int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float
 /* fp32 master weight [N,K] -> bf16 copy wb[N,ldb] and/or transposed bf16 copy wt[K,ldt] (zero padded). */
 int xfm_cast_transpose(const float* w, int N, int K, xfm_bf16* wb, long ldb, xfm_bf16* wt, long ldt, void* stream);
 
+/* The same for a table of weights in one launch.  `items` is DEVICE memory, sorted by tile_start; item i covers the 32x32
+ * tiles [tile_start, tile_start + tiles_x * tiles_y) with tiles_x = ceil(max(K, ldb if wb) / 32), tiles_y = ceil(max(N, ldt
+ * if wt) / 32) (the padded extents, so the zero padding is rewritten too); total_tiles = the sum. */
+typedef struct {
+  const float* w;
+  xfm_bf16* wb;
+  xfm_bf16* wt;
+  long ldb, ldt;
+  int N, K;
+  int tiles_x, reserved;
+  long tile_start;
+} xfm_cast_item;
+int xfm_cast_transpose_batch(const xfm_cast_item* items, int n_items, long total_tiles, void* stream);
+
 /* out[n] += sum_m Y[m,n]  (bias gradients).  workspace >= xfm_colsum_workspace(M,N) bytes. */
 long xfm_colsum_workspace(int M, int N);
 int xfm_colsum(const xfm_bf16* Y, long ldy, int M, int N, float* out, float* workspace, long workspace_bytes,

@@ -143,6 +143,31 @@ def test_cast_transpose_and_colsum():
     _close(out, y.float().sum(0) + 1.0, 1e-5, "colsum")
 
 
+def test_cast_transpose_batch_matches_single():
+    """One launch over a table of weights (ragged shapes, padded leading dimensions, copies that are absent) writes exactly
+    what the per-weight launches write."""
+    Fx = _fx()
+    shapes = [(300, 136, 136, 320), (768, 768, 768, 768), (50, 64, 64, 56), (2304, 768, 768, 2304), (7, 33, 40, 8)]
+    entries, want = [], []
+    for i, (N, K, ldb, ldt) in enumerate(shapes):
+        w = _rand((N, K), dtype=F32, seed=40 + i)
+        wb = None if i == 2 else torch.full((N, ldb), 5.0, dtype=BF16, device="cuda")
+        wt = None if i == 3 else torch.full((K, ldt), 5.0, dtype=BF16, device="cuda")
+        rb = None if wb is None else torch.full((N, ldb), 7.0, dtype=BF16, device="cuda")
+        rt = None if wt is None else torch.full((K, ldt), 7.0, dtype=BF16, device="cuda")
+        Fx.cast_transpose(w, rb, rt)
+        entries.append((w, wb, wt))
+        want.append((rb, rt))
+    table, n, tiles = Fx.cast_table(entries, torch.device("cuda"))
+    Fx.cast_transpose_batch(table, n, tiles)
+    for (w, wb, wt), (rb, rt) in zip(entries, want):
+        if wb is not None:
+            assert torch.equal(wb, rb)
+            assert torch.equal(wb[:, :w.shape[1]], w.to(BF16))
+        if wt is not None:
+            assert torch.equal(wt, rt)
+
+
 def _ln_ref(x, w, b, eps):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps)
 

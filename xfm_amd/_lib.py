@@ -36,6 +36,11 @@ class LnBwdArgs(ctypes.Structure):
                 ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32)]
 
 
+class CastItem(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("wb", c_void_p), ("wt", c_void_p), ("ldb", c_long), ("ldt", c_long), ("N", c_int), ("K", c_int),
+                ("tiles_x", c_int), ("reserved", c_int), ("tile_start", c_long)]
+
+
 class AttnArgs(ctypes.Structure):
     _fields_ = [("q", c_void_p), ("q_rs", c_long), ("k", c_void_p), ("k_rs", c_long), ("v", c_void_p), ("v_rs", c_long),
                 ("o", c_void_p), ("o_rs", c_long), ("lse", c_void_p), ("bias", c_void_p), ("bias_ld", c_long),
@@ -73,6 +78,7 @@ SIGNATURES = {
     "xfm_gemm_tn": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int,
                             c_void_p, c_long, c_void_p]),
     "xfm_cast_transpose": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
+    "xfm_cast_transpose_batch": (c_int, [c_void_p, c_int, c_long, c_void_p]),
     "xfm_colsum_workspace": (c_long, [c_int, c_int]),
     "xfm_colsum": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_long, c_void_p]),
     "xfm_layernorm_fwd": (c_int, [ctypes.POINTER(LnFwdArgs), c_int, c_int, c_void_p]),

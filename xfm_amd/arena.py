@@ -12,6 +12,7 @@ Every 2-D weight also keeps a bf16 copy and a transposed bf16 copy resident (for
 `nn.Parameter` objects keep their identity and names (state_dict compatibility with the reference); only their
 storage is re-pointed into the arena.
 """
+import os
 import weakref
 
 import torch
@@ -38,6 +39,7 @@ def _install_optimizer_hook():
         pass
     _hook_installed[0] = True
 
+_CAST_BATCH = os.environ.get("XFM_CAST_BATCH", "1") != "0"  # A/B knob: one batched refresh of the bf16 operand copies per step
 ALIGN = 256  # elements; arena segments are 1 KiB aligned (vector loads, per-block optimiser groups)
 
 
@@ -60,20 +62,23 @@ class LinearSlot:
         self._wb = self._wt = None
         self._ver = None
         self._arena = None
+        self._listed = False
         self.need_t = True
 
     # bf16 operands are (re)built lazily, on first use after the arena version moved: slots a step never touches (the
     # text tower's LM head, both caption heads, the bbox head) are never cast at all
-    def _ensure(self):
-        ver = self._arena._manual_ver
-        if self._ver == ver:
-            return
+    def _alloc(self):
         if self._wb is None:
             dev = self.w.device
             self._wb = torch.empty((self.N, self.K), dtype=torch.bfloat16, device=dev)
             self._wt = torch.zeros((self.K, self.ldt), dtype=torch.bfloat16, device=dev) if self.need_t else None
-        Fx.cast_transpose(self.w, self._wb, self._wt)
-        self._ver = ver
+
+    def _ensure(self):
+        a = self._arena
+        if self._ver != a._manual_ver:
+            a._cast(self)
+        if a._batch_event is not None:
+            a._batch_wait()
 
     @property
     def wb(self):
@@ -156,10 +161,45 @@ class ParamArena:
                 s.db = self.grad[br[0]:br[1]]
                 assert s.b.numel() == s.N, s.name
         self._manual_ver = 0
+        # slots a step has touched: after the next version bump their bf16 copies are rebuilt by ONE batched launch, on
+        # the stream of the first slot used; other streams wait for its event the first time they read a copy
+        self._active = []
+        self._table = None
+        self._batch_ver = -1
+        self._batch_event = None
+        self._batch_synced = set()
         self.params = [p for _, p in params]
         _ARENAS.add(self)
         _install_optimizer_hook()
         module.register_load_state_dict_post_hook(lambda mod, keys: self.bump())
+
+    def _cast(self, slot):
+        ver = self._manual_ver
+        if _CAST_BATCH and slot._listed and self._batch_ver != ver and len(self._active) > 1:
+            if self._table is None:
+                self._table = Fx.cast_table([(s.w, s._wb, s._wt) for s in self._active], self.device)
+            Fx.cast_transpose_batch(*self._table)
+            for s in self._active:
+                s._ver = ver
+            self._batch_ver = ver
+            stream = torch.cuda.current_stream()
+            self._batch_event = torch.cuda.Event()
+            self._batch_event.record(stream)
+            self._batch_synced = {stream.cuda_stream}
+            return
+        slot._alloc()
+        Fx.cast_transpose(slot.w, slot._wb, slot._wt)
+        slot._ver = ver
+        if not slot._listed:
+            slot._listed = True
+            self._active.append(slot)
+            self._table = None
+
+    def _batch_wait(self):
+        if Fx._stream() not in self._batch_synced:
+            stream = torch.cuda.current_stream()
+            stream.wait_event(self._batch_event)
+            self._batch_synced.add(stream.cuda_stream)
 
     # bf16 caches are valid for one version; bumped by optimiser steps, load_state_dict and explicit bump()
     def version(self):

@@ -50,6 +50,10 @@ int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float
   return xfm_gemm_tn_impl(dY, ldy, X, ldx, dW, ldw, dbias, M, N, K, splits_hint, workspace, workspace_bytes, ST(stream));
 }
 
+int xfm_cast_transpose_batch(const xfm_cast_item* items, int n_items, long total_tiles, void* stream) {
+  return xfm_cast_transpose_batch_impl(items, n_items, total_tiles, ST(stream));
+}
+
 int xfm_cast_transpose(const float* w, int N, int K, xfm_bf16* wb, long ldb, xfm_bf16* wt, long ldt, void* stream) {
   XFM_REQUIRE(w && (wb || wt), "cast_transpose: null operand");
   return xfm_cast_transpose_impl(w, N, K, wb, ldb, wt, ldt, ST(stream));

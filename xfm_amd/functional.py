@@ -12,7 +12,13 @@ EPI_BF16, EPI_F32, EPI_GELU, EPI_DGELU, EPI_F32_ACC = 0, 1, 2, 3, 4
 LN_PLAIN, LN_POST, LN_LS = 0, 1, 2
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Raw HIP handle of torch's current stream (every kernel of the library is launched on it)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -79,6 +85,29 @@ def gemm_tn(dy, x, dw, n=None, splits=0, dbias=None):
     ws = workspace(need, dy.device) if need > 0 else None
     check(lib.xfm_gemm_tn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0), _ptr(dbias), M, N, K,
                           splits, _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream()), "gemm_tn")
+
+
+def cast_table(entries, device):
+    """Device-resident xfm_cast_item table for cast_transpose_batch.  entries: (w fp32 [N,K], wb bf16 [N,ldb] | None,
+    wt bf16 [K,ldt] | None).  Returns (table uint8 tensor, n_items, total_tiles)."""
+    items = (_lib.CastItem * len(entries))()
+    tiles = 0
+    for i, (w, wb, wt) in enumerate(entries):
+        N, K = w.shape
+        assert w.dtype == F32 and w.is_contiguous()
+        ldb = 0 if wb is None else wb.stride(0)
+        ldt = 0 if wt is None else wt.stride(0)
+        tx, ty = (max(K, ldb) + 31) // 32, (max(N, ldt) + 31) // 32
+        items[i] = _lib.CastItem(w.data_ptr(), _ptr(wb), _ptr(wt), ldb, ldt, N, K, tx, 0, tiles)
+        tiles += tx * ty
+    table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(device)
+    return table, len(entries), tiles
+
+
+def cast_transpose_batch(table, n_items, total_tiles):
+    """One launch refreshing every bf16 operand copy listed in `table` (cast_table)."""
+    _dev(table)
+    check(_lib.load().xfm_cast_transpose_batch(table.data_ptr(), n_items, total_tiles, _stream()), "cast_transpose_batch")
 
 
 def cast_transpose(w, wb=None, wt=None):
