@@ -38,7 +38,8 @@ int xfm_abi_version(void);
 enum { XFM_EPI_BF16 = 0, XFM_EPI_F32 = 1, XFM_EPI_GELU = 2, XFM_EPI_DGELU = 3, XFM_EPI_F32_ACC = 4 };
 
 /* C[M,N] = A[M,K] . B[N,K]^T + bias.  A, B bf16 (K contiguous).  Epilogues: bf16 out | fp32 out |
- * aux = pre-activation (bf16), C = gelu(aux)  | C = acc * gelu'(aux) | fp32 C += acc.  K % 64 == 0; lda, ldb % 8 == 0.
+ * C = gelu(x), aux = gelu'(x) (bf16; x = the bf16-rounded pre-activation)  | C = acc * aux (the GELU dgrad, aux from the
+ * forward) | fp32 C += acc.  K % 64 == 0; lda, ldb % 8 == 0.
  * tile_hint: 0 = auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x128 with a 3-slot LDS ring, 5 = 256x256 phase pipeline
  * (large M), 7 = 64x128 with 3 LDS stages, 8 = 64x64 with 4 (few workgroups, long K). */
 int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* C, long ldc, const float* bias,

@@ -82,14 +82,15 @@ def test_gemm_nt_gelu_and_dgelu(M, N, K, hint):
     bias = _rand((N,), 0.5, F32, seed=6)
     pre = a.float() @ b.float().t() + bias
     h, u = Fx.gemm_nt(a, b, bias, epi=Fx.EPI_GELU, tile_hint=hint)
-    _close(u, pre, 1e-2, "pre-activation")
-    _close(h, torch.nn.functional.gelu(u.float()), 1e-2, "gelu(pre)")
-    # dgrad with the GELU derivative folded in: C = (dY . Wt^T) * gelu'(aux)
+    x = pre.to(BF16).float()  # the GELU sees the bf16-rounded pre-activation (the reference's autocast linear output)
+    _close(h, torch.nn.functional.gelu(x), 1e-2, "gelu(pre)")
+    _close(u, gelu_grad(x), 1e-2, "gelu'(pre), stored for the backward")
+    # dgrad with the GELU derivative folded in: C = (dY . Wt^T) * aux
     dy = _rand((M, N), seed=7)
     wt = _rand((K, N), 0.05, seed=8)  # plays W^T: [K_out, N_contract]
-    aux = _rand((M, K), 1.0, seed=9)
+    aux = gelu_grad(_rand((M, K), 1.0, seed=9).float()).to(BF16)
     got = Fx.gemm_nt(dy, wt, epi=Fx.EPI_DGELU, aux=aux, tile_hint=hint)
-    ref = (dy.float() @ wt.float().t()) * gelu_grad(aux.float())
+    ref = (dy.float() @ wt.float().t()) * aux.float()
     _close(got, ref, 1e-2, "dgelu")
 
 

@@ -1,6 +1,9 @@
-"""Which torch-side (non-library) ops run in one training step of the bench model: torch.profiler CPU-op table."""
+"""Which torch (aten) ops still run in one pre-training step, by GPU time and input shapes: the glue around the HIP library
+(copies, fills, cats, index_selects).  python tools/torch_ops.py > gpurun_out/torch_ops.log"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("XFM_WGRAD_STREAM", "0")
+os.environ.setdefault("XFM_TEXT_STREAM", "0")
 import torch
 from torch.profiler import profile, ProfilerActivity
 import bench
@@ -9,9 +12,9 @@ from xfm_amd.accelerators import RCCLDDPAccelerator
 
 device = torch.device("cuda", 0)
 model = bench.build_model(device)
-opt = bench.make_optimizer(model)
+optimizer = bench.make_optimizer(model)
 acc = RCCLDDPAccelerator({"RNG_SEED": 42, "CLIP_GRAD_NORM": 1.0, "GRAD_ACCUMULATE_STEPS": 1})
-wrapped, opt, _ = acc.set_up(model, opt, None, 0, 1, 0)
+wrapped, optimizer, _ = acc.set_up(model, optimizer, None, 0, 1, 0)
 model.train(True)
 batch = {k: v.to(device) for k, v in syn.pretrain_batch(64, seed=1234).items()}
 
@@ -20,14 +23,28 @@ def step():
     losses = wrapped(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
                      masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], ret_mim_loss=True, data_source="image")
     total = losses["loss_itc"] + losses["loss_itm"] + losses["loss_mlm"] + losses["loss_mim"]
-    acc.backward_step(total, opt)
-    acc.optimizer_step(opt, model)
+    acc.backward_step(total, optimizer)
+    acc.optimizer_step(optimizer, model)
 
 
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=False) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=False).table(sort_by="cuda_time_total", row_limit=400, max_name_column_width=50, max_shapes_column_width=70))
+def dev_us(e):
+    return getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0.0))
+
+
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and dev_us(e) > 0]
+rows.sort(key=lambda e: -dev_us(e))
+print("== aten ops with GPU time, by input shape")
+for e in rows[:40]:
+    print(f"{e.key:28s} calls={e.count:4d} gpu={dev_us(e):9.1f}us  {str(e.input_shapes)[:110]}")
+rows = [e for e in prof.key_averages(group_by_stack_n=6) if e.key.startswith("aten::") and dev_us(e) > 0]
+rows.sort(key=lambda e: -dev_us(e))
+print("== the same by call site")
+for e in rows[:40]:
+    stack = [f for f in e.stack if "xfm_amd" in f or "bench.py" in f][:2]
+    print(f"{e.key:22s} calls={e.count:4d} gpu={dev_us(e):9.1f}us  {' <- '.join(x.strip()[-70:] for x in stack)}")

@@ -46,7 +46,7 @@ __device__ __forceinline__ int swz_w(int r) { return ((r >> 1) & 1) | (((r >> 3)
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmNT& g, f32x4 (&acc)[MT][NT], int m_base, int n_base, int lr, int lg) {
   const bool vec_c = (g.ldc % 8) == 0;
-  // DGELU: all pre-activation loads of the sub-tile go out first, so their latency is paid once, not once per (mt, np)
+  // DGELU: all gelu'(x) loads of the sub-tile go out first, so their latency is paid once, not once per (mt, np)
   bf16x8 pre_all[EPI == EPI_DGELU ? NT / 2 : 1][EPI == EPI_DGELU ? MT : 1];
   const bool vec_aux = (g.ldaux % 8) == 0;
   if (EPI == EPI_DGELU && vec_aux) {
@@ -98,25 +98,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNT& g, f32x4 (&acc)[MT][
         bf16* cp = reinterpret_cast<bf16*>(g.C) + (long)m * g.ldc + nb;
         bf16x8 o;
         if (EPI == EPI_GELU) {
+          // GELU and its derivative share one erf / exp evaluation, so the forward stores gelu'(x) for the backward (x = the
+          // bf16-rounded pre-activation, the value the reference's autocast GELU sees): the dgrad epilogue is then one
+          // multiply per element instead of a second erf evaluation that costs as much as a whole K = 768 MFMA loop.
           bf16* ap = g.aux + (long)m * g.ldaux + nb;
-          bf16x8 pre;
+          bf16x8 dact;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            pre[i] = f2bf(v[i]);
-            o[i] = f2bf(gelu_f(bf2f(pre[i])));  // GELU of the bf16-rounded pre-activation: bwd recomputes from `aux`
+            const float x = bf2f(f2bf(v[i]));
+            float cdf, pdf;
+            gelu_parts(x, cdf, pdf);
+            o[i] = f2bf(x * cdf);
+            dact[i] = f2bf(fmaf(x, pdf, cdf));
           }
-          if (full) *reinterpret_cast<bf16x8*>(ap) = pre;
+          if (full) *reinterpret_cast<bf16x8*>(ap) = dact;
           else
             for (int i = 0; i < 8; ++i)
-              if (nb + i < g.N) ap[i] = pre[i];
+              if (nb + i < g.N) ap[i] = dact[i];
         } else if (EPI == EPI_DGELU) {
           const bf16* ap = g.aux + (long)m * g.ldaux + nb;
           if (full && vec_aux) {
-            const bf16x8 pre = pre_all[np][mt];
+            const bf16x8 dact = pre_all[np][mt];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i] * gelu_grad_f(bf2f(pre[i])));
+            for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i] * bf2f(dact[i]));
           } else {
-            for (int i = 0; i < 8; ++i) o[i] = (nb + i < g.N) ? f2bf(v[i] * gelu_grad_f(bf2f(ap[i]))) : f2bf(0.f);
+            for (int i = 0; i < 8; ++i) o[i] = (nb + i < g.N) ? f2bf(v[i] * bf2f(ap[i])) : f2bf(0.f);
           }
         } else {
 #pragma unroll

@@ -140,7 +140,7 @@ class _LMHeadCEFn(torch.autograd.Function):
         dhact = torch.empty_like(hact)
         ln = head.layer_norm
         Fx.ln_bwd(dy, hact, mean, rstd, ln.weight, grad_view(ln.weight), grad_view(ln.bias), dx16=dhact)
-        du = (dhact.float() * gelu_grad(u)).to(BF16)
+        du = (dhact.float() * u.float()).to(BF16)  # u = gelu'(pre-activation), stored by the forward epilogue
         Fx.gemm_tn(du, x, sd.dw, dbias=sd.db)
         dx = Fx.gemm_nt(du, sd.wt, n=sd.K)
         return dx, None, None, None
