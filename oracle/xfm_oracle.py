@@ -259,13 +259,22 @@ def masked_lm_loss(P, model_pre, seq_out, masked_pos, labels, head="lm_head", ca
     return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1), reduction=reduction), logits
 
 
-def causal_lm_loss(P, input_ids, att, enc, enc_att, labels, num_layers, reduction="none"):
+def causal_lm_loss(P, input_ids, att, enc, enc_att, labels, num_layers, reduction="none", pre="", fusion_layer=0):
     """RobertaForCausalLM.forward xroberta.py:1025-1113 (the VQA answer decoder, model_generation.py:119-128): causal
-    self mask, cross-attention in every layer, lm_head, logits[:, :-1] vs labels[:, 1:], then view(B, -1).sum(1)."""
-    seq = roberta_model(P, "roberta.", input_ids=input_ids, att=att, enc=enc, enc_att=enc_att, num_layers=num_layers,
-                        fusion_layer=0, causal=True)
-    loss, logits = masked_lm_loss(P, "", seq, None, labels, head="lm_head", causal_shift=True, reduction=reduction)
+    self mask, cross-attention from layer `fusion_layer` on, lm_head, logits[:, :-1] vs labels[:, 1:], then view(B, -1).sum(1)."""
+    seq = roberta_model(P, pre + "roberta.", input_ids=input_ids, att=att, enc=enc, enc_att=enc_att, num_layers=num_layers,
+                        fusion_layer=fusion_layer, causal=True)
+    loss, logits = masked_lm_loss(P, pre, seq, None, labels, head="lm_head", causal_shift=True, reduction=reduction)
     return loss.view(input_ids.shape[0], -1).sum(1), logits
+
+
+def causal_lm_logits(P, input_ids, att, enc, enc_att, num_layers, pre="", fusion_layer=0):
+    """The same decoder without labels: full-length logits (rank_answer's first step, model_generation.py:149-155)."""
+    if att is None:
+        att = torch.ones_like(input_ids)
+    seq = roberta_model(P, pre + "roberta.", input_ids=input_ids, att=att, enc=enc, enc_att=enc_att, num_layers=num_layers,
+                        fusion_layer=fusion_layer, causal=True)
+    return roberta_lm_head(P, pre + "lm_head.", seq)
 
 
 # --------------------------------------------------------------------------------------
@@ -462,3 +471,64 @@ def classification_forward(P, cfg, image, text_ids, text_atts, deep_head):
                              num_layers=cfg["fusion_layers"], fusion_layer=cfg["fusion_start"])[:, 0, :]
     return deep_mlp_forward(P, "cls_head.", feat) if deep_head else build_mlp_forward(P, "cls_head.", feat)
 
+
+
+# --------------------------------------------------------------------------------------
+# XFMForVQA (models/model_generation.py) and XFMForNLVR (models/model_nlvr.py)
+# --------------------------------------------------------------------------------------
+def fused_question_states(P, cfg, image, q_ids, q_atts):
+    """model_generation.py:94,103-110: image through the vision tower, question through the bare text tower, then the fusion
+    tower's cross-attention to the image (is_pretrain=False: nothing detached)."""
+    emb = beit_forward(P, "vision_encoder.", image, depth=cfg["vit_depth"])
+    atts = torch.ones(emb.shape[:2], dtype=torch.long)
+    txt = roberta_model(P, "text_encoder.", input_ids=q_ids, att=q_atts, num_layers=cfg["text_layers"], fusion_layer=cfg["text_layers"])
+    return roberta_model(P, "fusion_encoder.roberta.", att=q_atts, encoder_embeds=txt, enc=emb, enc_att=atts,
+                         num_layers=cfg["fusion_layers"], fusion_layer=cfg["fusion_start"])
+
+
+def vqa_train_loss(P, cfg, image, q_ids, q_atts, a_ids, a_atts, k, weights, pad_token_id):
+    """XFMForVQA.forward(train=True) model_generation.py:96-133: question states repeated once per answer, per-answer sequence loss
+    (pad -> -100) weighted and summed, divided by the number of images."""
+    qs = fused_question_states(P, cfg, image, q_ids, q_atts)
+    rep = torch.tensor([b for b, n in enumerate(k) for _ in range(n)])
+    targets = a_ids.masked_fill(a_ids == pad_token_id, -100)
+    loss, _ = causal_lm_loss(P, a_ids, a_atts, qs[rep], q_atts[rep], targets, cfg["dec_layers"], pre="text_decoder.",
+                             fusion_layer=cfg["dec_fusion_start"])
+    return (weights * loss).sum() / image.shape[0]
+
+
+def vqa_rank_answer(P, cfg, image, q_ids, q_atts, answer_ids, answer_atts, k, pad_token_id):
+    """XFMForVQA.forward(train=False) -> rank_answer model_generation.py:135-202.  Returns (topk_ids, topk_probs, first-token
+    probabilities of every candidate) -- the last for tolerance-aware comparisons of the discrete ranking."""
+    qs = fused_question_states(P, cfg, image, q_ids, q_atts)
+    q_ones = torch.ones(qs.shape[:2], dtype=torch.long)
+    nq = qs.shape[0]
+    start_ids = answer_ids[0, 0].repeat(nq, 1)
+    logits = causal_lm_logits(P, start_ids, None, qs, q_ones, cfg["dec_layers"], pre="text_decoder.",
+                              fusion_layer=cfg["dec_fusion_start"])[:, 0, :]
+    prob_first = F.softmax(logits, dim=1).index_select(1, answer_ids[:, 1])
+    topk_probs, topk_ids = prob_first.topk(k, dim=1)
+    flat = topk_ids.reshape(-1)
+    ids, atts = answer_ids[flat], answer_atts[flat]
+    targets = ids.masked_fill(ids == pad_token_id, -100)
+    rep = torch.arange(nq).repeat_interleave(k)
+    loss, _ = causal_lm_loss(P, ids, atts, qs[rep], q_ones[rep], targets, cfg["dec_layers"], pre="text_decoder.",
+                             fusion_layer=cfg["dec_fusion_start"])
+    log_probs_sum = (topk_probs.view(-1).log() - loss).view(nq, k)
+    probs = F.softmax(log_probs_sum, dim=-1)
+    probs, rerank = probs.topk(k, dim=1)
+    return torch.gather(topk_ids, 1, rerank), probs, prob_first
+
+
+def nlvr_forward(P, cfg, image, text_ids, text_atts):
+    """XFMForNLVR.forward model_nlvr.py:27-44 -> prediction logits [B, 2]; image = B first images then B second images."""
+    emb = beit_forward(P, "vision_encoder.", image, depth=cfg["vit_depth"])
+    atts = torch.ones(emb.shape[:2], dtype=torch.long)
+    txt = roberta_model(P, "text_encoder.", input_ids=text_ids, att=text_atts, num_layers=cfg["text_layers"],
+                        fusion_layer=cfg["text_layers"])
+    n = text_ids.shape[0]
+    cls = []
+    for half in (slice(0, n), slice(n, 2 * n)):
+        cls.append(roberta_model(P, "fusion_encoder.roberta.", att=text_atts, encoder_embeds=txt, enc=emb[half], enc_att=atts[half],
+                                 num_layers=cfg["fusion_layers"], fusion_layer=cfg["fusion_start"])[:, 0, :])
+    return build_mlp_forward(P, "cls_head.", torch.cat(cls, dim=-1))

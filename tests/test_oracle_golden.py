@@ -211,6 +211,39 @@ def test_classification_models():
     _check_grads(z, "grad_text", P)
 
 
+def test_vqa_model_loss_and_answer_ranking():
+    """BASELINE configs[3]: XFMForVQA's weighted answer loss + gradients, and rank_answer's re-ranked shortlist."""
+    z, meta = load("vqa_small")
+    P = _params(meta["spec"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    cfg.update(dec_layers=meta["dec_layers"], dec_fusion_start=meta["dec_fusion_start"])
+    x = syn.vqa_inputs()
+    loss = O.vqa_train_loss(P, cfg, x.image, x.q_ids, x.q_atts, x.a_ids, x.a_atts, x.k, x.weights, meta["pad_token_id"])
+    assert abs(float(loss) - float(z["loss_vqa"])) < 2e-4 * abs(float(z["loss_vqa"])), (float(loss), float(z["loss_vqa"]))
+    loss.backward()
+    _check_grads(z, "grad", P)
+    unused = set(meta["unused"])
+    assert all(P[k].grad is None or float(P[k].grad.abs().max()) == 0.0 for k in unused if k in P and P[k].dtype.is_floating_point)
+    with torch.no_grad():
+        ids, probs, _ = O.vqa_rank_answer(P, cfg, x.image, x.q_ids, x.q_atts, x.c_ids, x.c_atts, x.topk, meta["pad_token_id"])
+    assert ids.tolist() == z["topk_ids"].tolist()
+    assert np.allclose(probs.numpy(), z["topk_probs"], rtol=1e-3, atol=1e-6)
+
+
+def test_nlvr_model():
+    z, meta = load("nlvr_small")
+    P = _params(meta["spec"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    B = meta["B"]
+    b = syn.pretrain_batch(2 * B, seed=95)
+    pred = O.nlvr_forward(P, cfg, b["image"], b["text_ids"][:B], b["text_atts"][:B])
+    check(z, "pred_nlvr", pred, 1e-4, RTOL)
+    loss = torch.nn.functional.cross_entropy(pred, torch.tensor(meta["targets"]))
+    assert abs(float(loss) - float(z["loss_nlvr"])) < 2e-4
+    loss.backward()
+    _check_grads(z, "grad", P)
+
+
 def _pretrain(name):
     z, meta = load(name)
     B = meta["B"]

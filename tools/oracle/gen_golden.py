@@ -424,6 +424,66 @@ def gen_classification(B=4):
     save("classification_mm", out2, {"spec": spec_of(m2), "B": B, "targets": t2.tolist(), "text_layers": 2, "fusion_layers": 2})
 
 
+def gen_vqa():
+    """models/model_generation.py XFMForVQA (BASELINE configs[3]): weighted answer-decoder loss + its gradients, and the
+    inference-time answer ranking (first-token shortlist, sequence log-likelihood re-rank)."""
+    from types import SimpleNamespace as NS
+
+    def build_tokenizer(*a, **kw):  # only the captioning classes of model_generation.py call it
+        raise RuntimeError("dataset.build_tokenizer is stubbed: the reference's dataset package needs torchvision / PIL")
+
+    ref_shim._stub("dataset", build_tokenizer=build_tokenizer)  # import stub, as in ref_shim.install()
+    from models.model_generation import XFMForVQA
+    ref_shim.init_single_process_group()
+    torch.manual_seed(0)
+    cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2,
+                                   overrides={"pad_token_id": 1, "decoder_fusion_start_at": 0, "num_dec_layers": 2})
+    m = XFMForVQA(cfg)
+    load_formula(m)
+    m.eval()
+    x = syn.vqa_inputs()
+    q, a, c = NS(input_ids=x.q_ids, attention_mask=x.q_atts), NS(input_ids=x.a_ids, attention_mask=x.a_atts), \
+        NS(input_ids=x.c_ids, attention_mask=x.c_atts)
+    out = {}
+    loss = m(x.image, q, a, k=x.k, weights=x.weights, train=True)
+    out["loss_vqa"] = np.asarray(float(loss.detach()))
+    print("loss_vqa", float(loss), flush=True)
+    loss.backward()
+    grads_of(m, out)
+    unused = [n for n, p in m.named_parameters() if p.grad is None]
+    with torch.no_grad():
+        topk_ids, topk_probs = m(x.image, q, c, k=x.topk, train=False)
+    out["topk_ids"] = topk_ids.numpy()
+    out["topk_probs"] = topk_probs.numpy()
+    print("topk", topk_ids.tolist(), topk_probs.tolist(), flush=True)
+    save("vqa_small", out, {"spec": spec_of(m), "B": 3, "text_layers": 2, "fusion_layers": 2, "dec_layers": 2, "dec_fusion_start": 0,
+                            "pad_token_id": 1, "unused": unused})
+
+
+def gen_nlvr(B=2):
+    """models/model_nlvr.py XFMForNLVR: 2B images (first images, then second images) against B statements."""
+    from models.model_nlvr import XFMForNLVR
+    ref_shim.init_single_process_group()
+    torch.manual_seed(0)
+    cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2)
+    m = XFMForNLVR(cfg)
+    load_formula(m)
+    m.eval()
+    b = syn.pretrain_batch(2 * B, seed=95)
+    ids, atts = b["text_ids"][:B], b["text_atts"][:B]
+    targets = torch.tensor([1, 0][:B])
+    out = {}
+    loss = m(b["image"], ids, atts, targets, train=True)
+    out["loss_nlvr"] = np.asarray(float(loss.detach()))
+    with torch.no_grad():
+        pack("pred_nlvr", m(b["image"], ids, atts, targets, train=False), out)
+    loss.backward()
+    grads_of(m, out)
+    unused = [n for n, p in m.named_parameters() if p.grad is None]
+    save("nlvr_small", out, {"spec": spec_of(m), "B": B, "targets": targets.tolist(), "text_layers": 2, "fusion_layers": 2,
+                             "unused": unused})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -432,7 +492,7 @@ def main():
     torch.set_num_threads(8)
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification()}
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr}
     if a.full:
         jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
     for k, fn in jobs.items():

@@ -209,8 +209,10 @@ class RCCLDDPAccelerator(Accelerator):
         self._live = out
 
     def _grad_norm_sq(self):
+        """Over the live ranges only: blocks that never receive a gradient are zero (and stay zero), no need to read them."""
         out = torch.zeros(1, dtype=torch.float32, device=self.arena.grad.device)
-        Fx.sumsq(self.arena.grad, out)
+        for a, b in (self._live if self._live is not None else [(0, self.arena.numel)]):
+            Fx.sumsq(self.arena.grad[a:b], out)
         return out
 
     def optimizer_step(self, optimizer, model, grad_norm: float = 0.0):
@@ -240,7 +242,7 @@ class RCCLDDPAccelerator(Accelerator):
                 arena.grad.mul_(clip_coef)
             optimizer.step()
         arena.bump()
-        arena.zero_grad()
+        arena.zero_grad(self._live)
         self.last_grad_norm = norm  # device tensor: no host sync on the step path
         return norm
 

@@ -211,8 +211,13 @@ class ParamArena:
     def refresh(self):
         """bf16 operand copies refresh themselves lazily (LinearSlot.wb / .wt); kept for callers of the old eager API."""
 
-    def zero_grad(self):
-        self.grad.zero_()
+    def zero_grad(self, ranges=None):
+        """ranges: the (start, end) arena ranges that ever receive a gradient (the accelerator's live map); None = everything."""
+        if ranges is None:
+            self.grad.zero_()
+        else:
+            for a, b in ranges:
+                self.grad[a:b].zero_()
         for p in self.params:
             if p.grad is not p._xfm_grad:
                 p.grad = p._xfm_grad

@@ -160,3 +160,16 @@ def mim_block_mask(batch_size, grid=14, num_masking=75, seed=1234):
             free = np.flatnonzero(~flat)
             flat[free[:need]] = True
     return torch.from_numpy(out.reshape(B, grid * grid))
+
+
+def vqa_inputs(B=3):
+    """VQA fixture inputs shared by the golden generator, the oracle test and the HIP test: B images + questions, k[b] answers per
+    question with annotator weights, and a candidate answer list for the inference-time ranking (top `topk`)."""
+    from types import SimpleNamespace as NS
+    b = pretrain_batch(B, seed=91)
+    k = [2, 1, 3][:B]
+    ans = pretrain_batch(sum(k), seed=92, max_tokens=7, min_len=3, with_image=False)
+    cand = pretrain_batch(5, seed=93, max_tokens=6, min_len=3, with_image=False)
+    weights = torch.tensor([0.6, 0.4, 1.0, 0.5, 0.3, 0.2][:sum(k)])
+    return NS(image=b["image"], q_ids=b["text_ids"], q_atts=b["text_atts"], k=k, a_ids=ans["text_ids"], a_atts=ans["text_atts"],
+              weights=weights, c_ids=cand["text_ids"], c_atts=cand["text_atts"], topk=3)

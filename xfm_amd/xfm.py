@@ -261,12 +261,16 @@ class XFMBase(nn.Module):
             slots += self.itm_head.linear_slots("itm_head.")
         if hasattr(self, "bbox_head"):
             slots += self.bbox_head.linear_slots("bbox_head.")
-        if hasattr(self, "cls_head"):  # task models (model_classification.py)
+        if hasattr(self, "cls_head"):  # task models (model_classification.py, model_nlvr.py)
             slots += self.cls_head.linear_slots("cls_head.")
+        if hasattr(self, "text_decoder"):  # the answer decoder of model_generation.py
+            slots += self.text_decoder.linear_slots("text_decoder.")
         self._arena = ParamArena(self, slots, device)
         self.vision_encoder.attach(self._arena)
         self.text_encoder.attach(self._arena)
         self.fusion_encoder.attach(self._arena)
+        if hasattr(self, "text_decoder"):
+            self.text_decoder.attach(self._arena)
         return self
 
     def _ready(self):
