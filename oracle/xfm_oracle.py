@@ -532,3 +532,58 @@ def nlvr_forward(P, cfg, image, text_ids, text_atts):
         cls.append(roberta_model(P, "fusion_encoder.roberta.", att=text_atts, encoder_embeds=txt, enc=emb[half], enc_att=atts[half],
                                  num_layers=cfg["fusion_layers"], fusion_layer=cfg["fusion_start"])[:, 0, :])
     return build_mlp_forward(P, "cls_head.", torch.cat(cls, dim=-1))
+
+
+# --------------------------------------------------------------------------------------
+# Retrieval evaluation (Retrieval.py:76-240): k-test re-rank and recall metrics
+# --------------------------------------------------------------------------------------
+def retrieval_score_matrices(P, cfg, images, text_ids, text_atts, k_test):
+    """Retrieval.py:92-166 at world_size 1, one row at a time like the reference: dual-encoder similarities, the k_test best
+    candidates of every row re-scored by fusion tower + ITM head (logit of class 1), -100 elsewhere."""
+    txt = roberta_model(P, "text_encoder.", input_ids=text_ids, att=text_atts, num_layers=cfg["text_layers"], fusion_layer=cfg["text_layers"])
+    img = beit_forward(P, "vision_encoder.", images, depth=cfg["vit_depth"])
+    image_feat, text_feat = get_features(P, img, txt)
+    sims = image_feat @ text_feat.t()
+
+    def itm(image_rows, text_rows, att_rows):
+        atts = torch.ones(image_rows.shape[:2], dtype=torch.long)
+        out = roberta_model(P, "fusion_encoder.roberta.", att=att_rows, encoder_embeds=text_rows, enc=image_rows, enc_att=atts,
+                            num_layers=cfg["fusion_layers"], fusion_layer=cfg["fusion_start"])
+        return build_mlp_forward(P, "itm_head.", out[:, 0, :])[:, 1]
+
+    i2t = torch.full(sims.shape, -100.0)
+    for i, row in enumerate(sims):
+        idx = row.topk(k_test).indices
+        i2t[i, idx] = itm(img[i].repeat(k_test, 1, 1), txt[idx], text_atts[idx])
+    t2i = torch.full(sims.t().shape, -100.0)
+    for i, row in enumerate(sims.t()):
+        idx = row.topk(k_test).indices
+        t2i[i, idx] = itm(img[idx], txt[i].repeat(k_test, 1, 1), text_atts[i].repeat(k_test, 1))
+    return i2t, t2i, sims
+
+
+def itm_eval(scores_i2t, scores_t2i, txt2img, img2txt):
+    """Retrieval.py:187-240, numpy as in the reference."""
+    import numpy as np
+    ranks = np.zeros(scores_i2t.shape[0])
+    for index, score in enumerate(scores_i2t):
+        inds = np.argsort(score)[::-1]
+        rank = 1e20
+        for i in img2txt[index]:
+            tmp = np.where(inds == i)[0][0]
+            if tmp < rank:
+                rank = tmp
+        ranks[index] = rank
+    tr1 = 100.0 * len(np.where(ranks < 1)[0]) / len(ranks)
+    tr5 = 100.0 * len(np.where(ranks < 5)[0]) / len(ranks)
+    tr10 = 100.0 * len(np.where(ranks < 10)[0]) / len(ranks)
+    ranks = np.zeros(scores_t2i.shape[0])
+    for index, score in enumerate(scores_t2i):
+        inds = np.argsort(score)[::-1]
+        ranks[index] = np.where(inds == txt2img[index])[0][0]
+    ir1 = 100.0 * len(np.where(ranks < 1)[0]) / len(ranks)
+    ir5 = 100.0 * len(np.where(ranks < 5)[0]) / len(ranks)
+    ir10 = 100.0 * len(np.where(ranks < 10)[0]) / len(ranks)
+    tr_mean, ir_mean = (tr1 + tr5 + tr10) / 3, (ir1 + ir5 + ir10) / 3
+    return {'txt_r1': tr1, 'txt_r5': tr5, 'txt_r10': tr10, 'txt_r_mean': tr_mean, 'img_r1': ir1, 'img_r5': ir5, 'img_r10': ir10,
+            'img_r_mean': ir_mean, 'r_mean': (tr_mean + ir_mean) / 2}

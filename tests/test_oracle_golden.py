@@ -244,6 +244,32 @@ def test_nlvr_model():
     _check_grads(z, "grad", P)
 
 
+def test_retrieval_evaluation_rerank_and_recall():
+    """Retrieval.py:76-240: the k-test re-rank score matrices against the reference model's, and the recall metrics against a
+    hand-worked case (product-side numpy restatement and the oracle's must agree on it too)."""
+    z, meta = load("retrieval_eval")
+    P = _params(meta["spec"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    x = syn.retrieval_eval_inputs()
+    with torch.no_grad():
+        i2t, t2i, sims = O.retrieval_score_matrices(P, cfg, x.image, x.text_ids, x.text_atts, x.k_test)
+    assert np.allclose(sims.numpy(), z["sims"], atol=2e-5)
+    assert np.allclose(i2t.numpy(), z["score_i2t"], atol=2e-4) and np.allclose(t2i.numpy(), z["score_t2i"], atol=2e-4)
+    # hand-worked: 3 images, 4 captions (caption 3 is a second caption of image 0)
+    s_i2t = np.array([[0.1, 0.9, 0.2, 0.8],    # image 0: order 1,3,2,0 -> best ground truth (0 or 3) at rank 1
+                      [0.7, 0.6, 0.1, 0.0],    # image 1: truth 1 at rank 1
+                      [0.0, 0.1, 0.9, 0.3]])   # image 2: truth 2 at rank 0
+    s_t2i = np.array([[0.9, 0.1, 0.0], [0.2, 0.1, 0.3], [0.1, 0.2, 0.3], [0.3, 0.2, 0.1]])  # ranks 0, 2, 0, 0
+    txt2img, img2txt = [0, 1, 2, 0], [[0, 3], [1], [2]]
+    want = {'txt_r1': 100.0 / 3, 'txt_r5': 100.0, 'txt_r10': 100.0, 'img_r1': 75.0, 'img_r5': 100.0, 'img_r10': 100.0}
+    from xfm_amd.retrieval_eval import itm_eval
+    for fn in (O.itm_eval, itm_eval):
+        got = fn(s_i2t, s_t2i, txt2img, img2txt)
+        for k, v in want.items():
+            assert abs(got[k] - v) < 1e-9, (fn.__module__, k, got[k], v)
+        assert abs(got['r_mean'] - ((100.0 / 3 + 200.0) / 3 + (75.0 + 200.0) / 3) / 2) < 1e-9
+
+
 def _pretrain(name):
     z, meta = load(name)
     B = meta["B"]

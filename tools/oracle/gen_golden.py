@@ -484,6 +484,47 @@ def gen_nlvr(B=2):
                              "unused": unused})
 
 
+def gen_retrieval_eval():
+    """The k-test re-rank of Retrieval.py:76-184 at world_size 1.  Retrieval.py itself cannot be imported here (its dataset / utils
+    imports need torchvision, PIL and ruamel), so the LOOP below restates :128-166 call for call, while every tensor comes from the
+    reference model's own methods (get_text_embeds / get_vision_embeds / get_features / get_cross_embeds / itm_head)."""
+    from models.model_retrieval import XFMForRetrieval
+    ref_shim.init_single_process_group()
+    torch.manual_seed(0)
+    cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2)
+    m = XFMForRetrieval(cfg)
+    load_formula(m)
+    m.eval()
+    x = syn.retrieval_eval_inputs()
+    k = x.k_test
+    with torch.no_grad():
+        text_feats = m.get_text_embeds(x.text_ids, x.text_atts)
+        text_embeds = m.get_features(text_embeds=text_feats)
+        image_feats, _ = m.get_vision_embeds(x.image)
+        image_embeds = m.get_features(image_embeds=image_feats)
+        sims_matrix = image_embeds @ text_embeds.t()
+        i2t = torch.full(sims_matrix.shape, -100.0)
+        for i, sims in enumerate(sims_matrix):
+            topk_sim, topk_idx = sims.topk(k=k, dim=0)
+            encoder_output = image_feats[i].repeat(k, 1, 1)
+            encoder_att = torch.ones(encoder_output.size()[:-1], dtype=torch.long)
+            output = m.get_cross_embeds(image_embeds=encoder_output, image_atts=encoder_att, text_ids=x.text_ids[topk_idx],
+                                        text_atts=x.text_atts[topk_idx], text_embeds=text_feats[topk_idx])
+            i2t[i, topk_idx] = m.itm_head(output[:, 0, :])[:, 1]
+        sims_matrix = sims_matrix.t()
+        t2i = torch.full(sims_matrix.shape, -100.0)
+        for i, sims in enumerate(sims_matrix):
+            topk_sim, topk_idx = sims.topk(k=k, dim=0)
+            encoder_output = image_feats[topk_idx]
+            encoder_att = torch.ones(encoder_output.size()[:-1], dtype=torch.long)
+            output = m.get_cross_embeds(image_embeds=encoder_output, image_atts=encoder_att, text_ids=x.text_ids[i].repeat(k, 1),
+                                        text_atts=x.text_atts[i].repeat(k, 1), text_embeds=text_feats[i].repeat(k, 1, 1))
+            t2i[i, topk_idx] = m.itm_head(output[:, 0, :])[:, 1]
+    out = {"sims": sims_matrix.t().numpy(), "score_i2t": i2t.numpy(), "score_t2i": t2i.numpy()}
+    print(out["score_i2t"], flush=True)
+    save("retrieval_eval", out, {"spec": spec_of(m), "text_layers": 2, "fusion_layers": 2})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -492,7 +533,7 @@ def main():
     torch.set_num_threads(8)
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr}
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval}
     if a.full:
         jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
     for k, fn in jobs.items():

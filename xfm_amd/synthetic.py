@@ -173,3 +173,12 @@ def vqa_inputs(B=3):
     weights = torch.tensor([0.6, 0.4, 1.0, 0.5, 0.3, 0.2][:sum(k)])
     return NS(image=b["image"], q_ids=b["text_ids"], q_atts=b["text_atts"], k=k, a_ids=ans["text_ids"], a_atts=ans["text_atts"],
               weights=weights, c_ids=cand["text_ids"], c_atts=cand["text_atts"], topk=3)
+
+
+def retrieval_eval_inputs(n_img=5, n_txt=8):
+    """Retrieval-evaluation fixture inputs: n_img images, n_txt captions (caption j describes image txt2img[j]), k_test = 3."""
+    from types import SimpleNamespace as NS
+    b = pretrain_batch(n_txt, seed=97)
+    txt2img = [j % n_img for j in range(n_txt)]
+    img2txt = [[j for j in range(n_txt) if txt2img[j] == i] for i in range(n_img)]
+    return NS(image=b["image"][:n_img], text_ids=b["text_ids"], text_atts=b["text_atts"], k_test=3, txt2img=txt2img, img2txt=img2txt)
