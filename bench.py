@@ -53,17 +53,10 @@ def build_model(device):
 
 
 def make_optimizer(model):
-    """optim.py:4-50: AdamW, lr 1e-4, wd 0.01, no decay on bias / LayerNorm, lr_mult 2 on init_params."""
-    no_decay = ("bias", "LayerNorm.bias", "LayerNorm.weight", "norm1", "norm2", "fc_norm", "layer_norm")
-    init = set(model.init_params)
-    groups = [[], [], [], []]
-    for n, p in model.named_parameters():
-        nd = any(t in n for t in no_decay) or p.dim() < 2
-        groups[(2 if n in init else 0) + (1 if nd else 0)].append(p)
-    lr, wd, mult = 1e-4, 0.01, 2
-    pg = [{"params": groups[0], "weight_decay": wd, "lr": lr}, {"params": groups[1], "weight_decay": 0.0, "lr": lr},
-          {"params": groups[2], "weight_decay": wd, "lr": lr * mult}, {"params": groups[3], "weight_decay": 0.0, "lr": lr * mult}]
-    return torch.optim.AdamW(pg, lr=lr, betas=(0.9, 0.98), eps=1e-8)
+    """optim.py:4-50 via the harness mirror: AdamW (0.9, 0.98), lr 1e-4, wd 0.01, the reference's name-based no-decay rule,
+    lr_mult 2 on model.init_params."""
+    from xfm_amd.pretrain_loop import AttrDict, create_optimizer
+    return create_optimizer(AttrDict(lr=1e-4, weight_decay=0.01, lr_mult=2), model)
 
 
 class GemmTimer:

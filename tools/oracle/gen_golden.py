@@ -525,6 +525,37 @@ def gen_retrieval_eval():
     save("retrieval_eval", out, {"spec": spec_of(m), "text_layers": 2, "fusion_layers": 2})
 
 
+def gen_harness():
+    """optim.py create_optimizer's four parameter groups on the reference pre-training model, and scheduler.py's linear schedule.
+    (transformers 5.x dropped `transformers.optimization.AdamW`; it is aliased to torch.optim.AdamW -- an API alias, the grouping
+    code under test is the reference's.)"""
+    import transformers.optimization as topt
+    if not hasattr(topt, "AdamW"):
+        topt.AdamW = torch.optim.AdamW
+    import optim as ref_optim
+    import scheduler as ref_sched
+    from models.model_pretrain import XFM
+    ref_shim.init_single_process_group()
+
+    class AD(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    m = XFM(ref_shim.pretrain_config(text_layers=2, fusion_layers=2), load_vision_params=False, load_text_params=False)
+    opt = ref_optim.create_optimizer(AD(lr=1e-4, weight_decay=0.01, lr_mult=2), m)
+    names = {id(p): n for n, p in m.named_parameters()}
+    groups = [[names[id(p)] for p in g["params"]] for g in opt.param_groups]
+    hyper = [[g["lr"], g["weight_decay"], list(g["betas"]), g["eps"]] for g in opt.param_groups]
+    sch = ref_sched.create_scheduler(AD(sched="linear", num_warmup_steps=0.1, epochs=2, step_per_epoch=10), opt)
+    lrs = []
+    for _ in range(23):
+        lrs.append([opt.param_groups[0]["lr"], opt.param_groups[2]["lr"]])
+        opt.step()
+        sch.step()
+    save("harness", {"lrs": np.asarray(lrs)}, {"groups": groups, "hyper": hyper, "init_params": list(m.init_params),
+                                               "text_layers": 2, "fusion_layers": 2})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -533,7 +564,7 @@ def main():
     torch.set_num_threads(8)
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval}
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval, "harness": gen_harness}
     if a.full:
         jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
     for k, fn in jobs.items():
