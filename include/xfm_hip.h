@@ -58,9 +58,9 @@ int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float
 /* fp32 master weight [N,K] -> bf16 copy wb[N,ldb] and/or transposed bf16 copy wt[K,ldt] (zero padded). */
 int xfm_cast_transpose(const float* w, int N, int K, xfm_bf16* wb, long ldb, xfm_bf16* wt, long ldt, void* stream);
 
-/* The same for a table of weights in one launch.  `items` is DEVICE memory, sorted by tile_start; item i covers the 32x32
- * tiles [tile_start, tile_start + tiles_x * tiles_y) with tiles_x = ceil(max(K, ldb if wb) / 32), tiles_y = ceil(max(N, ldt
- * if wt) / 32) (the padded extents, so the zero padding is rewritten too); total_tiles = the sum. */
+/* The same for a table of weights in one launch.  `items` is DEVICE memory, sorted by tile_start; item i covers the 64x64
+ * tiles [tile_start, tile_start + tiles_x * tiles_y) with tiles_x = ceil(max(K, ldb if wb) / 64), tiles_y = ceil(max(N, ldt
+ * if wt) / 64) (the padded extents, so the zero padding is rewritten too); total_tiles = the sum. */
 typedef struct {
   const float* w;
   xfm_bf16* wb;

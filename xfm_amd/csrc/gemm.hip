@@ -1208,10 +1208,10 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
 }
 
 // The same for a whole table of weights in ONE launch (a training step refreshes ~200 operands after the optimiser; at 7 us
-// a launch that is 1.3 ms of 32x32-tile kernels that each fill a fraction of the chip).  Workgroup -> item by binary search
-// over the items' first tile.
+// a launch that is 1.3 ms of 32x32-tile kernels that each fill a fraction of the chip).  64x64 tiles; workgroup -> item by
+// binary search over the items' first tile.
 __global__ __launch_bounds__(256) void cast_transpose_batch_kernel(const xfm_cast_item* __restrict__ items, int n_items) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[64][65];
   const long t = blockIdx.x;
   int lo = 0, hi = n_items - 1;
   while (lo < hi) {  // last item whose tile_start <= t
@@ -1220,25 +1220,54 @@ __global__ __launch_bounds__(256) void cast_transpose_batch_kernel(const xfm_cas
   }
   const xfm_cast_item it = items[lo];
   const long local = t - it.tile_start;
-  const int n0 = (int)(local / it.tiles_x) * 32, k0 = (int)(local % it.tiles_x) * 32;
+  const int n0 = (int)(local / it.tiles_x) * 64, k0 = (int)(local % it.tiles_x) * 64;
   const int N = it.N, K = it.K;
   const float* __restrict__ w = it.w;
   bf16* __restrict__ wb = reinterpret_cast<bf16*>(it.wb);
   bf16* __restrict__ wt = reinterpret_cast<bf16*>(it.wt);
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16: a thread owns 4 consecutive elements of a row
+  // fast path: a full interior tile with 16-B / 8-B aligned rows -> float4 loads, 8-B bf16x4 stores (128-B row segments both ways)
+  const bool fast = n0 + 64 <= N && k0 + 64 <= K && (K & 3) == 0 && ((uintptr_t)w & 15) == 0 &&
+                    (wb == nullptr || ((it.ldb & 3) == 0 && ((uintptr_t)wb & 7) == 0)) &&
+                    (wt == nullptr || ((it.ldt & 3) == 0 && ((uintptr_t)wt & 7) == 0));
+  if (fast) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + ty + i * 8, k = k0 + tx;
+    for (int i = 0; i < 4; ++i) {
+      const int n = ty + i * 16;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(w + (long)(n0 + n) * K + k0 + 4 * tx);
+      tile[n][4 * tx] = v[0]; tile[n][4 * tx + 1] = v[1]; tile[n][4 * tx + 2] = v[2]; tile[n][4 * tx + 3] = v[3];
+      if (wb != nullptr) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+        *reinterpret_cast<bf16x4*>(wb + (long)(n0 + n) * it.ldb + k0 + 4 * tx) = o;
+      }
+    }
+    __syncthreads();
+    if (wt != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = ty + i * 16;
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(tile[4 * tx + j][k]);
+        *reinterpret_cast<bf16x4*>(wt + (long)(k0 + k) * it.ldt + n0 + 4 * tx) = o;
+      }
+    }
+    return;
+  }
+  // edge tiles (and the zero padding out to ldb / ldt): element-wise
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int n = n0 + (e >> 6), k = k0 + (e & 63);
     const float v = (n < N && k < K) ? w[(long)n * K + k] : 0.f;
-    tile[ty + i * 8][tx] = v;
+    tile[e >> 6][e & 63] = v;
     if (wb != nullptr && n < N && k < it.ldb) wb[(long)n * it.ldb + k] = f2bf(v);
   }
   __syncthreads();
   if (wt != nullptr) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = k0 + ty + i * 8, n = n0 + tx;
-      if (k < K && n < it.ldt) wt[(long)k * it.ldt + n] = f2bf(tile[tx][ty + i * 8]);
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+      const int k = k0 + (e >> 6), n = n0 + (e & 63);
+      if (k < K && n < it.ldt) wt[(long)k * it.ldt + n] = f2bf(tile[e & 63][e >> 6]);
     }
   }
 }

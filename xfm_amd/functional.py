@@ -97,7 +97,7 @@ def cast_table(entries, device):
         assert w.dtype == F32 and w.is_contiguous()
         ldb = 0 if wb is None else wb.stride(0)
         ldt = 0 if wt is None else wt.stride(0)
-        tx, ty = (max(K, ldb) + 31) // 32, (max(N, ldt) + 31) // 32
+        tx, ty = (max(K, ldb) + 63) // 64, (max(N, ldt) + 63) // 64
         items[i] = _lib.CastItem(w.data_ptr(), _ptr(wb), _ptr(wt), ldb, ldt, N, K, tx, 0, tiles)
         tiles += tx * ty
     table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(device)
