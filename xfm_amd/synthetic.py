@@ -163,7 +163,7 @@ def mim_block_mask(batch_size, grid=14, num_masking=75, seed=1234):
 
 
 def vqa_inputs(B=3):
-    """VQA fixture inputs shared by the golden generator, the oracle test and the HIP test: B images + questions, k[b] answers per
+    """VQA fixture inputs shared by the golden generator and the CPU / GPU parity tests: B images + questions, k[b] answers per
     question with annotator weights, and a candidate answer list for the inference-time ranking (top `topk`)."""
     from types import SimpleNamespace as NS
     b = pretrain_batch(B, seed=91)
