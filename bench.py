@@ -225,11 +225,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    # Rehearsal knobs (not used by the driver): XFM_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and XFM_BENCH_BACKEND=gloo swaps RCCL
+    # for gloo, so the N > 1 code path (arena all-reduce on the side stream, ITC all-gather, per-rank batches) can be exercised with
+    # real kernels on a one-GPU box -- RCCL itself refuses two ranks on one device.  Numbers from such a run are meaningless.
+    if os.environ.get("XFM_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", world_size=world, rank=rank)
+        dist.init_process_group(os.environ.get("XFM_BENCH_BACKEND", "nccl"), world_size=world, rank=rank)
 
     from xfm_amd import synthetic as syn
     from xfm_amd.accelerators import RCCLDDPAccelerator

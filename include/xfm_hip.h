@@ -28,7 +28,7 @@ extern "C" {
 #define XFM_E_LAUNCH (-2)
 #define XFM_E_UNSUPPORTED (-3)
 
-#define XFM_ABI_VERSION 1
+#define XFM_ABI_VERSION 2
 
 const char* xfm_last_error(void);
 int xfm_abi_version(void);
@@ -194,7 +194,11 @@ typedef struct {
   long n;
 } xfm_adamw_args;
 int xfm_adamw(const xfm_adamw_args* a, void* stream);
-int xfm_sumsq(const float* x, long n, float* out, void* stream);
+/* out[0] += sum x[i]^2 (n % 4 == 0), bit-reproducible: fixed-grid block partials through `workspace`
+ * (XFM_SUMSQ_WORKSPACE_FLOATS floats, contents irrelevant) summed in a fixed order -- the clip coefficient derived from it must be
+ * identical on every data-parallel rank (apex_ddp_accelerator.py:100-110 clips after the all-reduce). */
+#define XFM_SUMSQ_WORKSPACE_FLOATS 1024
+int xfm_sumsq(const float* x, long n, float* out, float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

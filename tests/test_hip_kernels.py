@@ -482,6 +482,17 @@ def test_adamw_and_sumsq_flat_arena():
     ss = torch.zeros(1, device="cuda")
     Fx.sumsq(g, ss)
     _close(ss, (g.double() ** 2).sum().float().view(1), 1e-5, "sumsq")
+    # bit-reproducible (fixed-order partials, no atomics): data-parallel ranks derive the clip coefficient from it independently
+    big = _rand((1024 * 1024 * 8 + 4,), 0.1, F32, 112)
+    outs = []
+    for _ in range(3):
+        o = torch.zeros(1, device="cuda")
+        Fx.sumsq(big, o)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    _close(outs[0], (big.double() ** 2).sum().float().view(1), 1e-5, "sumsq (grid-capped)")
+    Fx.sumsq(g, outs[0])  # accumulates into out
+    _close(outs[0], ((big.double() ** 2).sum() + (g.double() ** 2).sum()).float().view(1), 1e-5, "sumsq accumulate")
     clip = torch.tensor([0.5], device="cuda")
     for step in (1, 2):
         Fx.adamw(p, g, m, v, group, lrs, wds, 0.9, 0.98, 1e-8, step, clip)

@@ -153,9 +153,9 @@ int xfm_adamw(const xfm_adamw_args* a, void* stream) {
   XFM_REQUIRE(a->p && a->g && a->m && a->v && a->group, "adamw: null operand");
   return xfm_adamw_impl(*a, ST(stream));
 }
-int xfm_sumsq(const float* x, long n, float* out, void* stream) {
-  XFM_REQUIRE(x && out, "sumsq: null operand");
-  return xfm_sumsq_impl(x, n, out, ST(stream));
+int xfm_sumsq(const float* x, long n, float* out, float* workspace, void* stream) {
+  XFM_REQUIRE(x && out && workspace, "sumsq: null operand");
+  return xfm_sumsq_impl(x, n, out, workspace, ST(stream));
 }
 
 }  // extern "C"

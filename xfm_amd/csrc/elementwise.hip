@@ -326,8 +326,11 @@ int xfm_adamw_impl(const AdamArgs& a, hipStream_t st) {
   return xfm_check_launch("adamw");
 }
 
-// sum of squares of an fp32 vector into out[0] (atomic across blocks; caller zeroes out)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+// out[0] += sum of squares of an fp32 vector, DETERMINISTIC: block partials in a fixed grid, then one workgroup adds them in a
+// fixed order.  The gradient norm feeds the clip coefficient of the optimizer, i.e. it is evaluated after the all-reduce on
+// every data-parallel rank: an atomic accumulation (rank-dependent rounding) makes the replicas' weights drift apart by an ulp
+// per step, which nothing ever re-synchronises.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
   __shared__ float red[4];
   float s = 0.f;
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
@@ -337,12 +340,24 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-int xfm_sumsq_impl(const float* x, long n, float* out, hipStream_t st) {
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] += (red[0] + red[1]) + (red[2] + red[3]);
+}
+int xfm_sumsq_impl(const float* x, long n, float* out, float* workspace, hipStream_t st) {
   XFM_REQUIRE(n > 0 && n % 4 == 0, "sumsq: length %ld must be a positive multiple of 4", n);
   int grid = cdiv(n, 1024);
-  if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, st, x, n, out);
-  return xfm_check_launch("sumsq");
+  if (grid > XFM_SUMSQ_WORKSPACE_FLOATS) grid = XFM_SUMSQ_WORKSPACE_FLOATS;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, st, x, n, workspace);
+  int rc = xfm_check_launch("sumsq");
+  if (rc != XFM_OK) return rc;
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, workspace, grid, out);
+  return xfm_check_launch("sumsq_final");
 }

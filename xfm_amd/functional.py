@@ -381,7 +381,8 @@ def ce_bwd(logits, V, labels, lse, scale, ldd):
 
 
 def sumsq(x, out):
-    check(_lib.load().xfm_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "sumsq")
+    ws = workspace(4096, x.device)  # XFM_SUMSQ_WORKSPACE_FLOATS block partials
+    check(_lib.load().xfm_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), _stream()), "sumsq")
 
 
 def adamw(p, g, m, v, group, lrs, wds, beta1, beta2, eps, step, clip_coef=None):
