@@ -38,12 +38,42 @@ def same_everywhere(t, what):
 
 
 same_everywhere(model._arena.data, "parameters after set_up")
-for step in range(3):
+
+
+fixed_mask = syn.mim_block_mask(B, 14, 75, seed=77 + rank)
+fixed_mask = (fixed_mask if torch.is_tensor(fixed_mask) else torch.from_numpy(fixed_mask)).to(dev)
+fixed_neg = ([(i + 1) % B for i in range(B)], [(i + 3) % B for i in range(B)])
+
+
+def fwd_bwd(fixed):
+    """fixed: eval mode (no dropout / drop-path) with given MIM masks and hard negatives -> two calls compute the same gradient."""
+    model.train(not fixed)
+    kw = dict(ids_mask=fixed_mask, neg_idx=fixed_neg) if fixed else {}
     losses = wrapped(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
-                     masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], ret_mim_loss=True, data_source="image")
+                     masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], ret_mim_loss=True, data_source="image", **kw)
     total = losses["loss_itc"] + losses["loss_itm"] + losses["loss_mlm"] + losses["loss_mim"]
     acc.backward_step(total, opt)
     torch.cuda.synchronize()
+    return losses
+
+
+for step in range(4):
+    err = float("nan")
+    if step < 2:  # step 0: plain sweep after backward (live ranges unknown yet); step 1: the overlapped, chunked exchange
+        # (a) what the exchange must produce: every rank's LOCAL gradient (accelerator told it is alone), averaged by hand
+        acc.world_size = 1
+        fwd_bwd(True)
+        expect = model._arena.grad.clone()
+        acc.world_size = world
+        dist.all_reduce(expect)
+        expect /= world
+        model._arena.zero_grad()
+        # (b) the same step, data parallel (tower hooks, chunked ViT exchange, final sweep)
+        losses = fwd_bwd(True)
+        err = float((model._arena.grad - expect).norm() / expect.norm())
+        assert err < 1e-3, f"rank {rank}: exchanged gradient is off the mean of the local gradients by {err:.3e} (rel. L2)"
+    else:
+        losses = fwd_bwd(False)  # training mode: dropout, drop-path, sampled masks and negatives
     same_everywhere(model._arena.grad, f"step {step}: exchanged gradients")
     assert bool(torch.isfinite(model._arena.grad).all()) and float(model._arena.grad.abs().max()) > 0
     acc.optimizer_step(opt, model)
@@ -51,8 +81,10 @@ for step in range(3):
     same_everywhere(model._arena.data, f"step {step}: parameters after the optimizer step")
     live = sum(b - a for a, b in acc._live)
     print(f"rank {rank} step {step}: losses {[round(float(v), 4) for v in losses.values()]} live {live}/{model._arena.numel} "
-          f"grad-norm {float(acc.last_grad_norm):.4f}", flush=True)
+          f"grad-norm {float(acc.last_grad_norm):.4f} exchange-vs-mean-of-locals {err:.2e} "
+          f"ranges sent from inside backward {[(b - a) // 2 ** 20 for a, b in acc.overlapped_ranges]} Mi-elements", flush=True)
 dist.barrier()
 if rank == 0:
-    print("DP2 REHEARSAL OK: gradients and parameters bit-identical across ranks for 3 steps", flush=True)
+    print("DP2 REHEARSAL OK: exchanged gradients = mean of the ranks' local gradients; gradients and parameters bit-identical "
+          "across ranks for 4 steps", flush=True)
 dist.destroy_process_group()

@@ -109,7 +109,13 @@ class RCCLDDPAccelerator(Accelerator):
         self._use = {}
         for name, mod, rng in self._towers:
             if not hasattr(mod, "roberta"):
-                continue  # the vision tower finishes last (patch-embed / cls grads trail its trunk): swept after backward
+                # the vision tower finishes last and its patch-embed / cls gradients trail the trunk (swept after backward), but
+                # the trunk's blocks can leave in chunks from inside its backward (beit2._TrunkFn.backward)
+                if hasattr(mod, "blocks"):
+                    self._use[id(mod)] = [0, name, None]
+                    mod._use_hook = self._on_use
+                    mod._block_grad_hook = self._on_blocks_done
+                continue
             nodes = [mod.roberta]
             for node in nodes:
                 self._use[id(node)] = [0, name, rng]
@@ -119,18 +125,31 @@ class RCCLDDPAccelerator(Accelerator):
         rec = self._use[id(node)]
         rec[0] += delta
         # overlap starts on step 2: step 1 first has to find out which arena ranges ever receive a gradient
-        if delta < 0 and rec[0] == 0 and self.world_size > 1 and self._sync_now and self._live is not None:
+        if delta < 0 and rec[0] == 0 and rec[2] is not None and self.world_size > 1 and self._sync_now and self._live is not None:
             self._launch(rec[2])
+
+    def _on_blocks_done(self, vit, lo, hi, wgrad_stream):
+        """Blocks [lo, hi) of the vision trunk have their final gradients (called from the trunk's backward).  Only when this
+        backward is the tower's last pending use of the step (two ViT passes accumulate into the same range).  Returns whether the
+        range was handed to the all-reduce."""
+        rec = self._use[id(vit)]
+        if not (rec[0] == 1 and self.world_size > 1 and self._sync_now and self._live is not None):
+            return False
+        ps = [p for b in vit.blocks[lo:hi] for p in b.parameters()]
+        self._launch(self.arena.range_of(ps), extra_stream=wgrad_stream)
+        return True
 
     def _live_chunks(self, lo, hi):
         """Sub-ranges of [lo, hi) that received a gradient on the first step (static afterwards)."""
         if self._live is None:
             return [(lo, hi)]
-        return [(a, b) for a, b in self._live if a >= lo and b <= hi]
+        return [(max(a, lo), min(b, hi)) for a, b in self._live if max(a, lo) < min(b, hi)]
 
-    def _launch(self, rng):
+    def _launch(self, rng, extra_stream=None):
         cur = torch.cuda.current_stream()
         self._comm_stream.wait_stream(cur)
+        if extra_stream is not None:  # weight-gradient GEMMs of the range still in flight on their own stream
+            self._comm_stream.wait_stream(extra_stream)
         with torch.cuda.stream(self._comm_stream):
             for a, b in self._live_chunks(*rng):
                 self._pending.append(dist.all_reduce(self.arena.grad[a:b], op=self._op, async_op=True))
@@ -156,8 +175,10 @@ class RCCLDDPAccelerator(Accelerator):
         if self._live is None:
             self._discover_live()
         done = sorted(self._done_ranges)
+        self.overlapped_ranges = list(done)  # (for logs / tests) what left for the all-reduce from inside backward this step
         todo, pos = [], 0
         for a, b in done + [(arena.numel, arena.numel)]:
+            assert a >= pos or a == b, f"arena range ({a}, {b}) was handed to the all-reduce twice in one step"
             if a > pos:
                 todo.append((pos, a))
             pos = max(pos, b)

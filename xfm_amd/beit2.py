@@ -203,6 +203,7 @@ class _TrunkFn(torch.autograd.Function):
         dstream = torch.zeros((M, D), dtype=torch.float32, device=dy.device)
         from .xroberta import _WgradStream
         wg = _WgradStream(dy.device)
+        done = len(blocks)
         for i in reversed(range(len(blocks))):
             blk, s = blocks[i], vit._slots[i]
             (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t) = ctx.saved[i]
@@ -232,6 +233,13 @@ class _TrunkFn(torch.autograd.Function):
             wg.gemm_tn(dqkv, y, s["qkv"].dw, dbias=s["qkv"].db)
             dy = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K)
             ctx.saved[i] = None
+            # data parallel: the gradients of blocks [i + 1, done) are final now (block i's own norm1 gradient is only written while
+            # block i - 1 is processed) once this pass is the tower's last pending use -- hand that arena range to the accelerator,
+            # so its all-reduce runs under the remaining blocks' backward
+            if ctx.noted and i > 0 and i % _GRAD_CHUNK_BLOCKS == 0 and i + 1 < done:
+                hook = getattr(vit, "_block_grad_hook", None)
+                if hook is not None and hook(vit, i + 1, done, wg.side if wg.on else None):
+                    done = i + 1
         x0, mean0, rstd0 = ctx.first
         n0 = blocks[0].norm1
         Fx.ln_bwd(dy, x0, mean0, rstd0, n0.weight, _g(n0.weight), _g(n0.bias), dx32=dstream, dx_accum=True)
@@ -239,6 +247,9 @@ class _TrunkFn(torch.autograd.Function):
         if ctx.noted:
             arena_note_grad(vit)
         return dstream.view(B, N, D), None, None
+
+
+_GRAD_CHUNK_BLOCKS = 4  # the trunk's gradients leave for the all-reduce in chunks of this many blocks (12 blocks: 3 chunks)
 
 
 def _g(p):
