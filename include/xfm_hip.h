@@ -162,6 +162,15 @@ int xfm_relpos_scatter_sorted(const float* ddense, const int* order, const int* 
 /* ---- Patch gather for the patch-embed GEMM (beit2.py:224-230) --------------------------------------------------- */
 int xfm_patchify(const float* image, int B, int C, int H, int W, int P, xfm_bf16* out, void* stream);
 
+/* ---- ViT token assembly (beit2.py:432-446: mask-token mix `x * (1 - w) + mask_token * w`, then cat(cls, x)) ----------------
+ * x0[b] = [cls | tok[b mod Bt], masked patches (mask[b, i] != 0) replaced by mask_token], fp32 [Bx, P + 1, D]; Bx a multiple
+ * of Bt (several masked views of the same patch-embedded images), mask [Bx, P] bytes or NULL.
+ * bwd: dtok [Bt, P, D] is written (sum over the views that kept the patch); dcls [D] and dmask_token [D] are accumulated. */
+int xfm_vit_tokens_fwd(const float* tok, const float* cls, const float* mask_token, const uint8_t* mask, int Bt, int Bx, int P,
+                       int D, float* x0, void* stream);
+int xfm_vit_tokens_bwd(const float* dx0, const uint8_t* mask, int Bt, int Bx, int P, int D, float* dtok, float* dcls,
+                       float* dmask_token, void* stream);
+
 /* ---- RoBERTa embeddings + LayerNorm + dropout (xroberta.py:104-137, 1747-1757) ----------------------------------- */
 typedef struct {
   const int64_t* ids;

@@ -169,6 +169,35 @@ def test_cast_transpose_batch_matches_single():
             assert torch.equal(wt, rt)
 
 
+@pytest.mark.parametrize("reps,masked", [(1, True), (2, True), (1, False)])
+def test_vit_token_assembly_fwd_bwd(reps, masked):
+    """beit2.py:432-446: x * (1 - w) + mask_token * w, then cat(cls, x) -- here for `reps` masked views of the same Bt images."""
+    Fx = _fx()
+    Bt, P, D = 3, 20, 768
+    Bx = Bt * reps
+    tok = _rand((Bt, P, D), 1.0, F32, 50).requires_grad_(True)
+    cls = _rand((1, 1, D), 1.0, F32, 51).requires_grad_(True)
+    mtok = _rand((1, 1, D), 1.0, F32, 52).requires_grad_(True)
+    mask = (_rand((Bx, P), 1.0, F32, 53) > 0.3) if masked else None
+    if masked:
+        mask[0] = False  # a clean view
+    x = tok.repeat(reps, 1, 1)
+    if masked:
+        w = mask.unsqueeze(-1).float()
+        x = x * (1 - w) + mtok.expand(Bx, P, -1) * w
+    ref = torch.cat([cls.expand(Bx, -1, -1), x], dim=1)
+    dx0 = _rand((Bx, P + 1, D), 1.0, F32, 54)
+    ref.backward(dx0)
+    got = Fx.vit_tokens_fwd(tok.detach(), cls.detach().view(-1), mtok.detach().view(-1), None if mask is None else mask.view(torch.uint8), Bx)
+    assert torch.equal(got, ref.detach())
+    dcls, dm = torch.ones(D, device="cuda"), torch.ones(D, device="cuda")
+    dtok = Fx.vit_tokens_bwd(dx0, None if mask is None else mask.view(torch.uint8), Bt, dcls, dm if masked else None)
+    _close(dtok, tok.grad, 1e-6, "dtok")
+    _close(dcls, cls.grad.view(-1) + 1.0, 1e-5, "dcls (accumulated)")
+    if masked:
+        _close(dm, mtok.grad.view(-1) + 1.0, 1e-5, "dmask_token (accumulated)")
+
+
 def _ln_ref(x, w, b, eps):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps)
 

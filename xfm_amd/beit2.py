@@ -249,6 +249,23 @@ class _TrunkFn(torch.autograd.Function):
         return dstream.view(B, N, D), None, None
 
 
+class _TokensFn(torch.autograd.Function):
+    """x0 = cat(cls, where(mask, mask_token, tok[b mod Bt])) in fp32; the cls / mask-token gradients are accumulated straight into
+    the gradient arena."""
+
+    @staticmethod
+    def forward(ctx, tok, cls_token, mask_token, mask_u8, Bx):
+        ctx.mask, ctx.Bt = mask_u8, tok.shape[0]
+        ctx.cls_token, ctx.mask_token = cls_token, mask_token
+        return Fx.vit_tokens_fwd(tok.contiguous(), cls_token.detach().reshape(-1), mask_token.detach().reshape(-1), mask_u8, Bx)
+
+    @staticmethod
+    def backward(ctx, dx0):
+        dmask = _g(ctx.mask_token).view(-1) if ctx.mask is not None else None
+        dtok = Fx.vit_tokens_bwd(dx0.contiguous(), ctx.mask, ctx.Bt, _g(ctx.cls_token).view(-1), dmask)
+        return dtok, None, None, None, None
+
+
 _GRAD_CHUNK_BLOCKS = 4  # the trunk's gradients leave for the all-reduce in chunks of this many blocks (12 blocks: 3 chunks)
 
 
@@ -363,13 +380,18 @@ class VisionTransformer(nn.Module):
         P = self.patch_embed.patch_size[0]
         patches = Fx.patchify(x.float().contiguous(), P)
         tok = linear_slot(patches, self._slot_patch, x_requires_grad=False, out_fp32=True).view(B, -1, D)
+        mask_u8 = None
         if do_mask:
             if ids_mask is None:
                 ids_mask = self.generator.batch(B, x.device)
-            ids_mask = ids_mask.to(device=x.device, dtype=torch.bool)
-            w = ids_mask.unsqueeze(-1).to(tok.dtype)
-            tok = tok * (1 - w) + self.mask_token.expand(B, tok.shape[1], -1) * w
-        x0 = torch.cat([self.cls_token.expand(B, -1, -1), tok], dim=1)
+            ids_mask = ids_mask.to(device=x.device, dtype=torch.bool).contiguous()
+            # several masked views of the SAME images in one pass: ids_mask [k * B, P] against B images (the pre-training step's
+            # clean + MIM-masked pair) -- patch gather, patch-embed GEMM and its weight gradient run once per image
+            assert ids_mask.shape[0] % B == 0, "ids_mask rows must be a multiple of the image batch"
+            mask_u8 = ids_mask.view(torch.uint8)
+            B = ids_mask.shape[0]
+        # mask-token mix + cls concat (beit2.py:432-446) as one kernel, forward and backward
+        x0 = _TokensFn.apply(tok, self.cls_token, self.mask_token, mask_u8, B)
         dp = drop_path_scales
         if dp is None and self.training:
             keep = getattr(self, "_dp_keep", None)

@@ -122,6 +122,16 @@ int xfm_patchify(const float* image, int B, int C, int H, int W, int P, xfm_bf16
   XFM_REQUIRE(image && out, "patchify: null operand");
   return xfm_patchify_impl(image, B, C, H, W, P, out, ST(stream));
 }
+int xfm_vit_tokens_fwd(const float* tok, const float* cls, const float* mask_token, const uint8_t* mask, int Bt, int Bx, int P,
+                       int D, float* x0, void* stream) {
+  XFM_REQUIRE(tok && cls && x0 && (mask == nullptr || mask_token != nullptr), "vit_tokens_fwd: null operand");
+  return xfm_vit_tokens_fwd_impl(tok, cls, mask_token, mask, Bt, Bx, P, D, x0, ST(stream));
+}
+int xfm_vit_tokens_bwd(const float* dx0, const uint8_t* mask, int Bt, int Bx, int P, int D, float* dtok, float* dcls,
+                       float* dmask_token, void* stream) {
+  XFM_REQUIRE(dx0 && dtok && dcls && (mask == nullptr || dmask_token != nullptr), "vit_tokens_bwd: null operand");
+  return xfm_vit_tokens_bwd_impl(dx0, mask, Bt, Bx, P, D, dtok, dcls, dmask_token, ST(stream));
+}
 
 int xfm_embed_ln_fwd(const xfm_embed_args* a, int D, void* stream) {
   NOTNULL(a, "embed_ln_fwd");

@@ -38,6 +38,104 @@ int xfm_patchify_impl(const float* img, int B, int C, int H, int W, int P, void*
 }
 
 // ---------------------------------------------------------------------------------------------
+// ViT token assembly (beit2.py:432-446): x0[b] = [cls | tok[b mod Bt] with masked patches replaced by mask_token], fp32.
+// Bx = reps * Bt output rows read the SAME Bt patch-embedded images (the pre-training step runs the clean and the MIM-masked
+// view of an image in one 2B pass: the patch-embed GEMM, its weight gradient and the image gather are done once per image).
+// Replaces tok * (1 - w) + mask_token * w, the cls concat and their five autograd kernels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vit_tokens_fwd_kernel(const float* __restrict__ tok, const float* __restrict__ cls,
+                                                             const float* __restrict__ mask_token, const uint8_t* __restrict__ mask,
+                                                             int Bt, int Bx, int P, int D, float* __restrict__ x0) {
+  const int d4 = D / 4;
+  const long total = (long)Bx * (P + 1) * d4;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int c = (int)(t % d4) * 4;
+    const long row = t / d4;
+    const int i = (int)(row % (P + 1)), b = (int)(row / (P + 1));
+    const float* src;
+    if (i == 0) src = cls + c;
+    else if (mask != nullptr && mask[(long)b * P + i - 1]) src = mask_token + c;
+    else src = tok + ((long)(b % Bt) * P + i - 1) * D + c;
+    *reinterpret_cast<f32x4*>(x0 + row * D + c) = *reinterpret_cast<const f32x4*>(src);
+  }
+}
+
+// dtok[s, i] = sum over the rows b = s (mod Bt) that kept patch i of dx0[b, 1 + i]   (written, not accumulated)
+__global__ __launch_bounds__(256) void vit_tokens_bwd_tok_kernel(const float* __restrict__ dx0, const uint8_t* __restrict__ mask, int Bt,
+                                                                 int Bx, int P, int D, float* __restrict__ dtok) {
+  const int d4 = D / 4;
+  const long total = (long)Bt * P * d4;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int c = (int)(t % d4) * 4;
+    const long row = t / d4;
+    const int i = (int)(row % P), s0 = (int)(row / P);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int b = s0; b < Bx; b += Bt) {
+      if (mask != nullptr && mask[(long)b * P + i]) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dx0 + ((long)b * (P + 1) + 1 + i) * D + c);
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    *reinterpret_cast<f32x4*>(dtok + row * D + c) = acc;
+  }
+}
+
+// dcls += sum_b dx0[b, 0];  dmask_token += sum over masked (b, i) of dx0[b, 1 + i].  One workgroup per slice of batch rows,
+// thread = 4 columns (D <= 1024), row skips are workgroup-uniform; 2 * D atomics per workgroup.
+__global__ __launch_bounds__(256) void vit_tokens_bwd_vec_kernel(const float* __restrict__ dx0, const uint8_t* __restrict__ mask, int Bx,
+                                                                 int P, int D, float* __restrict__ dcls, float* __restrict__ dmask_token) {
+  const int c = threadIdx.x * 4;
+  if (c >= D) return;
+  f32x4 ac = {0.f, 0.f, 0.f, 0.f}, am = {0.f, 0.f, 0.f, 0.f};
+  for (int b = blockIdx.x; b < Bx; b += gridDim.x) {
+    const float* base = dx0 + (long)b * (P + 1) * D + c;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(base);
+    ac[0] += v[0]; ac[1] += v[1]; ac[2] += v[2]; ac[3] += v[3];
+    if (mask == nullptr) continue;
+    for (int i = 0; i < P; ++i) {
+      if (!mask[(long)b * P + i]) continue;
+      const f32x4 u = *reinterpret_cast<const f32x4*>(base + (long)(1 + i) * D);
+      am[0] += u[0]; am[1] += u[1]; am[2] += u[2]; am[3] += u[3];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    atomicAdd(dcls + c + j, ac[j]);
+    if (mask != nullptr) atomicAdd(dmask_token + c + j, am[j]);
+  }
+}
+
+static int vit_tokens_check(int Bt, int Bx, int P, int D) {
+  XFM_REQUIRE(Bt > 0 && Bx >= Bt && Bx % Bt == 0 && P > 0 && D > 0 && D % 4 == 0 && D <= 1024,
+              "vit_tokens: bad shape Bt=%d Bx=%d P=%d D=%d (Bx must be a multiple of Bt, D a multiple of 4 and <= 1024)", Bt, Bx, P, D);
+  return XFM_OK;
+}
+
+int xfm_vit_tokens_fwd_impl(const float* tok, const float* cls, const float* mask_token, const uint8_t* mask, int Bt, int Bx, int P,
+                            int D, float* x0, hipStream_t st) {
+  int rc = vit_tokens_check(Bt, Bx, P, D);
+  if (rc != XFM_OK) return rc;
+  const long total = (long)Bx * (P + 1) * (D / 4);
+  int grid = cdiv(total, 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(vit_tokens_fwd_kernel, dim3(grid), dim3(256), 0, st, tok, cls, mask_token, mask, Bt, Bx, P, D, x0);
+  return xfm_check_launch("vit_tokens_fwd");
+}
+
+int xfm_vit_tokens_bwd_impl(const float* dx0, const uint8_t* mask, int Bt, int Bx, int P, int D, float* dtok, float* dcls,
+                            float* dmask_token, hipStream_t st) {
+  int rc = vit_tokens_check(Bt, Bx, P, D);
+  if (rc != XFM_OK) return rc;
+  const long total = (long)Bt * P * (D / 4);
+  int grid = cdiv(total, 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(vit_tokens_bwd_tok_kernel, dim3(grid), dim3(256), 0, st, dx0, mask, Bt, Bx, P, D, dtok);
+  rc = xfm_check_launch("vit_tokens_bwd");
+  if (rc != XFM_OK) return rc;
+  hipLaunchKernelGGL(vit_tokens_bwd_vec_kernel, dim3(Bx < 128 ? Bx : 128), dim3(256), 0, st, dx0, mask, Bx, P, D, dcls, dmask_token);
+  return xfm_check_launch("vit_tokens_bwd_vec");
+}
+
+// ---------------------------------------------------------------------------------------------
 // RoBERTa embeddings: y = dropout(LN(word[id] + type[0] + pos[p])), p = cumsum(id != pad) * (id != pad) + pad
 // (xroberta.py:104-137, :1747-1757); pos_mode 1 = BERT: p = t, no padding row in the position table (xbert.py:188-215).
 // One wave per token.

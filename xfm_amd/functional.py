@@ -315,6 +315,30 @@ def relpos_scatter(ddense, index32, H, N, ld, dtable):
 
 
 # --------------------------------------------------------------------------------------------- misc
+def vit_tokens_fwd(tok, cls, mask_token, mask, Bx):
+    """x0 [Bx, P+1, D] fp32 = [cls | tok[b mod Bt] with mask[b, i] patches replaced by mask_token]; tok fp32 [Bt, P, D], mask
+    uint8 [Bx, P] or None."""
+    _dev(tok)
+    Bt, P, D = tok.shape
+    assert tok.dtype == F32 and tok.is_contiguous() and cls.dtype == F32 and cls.numel() == D
+    assert mask is None or (mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape == (Bx, P))
+    x0 = torch.empty((Bx, P + 1, D), dtype=F32, device=tok.device)
+    check(_lib.load().xfm_vit_tokens_fwd(tok.data_ptr(), cls.data_ptr(), _ptr(mask_token), _ptr(mask), Bt, Bx, P, D, x0.data_ptr(),
+                                         _stream()), "vit_tokens_fwd")
+    return x0
+
+
+def vit_tokens_bwd(dx0, mask, Bt, dcls, dmask_token):
+    """-> dtok fp32 [Bt, P, D]; dcls / dmask_token (fp32 [D]) are accumulated in place."""
+    _dev(dx0)
+    Bx, P1, D = dx0.shape
+    assert dx0.dtype == F32 and dx0.is_contiguous()
+    dtok = torch.empty((Bt, P1 - 1, D), dtype=F32, device=dx0.device)
+    check(_lib.load().xfm_vit_tokens_bwd(dx0.data_ptr(), _ptr(mask), Bt, Bx, P1 - 1, D, dtok.data_ptr(), dcls.data_ptr(),
+                                         _ptr(dmask_token), _stream()), "vit_tokens_bwd")
+    return dtok
+
+
 def patchify(image, patch):
     _dev(image)
     assert image.dtype == F32 and image.is_contiguous()

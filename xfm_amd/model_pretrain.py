@@ -80,7 +80,9 @@ class XFM(XFMBase):
             if ids_mask is None:
                 ids_mask = self.vision_encoder.generator.batch(B, image.device)
             ids_mask = ids_mask.to(device=image.device, dtype=torch.bool)
-            both, _, _ = self.get_vision_embeds(torch.cat([image, image], dim=0), do_mask=True,
+            # one 2B-row ViT pass over the B images: rows [0, B) see them clean, rows [B, 2B) MIM-masked (the token assembly reads
+            # every image's patch embedding for both views)
+            both, _, _ = self.get_vision_embeds(image, do_mask=True,
                                                 ids_mask=torch.cat([torch.zeros_like(ids_mask), ids_mask], dim=0))
             image_embeds, image_embeds_masked = both[:B], both[B:]
             image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
