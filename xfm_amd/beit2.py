@@ -204,6 +204,7 @@ class _TrunkFn(torch.autograd.Function):
         from .xroberta import _WgradStream
         wg = _WgradStream(dy.device)
         done = len(blocks)
+        ddense_all = None
         for i in reversed(range(len(blocks))):
             blk, s = blocks[i], vit._slots[i]
             (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t) = ctx.saved[i]
@@ -225,7 +226,11 @@ class _TrunkFn(torch.autograd.Function):
             wg.gemm_tn(dh1, ctxv, s["proj"].dw)
             dctx = Fx.gemm_nt(dh1, s["proj"].wt, n=s["proj"].K)
             dqkv = torch.empty_like(qkv)
-            ddense = torch.zeros_like(dense) if dense is not None else None
+            ddense = None
+            if dense is not None:  # one zero fill for the whole trunk's bias-gradient scratch instead of one per block
+                if ddense_all is None:
+                    ddense_all = torch.zeros((len(blocks),) + tuple(dense.shape), dtype=dense.dtype, device=dense.device)
+                ddense = ddense_all[i]
             Fx.attn_bwd(dctx, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ctxv, lse, dqkv[:, :D], dqkv[:, D:2 * D],
                         dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense, bias_t=dense_t)
             if dense is not None:
