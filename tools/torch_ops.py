@@ -48,3 +48,13 @@ print("== the same by call site")
 for e in rows[:40]:
     stack = [f for f in e.stack if "xfm_amd" in f or "bench.py" in f][:2]
     print(f"{e.key:22s} calls={e.count:4d} gpu={dev_us(e):9.1f}us  {' <- '.join(x.strip()[-70:] for x in stack)}")
+print("== device activities named like copies / fills")
+for e in prof.key_averages():
+    n = e.key.lower()
+    if ("memcpy" in n or "memset" in n or "rocclr" in n or "fill" in n) and dev_us(e) > 0:
+        print(f"{e.key[:90]:90s} calls={e.count:4d} gpu={dev_us(e):9.1f}us")
+print("== host <-> device traffic and scalar materialisations (every one is a blit kernel or a sync on the stream)")
+for e in sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.count):
+    if e.key in ("aten::_to_copy", "aten::scalar_tensor", "aten::_local_scalar_dense", "aten::item", "aten::lift_fresh", "aten::tensor",
+                 "aten::full", "aten::arange", "aten::zeros", "aten::ones", "aten::empty_strided") or "Memcpy" in e.key:
+        print(f"{e.key:32s} calls={e.count:4d} cpu={e.cpu_time_total:9.1f}us gpu={dev_us(e):8.1f}us {str(e.input_shapes)[:90]}")
