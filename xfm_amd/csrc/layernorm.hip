@@ -370,7 +370,8 @@ static int reduce_sets_groups(int nblocks) { return nblocks >= 64 * REDUCE_SETS_
 int xfm_ln_bwd_grid(int rows) {
   static const int rpb = getenv("XFM_LN_BWD_ROWS") ? atoi(getenv("XFM_LN_BWD_ROWS")) : 8;  // tuning knob (8 measured: fusion tower 13.95 -> 13.56 ms)
   int blocks = cdiv(rows, rpb);  // rows per workgroup: enough waves per CU for an HBM-bound kernel at M = 7680
-  if (blocks > 768) blocks = 768;  // 3 blocks (12 waves) per CU: the kernel is HBM-bound and needs the loads in flight
+  static const int cap = getenv("XFM_LN_BWD_BLOCKS") ? atoi(getenv("XFM_LN_BWD_BLOCKS")) : 768;  // tuning knob
+  if (blocks > cap) blocks = cap;  // 3 blocks (12 waves) per CU: the kernel is HBM-bound and needs the loads in flight
   if (blocks < 1) blocks = 1;
   return blocks;
 }
