@@ -43,7 +43,11 @@ def test_pretrain_checkpoint_into_retrieval_model(tmp_path):
     assert set(raw.keys()) == set(meta["pretrain_spec"].keys())
 
 
-def test_resolution_change_is_refused(tmp_path):
+def test_resolution_change_resamples_relative_position_tables(tmp_path):
+    """224 -> 384 px: every block's table goes from 27 x 27 + 3 to 47 x 47 + 3 entries (beit2.py:763-821).  The reference's interp2d
+    call is gone from SciPy (parity unpinned, see beit2.interpolate_rel_pos_bias); what can be held is checked below."""
+    import numpy as np
+    from xfm_amd.beit2 import interpolate_rel_pos_bias, rel_pos_source_coordinates
     from xfm_amd.model_retrieval import XFMForRetrieval
     from xfm_amd.xfm import load_pretrained
     _, meta = load("checkpoint_surgery")
@@ -53,5 +57,30 @@ def test_resolution_change_is_refused(tmp_path):
     cfg = dict(_cfg(), image_res=384)
     with torch.device("meta"):
         m = XFMForRetrieval(cfg)
-    with pytest.raises(NotImplementedError, match="interp2d"):
-        load_pretrained(m, path, cfg, load_text=True)
+    out = load_pretrained(m, path, cfg, load_text=True)
+    tabs = [k for k in out if "relative_position_bias_table" in k]
+    assert len(tabs) == 12 and all(tuple(out[k].shape) == (47 * 47 + 3, 12) for k in tabs)
+    msg = m.load_state_dict(out, strict=False, assign=True)
+    assert not [k for k in msg.missing_keys if "relative_position_bias_table" in k]
+    # source coordinates: symmetric geometric progression through 0 and +-1 whose extent is the target's half-width
+    x = np.asarray(rel_pos_source_coordinates(27, 47))
+    assert len(x) == 27 and x[13] == 0 and x[14] == 1 and x[12] == -1 and np.allclose(x, -x[::-1]) and abs(x[-1] - 23.0) < 1e-3
+    assert np.all(np.diff(np.diff(x[13:])) > 0)  # spacing grows away from the centre
+    # a bicubic interpolating spline reproduces cubic polynomials of the coordinates exactly -> pins orientation and coordinates
+    yy, xx = np.meshgrid(x, x, indexing="ij")                      # table entry [j, i] sits at (x[i], y[j])
+    poly = lambda X, Y: 0.3 * X - 0.2 * Y + 0.01 * X * X * Y - 0.002 * Y ** 3 + 1.5
+    heads = 12
+    src = torch.tensor(poly(xx, yy), dtype=torch.float32).reshape(-1, 1).repeat(1, heads) * torch.arange(1, heads + 1)
+    extra = torch.arange(3 * heads, dtype=torch.float32).view(3, heads)
+    got = interpolate_rel_pos_bias(torch.cat([src, extra]), 47 * 47 + 3, (24, 24))
+    assert torch.equal(got[-3:], extra)
+    t = np.arange(-23.0, 23.1, 1.0)
+    ty, tx = np.meshgrid(t, t, indexing="ij")
+    want = torch.tensor(poly(tx, ty), dtype=torch.float32).reshape(-1, 1) * torch.arange(1, heads + 1)
+    assert torch.allclose(got[:-3], want, rtol=1e-4, atol=1e-3), float((got[:-3] - want).abs().max())
+    # an arbitrary table is reproduced wherever a target offset coincides with a source offset (0, +-1)
+    g = torch.Generator().manual_seed(0)
+    rnd = torch.randn(27 * 27 + 3, heads, generator=g)
+    got = interpolate_rel_pos_bias(rnd, 47 * 47 + 3, (24, 24))
+    assert torch.allclose(got[:-3].view(47, 47, heads)[22:25, 22:25], rnd[:-3].view(27, 27, heads)[12:15, 12:15], atol=1e-5)
+    assert interpolate_rel_pos_bias(rnd, 27 * 27 + 3, (14, 14)) is rnd  # same grid: untouched

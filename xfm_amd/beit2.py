@@ -410,11 +410,63 @@ class VisionTransformer(nn.Module):
         return (out, ids_mask) if do_mask else out
 
 
+def interpolate_rel_pos_bias(rel_pos_bias, dst_num_pos, dst_patch_shape):
+    """Relative-position table [src_num_pos, heads] -> [dst_num_pos, heads] for another patch grid (fine-tuning at 384 / 480 px),
+    beit2.py:763-821: the (2s-1)^2 grid part is resampled from geometric-progression source coordinates to the integer target
+    coordinates with a bicubic interpolating spline, the 3 extra (cls) entries are carried over.
+
+    PARITY UNPINNED: the reference calls `scipy.interpolate.interp2d(x, y, z, kind='cubic')`, removed in SciPy 1.14 (this image
+    has 1.15), so no fixture could be taken from it.  `RectBivariateSpline(kx=3, ky=3, s=0)` is the replacement SciPy's own
+    interp2d transition guide gives for rectilinear grids (same FITPACK interpolating spline; the guide states agreement to 1e-14).
+    What the tests do hold: exact reproduction of the source values wherever a target coordinate coincides with a source
+    coordinate (0 and +-1), the untouched extra tokens, and the geometric-progression coordinates themselves."""
+    import numpy as np
+    from scipy.interpolate import RectBivariateSpline
+    src_num_pos, num_attn_heads = rel_pos_bias.shape
+    if dst_patch_shape[0] != dst_patch_shape[1]:
+        raise NotImplementedError()
+    num_extra_tokens = dst_num_pos - (dst_patch_shape[0] * 2 - 1) * (dst_patch_shape[1] * 2 - 1)
+    src_size = int((src_num_pos - num_extra_tokens) ** 0.5)
+    dst_size = int((dst_num_pos - num_extra_tokens) ** 0.5)
+    if src_size == dst_size:
+        return rel_pos_bias
+    extra_tokens = rel_pos_bias[-num_extra_tokens:, :]
+    grid = rel_pos_bias[:-num_extra_tokens, :]
+    x = rel_pos_source_coordinates(src_size, dst_size)
+    t = dst_size // 2.0
+    dx = np.arange(-t, t + 0.1, 1.0)
+    out = []
+    for i in range(num_attn_heads):
+        z = grid[:, i].view(src_size, src_size).float().numpy().astype(np.float64)  # z[j, i] sits at (x[i], y[j]), interp2d's convention
+        f = RectBivariateSpline(x, x, z, kx=3, ky=3, s=0)                            # first axis = y: f(dy, dx)[j, i]
+        out.append(torch.tensor(f(dx, dx), dtype=torch.float32).contiguous().view(-1, 1).to(rel_pos_bias.device))
+    return torch.cat((torch.cat(out, dim=-1), extra_tokens), dim=0)
+
+
+def rel_pos_source_coordinates(src_size, dst_size):
+    """beit2.py:780-803: source relative offsets placed on a geometric progression whose half-extent matches the target's."""
+    def geometric_progression(a, r, n):
+        return a * (1.0 - r ** n) / (1.0 - r)
+
+    left, right = 1.01, 1.5
+    while right - left > 1e-6:
+        q = (left + right) / 2.0
+        gp = geometric_progression(1, q, src_size // 2)
+        if gp > dst_size // 2:
+            right = q
+        else:
+            left = q
+    dis, cur = [], 1
+    for i in range(src_size // 2):
+        dis.append(cur)
+        cur += q ** (i + 1)
+    return [-d for d in reversed(dis)] + [0] + dis
+
+
 def load_pretrained_beit2(model, ckpt_rpath):
-    """beit2.py:572-660 at equal resolution: unwrap `model` / `module`, drop the classification head and the
-    `relative_position_index` buffers, expand a shared relative-position table to every block, load with strict=False.
-    A table of another grid size would need the reference's `scipy.interpolate.interp2d` call (:640-655), which SciPy >= 1.14
-    removed -- refused, not approximated."""
+    """beit2.py:572-660: unwrap `model` / `module`, drop the classification head and the `relative_position_index` buffers, expand
+    a shared relative-position table to every block, resample tables of another grid size (`interpolate_rel_pos_bias`, parity
+    unpinned -- see there), load with strict=False."""
     checkpoint = torch.load(ckpt_rpath, map_location='cpu')
     checkpoint_model = None
     for model_key in ('model', 'module'):
@@ -434,8 +486,7 @@ def load_pretrained_beit2(model, ckpt_rpath):
         if "relative_position_index" in key:
             checkpoint_model.pop(key)
         elif "relative_position_bias_table" in key and key in own and own[key].shape != checkpoint_model[key].shape:
-            raise NotImplementedError(f"{key}: {tuple(checkpoint_model[key].shape)} -> {tuple(own[key].shape)} needs the reference's "
-                                      "interp2d-based interpolation (beit2.py:626-655), unavailable with SciPy >= 1.14")
+            checkpoint_model[key] = interpolate_rel_pos_bias(checkpoint_model[key], own[key].shape[0], model.patch_embed.patch_shape)
     msg = model.load_state_dict(checkpoint_model, strict=False)
     if getattr(model, "_arena", None) is not None:
         model._arena.bump()

@@ -157,8 +157,8 @@ def load_pretrained(model, ckpt_rpath, config, is_eval=False, load_text=False):
     drop the `relative_position_index` buffers (rebuilt by the model), and -- with `load_text` -- strip the `roberta.` / `bert.`
     level from `text_encoder.*` keys so that a pre-training checkpoint (text tower with LM heads) loads into a fine-tuning model
     (bare encoder).  Returns the state_dict to pass to `load_state_dict(strict=False)`.
-    Resolution changes are NOT handled: the reference interpolates the relative-position tables with
-    `scipy.interpolate.interp2d` (beit2.py:753-821), which SciPy >= 1.14 removed, so that arithmetic cannot be pinned here."""
+    A change of image resolution resamples the relative-position tables (`beit2.interpolate_rel_pos_bias`; the reference's
+    `scipy.interpolate.interp2d` call, beit2.py:753-821, no longer exists in SciPy >= 1.14, so that one function is parity-unpinned)."""
     checkpoint = torch.load(ckpt_rpath, map_location='cpu')
     state_dict = checkpoint['model'] if 'model' in checkpoint.keys() else checkpoint
     if is_eval:
@@ -171,8 +171,8 @@ def load_pretrained(model, ckpt_rpath, config, is_eval=False, load_text=False):
             if 'relative_position_index' in k:
                 del state_dict[k]
             elif 'relative_position_bias_table' in k and k[15:] in own and own[k[15:]].shape != state_dict[k].shape:
-                raise NotImplementedError(f"{k}: {tuple(state_dict[k].shape)} -> {tuple(own[k[15:]].shape)} needs the reference's "
-                                          "interp2d-based table interpolation (beit2.py:775-821), unavailable with SciPy >= 1.14")
+                from .beit2 import interpolate_rel_pos_bias
+                state_dict[k] = interpolate_rel_pos_bias(state_dict[k], own[k[15:]].shape[0], model.vision_encoder.patch_embed.patch_shape)
     if load_text:
         name_to_replace = 'roberta.' if 'roberta' in config['text_encoder'] else 'bert.'
         for key in list(state_dict.keys()):
