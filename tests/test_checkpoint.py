@@ -84,3 +84,38 @@ def test_resolution_change_resamples_relative_position_tables(tmp_path):
     got = interpolate_rel_pos_bias(rnd, 47 * 47 + 3, (24, 24))
     assert torch.allclose(got[:-3].view(47, 47, heads)[22:25, 22:25], rnd[:-3].view(27, 27, heads)[12:15, 12:15], atol=1e-5)
     assert interpolate_rel_pos_bias(rnd, 27 * 27 + 3, (14, 14)) is rnd  # same grid: untouched
+
+
+def test_pretrain_checkpoint_into_vqa_model(tmp_path):
+    """XFMForVQA.load_pretrained (model_generation.py:61-91) against what the reference's method did with the same checkpoint: which
+    parameters got loaded, and from which checkpoint key each came (text tower without its `roberta.` level; the answer decoder = a
+    copy of the fusion tower)."""
+    from xfm_amd.model_generation import XFMForVQA
+    _, meta = load("checkpoint_vqa")
+    spec = meta["pretrain_spec"]
+    # a checkpoint whose every tensor is filled with its own index: origins are readable from the values
+    names = sorted(spec.keys())
+    sd = {k: torch.full(spec[k][0], float(i + 1), dtype=_DT[spec[k][1]]) if len(spec[k][0]) else torch.tensor(float(i + 1)).to(_DT[spec[k][1]])
+          for i, k in enumerate(names)}
+    path = os.path.join(tmp_path, "ckpt.th")
+    torch.save({"model": sd, "epoch": 3}, path)
+    cfg = dict(_cfg(), pad_token_id=1, decoder_fusion_start_at=0, num_dec_layers=2)
+    with torch.device("meta"):
+        m = XFMForVQA(cfg)
+    ours = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+    assert ours == meta["vqa_spec"]
+    m = m.to_empty(device="cpu")  # real storage without the 300 M-parameter random init; zeroed below
+    with torch.no_grad():
+        for p in m.parameters():
+            p.zero_()
+        for b in m.buffers():
+            if b.dtype.is_floating_point:
+                b.zero_()
+    m.load_pretrained(path, cfg, is_eval=False)
+    after = m.state_dict()
+    loaded = sorted(k for k, v in after.items() if v.dtype.is_floating_point and float(v.double().abs().sum()) != 0.0)
+    want = [k for k in meta["loaded"] if after[k].dtype.is_floating_point]
+    assert loaded == sorted(want), (set(loaded) ^ set(want))
+    for k in loaded:
+        src = names[int(round(float(after[k].flatten()[0]))) - 1]
+        assert src in meta["origin"][k], (k, src, meta["origin"][k])

@@ -364,6 +364,38 @@ def gen_checkpoint():
                                     "unexpected": sorted(msg.unexpected_keys), "sums": sums})
 
 
+def gen_checkpoint_vqa():
+    """XFMForVQA.load_pretrained (model_generation.py:61-91): the same pre-training checkpoint into the VQA model -- text tower keys
+    lose their `roberta.` level, the answer decoder starts as a copy of the fusion tower."""
+    import tempfile
+    from models.model_pretrain import XFM
+
+    def build_tokenizer(*a, **kw):
+        raise RuntimeError("stub")
+
+    ref_shim._stub("dataset", build_tokenizer=build_tokenizer)
+    from models.model_generation import XFMForVQA
+    ref_shim.init_single_process_group()
+    torch.manual_seed(0)
+    cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2,
+                                   overrides={"pad_token_id": 1, "decoder_fusion_start_at": 0, "num_dec_layers": 2})
+    pre = XFM(cfg, load_vision_params=False, load_text_params=False)
+    sd = syn.formula_state_dict(pre.state_dict())
+    path = os.path.join(tempfile.mkdtemp(), "ckpt.th")
+    torch.save({"model": sd, "epoch": 3}, path)
+    m = XFMForVQA(cfg)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_pretrained(path, cfg, is_eval=False)
+    after = m.state_dict()
+    loaded = sorted(k for k in after if not torch.equal(after[k], before[k]))
+    # where did every loaded tensor come from?  (checksum match against the checkpoint)
+    by_sum = {}
+    for k, v in sd.items():
+        by_sum.setdefault(round(float(v.double().sum()), 6), []).append(k)
+    origin = {k: sorted(by_sum.get(round(float(after[k].double().sum()), 6), [])) for k in loaded}
+    save("checkpoint_vqa", {}, {"pretrain_spec": spec_of(pre), "vqa_spec": spec_of(m), "loaded": loaded, "origin": origin})
+
+
 def _beit_ckpt_config(depth_spec_model):
     """A synthetic BEiT-v2 checkpoint + vision_config json for models that are built with load_vision_params=True."""
     import tempfile
@@ -564,7 +596,7 @@ def main():
     torch.set_num_threads(8)
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval, "harness": gen_harness}
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval, "harness": gen_harness, "checkpoint_vqa": gen_checkpoint_vqa}
     if a.full:
         jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
     for k, fn in jobs.items():
