@@ -587,3 +587,52 @@ def itm_eval(scores_i2t, scores_t2i, txt2img, img2txt):
     tr_mean, ir_mean = (tr1 + tr5 + tr10) / 3, (ir1 + ir5 + ir10) / 3
     return {'txt_r1': tr1, 'txt_r5': tr5, 'txt_r10': tr10, 'txt_r_mean': tr_mean, 'img_r1': ir1, 'img_r5': ir5, 'img_r10': ir10,
             'img_r_mean': ir_mean, 'r_mean': (tr_mean + ir_mean) / 2}
+
+
+# --------------------------------------------------------------------------------------
+# XFMForGrounding (models/model_grounding.py) and the box loss (xfm.py:815-854, models/box_ops.py)
+# --------------------------------------------------------------------------------------
+def box_cxcywh_to_xyxy(x):
+    """box_ops.py:9-13."""
+    x_c, y_c, w, h = x.unbind(-1)
+    return torch.stack([x_c - 0.5 * w, y_c - 0.5 * h, x_c + 0.5 * w, y_c + 0.5 * h], dim=-1)
+
+
+def generalized_box_iou(boxes1, boxes2):
+    """box_ops.py:24-59, the full N x M matrix as the reference builds it (torchvision's box_area = (x1 - x0)(y1 - y0))."""
+    area1 = (boxes1[:, 2] - boxes1[:, 0]) * (boxes1[:, 3] - boxes1[:, 1])
+    area2 = (boxes2[:, 2] - boxes2[:, 0]) * (boxes2[:, 3] - boxes2[:, 1])
+    lt = torch.max(boxes1[:, None, :2], boxes2[:, :2])
+    rb = torch.min(boxes1[:, None, 2:], boxes2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    union = area1[:, None] + area2 - inter
+    iou = inter / union
+    lt = torch.min(boxes1[:, None, :2], boxes2[:, :2])
+    rb = torch.max(boxes1[:, None, 2:], boxes2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    area = wh[:, :, 0] * wh[:, :, 1]
+    return iou - (area - union) / area
+
+
+def bbox_loss(output_coord, target_bbox, is_image=None):
+    """XFMBase.get_bbox_loss xfm.py:815-840."""
+    loss_bbox = F.l1_loss(output_coord, target_bbox, reduction="none")
+    boxes1, boxes2 = box_cxcywh_to_xyxy(output_coord), box_cxcywh_to_xyxy(target_bbox)
+    if (boxes1[:, 2:] < boxes1[:, :2]).any() or (boxes2[:, 2:] < boxes2[:, :2]).any():
+        loss_giou = torch.zeros(output_coord.size(0))
+    else:
+        loss_giou = 1 - torch.diag(generalized_box_iou(boxes1, boxes2))
+    if is_image is None:
+        num_boxes = target_bbox.size(0)
+    else:
+        num_boxes = torch.sum(1 - is_image)
+        loss_bbox = loss_bbox * (1 - is_image.view(-1, 1))
+        loss_giou = loss_giou * (1 - is_image)
+    return loss_bbox.sum() / num_boxes, loss_giou.sum() / num_boxes
+
+
+def grounding_forward(P, cfg, image, text_ids, text_atts):
+    """XFMForGrounding.forward model_grounding.py:50-62 -> output_coord [B, 4] (predict_bbox xfm.py:843-854, is_pretrain=False)."""
+    states = fused_question_states(P, cfg, image, text_ids, text_atts)  # the same image / text / fusion composition as the VQA model
+    return build_mlp_forward(P, "bbox_head.", states[:, 0, :]).sigmoid()

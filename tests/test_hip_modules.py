@@ -437,6 +437,26 @@ def test_retrieval_evaluation_vs_golden():
         assert np.allclose(np.where(owned_a[:, None], a, b), full, atol=2e-2)
 
 
+def test_grounding_model_vs_golden():
+    """model_grounding.XFMForGrounding: box regression from the fused [CLS], L1 + GIoU losses and gradients."""
+    from xfm_amd.model_grounding import XFMForGrounding
+    z, meta = load("grounding_small")
+    m = XFMForGrounding(_pretrain_cfg(meta))
+    ours = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+    assert ours == meta["spec"]
+    _load_into(m, meta["spec"])
+    m.cuda().finalize().eval()
+    b = {k: v.cuda() for k, v in syn.pretrain_batch(meta["B"], seed=99).items()}
+    target = torch.tensor(meta["target"]).cuda()
+    with torch.no_grad():
+        coord = m(b["image"], b["text_ids"], b["text_atts"])
+    assert np.abs(coord.float().cpu().numpy() - z["coord"]).max() < 1e-2
+    coord, l1, giou = m(b["image"], b["text_ids"], b["text_atts"], target_bbox=target)
+    assert abs(float(l1) - float(z["loss_bbox"])) < 2e-2 and abs(float(giou) - float(z["loss_giou"])) < 2e-2
+    (l1 + giou).backward()
+    _check_grads(z, "grad", m, min_rms=1e-6)
+
+
 def test_nlvr_model_vs_golden():
     from xfm_amd.model_nlvr import XFMForNLVR
     z, meta = load("nlvr_small")

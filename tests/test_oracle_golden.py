@@ -270,6 +270,33 @@ def test_retrieval_evaluation_rerank_and_recall():
         assert abs(got['r_mean'] - ((100.0 / 3 + 200.0) / 3 + (75.0 + 200.0) / 3) / 2) < 1e-9
 
 
+def test_grounding_model_and_box_losses():
+    z, meta = load("grounding_small")
+    P = _params(meta["spec"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    b = syn.pretrain_batch(meta["B"], seed=99)
+    target = torch.tensor(meta["target"])
+    coord = O.grounding_forward(P, cfg, b["image"], b["text_ids"], b["text_atts"])
+    assert np.allclose(coord.detach().numpy(), z["coord"], atol=2e-5)
+    l1, giou = O.bbox_loss(coord, target)
+    assert abs(float(l1) - float(z["loss_bbox"])) < 2e-5 and abs(float(giou) - float(z["loss_giou"])) < 2e-5
+    (l1 + giou).backward()
+    _check_grads(z, "grad", P)
+    # the product path's paired (diagonal-only) GIoU and its sync-free degenerate-box rule agree with the reference formulation
+    from xfm_amd import box_ops
+    g = torch.Generator().manual_seed(3)
+    c1, c2 = torch.rand(16, 4, generator=g) * 0.5 + 0.1, torch.rand(16, 4, generator=g) * 0.5 + 0.1
+    b1, b2 = box_ops.box_cxcywh_to_xyxy(c1), box_ops.box_cxcywh_to_xyxy(c2)
+    assert torch.allclose(box_ops.paired_generalized_box_iou(b1, b2), torch.diag(O.generalized_box_iou(b1, b2)), atol=1e-6)
+    assert torch.allclose(box_ops.box_xyxy_to_cxcywh(b1), c1, atol=1e-6)
+    from xfm_amd.xfm import XFMBase
+    is_image = torch.tensor([0, 1] * 8)
+    for co, tg, im in ((c1, c2, None), (c1, c2, is_image), (c1, torch.cat([c2[:15], torch.tensor([[0.5, 0.5, -0.2, 0.1]])]), None)):
+        want = O.bbox_loss(co, tg, im)
+        got = XFMBase.get_bbox_loss(None, co, tg, im)
+        assert abs(float(got[0]) - float(want[0])) < 1e-6 and abs(float(got[1]) - float(want[1])) < 1e-6
+
+
 def _pretrain(name):
     z, meta = load(name)
     B = meta["B"]

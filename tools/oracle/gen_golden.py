@@ -557,6 +557,33 @@ def gen_retrieval_eval():
     save("retrieval_eval", out, {"spec": spec_of(m), "text_layers": 2, "fusion_layers": 2})
 
 
+def grounding_targets(B):
+    return torch.tensor([[0.5, 0.5, 0.4, 0.6], [0.3, 0.6, 0.2, 0.3], [0.7, 0.25, 0.5, 0.4], [0.45, 0.55, 0.9, 0.8]][:B])
+
+
+def gen_grounding(B=3):
+    """models/model_grounding.py XFMForGrounding: predicted box, L1 + GIoU losses and their gradients."""
+    from models.model_grounding import XFMForGrounding
+    ref_shim.init_single_process_group()
+    torch.manual_seed(0)
+    cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2)
+    m = XFMForGrounding(cfg)
+    load_formula(m)
+    m.eval()
+    b = syn.pretrain_batch(B, seed=99)
+    target = grounding_targets(B)
+    out = {}
+    coord, loss_bbox, loss_giou = m(b["image"], b["text_ids"], b["text_atts"], target_bbox=target)
+    out["coord"] = coord.detach().numpy()
+    out["loss_bbox"], out["loss_giou"] = np.asarray(float(loss_bbox.detach())), np.asarray(float(loss_giou.detach()))
+    print("coord", coord.tolist(), float(loss_bbox), float(loss_giou), flush=True)
+    (loss_bbox + loss_giou).backward()
+    grads_of(m, out)
+    unused = [n for n, p in m.named_parameters() if p.grad is None]
+    save("grounding_small", out, {"spec": spec_of(m), "B": B, "target": target.tolist(), "text_layers": 2, "fusion_layers": 2,
+                                  "unused": unused})
+
+
 def gen_harness():
     """optim.py create_optimizer's four parameter groups on the reference pre-training model, and scheduler.py's linear schedule.
     (transformers 5.x dropped `transformers.optimization.AdamW`; it is aliased to torch.optim.AdamW -- an API alias, the grouping
@@ -596,7 +623,7 @@ def main():
     torch.set_num_threads(8)
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval, "harness": gen_harness, "checkpoint_vqa": gen_checkpoint_vqa}
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval, "harness": gen_harness, "checkpoint_vqa": gen_checkpoint_vqa, "grounding": gen_grounding}
     if a.full:
         jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
     for k, fn in jobs.items():

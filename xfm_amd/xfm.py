@@ -334,6 +334,36 @@ class XFMBase(nn.Module):
         return enc(encoder_embeds=encoder_embeds, attention_mask=text_atts, encoder_hidden_states=image_embeds,
                    encoder_attention_mask=image_atts, return_dict=True).last_hidden_state
 
+    # ---- grounding head ----------------------------------------------------------------------------
+    def predict_bbox(self, image_embeds, text_ids, text_atts, text_embeds, is_pretrain=True):
+        """xfm.py:843-854: fused [CLS] -> bbox_head -> sigmoid, (cx, cy, w, h) in [0, 1]."""
+        assert image_embeds.size(0) == text_ids.size(0) == text_atts.size(0)
+        image_atts = torch.ones(image_embeds.shape[:2], dtype=torch.long, device=image_embeds.device)
+        output_cls = self.get_cross_embeds(image_embeds, image_atts, text_ids=text_ids, text_atts=text_atts, text_embeds=text_embeds,
+                                           is_pretrain=is_pretrain)[:, 0, :]
+        return self.bbox_head(output_cls).float().sigmoid()
+
+    def get_bbox_loss(self, output_coord, target_bbox, is_image=None):
+        """L1 + GIoU (xfm.py:815-840).  The reference checks for degenerate boxes with `.any()` on the host and then zeroes the GIoU
+        term of the whole batch; the same rule here is a device-side select (no sync), evaluated on stand-in boxes when it fires so
+        that no NaN reaches the backward."""
+        from . import box_ops
+        output_coord, target_bbox = output_coord.float(), target_bbox.float()
+        loss_bbox = F.l1_loss(output_coord, target_bbox, reduction='none')
+        boxes1 = box_ops.box_cxcywh_to_xyxy(output_coord)
+        boxes2 = box_ops.box_cxcywh_to_xyxy(target_bbox)
+        degenerate = (boxes1[:, 2:] < boxes1[:, :2]).any() | (boxes2[:, 2:] < boxes2[:, :2]).any()
+        unit = torch.tensor([0.0, 0.0, 1.0, 1.0], device=boxes1.device).expand_as(boxes1)
+        giou = box_ops.paired_generalized_box_iou(torch.where(degenerate, unit, boxes1), torch.where(degenerate, unit, boxes2))
+        loss_giou = torch.where(degenerate, torch.zeros_like(giou), 1 - giou)
+        if is_image is None:
+            num_boxes = target_bbox.size(0)
+        else:
+            num_boxes = torch.sum(1 - is_image)
+            loss_bbox = loss_bbox * (1 - is_image.view(-1, 1))
+            loss_giou = loss_giou * (1 - is_image)
+        return loss_bbox.sum() / num_boxes, loss_giou.sum() / num_boxes
+
     # ---- losses ---------------------------------------------------------------------------------
     def get_contrastive_loss(self, image_feat, text_feat, idx=None):
         assert image_feat.size(-1) == self.embed_dim and text_feat.size(-1) == self.embed_dim
