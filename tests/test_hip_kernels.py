@@ -330,6 +330,9 @@ def _attn_ref(q, k, v, B, H, Sq, Sk, scale, bias=None, keep=None, causal=False, 
     (3, 12, 30, 197, False, True, False),    # cross-attention text -> image tokens
     (2, 4, 30, 30, False, True, True),       # causal decoder
     (1, 2, 130, 300, True, True, False),     # several key chunks, tails on both sides
+    (1, 12, 577, 577, True, False, False),   # BEiT at 384 px (BASELINE configs[2]): streamed keys, bias gradient by atomics
+    (2, 12, 40, 577, False, True, False),    # cross-attention of 40-token captions onto a 384 px image
+    (1, 3, 901, 901, True, False, False),    # 480 px (VQA fine-tuning)
     (1, 1, 2, 3, False, False, False),
 ])
 def test_attention_fwd_bwd(B, H, Sq, Sk, use_bias, use_keep, causal):

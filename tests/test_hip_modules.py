@@ -108,6 +108,37 @@ def test_beit_tower_vs_golden():
     _check_grads(z, "grad_masked", m)
 
 
+def test_beit_tower_at_384px_vs_oracle():
+    """The fine-tuning resolution of BASELINE configs[2] (retrieval, 384 px: 24 x 24 patches, 577 tokens, 47 x 47 + 3 relative
+    positions): streamed attention keys, the larger relative-position table and its gradient.  No reference fixture at this size; the
+    CPU oracle (itself pinned at 224 px) is the checker."""
+    from oracle import xfm_oracle as O
+    from xfm_amd.beit2 import VisionTransformer
+    m = VisionTransformer(img_size=384, depth=1, drop_path_rate=0.0)
+    spec = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+    sd = _load_into(m, spec)
+    assert tuple(sd["blocks.0.attn.relative_position_bias_table"].shape) == (47 * 47 + 3, 12)
+    m.cuda().finalize().eval()
+    image = syn.gaussian("beit384.image", (1, 3, 384, 384))
+    cot = syn.symmetric("beit384.cot", (1, 577, 768), 1.0)
+    y = m(image.cuda())
+    (y.float() * cot.cuda()).sum().backward()
+    P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    ref = O.beit_forward({"v." + k: v for k, v in P.items()}, "v.", image, depth=1)
+    (ref * cot).sum().backward()
+    err = float((y.float().cpu() - ref).norm() / ref.norm())
+    assert err <= OUT_TOL, err
+    worst = 0.0
+    for name, p in m.named_parameters():
+        g = P[name].grad
+        if g is None or float(g.norm()) < 1e-6:
+            continue
+        e = float((p.grad.float().cpu() - g).norm() / g.norm())
+        worst = max(worst, e)
+        assert e <= GRAD_TOL, (name, e)
+    print(f"384 px: output rel-L2 {err:.4f}, worst gradient rel-L2 {worst:.4f}")
+
+
 def _roberta(layers, fusion_layer):
     from xfm_amd.xroberta import RobertaConfig, RobertaForMaskedLM
     cfg = RobertaConfig(num_hidden_layers=layers, fusion_layer=fusion_layer, encoder_width=768)
