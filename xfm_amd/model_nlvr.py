@@ -17,16 +17,16 @@ class XFMForNLVR(XFMBase):
             self.init_params = ['cls_head.' + n for n, _ in self.cls_head.named_parameters()]
 
     def forward(self, image, text_ids, text_atts, targets, train=True):
-        """image: [2B, 3, H, W] -- the B first images followed by the B second images (model_nlvr.py:28)."""
+        """image: [2B, 3, H, W] -- the B first images followed by the B second images (model_nlvr.py:28).
+        The reference fuses the statement with each image in two B-row passes (:31-35); here both pairs go through the fusion tower as
+        ONE 2B-row pass (statement rows repeated), which computes the same rows with half the launches."""
         image_embeds, image_atts = self.get_vision_embeds(image)
-        encoder_embeds = self.get_text_embeds(text_ids, text_atts)
+        statement = self.get_text_embeds(text_ids, text_atts)
         n = targets.size(0)
-        image0_embeds, image1_embeds = torch.split(image_embeds, n)
-        cls0 = self.get_cross_embeds(image0_embeds, image_atts[:n], text_embeds=encoder_embeds, text_atts=text_atts,
-                                     is_pretrain=False)[:, 0, :]
-        cls1 = self.get_cross_embeds(image1_embeds, image_atts[n:], text_embeds=encoder_embeds, text_atts=text_atts,
-                                     is_pretrain=False)[:, 0, :]
-        output_cls = torch.cat((cls0, cls1), dim=-1)
-        assert output_cls.shape[-1] == self.text_width * 2
-        prediction = self.cls_head(output_cls)
-        return F.cross_entropy(prediction.float(), targets) if train else prediction
+        assert image_embeds.size(0) == 2 * n, "two images per statement"
+        fused_cls = self.get_cross_embeds(image_embeds, image_atts, text_embeds=statement.repeat(2, 1, 1), text_atts=text_atts.repeat(2, 1),
+                                          is_pretrain=False)[:, 0, :]
+        pair = torch.cat((fused_cls[:n], fused_cls[n:]), dim=-1)   # [B, 2 * width]: (first image | second image)
+        assert pair.shape[-1] == self.text_width * 2
+        logits = self.cls_head(pair)
+        return F.cross_entropy(logits.float(), targets) if train else logits
