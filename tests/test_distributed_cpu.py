@@ -99,6 +99,49 @@ def test_accelerator_broadcast_allreduce_and_step_world2():
     assert r0["grad_after"] == 0.0
 
 
+def _multi_source_worker(rank, world, init_file, out):
+    """Pretrain.py:219-239: several backward_steps (web, imagenet, image batches) before ONE optimizer_step."""
+    from xfm_amd.accelerators import ACCELERATOR_MAP
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    model = Tiny()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    acc = ACCELERATOR_MAP["RCCLDDP"]({"RNG_SEED": 1, "CLIP_GRAD_NORM": 0.0, "GRAD_ACCUMULATE_STEPS": 1})
+    wrapped, opt, _ = acc.set_up(model, opt, None, local_rank=rank, world_size=world, rank=rank)
+    w0 = model.vision_encoder.weight.detach().clone()
+    xs = []
+    for k in range(3):  # three sources, one backward each, gradients accumulate in the arena
+        torch.manual_seed(1000 * k + rank)
+        x = torch.randn(4, 8)
+        xs.append(x)
+        acc.backward_step(wrapped(x).pow(2).mean() * (k + 1), opt)
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    acc.optimizer_step(opt, model)
+    torch.save({"w0": w0, "xs": xs, "grads": grads, "w1": model.vision_encoder.weight.detach().clone()}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_several_backward_steps_before_one_optimizer_step_world2():
+    """The reference's Apex DDP all-reduces at the end of every backward; re-averaging the already averaged part of the arena leaves
+    it unchanged, so after three sources the gradient is the sum over sources of the rank-mean."""
+    r0, r1 = _spawn(_multi_source_worker)
+    ref = Tiny()
+    want = None
+    for k in range(3):
+        per_rank = []
+        for r in (r0, r1):
+            ref.zero_grad()
+            (ref(r["xs"][k]).pow(2).mean() * (k + 1)).backward()
+            per_rank.append({n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None})
+        mean = {n: (per_rank[0][n] + per_rank[1][n]) / 2 for n in per_rank[0]}
+        want = mean if want is None else {n: want[n] + mean[n] for n in mean}
+    for n, g in want.items():
+        if n.startswith("unused_head"):
+            continue
+        assert torch.allclose(r0["grads"][n], g, atol=2e-6), n
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), n
+    assert torch.allclose(r0["w1"], r0["w0"] - 0.1 * want["vision_encoder.weight"], atol=2e-6) and torch.equal(r0["w1"], r1["w1"])
+
+
 def _itc_worker(rank, world, init_file, out):
     from xfm_amd.xfm import allgather
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
