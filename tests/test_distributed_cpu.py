@@ -55,8 +55,8 @@ def _accelerator_worker(rank, world, init_file, out):
     loss = wrapped(x).pow(2).mean()
     acc.backward_step(loss, opt)
     grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
-    live = list(acc._live)
     acc.optimizer_step(opt, model)
+    live = list(acc._live)  # decided at the first optimizer step, once every source of the step has run its backward
     torch.save({"w0": w0, "grads": grads, "live": live, "x": x, "numel": model._arena.numel,
                 "unused_range": model._arena.range_of(list(model.unused_head.parameters())),
                 "w1": model.vision_encoder.weight.detach().clone(),
@@ -113,10 +113,13 @@ def _multi_source_worker(rank, world, init_file, out):
         torch.manual_seed(1000 * k + rank)
         x = torch.randn(4, 8)
         xs.append(x)
-        acc.backward_step(wrapped(x).pow(2).mean() * (k + 1), opt)
+        # the FIRST source only reaches the vision tower (like an ImageNet MIM batch): the live-range map must not be frozen on it
+        y = model.vision_encoder(x) if k == 0 else wrapped(x)
+        acc.backward_step(y.pow(2).mean() * (k + 1), opt)
     grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
     acc.optimizer_step(opt, model)
-    torch.save({"w0": w0, "xs": xs, "grads": grads, "w1": model.vision_encoder.weight.detach().clone()}, out + f".{rank}")
+    torch.save({"w0": w0, "xs": xs, "grads": grads, "w1": model.vision_encoder.weight.detach().clone(), "live": list(acc._live or []),
+                "text_range": model._arena.range_of(list(model.text_encoder.parameters()))}, out + f".{rank}")
     dist.destroy_process_group()
 
 
@@ -130,16 +133,20 @@ def test_several_backward_steps_before_one_optimizer_step_world2():
         per_rank = []
         for r in (r0, r1):
             ref.zero_grad()
-            (ref(r["xs"][k]).pow(2).mean() * (k + 1)).backward()
+            y = ref.vision_encoder(r["xs"][k]) if k == 0 else ref(r["xs"][k])
+            (y.pow(2).mean() * (k + 1)).backward()
             per_rank.append({n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None})
         mean = {n: (per_rank[0][n] + per_rank[1][n]) / 2 for n in per_rank[0]}
-        want = mean if want is None else {n: want[n] + mean[n] for n in mean}
+        want = dict(mean) if want is None else {n: want.get(n, 0) + mean[n] for n in mean}
     for n, g in want.items():
         if n.startswith("unused_head"):
             continue
         assert torch.allclose(r0["grads"][n], g, atol=2e-6), n
         assert torch.equal(r0["grads"][n], r1["grads"][n]), n
     assert torch.allclose(r0["w1"], r0["w0"] - 0.1 * want["vision_encoder.weight"], atol=2e-6) and torch.equal(r0["w1"], r1["w1"])
+    # every tower that got a gradient from ANY source is in the live map (and so is stepped by the fused optimizer on a GPU)
+    lo, hi = r0["text_range"]
+    assert any(a <= lo and hi <= b or (a < hi and lo < b) for a, b in r0["live"]), (r0["live"], r0["text_range"])
 
 
 def _itc_worker(rank, world, init_file, out):

@@ -172,8 +172,8 @@ class RCCLDDPAccelerator(Accelerator):
                     dist.all_reduce(p.grad)
                     p.grad.div_(self.world_size)
             return
-        if self._live is None:
-            self._discover_live()
+        # (which ranges ever receive a gradient is only decided at the first optimizer step, after EVERY source of a multi-source
+        # step has run its backward -- Pretrain.py:211-239; until then the whole arena is exchanged)
         done = sorted(self._done_ranges)
         self.overlapped_ranges = list(done)  # (for logs / tests) what left for the all-reduce from inside backward this step
         todo, pos = [], 0
@@ -242,6 +242,8 @@ class RCCLDDPAccelerator(Accelerator):
             return 0.0
         arena = self.arena
         if arena is None or not arena.grad.is_cuda:
+            if arena is not None and self._live is None:
+                self._discover_live()  # later exchanges skip the ranges that never get a gradient
             total = torch.nn.utils.clip_grad_norm_(model.parameters(), self.clip if self.clip > 0 else float("inf"))
             optimizer.step()
             if arena is not None:
