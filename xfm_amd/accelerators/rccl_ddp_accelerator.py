@@ -229,6 +229,14 @@ class RCCLDDPAccelerator(Accelerator):
             out.extend(zip(pts[:-1], pts[1:]))
         self._live = out
 
+    def reset_live(self):
+        """Forget which arena ranges receive gradients (call when the loss mix GROWS mid-run, e.g. a head that was unused so far
+        starts to train: the map is decided once, at the first optimizer step, and the reference's configs only ever turn losses
+        off).  The whole gradient arena is zeroed and exchanged until the next optimizer step re-decides."""
+        self._live = None
+        if self.arena is not None:
+            self.arena.zero_grad()
+
     def _grad_norm_sq(self):
         """Over the live ranges only: blocks that never receive a gradient are zero (and stay zero), no need to read them."""
         out = torch.zeros(1, dtype=torch.float32, device=self.arena.grad.device)
