@@ -171,7 +171,7 @@ def test_plain_vit_tower():
 def test_retrieval_model():
     z, meta = load("retrieval_small")
     P = _params(meta["spec"])
-    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"], vit_depth=meta.get("vit_depth", 12))
     b = syn.pretrain_batch(meta["B"], seed=77)
     idx = torch.tensor(meta["idx"])
     itc, itm = O.retrieval_forward(P, cfg, b, idx, meta["image_neg_idx"], meta["text_neg_idx"], text_prefix="text_encoder.")
@@ -186,7 +186,7 @@ def test_retrieval_model():
 def test_classification_models():
     z, meta = load("classification_imagenet")
     P = _params(meta["spec"])
-    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"], vit_depth=meta.get("vit_depth", 12))
     b = syn.pretrain_batch(meta["B"], seed=55)
     pred = O.classification_forward(P, cfg, b["image"], None, None, deep_head=True)
     check(z, "pred_imagenet", pred, 1e-4, RTOL)
@@ -215,7 +215,7 @@ def test_vqa_model_loss_and_answer_ranking():
     """BASELINE configs[3]: XFMForVQA's weighted answer loss + gradients, and rank_answer's re-ranked shortlist."""
     z, meta = load("vqa_small")
     P = _params(meta["spec"])
-    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"], vit_depth=meta.get("vit_depth", 12))
     cfg.update(dec_layers=meta["dec_layers"], dec_fusion_start=meta["dec_fusion_start"])
     x = syn.vqa_inputs()
     loss = O.vqa_train_loss(P, cfg, x.image, x.q_ids, x.q_atts, x.a_ids, x.a_atts, x.k, x.weights, meta["pad_token_id"])
@@ -233,7 +233,7 @@ def test_vqa_model_loss_and_answer_ranking():
 def test_nlvr_model():
     z, meta = load("nlvr_small")
     P = _params(meta["spec"])
-    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"], vit_depth=meta.get("vit_depth", 12))
     B = meta["B"]
     b = syn.pretrain_batch(2 * B, seed=95)
     pred = O.nlvr_forward(P, cfg, b["image"], b["text_ids"][:B], b["text_atts"][:B])
@@ -249,7 +249,7 @@ def test_retrieval_evaluation_rerank_and_recall():
     hand-worked case (product-side numpy restatement and the oracle's must agree on it too)."""
     z, meta = load("retrieval_eval")
     P = _params(meta["spec"])
-    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"], vit_depth=meta.get("vit_depth", 12))
     x = syn.retrieval_eval_inputs()
     with torch.no_grad():
         i2t, t2i, sims = O.retrieval_score_matrices(P, cfg, x.image, x.text_ids, x.text_atts, x.k_test)
@@ -273,7 +273,7 @@ def test_retrieval_evaluation_rerank_and_recall():
 def test_grounding_model_and_box_losses():
     z, meta = load("grounding_small")
     P = _params(meta["spec"])
-    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"], vit_depth=meta.get("vit_depth", 12))
     b = syn.pretrain_batch(meta["B"], seed=99)
     target = torch.tensor(meta["target"])
     coord = O.grounding_forward(P, cfg, b["image"], b["text_ids"], b["text_atts"])
@@ -301,7 +301,7 @@ def _pretrain(name):
     z, meta = load(name)
     B = meta["B"]
     P = _params(meta["spec"])
-    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"], vit_depth=meta.get("vit_depth", 12))
     b = syn.pretrain_batch(B, seed=1234)
     masks = syn.mim_block_mask(B, 14, 75, seed=1234)
     out = O.pretrain_forward(P, cfg, b, meta["image_neg_idx"], meta["text_neg_idx"], masks)

@@ -309,6 +309,33 @@ def gen_pretrain(name, text_layers, fusion_layers, B=4):
                      "text_neg_idx": [int(i) for i in captured["text_neg_idx"]], "unused": unused})
 
 
+import contextlib
+
+SHALLOW = 2  # ViT blocks in the task-model fixtures (the towers themselves are pinned at full depth by pretrain_full / beit_2blk)
+
+
+@contextlib.contextmanager
+def shallow_vit(depth=SHALLOW):
+    """The reference's `beit_base_patch16` hard-codes depth 12 (beit2.py:540-545); the task-model fixtures only exercise the glue
+    around the towers, so they are generated with a `depth`-block vision tower to keep the CPU test suite short.  The factory is
+    re-bound for the duration of the model construction; no reference source is touched."""
+    from functools import partial
+    import models.beit2 as rb
+    orig = rb.beit_base_patch16
+
+    def factory(img_size, **kwargs):
+        model = rb.VisionTransformer(img_size=img_size, patch_size=16, embed_dim=768, depth=depth, num_heads=12, mlp_ratio=4,
+                                     norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), **kwargs)
+        model.default_cfg = rb._cfg()
+        return model
+
+    rb.beit_base_patch16 = factory
+    try:
+        yield
+    finally:
+        rb.beit_base_patch16 = orig
+
+
 def gen_retrieval(B=4):
     """models/model_retrieval.py XFMForRetrieval: ITC with duplicated `idx` (soft labels, xfm.py:705-713), hard negatives that
     avoid same-idx pairs (:731-734), ITM with the text gradient kept (is_pretrain=False)."""
@@ -316,7 +343,8 @@ def gen_retrieval(B=4):
     ref_shim.init_single_process_group()
     torch.manual_seed(0)
     cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2)
-    m = XFMForRetrieval(cfg)
+    with shallow_vit():
+        m = XFMForRetrieval(cfg)
     load_formula(m)
     m.eval()
     b = syn.pretrain_batch(B, seed=77)
@@ -336,7 +364,7 @@ def gen_retrieval(B=4):
     (loss_itc + loss_itm).backward()
     grads_of(m, out)
     unused = [n for n, p in m.named_parameters() if p.grad is None]
-    save("retrieval_small", out, {"spec": spec_of(m), "B": B, "text_layers": 2, "fusion_layers": 2, "idx": idx.tolist(),
+    save("retrieval_small", out, {"spec": spec_of(m), "B": B, "text_layers": 2, "fusion_layers": 2, "vit_depth": SHALLOW, "idx": idx.tolist(),
                                   "image_neg_idx": [int(i) for i in captured["image_neg_idx"]],
                                   "text_neg_idx": [int(i) for i in captured["text_neg_idx"]], "unused": unused})
 
@@ -470,7 +498,8 @@ def gen_vqa():
     torch.manual_seed(0)
     cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2,
                                    overrides={"pad_token_id": 1, "decoder_fusion_start_at": 0, "num_dec_layers": 2})
-    m = XFMForVQA(cfg)
+    with shallow_vit():
+        m = XFMForVQA(cfg)
     load_formula(m)
     m.eval()
     x = syn.vqa_inputs()
@@ -488,7 +517,7 @@ def gen_vqa():
     out["topk_ids"] = topk_ids.numpy()
     out["topk_probs"] = topk_probs.numpy()
     print("topk", topk_ids.tolist(), topk_probs.tolist(), flush=True)
-    save("vqa_small", out, {"spec": spec_of(m), "B": 3, "text_layers": 2, "fusion_layers": 2, "dec_layers": 2, "dec_fusion_start": 0,
+    save("vqa_small", out, {"spec": spec_of(m), "B": 3, "text_layers": 2, "fusion_layers": 2, "vit_depth": SHALLOW, "dec_layers": 2, "dec_fusion_start": 0,
                             "pad_token_id": 1, "unused": unused})
 
 
@@ -498,7 +527,8 @@ def gen_nlvr(B=2):
     ref_shim.init_single_process_group()
     torch.manual_seed(0)
     cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2)
-    m = XFMForNLVR(cfg)
+    with shallow_vit():
+        m = XFMForNLVR(cfg)
     load_formula(m)
     m.eval()
     b = syn.pretrain_batch(2 * B, seed=95)
@@ -512,7 +542,7 @@ def gen_nlvr(B=2):
     loss.backward()
     grads_of(m, out)
     unused = [n for n, p in m.named_parameters() if p.grad is None]
-    save("nlvr_small", out, {"spec": spec_of(m), "B": B, "targets": targets.tolist(), "text_layers": 2, "fusion_layers": 2,
+    save("nlvr_small", out, {"spec": spec_of(m), "B": B, "targets": targets.tolist(), "text_layers": 2, "fusion_layers": 2, "vit_depth": SHALLOW,
                              "unused": unused})
 
 
@@ -524,7 +554,8 @@ def gen_retrieval_eval():
     ref_shim.init_single_process_group()
     torch.manual_seed(0)
     cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2)
-    m = XFMForRetrieval(cfg)
+    with shallow_vit():
+        m = XFMForRetrieval(cfg)
     load_formula(m)
     m.eval()
     x = syn.retrieval_eval_inputs()
@@ -554,11 +585,13 @@ def gen_retrieval_eval():
             t2i[i, topk_idx] = m.itm_head(output[:, 0, :])[:, 1]
     out = {"sims": sims_matrix.t().numpy(), "score_i2t": i2t.numpy(), "score_t2i": t2i.numpy()}
     print(out["score_i2t"], flush=True)
-    save("retrieval_eval", out, {"spec": spec_of(m), "text_layers": 2, "fusion_layers": 2})
+    save("retrieval_eval", out, {"spec": spec_of(m), "text_layers": 2, "fusion_layers": 2, "vit_depth": SHALLOW})
 
 
 def grounding_targets(B):
-    return torch.tensor([[0.5, 0.5, 0.4, 0.6], [0.3, 0.6, 0.2, 0.3], [0.7, 0.25, 0.5, 0.4], [0.45, 0.55, 0.9, 0.8]][:B])
+    # chosen so that, against the boxes the formula weights predict, every min / max / clamp of the GIoU and every sign of the L1 term
+    # is decided by a margin >= 0.05: the bf16 path moves a coordinate by up to 0.01 and must not land on the other side of a kink
+    return torch.tensor([[0.5, 0.3, 0.4, 0.4], [0.45, 0.3, 0.2, 0.3], [0.55, 0.4, 0.5, 0.5], [0.45, 0.55, 0.9, 0.8]][:B])
 
 
 def gen_grounding(B=3):
@@ -567,7 +600,8 @@ def gen_grounding(B=3):
     ref_shim.init_single_process_group()
     torch.manual_seed(0)
     cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2)
-    m = XFMForGrounding(cfg)
+    with shallow_vit():
+        m = XFMForGrounding(cfg)
     load_formula(m)
     m.eval()
     b = syn.pretrain_batch(B, seed=99)
@@ -580,7 +614,7 @@ def gen_grounding(B=3):
     (loss_bbox + loss_giou).backward()
     grads_of(m, out)
     unused = [n for n, p in m.named_parameters() if p.grad is None]
-    save("grounding_small", out, {"spec": spec_of(m), "B": B, "target": target.tolist(), "text_layers": 2, "fusion_layers": 2,
+    save("grounding_small", out, {"spec": spec_of(m), "B": B, "target": target.tolist(), "text_layers": 2, "fusion_layers": 2, "vit_depth": SHALLOW,
                                   "unused": unused})
 
 
