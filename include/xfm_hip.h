@@ -171,6 +171,14 @@ int xfm_vit_tokens_fwd(const float* tok, const float* cls, const float* mask_tok
 int xfm_vit_tokens_bwd(const float* dx0, const uint8_t* mask, int Bt, int Bx, int P, int D, float* dtok, float* dcls,
                        float* dmask_token, void* stream);
 
+/* ---- MIM loss (xfm.py:624-635): x = embeddings of the masked view, t = of the clean view (detached), bf16 [B, N, D]; mask [B, N-1]
+ * bytes.  fwd: sums[3] += {sum (x-t)^2 over masked patch rows, the same over the cls rows, number of masked patches} (caller zeroes);
+ * loss = sums[0] / max(sums[2] * D, 1) + sums[1] / (B * D).  bwd: dx (bf16 [B, N, D], fully written) = gout[0] * d loss / d x;
+ * cls_term = 0 drops the cls part (the reference's `mim_cls_only` flag returns the patch term alone). */
+int xfm_mim_loss_fwd(const xfm_bf16* x, const xfm_bf16* t, const uint8_t* mask, int B, int N, int D, float* sums, void* stream);
+int xfm_mim_loss_bwd(const xfm_bf16* x, const xfm_bf16* t, const uint8_t* mask, const float* sums, const float* gout, int cls_term,
+                     int B, int N, int D, xfm_bf16* dx, void* stream);
+
 /* ---- RoBERTa embeddings + LayerNorm + dropout (xroberta.py:104-137, 1747-1757) ----------------------------------- */
 typedef struct {
   const int64_t* ids;

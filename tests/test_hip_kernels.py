@@ -198,6 +198,30 @@ def test_vit_token_assembly_fwd_bwd(reps, masked):
         _close(dm, mtok.grad.view(-1) + 1.0, 1e-5, "dmask_token (accumulated)")
 
 
+@pytest.mark.parametrize("cls_term", [True, False])
+def test_mim_loss_fwd_bwd(cls_term):
+    """xfm.py:624-635: masked-patch MSE (+ pooled-cls MSE) between the masked and the clean view."""
+    Fx = _fx()
+    B, N, D = 5, 37, 768
+    x = _rand((B, N, D), 1.0, seed=60)
+    t = _rand((B, N, D), 1.0, seed=61)
+    mask = _rand((B, N - 1), 1.0, F32, 62) > 0.2
+    xr = x.float().requires_grad_(True)
+    w = mask.unsqueeze(-1).float()
+    ref = (((xr[:, 1:] - t.float()[:, 1:]) ** 2) * w).sum() / (w.sum() * D).clamp(min=1.0)
+    if cls_term:
+        ref = ref + torch.nn.functional.mse_loss(xr[:, 0], t.float()[:, 0])
+    (ref * 3.0).backward()
+    m8 = mask.contiguous().view(torch.uint8)
+    sums = Fx.mim_loss_fwd(x, t, m8)
+    got = sums[0] / (sums[2] * D).clamp(min=1.0) + (sums[1] / (B * D) if cls_term else 0.0)
+    assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref)), (float(got), float(ref))
+    assert float(sums[2]) == float(mask.sum())
+    dx = Fx.mim_loss_bwd(x, t, m8, sums, torch.full((1,), 3.0, device="cuda"), cls_term)
+    _close(dx, xr.grad, 1e-2, "mim dx")
+    assert float(dx[:, 1:][~mask].float().abs().max()) == 0.0  # unmasked patches carry no gradient
+
+
 def _ln_ref(x, w, b, eps):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps)
 

@@ -132,6 +132,15 @@ int xfm_vit_tokens_bwd(const float* dx0, const uint8_t* mask, int Bt, int Bx, in
   XFM_REQUIRE(dx0 && dtok && dcls && (mask == nullptr || dmask_token != nullptr), "vit_tokens_bwd: null operand");
   return xfm_vit_tokens_bwd_impl(dx0, mask, Bt, Bx, P, D, dtok, dcls, dmask_token, ST(stream));
 }
+int xfm_mim_loss_fwd(const xfm_bf16* x, const xfm_bf16* t, const uint8_t* mask, int B, int N, int D, float* sums, void* stream) {
+  XFM_REQUIRE(x && t && mask && sums, "mim_loss_fwd: null operand");
+  return xfm_mim_loss_fwd_impl(x, t, mask, B, N, D, sums, ST(stream));
+}
+int xfm_mim_loss_bwd(const xfm_bf16* x, const xfm_bf16* t, const uint8_t* mask, const float* sums, const float* gout, int cls_term,
+                     int B, int N, int D, xfm_bf16* dx, void* stream) {
+  XFM_REQUIRE(x && t && mask && sums && gout && dx, "mim_loss_bwd: null operand");
+  return xfm_mim_loss_bwd_impl(x, t, mask, sums, gout, cls_term, B, N, D, dx, ST(stream));
+}
 
 int xfm_embed_ln_fwd(const xfm_embed_args* a, int D, void* stream) {
   NOTNULL(a, "embed_ln_fwd");

@@ -104,6 +104,87 @@ __global__ __launch_bounds__(256) void vit_tokens_bwd_vec_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MIM loss (xfm.py:624-635): MSE over the masked patch rows + MSE over the pooled cls row, between the masked view's embeddings x and
+// the (detached) clean view's t, both bf16 [B, N, D].  Forward: sums = {sum (x-t)^2 over masked patch rows, the same over cls rows,
+// number of masked patches}; backward: dx = g * 2 (x - t) / (count * D) on masked rows, g * 2 (x - t) / (B * D) on cls rows, 0 elsewhere.
+// One read of x and t each way instead of eight fp32 elementwise passes.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mim_loss_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ t,
+                                                           const uint8_t* __restrict__ mask, int B, int N, int D, float* __restrict__ sums) {
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * 256) >> 6;
+  float sp = 0.f, sc = 0.f, cnt = 0.f;
+  for (long r = wave; r < (long)B * N; r += nwaves) {
+    const int n = (int)(r % N), b = (int)(r / N);
+    const bool cls = n == 0;
+    if (!cls && !mask[(long)b * (N - 1) + n - 1]) continue;  // wave-uniform
+    float s = 0.f;
+    for (int c = lane * 8; c < D; c += 512) {
+      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + r * D + c);
+      const bf16x8 tv = *reinterpret_cast<const bf16x8*>(t + r * D + c);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = bf2f(xv[i]) - bf2f(tv[i]);
+        s = fmaf(d, d, s);
+      }
+    }
+    s = wave_sum(s);
+    if (cls) sc += s; else { sp += s; cnt += 1.f; }
+  }
+  if (lane == 0) {
+    if (sp != 0.f) atomicAdd(sums + 0, sp);
+    if (sc != 0.f) atomicAdd(sums + 1, sc);
+    if (cnt != 0.f) atomicAdd(sums + 2, cnt);
+  }
+}
+
+__global__ __launch_bounds__(256) void mim_loss_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ t,
+                                                           const uint8_t* __restrict__ mask, const float* __restrict__ sums,
+                                                           const float* __restrict__ gout, int cls_term, int B, int N, int D,
+                                                           bf16* __restrict__ dx) {
+  const int d8 = D / 8;
+  const long total = (long)B * N * d8;
+  const float g = gout[0];
+  const float patch_den = fmaxf(sums[2] * (float)D, 1.0f);
+  const float kp = 2.0f * g / patch_den, kc = cls_term ? 2.0f * g / ((float)B * (float)D) : 0.f;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / d8;
+    const int c = (int)(e % d8) * 8;
+    const int n = (int)(r % N), b = (int)(r / N);
+    const float k = n == 0 ? kc : (mask[(long)b * (N - 1) + n - 1] ? kp : 0.f);
+    bf16x8 o;
+    if (k != 0.f) {
+      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + r * D + c);
+      const bf16x8 tv = *reinterpret_cast<const bf16x8*>(t + r * D + c);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = f2bf(k * (bf2f(xv[i]) - bf2f(tv[i])));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = f2bf(0.f);
+    }
+    *reinterpret_cast<bf16x8*>(dx + r * D + c) = o;
+  }
+}
+
+int xfm_mim_loss_fwd_impl(const void* x, const void* t, const uint8_t* mask, int B, int N, int D, float* sums, hipStream_t st) {
+  XFM_REQUIRE(B > 0 && N > 1 && D > 0 && D % 8 == 0, "mim_loss: bad shape B=%d N=%d D=%d", B, N, D);
+  int grid = cdiv((long)B * N, 4);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(mim_loss_fwd_kernel, dim3(grid), dim3(256), 0, st, (const bf16*)x, (const bf16*)t, mask, B, N, D, sums);
+  return xfm_check_launch("mim_loss_fwd");
+}
+
+int xfm_mim_loss_bwd_impl(const void* x, const void* t, const uint8_t* mask, const float* sums, const float* gout, int cls_term, int B,
+                          int N, int D, void* dx, hipStream_t st) {
+  XFM_REQUIRE(B > 0 && N > 1 && D > 0 && D % 8 == 0, "mim_loss: bad shape B=%d N=%d D=%d", B, N, D);
+  int grid = cdiv((long)B * N * (D / 8), 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(mim_loss_bwd_kernel, dim3(grid), dim3(256), 0, st, (const bf16*)x, (const bf16*)t, mask, sums, gout, cls_term, B, N, D,
+                     (bf16*)dx);
+  return xfm_check_launch("mim_loss_bwd");
+}
+
 static int vit_tokens_check(int Bt, int Bx, int P, int D) {
   XFM_REQUIRE(Bt > 0 && Bx >= Bt && Bx % Bt == 0 && P > 0 && D > 0 && D % 4 == 0 && D <= 1024,
               "vit_tokens: bad shape Bt=%d Bx=%d P=%d D=%d (Bx must be a multiple of Bt, D a multiple of 4 and <= 1024)", Bt, Bx, P, D);

@@ -339,6 +339,25 @@ def vit_tokens_bwd(dx0, mask, Bt, dcls, dmask_token):
     return dtok
 
 
+def mim_loss_fwd(x, t, mask):
+    """-> sums fp32 [3] = (sum (x-t)^2 over masked patch rows, over cls rows, number of masked patches); x, t bf16 [B, N, D]."""
+    _dev(x)
+    B, N, D = x.shape
+    assert x.dtype == BF16 and t.dtype == BF16 and x.is_contiguous() and t.is_contiguous() and t.shape == x.shape
+    assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape == (B, N - 1)
+    sums = torch.zeros(3, dtype=F32, device=x.device)
+    check(_lib.load().xfm_mim_loss_fwd(x.data_ptr(), t.data_ptr(), mask.data_ptr(), B, N, D, sums.data_ptr(), _stream()), "mim_loss_fwd")
+    return sums
+
+
+def mim_loss_bwd(x, t, mask, sums, gout, cls_term):
+    B, N, D = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.load().xfm_mim_loss_bwd(x.data_ptr(), t.data_ptr(), mask.data_ptr(), sums.data_ptr(), gout.data_ptr(), int(cls_term), B, N, D,
+                                       dx.data_ptr(), _stream()), "mim_loss_bwd")
+    return dx
+
+
 def patchify(image, patch):
     _dev(image)
     assert image.dtype == F32 and image.is_contiguous()

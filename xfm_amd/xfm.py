@@ -17,6 +17,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import functional as Fx
 from .arena import LinearSlot, ParamArena
 from .beit2 import _Affine, beit_base_patch16
 from .ops import layer_norm, linear_slot
@@ -180,6 +181,29 @@ def load_pretrained(model, ckpt_rpath, config, is_eval=False, load_text=False):
                 state_dict[key.replace(name_to_replace, '')] = state_dict[key]
                 del state_dict[key]
     return state_dict
+
+
+class _MimLossFn(torch.autograd.Function):
+    """loss = sum_masked (x - t)^2 / max(count * D, 1) [+ mean over the cls rows]; t carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, t, mask, cls_term):
+        x, t = x.to(torch.bfloat16).contiguous(), t.to(torch.bfloat16).contiguous()
+        mask_u8 = mask.to(torch.bool).contiguous().view(torch.uint8)
+        sums = Fx.mim_loss_fwd(x, t, mask_u8)
+        ctx.save_for_backward(x, t, mask_u8, sums)
+        ctx.cls_term = cls_term
+        D = x.shape[-1]
+        loss = sums[0] / (sums[2] * D).clamp(min=1.0)
+        if cls_term:
+            loss = loss + sums[1] / float(x.shape[0] * D)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, mask_u8, sums = ctx.saved_tensors
+        dx = Fx.mim_loss_bwd(x, t, mask_u8, sums, g.reshape(1).float().contiguous(), ctx.cls_term)
+        return dx, None, None, None
 
 
 class XFMBase(nn.Module):
@@ -479,12 +503,5 @@ class XFMBase(nn.Module):
                                    masked_pos=masked_pos).loss
 
     def get_mim_loss(self, image_embeds_masked, targets, mask_tokens):
-        """MSE(masked patches) + MSE(pooled cls), xfm.py:624-635; sync-free masked mean."""
-        t = targets.detach().float()
-        x = image_embeds_masked.float()
-        w = mask_tokens.to(x.dtype).unsqueeze(-1)
-        diff2 = (x[:, 1:, :] - t[:, 1:, :]) ** 2
-        loss_patch = (diff2 * w).sum() / (w.sum() * x.shape[-1]).clamp(min=1.0)
-        if self.mim_cls_only:
-            return loss_patch
-        return loss_patch + F.mse_loss(x[:, 0, :], t[:, 0, :])
+        """MSE(masked patches) + MSE(pooled cls), xfm.py:624-635: one fused pass each way, sync-free masked mean."""
+        return _MimLossFn.apply(image_embeds_masked, targets.detach(), mask_tokens, not self.mim_cls_only)
