@@ -171,6 +171,11 @@ int xfm_vit_tokens_fwd(const float* tok, const float* cls, const float* mask_tok
 int xfm_vit_tokens_bwd(const float* dx0, const uint8_t* mask, int Bt, int Bx, int P, int D, float* dtok, float* dcls,
                        float* dmask_token, void* stream);
 
+/* ---- BEiT pooled-cls tail (beit2.py:455-466: drop cls, mean over the patch tokens, cat([mean, patches])) --------------------------
+ * fwd, in place: y[b, 0, :] = mean_i y[b, 1 + i, :] (bf16 [B, N, D], fp32 mean); bwd: out[b, 0] = 0, out[b, 1 + i] = dy[b, 1 + i] + dy[b, 0] / (N - 1). */
+int xfm_pool_rows_fwd(xfm_bf16* y, int B, int N, int D, void* stream);
+int xfm_pool_rows_bwd(const xfm_bf16* dy, int B, int N, int D, xfm_bf16* out, void* stream);
+
 /* ---- MIM loss (xfm.py:624-635): x = embeddings of the masked view, t = of the clean view (detached), bf16 [B, N, D]; mask [B, N-1]
  * bytes.  fwd: sums[3] += {sum (x-t)^2 over masked patch rows, the same over the cls rows, number of masked patches} (caller zeroes);
  * loss = sums[0] / max(sums[2] * D, 1) + sums[1] / (B * D).  bwd: dx (bf16 [B, N, D], fully written) = gout[0] * d loss / d x;

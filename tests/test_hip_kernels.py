@@ -222,6 +222,23 @@ def test_mim_loss_fwd_bwd(cls_term):
     assert float(dx[:, 1:][~mask].float().abs().max()) == 0.0  # unmasked patches carry no gradient
 
 
+def test_pooled_cls_tail_fwd_bwd():
+    """beit2.py:455-466: cat([mean over the patch rows, patch rows]) -- in place on the trunk output, and its gradient."""
+    Fx = _fx()
+    B, N, D = 3, 50, 768
+    y = _rand((B * N, D), 1.0, seed=70)
+    yr = y.float().view(B, N, D).requires_grad_(True)
+    ref = torch.cat([yr[:, 1:].mean(dim=1, keepdim=True), yr[:, 1:]], dim=1)
+    dy = _rand((B * N, D), 1.0, seed=71)
+    ref.backward(dy.float().view(B, N, D))
+    got = Fx.pool_rows_fwd_(y.clone(), B, N).view(B, N, D)
+    _close(got[:, 0], ref[:, 0], 1e-2, "pooled row")
+    assert torch.equal(got[:, 1:], y.view(B, N, D)[:, 1:])
+    g = Fx.pool_rows_bwd(dy, B, N).view(B, N, D)
+    _close(g, yr.grad, 1e-2, "pool tail gradient")
+    assert float(g[:, 0].float().abs().max()) == 0.0
+
+
 def _ln_ref(x, w, b, eps):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps)
 

@@ -94,6 +94,8 @@ SIGNATURES = {
     "xfm_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xfm_vit_tokens_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xfm_vit_tokens_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xfm_pool_rows_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "xfm_pool_rows_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xfm_mim_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xfm_mim_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xfm_embed_ln_fwd": (c_int, [ctypes.POINTER(EmbedArgs), c_int, c_void_p]),

@@ -191,6 +191,9 @@ class _TrunkFn(torch.autograd.Function):
         ctx.noted = bool(ctx.needs_input_grad[0])
         if ctx.noted:
             arena_note_use(vit)
+        ctx.pooled = bool(getattr(vit, "_pool_tail", False))
+        if ctx.pooled:  # beit2.py:455-466: the cls row leaves as the mean of the normalised patch rows (in place: y is not saved)
+            Fx.pool_rows_fwd_(y, B, N)
         return y.view(B, N, D)
 
     @staticmethod
@@ -200,6 +203,8 @@ class _TrunkFn(torch.autograd.Function):
         blocks = vit.blocks
         ld = vit._bias_ld
         dy = dy_out.reshape(M, D).contiguous()
+        if ctx.pooled:
+            dy = Fx.pool_rows_bwd(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16), B, N)
         dstream = torch.zeros((M, D), dtype=torch.float32, device=dy.device)
         from .xroberta import _WgradStream
         wg = _WgradStream(dy.device)
@@ -295,6 +300,7 @@ def arena_note_grad(mod):
 
 class VisionTransformer(nn.Module):
     """Drop-in for models.beit2.VisionTransformer (BEiT-v2 configuration used by XFM)."""
+    _pool_tail = True  # forward_avgpool (beit2.py:455-466): the trunk node replaces the cls row by the mean of the patch rows
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
                  mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.,
@@ -404,9 +410,7 @@ class VisionTransformer(nn.Module):
                 keep = 1.0 - torch.tensor([[b.drop_path_prob] * 2 for b in self.blocks], device=x.device).view(-1, 2, 1)
                 self._dp_keep = keep
             dp = (torch.rand(len(self.blocks), 2, B, device=x.device) < keep).float() / keep
-        y = _TrunkFn.apply(x0, self, dp)             # bf16 [B, N, D], fc_norm applied to every row
-        patches_n = y[:, 1:]
-        out = torch.cat([patches_n.float().mean(dim=1, keepdim=True).to(y.dtype), patches_n], dim=1)
+        out = _TrunkFn.apply(x0, self, dp)           # bf16 [B, N, D]: fc_norm on every row, then row 0 <- mean of the patch rows
         return (out, ids_mask) if do_mask else out
 
 

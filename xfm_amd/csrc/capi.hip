@@ -132,6 +132,14 @@ int xfm_vit_tokens_bwd(const float* dx0, const uint8_t* mask, int Bt, int Bx, in
   XFM_REQUIRE(dx0 && dtok && dcls && (mask == nullptr || dmask_token != nullptr), "vit_tokens_bwd: null operand");
   return xfm_vit_tokens_bwd_impl(dx0, mask, Bt, Bx, P, D, dtok, dcls, dmask_token, ST(stream));
 }
+int xfm_pool_rows_fwd(xfm_bf16* y, int B, int N, int D, void* stream) {
+  XFM_REQUIRE(y, "pool_rows_fwd: null operand");
+  return xfm_pool_rows_fwd_impl(y, B, N, D, ST(stream));
+}
+int xfm_pool_rows_bwd(const xfm_bf16* dy, int B, int N, int D, xfm_bf16* out, void* stream) {
+  XFM_REQUIRE(dy && out, "pool_rows_bwd: null operand");
+  return xfm_pool_rows_bwd_impl(dy, B, N, D, out, ST(stream));
+}
 int xfm_mim_loss_fwd(const xfm_bf16* x, const xfm_bf16* t, const uint8_t* mask, int B, int N, int D, float* sums, void* stream) {
   XFM_REQUIRE(x && t && mask && sums, "mim_loss_fwd: null operand");
   return xfm_mim_loss_fwd_impl(x, t, mask, B, N, D, sums, ST(stream));

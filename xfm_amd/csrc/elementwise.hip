@@ -185,6 +185,69 @@ int xfm_mim_loss_bwd_impl(const void* x, const void* t, const uint8_t* mask, con
   return xfm_check_launch("mim_loss_bwd");
 }
 
+// ---------------------------------------------------------------------------------------------
+// BEiT pooled-cls tail (beit2.py:455-466): y[b, 0, :] <- mean_i y[b, 1 + i, :] in place (bf16 rows, fp32 mean), and its backward
+// dy'[b, 0] = 0, dy'[b, 1 + i] = dy[b, 1 + i] + dy[b, 0] / P.  Replaces float() / mean / cast / cat and their autograd kernels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_rows_fwd_kernel(bf16* __restrict__ y, int N, int D) {
+  __shared__ float red[2][1024];
+  const int b = blockIdx.x, d8 = D / 8;
+  const int cg = threadIdx.x % d8, ph = threadIdx.x / d8;  // column group (8 columns), row phase; blockDim = 2 * d8
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  bf16* base = y + (long)b * N * D + cg * 8;
+  for (int i = 1 + ph; i < N; i += 2) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + (long)i * D);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ph][cg * 8 + j] = acc[j];
+  __syncthreads();
+  if (ph == 0) {
+    const float inv = 1.0f / (float)(N - 1);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf((red[0][cg * 8 + j] + red[1][cg * 8 + j]) * inv);
+    *reinterpret_cast<bf16x8*>(base) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_rows_bwd_kernel(const bf16* __restrict__ dy, int B, int N, int D, bf16* __restrict__ out) {
+  const int d8 = D / 8;
+  const long total = (long)B * N * d8;
+  const float inv = 1.0f / (float)(N - 1);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / d8;
+    const int c = (int)(e % d8) * 8;
+    const int n = (int)(r % N);
+    bf16x8 o;
+    if (n == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f2bf(0.f);
+    } else {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + r * D + c);
+      const bf16x8 g0 = *reinterpret_cast<const bf16x8*>(dy + (r - n) * D + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f2bf(fmaf(bf2f(g0[j]), inv, bf2f(v[j])));
+    }
+    *reinterpret_cast<bf16x8*>(out + r * D + c) = o;
+  }
+}
+
+int xfm_pool_rows_fwd_impl(void* y, int B, int N, int D, hipStream_t st) {
+  XFM_REQUIRE(B > 0 && N > 1 && D % 8 == 0 && D <= 1024 && D >= 8, "pool_rows: bad shape B=%d N=%d D=%d (D a multiple of 8, <= 1024)", B, N, D);
+  hipLaunchKernelGGL(pool_rows_fwd_kernel, dim3(B), dim3(2 * (D / 8)), 0, st, (bf16*)y, N, D);
+  return xfm_check_launch("pool_rows_fwd");
+}
+
+int xfm_pool_rows_bwd_impl(const void* dy, int B, int N, int D, void* out, hipStream_t st) {
+  XFM_REQUIRE(B > 0 && N > 1 && D % 8 == 0, "pool_rows: bad shape B=%d N=%d D=%d", B, N, D);
+  int grid = cdiv((long)B * N * (D / 8), 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(pool_rows_bwd_kernel, dim3(grid), dim3(256), 0, st, (const bf16*)dy, B, N, D, (bf16*)out);
+  return xfm_check_launch("pool_rows_bwd");
+}
+
 static int vit_tokens_check(int Bt, int Bx, int P, int D) {
   XFM_REQUIRE(Bt > 0 && Bx >= Bt && Bx % Bt == 0 && P > 0 && D > 0 && D % 4 == 0 && D <= 1024,
               "vit_tokens: bad shape Bt=%d Bx=%d P=%d D=%d (Bx must be a multiple of Bt, D a multiple of 4 and <= 1024)", Bt, Bx, P, D);

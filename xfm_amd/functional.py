@@ -339,6 +339,22 @@ def vit_tokens_bwd(dx0, mask, Bt, dcls, dmask_token):
     return dtok
 
 
+def pool_rows_fwd_(y, B, N):
+    """In place on bf16 y [B*N, D]: row 0 of every sample <- mean of its rows 1..N-1."""
+    _dev(y)
+    assert y.dtype == BF16 and y.is_contiguous() and y.shape[0] == B * N
+    check(_lib.load().xfm_pool_rows_fwd(y.data_ptr(), B, N, y.shape[1], _stream()), "pool_rows_fwd")
+    return y
+
+
+def pool_rows_bwd(dy, B, N):
+    """Gradient of pool_rows_fwd_ w.r.t. its input rows: out[b, 0] = 0, out[b, 1+i] = dy[b, 1+i] + dy[b, 0] / (N - 1)."""
+    assert dy.dtype == BF16 and dy.is_contiguous() and dy.shape[0] == B * N
+    out = torch.empty_like(dy)
+    check(_lib.load().xfm_pool_rows_bwd(dy.data_ptr(), B, N, dy.shape[1], out.data_ptr(), _stream()), "pool_rows_bwd")
+    return out
+
+
 def mim_loss_fwd(x, t, mask):
     """-> sums fp32 [3] = (sum (x-t)^2 over masked patch rows, over cls rows, number of masked patches); x, t bf16 [B, N, D]."""
     _dev(x)
