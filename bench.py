@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward(+all-reduce) only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fusion-probe", action="store_true", help="skip the stand-alone fusion-encoder fwd+bwd measurement (profiling runs)")
-    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=8, help="pairs per CPU-baseline step (SURVEY 8d: B = 8, 1 warm-up + 3 timed)")
+    ap.add_argument("--pool", type=int, default=4, help="distinct device-resident batches rotated through the steps")
     ap.add_argument("--eval-mode", action="store_true", help="disable dropout / drop-path (not the headline setting)")
     return ap.parse_args()
 
@@ -204,7 +205,7 @@ def cpu_baseline(model, batch_size):
     b = syn.pretrain_batch(batch_size, seed=1234)
     masks = syn.mim_block_mask(batch_size, 14, 75, seed=1234)
     times = []
-    for it in range(3):
+    for it in range(4):
         t0 = time.time()
         out = O.pretrain_forward(P, cfg, b, ids_mask=masks)
         total = out["loss_itc"] + out["loss_itm"] + out["loss_mlm"] + out["loss_mim"]
@@ -214,12 +215,18 @@ def cpu_baseline(model, batch_size):
         times.append(time.time() - t0)
     best = min(times[1:])
     return {"value": round(batch_size / best, 4), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32 full pre-train step fwd+bwd, B={batch_size}, 1 warm-up + 2 timed steps, best of 2 "
+            "sample": f"oracle fp32 full pre-train step fwd+bwd, B={batch_size}, 1 warm-up + 3 timed steps, best of 3 "
                       f"({best:.2f} s/step, {batch_size * PAIR_GFLOP / best / 1000:.3f} TFLOP/s)"}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # invoked bare (`python3 bench.py --gpus N`): start the N ranks ourselves, as the reference's launcher does (run.py:44-75).
+        # This parent has made no GPU call (importing torch does not initialise HIP); the ranks are CHILD processes of
+        # torch.distributed.run and their exit code is ours.  Rank 0's JSON line passes through on stdout.
+        from xfm_amd.launch import launch
+        sys.exit(launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -246,9 +253,14 @@ def main():
     model.train(not args.eval_mode)
 
     B = args.batch
-    batch = {k: v.to(device) for k, v in syn.pretrain_batch(B, seed=1234 + rank).items()}
+    # a small pool of distinct device-resident batches, rotated step by step (inputs are in HBM before the timed region; one batch
+    # replayed for the whole run would be trained to convergence on, e.g. an ITC loss of 0.01 after 25 steps)
+    batches = [{k: v.to(device) for k, v in syn.pretrain_batch(B, seed=1234 + rank + 7919 * j).items()} for j in range(args.pool)]
+    counter = [0]
 
     def step():
+        batch = batches[counter[0] % len(batches)]
+        counter[0] += 1
         losses = wrapped(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
                          masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], ret_mim_loss=True,
                          data_source="image")

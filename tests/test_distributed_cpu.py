@@ -56,7 +56,7 @@ def _accelerator_worker(rank, world, init_file, out):
     acc.backward_step(loss, opt)
     grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
     acc.optimizer_step(opt, model)
-    live = list(acc._live)  # decided at the first optimizer step, once every source of the step has run its backward
+    live = list(acc._ranges)  # whole live parameters, agreed across ranks
     torch.save({"w0": w0, "grads": grads, "live": live, "x": x, "numel": model._arena.numel,
                 "unused_range": model._arena.range_of(list(model.unused_head.parameters())),
                 "w1": model.vision_encoder.weight.detach().clone(),
@@ -118,7 +118,7 @@ def _multi_source_worker(rank, world, init_file, out):
         acc.backward_step(y.pow(2).mean() * (k + 1), opt)
     grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
     acc.optimizer_step(opt, model)
-    torch.save({"w0": w0, "xs": xs, "grads": grads, "w1": model.vision_encoder.weight.detach().clone(), "live": list(acc._live or []),
+    torch.save({"w0": w0, "xs": xs, "grads": grads, "w1": model.vision_encoder.weight.detach().clone(), "live": list(acc._ranges),
                 "text_range": model._arena.range_of(list(model.text_encoder.parameters()))}, out + f".{rank}")
     dist.destroy_process_group()
 
@@ -179,3 +179,103 @@ def test_itc_allgather_slice_backward_world2():
     # for the rows a rank owns it sees exactly the single-process gradient of those rows
     assert torch.allclose(r0["gi"], img.grad[:4], atol=1e-6) and torch.allclose(r1["gi"], img.grad[4:], atol=1e-6)
     assert torch.allclose(r0["gt"], txt.grad[:4], atol=1e-6) and torch.allclose(r1["gt"], txt.grad[4:], atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Liveness is per whole parameter and structural (never `grad != 0`): a text-only first step must not freeze the other
+# towers, and row-sparse embedding gradients must still exchange / decay / step every row (optim.py:4-50 of the reference
+# sees a dense `.grad`; torch-1.x zero_grad() zeroes in place, AdamW skips only `grad is None`).
+# ---------------------------------------------------------------------------------------------------------------------
+class Tiny2(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.fusion_encoder = nn.Module()
+        self.fusion_encoder.roberta = nn.Linear(8, 8)
+        self.text_encoder = nn.Module()
+        self.text_encoder.roberta = nn.Embedding(2000, 8)   # 2000 rows: a batch of 4 tokens touches 0.2 % of them
+        self.text_encoder.head = nn.Linear(8, 8)
+        self.vision_encoder = nn.Linear(8, 8)
+        self.unused_head = nn.Linear(8, 300)
+        self._arena = None
+
+    def finalize(self, device=None):
+        from xfm_amd.arena import ParamArena
+        self._arena = ParamArena(self, (), device or torch.device("cpu"))
+        return self
+
+    def forward_text(self, ids):
+        return self.text_encoder.head(self.text_encoder.roberta(ids))
+
+    def forward(self, x, ids):
+        return self.fusion_encoder.roberta(self.forward_text(ids) + self.vision_encoder(x))
+
+
+def _tiny2_batches(rank):
+    g = torch.Generator().manual_seed(50 + rank)
+    ids1 = torch.randint(0, 20, (4,), generator=g)          # step 1: text only, rows < 20
+    ids2 = torch.randint(1000, 2000, (4,), generator=g)     # step 2: image + text, other rows
+    ids3 = torch.randint(0, 2000, (4,), generator=g)
+    xs = [torch.randn(4, 8, generator=g) for _ in range(3)]
+    return [(None, ids1), (xs[1], ids2), (xs[2], ids3)]
+
+
+def _tiny2_loss(model, x, ids):
+    y = model.forward_text(ids) if x is None else model(x, ids)
+    return y.pow(2).mean()
+
+
+def _liveness_worker(rank, world, init_file, out):
+    from xfm_amd.accelerators import ACCELERATOR_MAP
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    model = Tiny2()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.1, betas=(0.9, 0.98), eps=1e-8)
+    acc = ACCELERATOR_MAP["RCCLDDP"]({"RNG_SEED": 1, "CLIP_GRAD_NORM": 1.0, "GRAD_ACCUMULATE_STEPS": 1})
+    wrapped, opt, _ = acc.set_up(model, opt, None, local_rank=rank, world_size=world, rank=rank)
+    ranges = []
+    for x, ids in _tiny2_batches(rank):
+        opt.zero_grad()  # the reference's loop does this (Pretrain.py:127); torch 2's set_to_none must not detach the arena
+        acc.backward_step(_tiny2_loss(model, x, ids), opt)
+        acc.optimizer_step(opt, model)
+        opt.zero_grad()
+        ranges.append(list(acc._ranges))
+    torch.save({"params": {n: p.detach().clone() for n, p in model.named_parameters()}, "ranges": ranges,
+                "unused_range": model._arena.range_of(list(model.unused_head.parameters())),
+                "vision_range": model._arena.range_of(list(model.vision_encoder.parameters())),
+                "grad_after": float(model._arena.grad.abs().max())}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_text_only_first_step_and_sparse_embedding_rows_world2():
+    r0, r1 = _spawn(_liveness_worker)
+    # single-process reference: mean of the two ranks' gradients, torch.optim.AdamW, clip 1.0, in-place zero_grad
+    ref = Tiny2()
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.1, betas=(0.9, 0.98), eps=1e-8)
+    b0, b1 = _tiny2_batches(0), _tiny2_batches(1)
+    for (x0, i0), (x1, i1) in zip(b0, b1):
+        opt.zero_grad(set_to_none=False)
+        ((_tiny2_loss(ref, x0, i0) + _tiny2_loss(ref, x1, i1)) / 2).backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        opt.step()
+    want = dict(ref.named_parameters())
+    for n, p in r0["params"].items():
+        assert torch.allclose(p, want[n].detach(), atol=2e-6), n
+        assert torch.equal(p, r1["params"][n]), f"replicas diverged on {n}"
+    # step 1 (text only) leaves the vision / fusion towers dead, step 2 brings them in; the unused head never joins
+    vlo, vhi = r0["vision_range"]
+    assert not any(a < vhi and vlo < b for a, b in r0["ranges"][0]), "vision tower must be dead after a text-only step"
+    assert any(a <= vlo and vhi <= b for a, b in r0["ranges"][1]), "vision tower must be live from the first image step on"
+    ulo, uhi = r0["unused_range"]
+    assert not any(a < uhi and ulo < b for a, b in r0["ranges"][2])
+    assert r0["ranges"] == r1["ranges"] and r0["grad_after"] == 0.0
+    # rows of the embedding no batch ever touched were still weight-decayed (dense-gradient semantics)
+    emb0 = Tiny2().text_encoder.roberta.weight
+    assert not torch.equal(r0["params"]["text_encoder.roberta.weight"][500], emb0[500].detach())
+
+
+def test_interval_helpers():
+    from xfm_amd.accelerators.rccl_ddp_accelerator import _clip, _subtract
+    assert _clip([(0, 10), (20, 30)], 5, 25) == [(5, 10), (20, 25)]
+    assert _subtract([(0, 10), (20, 30)], [(2, 4), (8, 22)]) == [(0, 2), (4, 8), (22, 30)]
+    assert _subtract([(0, 10)], []) == [(0, 10)]
+    assert _subtract([(0, 10)], [(0, 10)]) == []

@@ -1,0 +1,225 @@
+"""RCCLDDPAccelerator on a real MI355X (world size 1): liveness, fused clip + AdamW, the reference's loop around it, resume.
+
+What is pinned:
+  * the live-parameter set after one pre-training backward == the parameters whose `.grad` is not None in the REAL reference
+    (`unused` list of tests/golden/pretrain_small.npz), and no dead parameter ever holds a non-zero gradient;
+  * the parameters after a text-only step followed by two image steps, driven through xfm_amd.pretrain_loop exactly as
+    Pretrain.py:61-139 drives its accelerator (optimizer.zero_grad() calls included), equal torch.optim.AdamW + clip_grad_norm_
+    replayed on the gradients the kernels produced (per-parameter step counts, `grad is None` skipping, weight decay on
+    zero-gradient live parameters, the autograd-fed temperature);
+  * one oracle (CPU fp32) step + torch AdamW moves the parameters the same way;
+  * optimizer.state_dict() -> load_state_dict() into a fresh process state reproduces the next step bit for bit."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import load, state_from_spec  # noqa: E402
+from xfm_amd import pretrain_loop as PL  # noqa: E402
+from xfm_amd import synthetic as syn  # noqa: E402
+
+
+def _cfg(meta, **kw):
+    c = {"use_beit_v2": True, "image_res": 224, "patch_size": 16, "local_attn_depth": -1, "text_encoder": "roberta-base",
+         "text_num_hidden_layers": meta["text_layers"], "text_fusion_start_at": meta["text_layers"],
+         "fusion_num_hidden_layers": meta["fusion_layers"], "fusion_fusion_start_at": 0, "embed_dim": 256, "temp": 0.07,
+         "learnable_temp": True, "max_temp": 0.5, "min_temp": 0.001, "vision_depth": meta.get("vit_depth", 12)}
+    c.update(kw)
+    return c
+
+
+def _build(meta, clip=1.0, record=None):
+    from xfm_amd.accelerators import RCCLDDPAccelerator
+    from xfm_amd.model_pretrain import XFM
+
+    class Recording(RCCLDDPAccelerator):
+        def optimizer_step(self, optimizer, model, grad_norm=0.0):
+            if record is not None:
+                self.arena.reattach()
+                record.append((self.arena.grad.clone(), list(self.arena.live)))
+            return super().optimizer_step(optimizer, model, grad_norm)
+
+    m = XFM(_cfg(meta))
+    m.load_state_dict(state_from_spec(meta["spec"]), strict=True)
+    m.cuda()
+    opt = PL.create_optimizer(PL.AttrDict(lr=1e-3, weight_decay=0.05, lr_mult=2), m)
+    acc = Recording({"RNG_SEED": 3, "CLIP_GRAD_NORM": clip, "GRAD_ACCUMULATE_STEPS": 1})
+    wrapped, opt, _ = acc.set_up(m, opt, None, 0, 1, 0)
+    m.eval()  # dropout / drop-path off: the replayed steps must see reproducible activations
+    return m, wrapped, opt, acc
+
+
+def _batch(B, seed, with_image=True):
+    b = syn.pretrain_batch(B, seed=seed, with_image=with_image)
+    t = (b["text_ids"], b["text_atts"], b["text_ids_masked"], b["masked_pos"], b["masked_ids"])
+    return ((b["image"],) + t) if with_image else t
+
+
+def test_live_set_equals_the_reference_grad_not_none_set():
+    z, meta = load("pretrain_small")
+    m, wrapped, opt, acc = _build(meta)
+    B = meta["B"]
+    b = {k: v.cuda() for k, v in syn.pretrain_batch(B, seed=1234).items()}
+    masks = syn.mim_block_mask(B, 14, 75, seed=1234)
+    losses = wrapped(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"], masked_pos=b["masked_pos"],
+                     masked_ids=b["masked_ids"], ret_mim_loss=True, data_source="image", ids_mask=masks,
+                     neg_idx=(meta["image_neg_idx"], meta["text_neg_idx"]))
+    acc.backward_step(losses["loss_itc"] + losses["loss_itm"] + losses["loss_mlm"] + losses["loss_mim"], opt)
+    arena = m._arena
+    unused = set(meta["unused"])
+    dead = {n for n, p in m.named_parameters() if not arena.is_live(p)}
+    assert dead == unused, (sorted(dead - unused)[:8], sorted(unused - dead)[:8])
+    for n, p in m.named_parameters():
+        if n in dead:
+            assert float(p.grad.abs().max()) == 0.0, f"dead parameter {n} holds a gradient"
+    # whole parameters: every row of the word-embedding table is inside a live range although the batch touched < 0.3 % of its rows
+    o, n_el = arena.offsets[id(m.text_encoder.roberta.embeddings.word_embeddings.weight)]
+    assert any(a <= o and o + n_el <= b_ for a, b_ in acc.live_ranges())
+    touched = int((m.text_encoder.roberta.embeddings.word_embeddings.weight.grad.abs().sum(1) != 0).sum())
+    assert touched < 0.003 * 50265
+    live_elems = sum(b_ - a for a, b_ in acc.live_ranges())
+    assert live_elems < arena.numel  # ... and the never-used heads are not exchanged / stepped
+
+
+def test_loop_text_then_image_steps_match_torch_adamw_replay():
+    z, meta = load("pretrain_small")
+    rec = []
+    m, wrapped, opt, acc = _build(meta, record=rec)
+    params0 = {n: p.detach().clone() for n, p in m.named_parameters()}
+    B = meta["B"]
+    dev = torch.device("cuda")
+    meters = PL.LossMeters()
+    PL.run_text_iter(wrapped, _batch(B, 11, with_image=False), opt, acc, meters, dev)          # text-only MLM step first (Pretrain.py:218-219)
+    for k in range(2):
+        PL.run_image_iter(wrapped, _batch(B, 21 + k), opt, acc, meters, dev, data_source="image", do_optm=True)
+    torch.cuda.synchronize()
+    assert len(rec) == 3
+    live1, live3 = rec[0][1], rec[2][1]
+    arena = m._arena
+    assert not arena.live[arena._unit_of[id(m.vision_encoder.cls_token)]] or not live1[arena._unit_of[id(m.vision_encoder.cls_token)]]
+    assert live3[arena._unit_of[id(m.vision_encoder.cls_token)]], "the vision tower must join at the first image step"
+    assert live1[arena._unit_of[id(m.text_encoder.lm_head.bias)]], "the text-only step trains the text tower's own LM head"
+
+    # replay: torch.optim.AdamW on clones, fed the recorded gradients (dead parameters: grad None)
+    named = list(m.named_parameters())
+    clones = {n: torch.nn.Parameter(params0[n].clone()) for n, _ in named}
+    id2name = {id(p): n for n, p in named}
+    groups = [{"params": [clones[id2name[id(p)]] for p in g["params"]], "lr": g["lr"], "weight_decay": g["weight_decay"]}
+              for g in opt.param_groups]
+    ref = torch.optim.AdamW(groups, lr=1e-3, eps=1e-8, betas=(0.9, 0.98))
+    for grad, live in rec:
+        for n, p in named:
+            o, n_el = arena.offsets[id(p)]
+            clones[n].grad = grad[o:o + n_el].view(p.shape).clone() if live[arena._unit_of[id(p)]] else None
+        torch.nn.utils.clip_grad_norm_([c for c in clones.values() if c.grad is not None], 1.0)
+        ref.step()
+    worst = 0.0
+    for n, p in named:
+        d = float((p.detach() - clones[n].detach()).abs().max())
+        worst = max(worst, d)
+        assert d <= 2e-6, f"{n}: fused clip + AdamW differs from torch.optim.AdamW by {d:.3e}"
+    print(f"worst |fused - torch| over {len(named)} parameters after 3 steps: {worst:.3e}")
+    # the temperature is fed by plain autograd (AccumulateGrad into the arena view) and survives optimizer.zero_grad()
+    assert float((m.temp.detach() - params0["temp"]).abs()) > 0 and m.temp.grad is m.temp._xfm_grad
+    w = m.fusion_encoder.roberta.encoder.layer[0].intermediate.dense.weight
+    assert float((w.detach() - params0["fusion_encoder.roberta.encoder.layer.0.intermediate.dense.weight"]).abs().max()) > 0
+    # zero-gradient live rows still decay: a word-embedding row no batch used moved by exactly the weight-decay factor
+    we = m.text_encoder.roberta.embeddings.word_embeddings.weight
+    used = torch.zeros(50265, dtype=torch.bool)
+    for seed, img in ((11, False), (21, True), (22, True)):
+        b = syn.pretrain_batch(B, seed=seed, with_image=False)
+        used[b["text_ids"].reshape(-1)] = True
+        used[b["text_ids_masked"].reshape(-1)] = True
+    row = int((~used).nonzero()[0])
+    grp = next(g for g in opt.param_groups if any(q is we for q in g["params"]))
+    assert grp["weight_decay"] == 0.05
+    want = params0["text_encoder.roberta.embeddings.word_embeddings.weight"][row] * (1 - grp["lr"] * 0.05) ** 3
+    assert torch.allclose(we[row].detach(), want.cuda(), rtol=1e-6, atol=1e-9)
+    assert float(arena.grad.abs().max()) == 0.0  # zeroed for the next step
+
+
+def test_one_step_matches_oracle_plus_adamw_in_direction():
+    """The whole chain against the CPU oracle: oracle gradients + torch AdamW vs the HIP step.  After ONE AdamW step every element
+    moves by ~lr * sign(g), so the comparison is the agreement of the update directions on well-conditioned tensors."""
+    from oracle import xfm_oracle as O
+    z, meta = load("pretrain_small")
+    m, wrapped, opt, acc = _build(meta, clip=0.0)
+    sd = state_from_spec(meta["spec"])
+    B = meta["B"]
+    b = syn.pretrain_batch(B, seed=1234)
+    masks = syn.mim_block_mask(B, 14, 75, seed=1234)
+    neg = (meta["image_neg_idx"], meta["text_neg_idx"])
+    g = {k: v.cuda() for k, v in b.items()}
+    losses = wrapped(g["image"], g["text_ids"], g["text_atts"], text_ids_masked=g["text_ids_masked"], masked_pos=g["masked_pos"],
+                     masked_ids=g["masked_ids"], ret_mim_loss=True, data_source="image", ids_mask=masks, neg_idx=neg)
+    acc.backward_step(sum(losses[k] for k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim")), opt)
+    acc.optimizer_step(opt, m)
+    P = {k: v.clone() for k, v in sd.items()}
+    for k in list(P):
+        if k.endswith("decoder.bias"):
+            P[k] = P[k[:-len("decoder.bias")] + "bias"]
+    for v in P.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"], vit_depth=meta.get("vit_depth", 12))
+    ref = O.pretrain_forward(P, cfg, b, neg[0], neg[1], masks)
+    sum(ref[k] for k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim")).backward()
+    checked = 0
+    for n, p in m.named_parameters():
+        if P[n].grad is None or p.dim() < 2 or "embeddings" in n or "relative_position" in n:
+            continue
+        gr = P[n].grad
+        if float(gr.abs().mean()) < 1e-7:
+            continue
+        delta = p.detach().cpu().double() - sd[n].double()  # (the decoupled decay, lr * wd * |p| ~ 1e-6, is far below lr = 1e-3)
+        big = gr.abs() > 0.3 * gr.abs().mean()   # elements whose sign bf16 noise cannot flip
+        agree = float(((delta < 0) == (gr > 0))[big].double().mean())
+        assert agree > 0.97, f"{n}: update direction agrees with the oracle on {agree:.3f} of the well-conditioned elements"
+        checked += 1
+    assert checked > 40
+
+
+def test_resume_from_optimizer_state_dict_is_bit_identical():
+    z, meta = load("pretrain_small")
+    m, wrapped, opt, acc = _build(meta)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0 / (1 + s))
+    B = meta["B"]
+    dev = torch.device("cuda")
+    meters = PL.LossMeters()
+    PL.run_text_iter(wrapped, _batch(B, 11, with_image=False), opt, acc, meters, dev)
+    sched.step()
+    PL.run_image_iter(wrapped, _batch(B, 21), opt, acc, meters, dev, data_source="image", do_optm=True)
+    sched.step()
+    ckpt = copy.deepcopy({"model": m.state_dict(), "optimizer": opt.state_dict(), "lr_scheduler": sched.state_dict(), "epoch": 0})
+    # the state is torch.optim.AdamW's own format: per-parameter step / exp_avg / exp_avg_sq, only for parameters that were stepped
+    st = ckpt["optimizer"]["state"]
+    assert len(st) > 100 and all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in st.values())
+    assert {float(v["step"]) for v in st.values()} == {1.0, 2.0}  # the text tower is one step ahead of the towers that joined later
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    G = (torch.randn(m._arena.numel, generator=gen) * 1e-3).cuda()
+
+    def third_step(model, optimizer, accelerator):
+        accelerator._step += 1
+        model._arena.grad.copy_(G)
+        accelerator.optimizer_step(optimizer, model)
+        torch.cuda.synchronize()
+        return {n: p.detach().clone() for n, p in model.named_parameters()}
+
+    a = third_step(m, opt, acc)
+    # fresh objects, the reference's resume order: load optimizer + scheduler, then set_up (Pretrain.py:437-447)
+    from xfm_amd.accelerators import RCCLDDPAccelerator
+    from xfm_amd.model_pretrain import XFM
+    m2 = XFM(_cfg(meta))
+    m2.load_state_dict(ckpt["model"], strict=True)
+    m2.cuda()
+    opt2 = PL.create_optimizer(PL.AttrDict(lr=1e-3, weight_decay=0.05, lr_mult=2), m2)
+    sched2 = torch.optim.lr_scheduler.LambdaLR(opt2, lambda s: 1.0 / (1 + s))
+    assert PL.resume(ckpt, opt2, sched2) == 1
+    acc2 = RCCLDDPAccelerator({"RNG_SEED": 3, "CLIP_GRAD_NORM": 1.0, "GRAD_ACCUMULATE_STEPS": 1})
+    _, opt2, _ = acc2.set_up(m2, opt2, sched2, 0, 1, 0)
+    assert m2._arena.live == m._arena.live and acc2._t == [t - 1 if on else t for t, on in zip(acc._t, m._arena.live)]
+    b = third_step(m2, opt2, acc2)
+    for n in a:
+        assert torch.equal(a[n], b[n]), f"{n} differs after resume"

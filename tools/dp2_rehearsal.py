@@ -79,7 +79,7 @@ for step in range(4):
     acc.optimizer_step(opt, model)
     torch.cuda.synchronize()
     same_everywhere(model._arena.data, f"step {step}: parameters after the optimizer step")
-    live = sum(b - a for a, b in acc._live)
+    live = sum(b - a for a, b in acc._ranges)
     print(f"rank {rank} step {step}: losses {[round(float(v), 4) for v in losses.values()]} live {live}/{model._arena.numel} "
           f"grad-norm {float(acc.last_grad_norm):.4f} exchange-vs-mean-of-locals {err:.2e} "
           f"ranges sent from inside backward {[(b - a) // 2 ** 20 for a, b in acc.overlapped_ranges]} Mi-elements", flush=True)

@@ -8,11 +8,18 @@ MI355X-first design: gradients already live in one contiguous fp32 arena laid ou
 handful of LARGE in-place all-reduces over arena ranges (xGMI is point-to-point: few big collectives beat many
 25 MiB buckets), issued on a side HIP stream the moment a tower's last backward node has run (use-count hooks of the
 tower nodes) so they overlap the rest of backward -- in the pre-training step the fusion and text towers finish
-while the two ViT backward passes (56 % of the FLOPs) are still running.  Ranges that never receive a gradient
-(LM heads of the text tower, caption heads, fusion embeddings, bbox head: 158 M of 522 M elements) are
-found on the first step and skipped afterwards, identically on every rank.
+while the two ViT backward passes (56 % of the FLOPs) are still running.
+
+Which parameters take part is decided per WHOLE PARAMETER and structurally: a parameter is live from the first backward
+whose launch sites wrote a gradient for it (ParamArena.touch, called by grad_of() / slot.dw / slot.db and by an autograd hook)
+and stays live for the rest of the run -- exactly the parameters whose `.grad` is not None in the reference, where
+`optimizer.zero_grad()` zeroes in place (torch 1.x) and AdamW skips `grad is None` (optim.py:4-50).  Live parameters are
+exchanged, clipped, weight-decayed, stepped and zeroed every step, row-sparse embedding gradients included; parameters that
+never get a gradient (LM heads of the text tower, caption heads, fusion embeddings, bbox head: 158 M of 522 M elements,
+SURVEY 2.2) are skipped entirely.  The set only grows (a text-only first step followed by an image step simply adds the
+other towers), and ranks agree on it with one MAX all-reduce of the flag vector whenever it grew.
 """
-import math
+import os
 import random
 
 import numpy as np
@@ -34,7 +41,30 @@ class _Wrapped(torch.nn.Module):
         return self.module(*a, **kw)
 
 
+# ---- interval helpers (sorted, disjoint (start, end) lists) ----------------------------------------------------------
+def _clip(ranges, lo, hi):
+    return [(max(a, lo), min(b, hi)) for a, b in ranges if max(a, lo) < min(b, hi)]
+
+
+def _subtract(ranges, holes):
+    """ranges minus holes."""
+    out = []
+    for a, b in ranges:
+        pos = a
+        for c, d in holes:
+            if d <= pos or c >= b:
+                continue
+            if c > pos:
+                out.append((pos, c))
+            pos = max(pos, d)
+        if pos < b:
+            out.append((pos, b))
+    return out
+
+
 class RCCLDDPAccelerator(Accelerator):
+    takes_sync_hint = True  # backward_step(loss, optimizer, sync=...) -- see there
+
     def __init__(self, cfg, logger=None):
         super().__init__(cfg, logger)
         g = cfg.get if isinstance(cfg, dict) else lambda k, d=None: getattr(cfg, k, d)
@@ -42,13 +72,24 @@ class RCCLDDPAccelerator(Accelerator):
         self.clip = g("CLIP_GRAD_NORM", 0.0) or 0.0
         self.accum = max(int(g("GRAD_ACCUMULATE_STEPS", 1) or 1), 1)
         self.fused_optimizer = g("FUSED_ADAMW", True)
+        # wire format of the gradient exchange: 'fp32' (default; the reference's DDP reduces fp32 gradients) or 'bf16' (half the
+        # xGMI bytes: chunks are packed to bf16, averaged by RCCL and unpacked on the communication stream)
+        self.exchange_dtype = str(g("GRAD_EXCHANGE_DTYPE", os.environ.get("XFM_GRAD_EXCHANGE", "fp32"))).lower()
+        assert self.exchange_dtype in ("fp32", "bf16"), self.exchange_dtype
         self.world_size, self.rank = 1, 0
         self.model = None
+        self.arena = None
         self._pending = []
         self._comm_stream = None
-        self._live = None
+        self._ranges = []          # live arena ranges, split at tower boundaries (same on every rank)
+        self._agreed_ver = -1      # arena.live_ver the ranges were derived from
+        self._cuts = ()
+        self._towers = []
+        self._overlap_ok = False
         self._step = 0
-        self._opt_state = None
+        self._m = self._v = self._group = None
+        self._t = None             # optimizer steps taken per arena unit (bias correction is per parameter in torch's AdamW)
+        self._hooked = set()
         self._sync_now = False
         self._done_ranges = []
         self._use = {}
@@ -80,9 +121,16 @@ class RCCLDDPAccelerator(Accelerator):
         self.arena = arena
         if world_size > 1:
             self.broadcast()
-        if arena is not None and use_cuda:
-            self._comm_stream = torch.cuda.Stream()
-            self._install_tower_hooks(model)
+        if arena is not None:
+            self._towers = self._tower_ranges(model)
+            self._cuts = sorted({r[0] for _, _, r in self._towers} | {r[1] for _, _, r in self._towers})
+            self._t = [0] * len(arena._units)
+            if use_cuda:
+                self._comm_stream = torch.cuda.Stream()
+                self._install_tower_hooks(model)
+            if optimizer is not None:
+                self._hook_optimizer(optimizer)
+                self._adopt_optimizer_state(optimizer)  # a resumed optimizer.load_state_dict() precedes set_up (Pretrain.py:437-447)
         return _Wrapped(model), optimizer, lr_scheduler
 
     def broadcast(self):
@@ -94,6 +142,25 @@ class RCCLDDPAccelerator(Accelerator):
             for v in self.model.state_dict().values():
                 dist.broadcast(v, 0)
 
+    # ------------------------------------------------------------------------------------------ liveness
+    def _agree(self):
+        """Bring the live-parameter set up to date (and identical on every rank)."""
+        arena = self.arena
+        if self.world_size > 1:
+            flags = torch.tensor(arena.live, dtype=torch.uint8).to(arena.grad.device).to(torch.int32)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+            merged = flags.cpu().numpy().astype(bool).tolist()
+            if merged != arena.live:
+                arena.live = merged
+                arena.live_ver += 1
+        self._ranges = arena.live_ranges(self._cuts)
+        self._agreed_ver = arena.live_ver
+
+    def live_ranges(self):
+        if self.arena.live_ver != self._agreed_ver:
+            self._agree()
+        return self._ranges
+
     # ------------------------------------------------------------------------------------------ overlap
     def _tower_ranges(self, model):
         towers = []
@@ -101,11 +168,11 @@ class RCCLDDPAccelerator(Accelerator):
             mod = getattr(model, name, None)
             if mod is not None:
                 ps = list(mod.parameters())
-                towers.append((name, mod, self.arena.range_of(ps)))
+                if ps:
+                    towers.append((name, mod, self.arena.range_of(ps)))
         return towers
 
     def _install_tower_hooks(self, model):
-        self._towers = self._tower_ranges(model)
         self._use = {}
         for name, mod, rng in self._towers:
             if not hasattr(mod, "roberta"):
@@ -124,8 +191,8 @@ class RCCLDDPAccelerator(Accelerator):
     def _on_use(self, node, delta):
         rec = self._use[id(node)]
         rec[0] += delta
-        # overlap starts on step 2: step 1 first has to find out which arena ranges ever receive a gradient
-        if delta < 0 and rec[0] == 0 and rec[2] is not None and self.world_size > 1 and self._sync_now and self._live is not None:
+        # overlap needs a live set every rank already agrees on (i.e. from the second step with a given loss mix on)
+        if delta < 0 and rec[0] == 0 and rec[2] is not None and self._overlap_ok:
             self._launch(rec[2])
 
     def _on_blocks_done(self, vit, lo, hi, wgrad_stream):
@@ -133,17 +200,24 @@ class RCCLDDPAccelerator(Accelerator):
         backward is the tower's last pending use of the step (two ViT passes accumulate into the same range).  Returns whether the
         range was handed to the all-reduce."""
         rec = self._use[id(vit)]
-        if not (rec[0] == 1 and self.world_size > 1 and self._sync_now and self._live is not None):
+        if not (rec[0] == 1 and self._overlap_ok):
             return False
         ps = [p for b in vit.blocks[lo:hi] for p in b.parameters()]
         self._launch(self.arena.range_of(ps), extra_stream=wgrad_stream)
         return True
 
-    def _live_chunks(self, lo, hi):
-        """Sub-ranges of [lo, hi) that received a gradient on the first step (static afterwards)."""
-        if self._live is None:
-            return [(lo, hi)]
-        return [(max(a, lo), min(b, hi)) for a, b in self._live if max(a, lo) < min(b, hi)]
+    def _exchange(self, a, b, async_ok=True):
+        """All-reduce (mean) of arena.grad[a:b] on the current stream."""
+        g = self.arena.grad[a:b]
+        if self.exchange_dtype == "bf16":
+            buf = g.to(torch.bfloat16)
+            w = dist.all_reduce(buf, op=self._op, async_op=True)
+            w.wait()  # stream-ordered for RCCL (the host does not block); the unpack follows on this stream
+            g.copy_(buf)
+        elif async_ok and self._comm_stream is not None:
+            self._pending.append(dist.all_reduce(g, op=self._op, async_op=True))
+        else:
+            dist.all_reduce(g, op=self._op)
 
     def _launch(self, rng, extra_stream=None):
         cur = torch.cuda.current_stream()
@@ -151,16 +225,25 @@ class RCCLDDPAccelerator(Accelerator):
         if extra_stream is not None:  # weight-gradient GEMMs of the range still in flight on their own stream
             self._comm_stream.wait_stream(extra_stream)
         with torch.cuda.stream(self._comm_stream):
-            for a, b in self._live_chunks(*rng):
-                self._pending.append(dist.all_reduce(self.arena.grad[a:b], op=self._op, async_op=True))
+            for a, b in _clip(self._ranges, *rng):
+                self._exchange(a, b)
         self._done_ranges.append(rng)
 
     # ------------------------------------------------------------------------------------------ step
-    def backward_step(self, loss, optimizer):
+    def backward_step(self, loss, optimizer, sync=None):
+        """`sync=False` (extension; the reference's signature is (loss, optimizer)) keeps this backward's gradients local: a
+        multi-source step (Pretrain.py:211-239: web / imagenet / image batches before ONE optimizer step) then exchanges the summed
+        gradient once, on its last backward, instead of re-exchanging the arena after every source (the mean is linear)."""
         self._step += 1
-        self._sync_now = (self._step % self.accum) == 0
+        self._sync_now = (self._step % self.accum) == 0 and sync is not False
         self._done_ranges = []
+        arena = self.arena
+        if arena is not None:
+            arena.reattach()  # a caller's optimizer.zero_grad(set_to_none=True) must not detach .grad from the arena
+        self._overlap_ok = (self.world_size > 1 and self._sync_now and arena is not None and self._comm_stream is not None
+                            and arena.live_ver == self._agreed_ver and self._agreed_ver >= 0)
         loss.backward()
+        self._overlap_ok = False
         if self.world_size > 1 and self._sync_now:
             self._finish_allreduce()
 
@@ -172,75 +255,48 @@ class RCCLDDPAccelerator(Accelerator):
                     dist.all_reduce(p.grad)
                     p.grad.div_(self.world_size)
             return
-        # (which ranges ever receive a gradient is only decided at the first optimizer step, after EVERY source of a multi-source
-        # step has run its backward -- Pretrain.py:211-239; until then the whole arena is exchanged)
+        prev = list(self._ranges)
+        grew = arena.live_ver != self._agreed_ver
+        if grew:  # one MAX all-reduce + host read; ranks run the same program, so every rank's set grows on the same step
+            self._agree()
         done = sorted(self._done_ranges)
         self.overlapped_ranges = list(done)  # (for logs / tests) what left for the all-reduce from inside backward this step
-        todo, pos = [], 0
-        for a, b in done + [(arena.numel, arena.numel)]:
+        pos = 0
+        for a, b in done:
             assert a >= pos or a == b, f"arena range ({a}, {b}) was handed to the all-reduce twice in one step"
-            if a > pos:
-                todo.append((pos, a))
             pos = max(pos, b)
+        todo = _subtract(self._ranges, done)
+        if grew and done:  # parameters that became live during this backward inside a range that already left with the old map
+            late = _subtract(self._ranges, prev)
+            for lo, hi in done:
+                todo.extend(_clip(late, lo, hi))
+            todo.sort()
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm_stream):
-                for lo, hi in todo:
-                    for a, b in self._live_chunks(lo, hi):
-                        self._pending.append(dist.all_reduce(arena.grad[a:b], op=self._op, async_op=True))
+                for a, b in todo:
+                    self._exchange(a, b)
             for w in self._pending:
                 w.wait()
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         else:
-            for lo, hi in todo:
-                for a, b in self._live_chunks(lo, hi):
-                    dist.all_reduce(arena.grad[a:b], op=self._op)
+            for a, b in todo:
+                self._exchange(a, b, async_ok=False)
         self._pending = []
         for rec in self._use.values():
             rec[0] = 0
-        if self._op == dist.ReduceOp.SUM:  # gloo has no AVG: scale the exchanged chunks
-            for a, b in (self._live if self._live is not None else [(0, arena.numel)]):
+        if self._op == dist.ReduceOp.SUM:  # gloo has no AVG: scale the exchanged ranges
+            for a, b in self._ranges:
                 arena.grad[a:b].mul_(1.0 / self.world_size)
 
-    def _discover_live(self):
-        """1 KiB-granular map of arena blocks that got a gradient; agreed across ranks with one MAX all-reduce."""
-        g = self.arena.grad.view(-1, 256)
-        live = (g != 0).any(dim=1).to(torch.int32)
-        if self.world_size > 1:
-            dist.all_reduce(live, op=dist.ReduceOp.MAX)
-        live = live.cpu().numpy().astype(bool)
-        # merge into chunks, bridging dead gaps shorter than 1 MiB so the collectives stay few and large
-        idx = np.flatnonzero(live)
-        chunks = []
-        if idx.size:
-            start = prev = int(idx[0])
-            for i in idx[1:]:
-                i = int(i)
-                if i - prev > 1024:
-                    chunks.append((start * 256, (prev + 1) * 256))
-                    start = i
-                prev = i
-            chunks.append((start * 256, (prev + 1) * 256))
-        # never let a chunk straddle a tower boundary (they are launched per tower)
-        cuts = sorted({r[0] for _, _, r in getattr(self, "_towers", [])} | {r[1] for _, _, r in getattr(self, "_towers", [])})
-        out = []
-        for a, b in chunks:
-            pts = [a] + [c for c in cuts if a < c < b] + [b]
-            out.extend(zip(pts[:-1], pts[1:]))
-        self._live = out
-
-    def reset_live(self):
-        """Forget which arena ranges receive gradients (call when the loss mix GROWS mid-run, e.g. a head that was unused so far
-        starts to train: the map is decided once, at the first optimizer step, and the reference's configs only ever turn losses
-        off).  The whole gradient arena is zeroed and exchanged until the next optimizer step re-decides."""
-        self._live = None
+    def zero_grad(self):
         if self.arena is not None:
-            self.arena.zero_grad()
+            self.arena.zero_grad(self.live_ranges())
 
     def _grad_norm_sq(self):
-        """Over the live ranges only: blocks that never receive a gradient are zero (and stay zero), no need to read them."""
+        """Over the live ranges only: parameters that never receive a gradient are zero (and stay zero), no need to read them."""
         out = torch.zeros(1, dtype=torch.float32, device=self.arena.grad.device)
-        for a, b in (self._live if self._live is not None else [(0, self.arena.numel)]):
+        for a, b in self._ranges:
             Fx.sumsq(self.arena.grad[a:b], out)
         return out
 
@@ -249,67 +305,153 @@ class RCCLDDPAccelerator(Accelerator):
         if self._step % self.accum != 0:
             return 0.0
         arena = self.arena
-        if arena is None or not arena.grad.is_cuda:
-            if arena is not None and self._live is None:
-                self._discover_live()  # later exchanges skip the ranges that never get a gradient
+        if arena is None:
             total = torch.nn.utils.clip_grad_norm_(model.parameters(), self.clip if self.clip > 0 else float("inf"))
             optimizer.step()
-            if arena is not None:
-                arena.bump()
-                arena.zero_grad()  # keeps .grad attached to the arena (optimizer.zero_grad() would drop the views)
-            else:
-                optimizer.zero_grad()
+            optimizer.zero_grad()
             return float(total)
-        if self._live is None:
-            self._discover_live()  # world_size 1: the first step still has to learn which ranges ever get a gradient
+        arena.reattach()
+        self.live_ranges()
+        fused = arena.grad.is_cuda and self.fused_optimizer and _is_adamw(optimizer)
+        if not fused:
+            # a torch optimizer on the arena views: dead parameters look like `grad is None` to it, as in the reference
+            dead = [p for p in arena.params if not arena.is_live(p)]
+            for p in dead:
+                p.grad = None
+            total = torch.nn.utils.clip_grad_norm_([p for p in arena.params if p.grad is not None],
+                                                   self.clip if self.clip > 0 else float("inf"))
+            optimizer.step()
+            arena.bump()
+            arena.zero_grad(self._ranges)  # (re-attaches the dead parameters' views as well)
+            self.last_grad_norm = total
+            return total if arena.grad.is_cuda else float(total)
         norm = self._grad_norm_sq().sqrt()
         clip_coef = None
         if self.clip > 0:
             clip_coef = (self.clip / (norm + 1e-6)).clamp(max=1.0)
-        if self.fused_optimizer and _is_adamw(optimizer):
-            self._fused_adamw(optimizer, clip_coef)
-        else:
-            if clip_coef is not None:
-                arena.grad.mul_(clip_coef)
-            optimizer.step()
+        self._fused_adamw(optimizer, clip_coef)
         arena.bump()
-        arena.zero_grad(self._live)
+        arena.zero_grad(self._ranges)
         self.last_grad_norm = norm  # device tensor: no host sync on the step path
         return norm
 
     # ------------------------------------------------------------------------------------------ fused AdamW
+    def _alloc_moments(self):
+        if self._m is None:
+            self._m = torch.zeros_like(self.arena.data)
+            self._v = torch.zeros_like(self.arena.data)
+
     def _fused_adamw(self, optimizer, clip_coef):
         arena = self.arena
-        st = self._opt_state
-        if st is None:
-            groups = optimizer.param_groups
+        self._alloc_moments()
+        groups = optimizer.param_groups
+        if self._group is None:
             assert len(groups) <= 4, "fused AdamW supports up to 4 parameter groups (optim.py:4-50 builds 4)"
             gid = torch.zeros(arena.numel // 256, dtype=torch.uint8)
             for gi, grp in enumerate(groups):
                 for p in grp["params"]:
                     o, n = arena.offsets[id(p)]
                     gid[o // 256:(o + n + 255) // 256] = gi
-            st = self._opt_state = {"m": torch.zeros_like(arena.data), "v": torch.zeros_like(arena.data),
-                                    "group": gid.to(arena.data.device), "t": 0}
-        st["t"] += 1
-        groups = optimizer.param_groups
+            self._group = gid.to(arena.data.device)
         b1, b2 = groups[0]["betas"]
-        # parameters that never receive a gradient are skipped entirely, like `if p.grad is None: continue` in the reference's
-        # AdamW (no weight decay on the unused LM / caption / bbox heads), and it saves 30 % of the arena traffic
-        for a, b in (self._live if self._live is not None else [(0, arena.numel)]):
-            Fx.adamw(arena.data[a:b], arena.grad[a:b], st["m"][a:b], st["v"][a:b], st["group"][a // 256:(b + 255) // 256],
-                     [g["lr"] for g in groups], [g.get("weight_decay", 0.0) for g in groups], b1, b2, groups[0]["eps"], st["t"],
-                     clip_coef)
+        lrs = [g["lr"] for g in groups]
+        wds = [g.get("weight_decay", 0.0) for g in groups]
+        # one launch per run of live parameters that have taken the same number of steps (torch's AdamW counts steps, and so
+        # bias-corrects, per parameter: a tower that joined a step later stays one step behind)
+        t, units, live = self._t, arena._units, arena.live
+        runs = []
+        for u, ((a, b), on) in enumerate(zip(units, live)):
+            if not on:
+                continue
+            t[u] += 1
+            if runs and runs[-1][1] == a and runs[-1][2] == t[u]:
+                runs[-1][1] = b
+            else:
+                runs.append([a, b, t[u]])
+        for a, b, step in runs:
+            Fx.adamw(arena.data[a:b], arena.grad[a:b], self._m[a:b], self._v[a:b], self._group[a // 256:(b + 255) // 256],
+                     lrs, wds, b1, b2, groups[0]["eps"], step, clip_coef)
+
+    # ---- the moments live in flat arenas; torch's optimizer.state_dict() / load_state_dict() see them as ordinary AdamW state ----
+    def _hook_optimizer(self, optimizer):
+        if id(optimizer) in self._hooked or not hasattr(optimizer, "register_state_dict_pre_hook"):
+            return
+        self._hooked.add(id(optimizer))
+        # the reference's loop calls optimizer.zero_grad() itself (Pretrain.py:76,127,133); on an arena model that must zero the
+        # arena and keep every .grad attached to it (torch 2's set_to_none default would drop the views and leave the arena dirty)
+        optimizer.zero_grad = lambda set_to_none=True: self.zero_grad()
+        optimizer.register_state_dict_pre_hook(lambda opt: self._publish_optimizer_state(opt))
+        optimizer.register_load_state_dict_post_hook(lambda opt: self._adopt_optimizer_state(opt))
+
+    def _views(self, p):
+        o, n = self.arena.offsets[id(p)]
+        return self._m[o:o + n].view(p.shape), self._v[o:o + n].view(p.shape)
+
+    def _publish_optimizer_state(self, optimizer):
+        """Before optimizer.state_dict(): expose step / exp_avg / exp_avg_sq of every stepped parameter in torch.optim.AdamW's
+        own format (views into the moment arenas), so the reference's checkpoint code (Pretrain.py:264-274, utils/checkpointer.py)
+        saves -- and a later torch or fused run resumes -- the real optimizer state."""
+        if self._m is None or not _is_adamw(optimizer):
+            return
+        arena = self.arena
+        for grp in optimizer.param_groups:
+            for p in grp["params"]:
+                u = arena._unit_of.get(id(p))
+                if u is None or self._t[u] == 0:
+                    continue
+                m, v = self._views(p)
+                optimizer.state[p] = {"step": torch.tensor(float(self._t[u])), "exp_avg": m, "exp_avg_sq": v}
+
+    def _adopt_optimizer_state(self, optimizer):
+        """After optimizer.load_state_dict() (or at set_up for a state loaded earlier): copy per-parameter AdamW state into the moment
+        arenas, take over the step counts and mark those parameters live (they had gradients in the run that wrote the state)."""
+        arena = self.arena
+        if arena is None or not _is_adamw(optimizer) or not arena.grad.is_cuda or not self.fused_optimizer:
+            return
+        for grp in optimizer.param_groups:
+            for p in grp["params"]:
+                st = optimizer.state.get(p)
+                u = arena._unit_of.get(id(p))
+                if not st or u is None or "exp_avg" not in st:
+                    continue
+                self._alloc_moments()
+                m, v = self._views(p)
+                if st["exp_avg"].data_ptr() != m.data_ptr():
+                    m.copy_(st["exp_avg"])
+                    v.copy_(st["exp_avg_sq"])
+                self._t[u] = int(float(st["step"]))
+                arena.touch(p)
+                optimizer.state[p] = {"step": torch.tensor(float(self._t[u])), "exp_avg": m, "exp_avg_sq": v}
 
     def state_dict(self):
-        st = self._opt_state
-        return {} if st is None else {"m": st["m"], "v": st["v"], "t": st["t"]}
+        """Small metadata only: the moments travel in optimizer.state_dict() (see _publish_optimizer_state)."""
+        if self.arena is None:
+            return {}
+        return {"unit_steps": list(self._t), "live": list(self.arena.live), "step": self._step}
 
     def load_state_dict(self, sd):
-        if sd and self._opt_state is not None:
-            self._opt_state["m"].copy_(sd["m"])
-            self._opt_state["v"].copy_(sd["v"])
-            self._opt_state["t"] = sd["t"]
+        if not sd:
+            return
+        if self.arena is None:
+            raise RuntimeError("RCCLDDPAccelerator.load_state_dict before set_up (no parameter arena yet)")
+        if "m" in sd:  # round-1 format: whole moment arenas + one global step count
+            self._alloc_moments()
+            if sd["m"].numel() != self._m.numel():
+                raise ValueError("optimizer-state arena of another model layout")
+            self._m.copy_(sd["m"])
+            self._v.copy_(sd["v"])
+            for u, on in enumerate(self.arena.live):
+                if on:
+                    self._t[u] = int(sd["t"])
+            return
+        if len(sd["unit_steps"]) != len(self._t):
+            raise ValueError("accelerator state of another model layout")
+        self._t = [int(x) for x in sd["unit_steps"]]
+        for u, on in enumerate(sd["live"]):
+            if on and not self.arena.live[u]:
+                self.arena.live[u] = True
+                self.arena.live_ver += 1
+        self._step = int(sd.get("step", self._step))
 
 
 def _is_adamw(opt):

@@ -58,7 +58,8 @@ class LinearSlot:
         self.N = sum(w.shape[0] for w in self.weights)
         self.K = self.weights[0].numel() // self.weights[0].shape[0]
         self.ldt = _round(self.N, pad_k_to) if pad_k_to > 1 else _round(self.N, 8)
-        self.w = self.dw = self.b = self.db = None
+        self.w = self.b = None
+        self._dw = self._db = None
         self._wb = self._wt = None
         self._ver = None
         self._arena = None
@@ -80,6 +81,20 @@ class LinearSlot:
         if a._batch_event is not None:
             a._batch_wait()
 
+    # Gradient views are handed out through properties: every launch site that accumulates into the gradient arena asks for
+    # `slot.dw` / `slot.db`, which is what marks the slot's parameters as LIVE (ParamArena.touch) -- the data-parallel exchange,
+    # the optimizer and zero_grad work on whole live parameters, never on `grad != 0`.
+    @property
+    def dw(self):
+        self._arena.touch_all(self.weights)
+        return self._dw
+
+    @property
+    def db(self):
+        if self._db is not None:
+            self._arena.touch_all(self.biases)
+        return self._db
+
     @property
     def wb(self):
         self._ensure()
@@ -89,6 +104,15 @@ class LinearSlot:
     def wt(self):
         self._ensure()
         return self._wt
+
+
+def grad_of(p):
+    """Gradient view of a parameter inside its arena (re-attached if a caller dropped .grad); marks the parameter live -- every
+    kernel launch site that accumulates a parameter gradient gets its destination through here or through slot.dw / slot.db."""
+    p._xfm_arena.touch(p)
+    if p.grad is not p._xfm_grad:
+        p.grad = p._xfm_grad
+    return p._xfm_grad
 
 
 class ParamArena:
@@ -138,6 +162,24 @@ class ParamArena:
                 layout.append((p, p.numel(), off))
                 off = _round(off + p.numel())
         self.numel = _round(off)
+        # ---- liveness: a parameter is LIVE once any backward has written a gradient for it (launch sites ask for the gradient
+        # view through grad_of() / slot.dw / slot.db; autograd-fed parameters are caught by a tensor hook).  Live parameters are
+        # exchanged, clipped, stepped and zeroed as a whole, dead ones are skipped like `p.grad is None` in the reference's
+        # AdamW (optim.py:4-50 / DDP find_unused_parameters).  A fused group (q|k|v rows of one GEMM operand) is one unit.
+        self._units = []      # (start, end) 1-KiB aligned arena extents, in layout order
+        self._unit_of = {}    # id(param) -> unit index
+        extents = sorted((a, _round(b)) for a, b in group_ranges.values())
+        gi, cur = 0, None
+        for p, n, o in layout:
+            if cur is None or o >= cur[1]:
+                while gi < len(extents) and extents[gi][1] <= o:
+                    gi += 1
+                cur = extents[gi] if gi < len(extents) and extents[gi][0] <= o else (o, _round(o + n))
+                self._units.append(cur)
+            if p is not None:
+                self._unit_of[id(p)] = len(self._units) - 1
+        self.live = [False] * len(self._units)
+        self.live_ver = 0
         self.data = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.offsets = {}
@@ -149,16 +191,19 @@ class ParamArena:
             p.data = view
             p._xfm_grad = self.grad[o:o + n].view(p.shape)
             p.grad = p._xfm_grad
+            p._xfm_arena = self
             self.offsets[id(p)] = (o, n)
+            if p.requires_grad:  # gradients that arrive through autograd's AccumulateGrad (e.g. the ITC temperature)
+                p.register_hook(lambda g, _p=p: self.touch(_p))
         self.names = {id(p): name for name, p in params}
         for s in self.slots:
             s._arena = self
             wr, br = group_ranges[(id(s), "w")], group_ranges.get((id(s), "b"))
             s.w = self.data[wr[0]:wr[1]].view(s.N, s.K)
-            s.dw = self.grad[wr[0]:wr[1]].view(s.N, s.K)
+            s._dw = self.grad[wr[0]:wr[1]].view(s.N, s.K)
             if br is not None:
                 s.b = self.data[br[0]:br[1]]
-                s.db = self.grad[br[0]:br[1]]
+                s._db = self.grad[br[0]:br[1]]
                 assert s.b.numel() == s.N, s.name
         self._manual_ver = 0
         # slots a step has touched: after the next version bump their bf16 copies are rebuilt by ONE batched launch, on
@@ -208,19 +253,57 @@ class ParamArena:
     def bump(self):
         self._manual_ver += 1
 
-    def refresh(self):
-        """bf16 operand copies refresh themselves lazily (LinearSlot.wb / .wt); kept for callers of the old eager API."""
+    # ---- liveness -------------------------------------------------------------------------------
+    def touch(self, p):
+        u = self._unit_of[id(p)]
+        if not self.live[u]:
+            self.live[u] = True
+            self.live_ver += 1
+
+    def touch_all(self, plist):
+        for p in plist:
+            if not isinstance(p, int):
+                self.touch(p)
+
+    def is_live(self, p):
+        return self.live[self._unit_of[id(p)]]
+
+    def live_ranges(self, cuts=()):
+        """Maximal contiguous (start, end) arena ranges of live parameters, additionally split at `cuts` (tower boundaries)."""
+        out = []
+        for (a, b), on in zip(self._units, self.live):
+            if not on:
+                continue
+            if out and out[-1][1] == a:
+                out[-1][1] = b
+            else:
+                out.append([a, b])
+        res = []
+        for a, b in out:
+            pts = [a] + [c for c in sorted(cuts) if a < c < b] + [b]
+            res.extend(zip(pts[:-1], pts[1:]))
+        return res
+
+    def reattach(self):
+        """Point every parameter's .grad back at its arena view.  A caller that ran `optimizer.zero_grad()` (set_to_none=True is
+        torch 2's default; the reference's loop calls it after every optimizer step, Pretrain.py:76,127,133) drops the views: a
+        later autograd accumulation would then land in a fresh tensor the fused optimizer never sees.  A stray gradient tensor
+        that was accumulated while detached is folded into the arena."""
+        for p in self.params:
+            if p.grad is not p._xfm_grad:
+                if p.grad is not None:
+                    p._xfm_grad.add_(p.grad.to(p._xfm_grad.dtype))
+                    self.touch(p)
+                p.grad = p._xfm_grad
 
     def zero_grad(self, ranges=None):
-        """ranges: the (start, end) arena ranges that ever receive a gradient (the accelerator's live map); None = everything."""
+        """ranges: the (start, end) arena ranges of live parameters (dead ranges are never written and stay zero); None = everything."""
         if ranges is None:
             self.grad.zero_()
         else:
             for a, b in ranges:
                 self.grad[a:b].zero_()
-        for p in self.params:
-            if p.grad is not p._xfm_grad:
-                p.grad = p._xfm_grad
+        self.reattach()
 
     def attached(self):
         """True while the parameters still live in the arena (a .to()/.cuda() after finalize() breaks this; probing the

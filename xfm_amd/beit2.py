@@ -280,10 +280,9 @@ _GRAD_CHUNK_BLOCKS = 4  # the trunk's gradients leave for the all-reduce in chun
 
 
 def _g(p):
-    """gradient view of a parameter inside the arena (re-attached if a caller dropped .grad)."""
-    if p.grad is not p._xfm_grad:
-        p.grad = p._xfm_grad
-    return p._xfm_grad
+    """gradient view of a parameter inside the arena (marks it live; re-attached if a caller dropped .grad)."""
+    from .arena import grad_of
+    return grad_of(p)
 
 
 def arena_note_use(mod):
@@ -379,7 +378,6 @@ class VisionTransformer(nn.Module):
             if self._arena is not None and not self._own_arena:
                 raise RuntimeError("parameters were moved after the arena was built; call finalize() again")
             self.finalize()
-        self._arena.refresh()
 
     # ---- forward --------------------------------------------------------------------------------
     def forward(self, x, idx_to_group_img=None, image_atts=None, do_mask=False, ids_mask=None, drop_path_scales=None):

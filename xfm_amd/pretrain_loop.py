@@ -106,6 +106,15 @@ def _to(device, t):
     return None if t is None else t.to(device, non_blocking=True)
 
 
+def _backward(accelerator, loss, optimizer, last):
+    """accelerator.backward_step; accelerators that take the `sync` hint (RCCLDDPAccelerator) exchange gradients only on the last
+    backward before an optimizer step -- the sources of a multi-source step accumulate locally (the mean over ranks is linear)."""
+    if getattr(accelerator, "takes_sync_hint", False):
+        accelerator.backward_step(loss, optimizer, sync=last)
+    else:
+        accelerator.backward_step(loss, optimizer)
+
+
 def run_image_iter(model, image_batch, optimizer, accelerator, metric_logger, device, data_source, ret_mim_loss=True,
                    ret_match_loss=True, ret_mlm_loss=True, ret_itc_loss=True, do_optm=False):
     """Pretrain.py:61-91."""
@@ -114,7 +123,7 @@ def run_image_iter(model, image_batch, optimizer, accelerator, metric_logger, de
     loss = model(image, text_ids, text_atts, text_ids_masked=text_ids_masked, masked_pos=masked_pos, masked_ids=masked_ids,
                  ret_match_loss=ret_match_loss, ret_mim_loss=ret_mim_loss, ret_mlm_loss=ret_mlm_loss, ret_itc_loss=ret_itc_loss,
                  data_source=data_source)
-    accelerator.backward_step(loss['loss_itc'] + loss['loss_itm'] + loss['loss_mlm'] + loss['loss_mim'], optimizer)
+    _backward(accelerator, loss['loss_itc'] + loss['loss_itm'] + loss['loss_mlm'] + loss['loss_mim'], optimizer, do_optm)
     if do_optm:
         accelerator.optimizer_step(optimizer, model)
         optimizer.zero_grad()
@@ -128,7 +137,7 @@ def run_text_iter(model, batch, optimizer, accelerator, metric_logger, device):
     text_ids, text_atts, text_ids_masked, masked_pos, masked_ids = (_to(device, t) for t in batch)
     optimizer.zero_grad()
     loss = model(None, text_ids, text_atts, text_ids_masked=text_ids_masked, masked_pos=masked_pos, masked_ids=masked_ids)
-    accelerator.backward_step(loss['loss_mlm'], optimizer)
+    _backward(accelerator, loss['loss_mlm'], optimizer, True)
     accelerator.optimizer_step(optimizer, model)
     optimizer.zero_grad()
     metric_logger.update(loss_tmlm=loss['loss_mlm'])
@@ -184,12 +193,26 @@ def train(model, image_loader, data_loaders, optimizer, epoch_info, device, sche
             at_step = (global_step + 1) % config['ckpt_frequent_step'] == 0
             base = model.module if hasattr(model, 'module') else model
             if at_epoch:
-                checkpointer.save_checkpoint(model_state={'model': base.state_dict(), 'optimizer': optimizer.state_dict(),
+                # optimizer.state_dict() carries the fused AdamW moments in torch's own per-parameter format
+                # (RCCLDDPAccelerator._publish_optimizer_state), so the reference's save / resume code works unchanged
+                opt_state = optimizer.state_dict()
+                checkpointer.save_checkpoint(model_state={'model': base.state_dict(), 'optimizer': opt_state,
                                                           'lr_scheduler': scheduler.state_dict(), 'config': config,
                                                           'epoch': current_epoch},
-                                             epoch=current_epoch, training_states=optimizer.state_dict())
+                                             epoch=current_epoch, training_states=opt_state)
             if at_step:
                 checkpointer.save_checkpoint(model_state={'model': base.state_dict(), 'config': config}, epoch=current_epoch,
                                              step=global_step, training_states=optimizer.state_dict())
         global_step += 1
     return {k: "{:.5f}".format(v) for k, v in metric_logger.global_avg().items()}
+
+
+def resume(checkpoint, optimizer, lr_scheduler):
+    """Pretrain.py:437-445 (`config['resume']`): optimizer + scheduler state and the epoch to continue from.  Called BEFORE
+    accelerator.set_up like the reference does (set_up adopts the loaded AdamW moments, per-parameter step counts and live set
+    into its arenas) or after it (the optimizer's load hook does the same)."""
+    if isinstance(checkpoint, str):
+        checkpoint = torch.load(checkpoint, map_location='cpu', weights_only=False)
+    optimizer.load_state_dict(checkpoint['optimizer'])
+    lr_scheduler.load_state_dict(checkpoint['lr_scheduler'])
+    return checkpoint['epoch'] + 1

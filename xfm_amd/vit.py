@@ -118,7 +118,6 @@ class VisionTransformer(nn.Module):
             if self._arena is not None and not self._own_arena:
                 raise RuntimeError("parameters were moved after the arena was built; call finalize() again")
             self.finalize()
-        self._arena.refresh()
 
     def forward(self, x, register_blk=-1, idx_to_group_img=None, image_atts=None, drop_path_scales=None):
         if idx_to_group_img is not None or image_atts is not None or register_blk != -1:

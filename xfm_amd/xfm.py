@@ -300,7 +300,6 @@ class XFMBase(nn.Module):
     def _ready(self):
         if self._arena is None or not self._arena.attached():
             self.finalize()
-        self._arena.refresh()
 
     def zero_grad(self, set_to_none=False):
         if self._arena is not None:

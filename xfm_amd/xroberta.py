@@ -403,7 +403,6 @@ class RobertaModel(nn.Module):
             raise NotImplementedError("per-layer encoder_hidden_states lists (xroberta.py:435-444) are outside the hot-path scope")
         if self._arena is None:
             raise RuntimeError("RobertaModel is not attached to a parameter arena; build it through XFMBase or call finalize()")
-        self._arena.refresh()
         cfg = self.config
         if encoder_embeds is None:
             if input_ids is None:
