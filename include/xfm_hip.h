@@ -144,6 +144,13 @@ typedef struct {
      One workgroup per (source, head) keeps K/V LDS-resident for all of its rows; dk/dv are summed over the group and
      written per SOURCE ([n_groups*Sk] rows). */
   const int* grp_start; const int* grp_rows; int n_groups;
+  /* optional PACKED (unpadded) token rows: batch entry b's queries are rows q_start[b] .. q_start[b] + q_len[b] (q_len[b] in
+     [1, Sq]) of q / o / dout / dq, its keys rows k_start[b] .. + k_len[b] of k / v / dk / dv; NULL = dense b * S rows.  Sq / Sk
+     stay the padded lengths (grids, statistics [B,H,stat_ld], dropout counters).  Keys past k_len get probability exactly 0,
+     what the reference's additive -10000 mask yields in fp32 for a prefix-masked batch (xroberta.py:751-807), so no key_keep
+     is needed.  Rows of o / dq / dk / dv outside every sequence are not written.  No bias, no kv_index in this mode; in grouped
+     mode only the query side may be packed. */
+  const int* q_start; const int* q_len; const int* k_start; const int* k_len;
 } xfm_attn_args;
 
 int xfm_attn_fwd(const xfm_attn_args* a, void* stream);
@@ -194,11 +201,19 @@ typedef struct {
   uint32_t drop_thresh; float drop_scale; uint32_t seed_lo, seed_hi;
   const xfm_bf16* dy; float* dword; float* dpos; float* partial;
   int pos_mode; /* 0: RoBERTa pad-aware cumsum positions; 1: BERT absolute positions 0..T-1 (xbert.py:198-199) */
+  const int* row_map; /* optional [B*T]: token (b,t) is written to / its gradient read from row row_map[b*T+t] of y / dy (packed,
+                         unpadded rows); -1 skips the token (padding).  mean / rstd / pos_ids stay [B*T]. */
 } xfm_embed_args;
 int xfm_embed_ln_fwd(const xfm_embed_args* a, int D, void* stream);
 long xfm_embed_ln_bwd_workspace(int rows, int D);
 int xfm_embed_ln_bwd(const xfm_embed_args* a, int D, float* dgamma, float* dbeta, float* dtype, float* workspace,
                      long workspace_bytes, void* stream);
+
+/* ---- Row gather / scatter-add for packed token rows (the [CLS] / masked-position gathers of xroberta.py:1215-1216 and the
+ * batch assembly of xfm.py:781-793 on unpadded rows): dst[r,:] = index[r] >= 0 ? src[index[r],:] : 0 (bf16 rows of D elements,
+ * D % 8 == 0); and its adjoint dst32[index[r],:] += src[r,:] (fp32 accumulation, rows with index < 0 are skipped). ------------- */
+int xfm_rows_gather(const xfm_bf16* src, const int* index, int R, int D, xfm_bf16* dst, void* stream);
+int xfm_rows_scatter_add(const xfm_bf16* src, const int* index, int R, int D, float* dst32, void* stream);
 
 /* ---- Vocabulary cross-entropy, ignore_index -100 (xroberta.py:1296-1297, 1107-1114) ------------------------------ */
 int xfm_ce_fwd(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, void* stream);

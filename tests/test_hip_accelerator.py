@@ -4,8 +4,8 @@ What is pinned:
   * the live-parameter set after one pre-training backward == the parameters whose `.grad` is not None in the REAL reference
     (`unused` list of tests/golden/pretrain_small.npz), and no dead parameter ever holds a non-zero gradient;
   * the parameters after a text-only step followed by two image steps, driven through xfm_amd.pretrain_loop exactly as
-    Pretrain.py:61-139 drives its accelerator (optimizer.zero_grad() calls included), equal torch.optim.AdamW + clip_grad_norm_
-    replayed on the gradients the kernels produced (per-parameter step counts, `grad is None` skipping, weight decay on
+    Pretrain.py:61-139 drives its accelerator (optimizer.zero_grad() calls included), equal the reference's optimizer rule
+    (transformers' AdamW + clip_grad_norm_) replayed on the gradients the kernels produced (per-parameter step counts, `grad is None` skipping, weight decay on
     zero-gradient live parameters, the autograd-fed temperature);
   * one oracle (CPU fp32) step + torch AdamW moves the parameters the same way;
   * optimizer.state_dict() -> load_state_dict() into a fresh process state reproduces the next step bit for bit."""
@@ -102,25 +102,44 @@ def test_loop_text_then_image_steps_match_torch_adamw_replay():
     assert live3[arena._unit_of[id(m.vision_encoder.cls_token)]], "the vision tower must join at the first image step"
     assert live1[arena._unit_of[id(m.text_encoder.lm_head.bias)]], "the text-only step trains the text tower's own LM head"
 
-    # replay: torch.optim.AdamW on clones, fed the recorded gradients (dead parameters: grad None)
+    # replay on clones with the REFERENCE's optimizer rule -- transformers.optimization.AdamW (optim.py:1,26-50 of the reference;
+    # transformers 4.12.5): eps is added to sqrt(v) BEFORE the bias correction (torch.optim.AdamW adds it after, which differs
+    # once clipped gradients approach 1e-8) and the decoupled decay follows the Adam update.  Dead parameters: grad None, skipped.
     named = list(m.named_parameters())
-    clones = {n: torch.nn.Parameter(params0[n].clone()) for n, _ in named}
+    clones = {n: params0[n].clone() for n, _ in named}
     id2name = {id(p): n for n, p in named}
-    groups = [{"params": [clones[id2name[id(p)]] for p in g["params"]], "lr": g["lr"], "weight_decay": g["weight_decay"]}
-              for g in opt.param_groups]
-    ref = torch.optim.AdamW(groups, lr=1e-3, eps=1e-8, betas=(0.9, 0.98))
+    state = {}
+    b1, b2, eps = 0.9, 0.98, 1e-8
     for grad, live in rec:
+        grads = {}
         for n, p in named:
             o, n_el = arena.offsets[id(p)]
-            clones[n].grad = grad[o:o + n_el].view(p.shape).clone() if live[arena._unit_of[id(p)]] else None
-        torch.nn.utils.clip_grad_norm_([c for c in clones.values() if c.grad is not None], 1.0)
-        ref.step()
-    worst = 0.0
+            if live[arena._unit_of[id(p)]]:
+                grads[n] = grad[o:o + n_el].view(p.shape).clone()
+        total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()   # clip_grad_norm_(max_norm=1.0)
+        coef = torch.clamp(1.0 / (total + 1e-6), max=1.0)
+        for g in opt.param_groups:
+            for p in g["params"]:
+                n = id2name[id(p)]
+                if n not in grads:
+                    continue
+                gr = grads[n] * coef
+                st = state.setdefault(n, {"step": 0, "m": torch.zeros_like(gr), "v": torch.zeros_like(gr)})
+                st["step"] += 1
+                st["m"].mul_(b1).add_(gr, alpha=1 - b1)
+                st["v"].mul_(b2).addcmul_(gr, gr, value=1 - b2)
+                step_size = g["lr"] * (1 - b2 ** st["step"]) ** 0.5 / (1 - b1 ** st["step"])
+                clones[n].addcdiv_(st["m"], st["v"].sqrt().add_(eps), value=-step_size)
+                if g["weight_decay"] > 0:
+                    clones[n].add_(clones[n], alpha=-g["lr"] * g["weight_decay"])
+    worst, bad = 0.0, []
     for n, p in named:
-        d = float((p.detach() - clones[n].detach()).abs().max())
+        d = float((p.detach() - clones[n]).abs().max())
         worst = max(worst, d)
-        assert d <= 2e-6, f"{n}: fused clip + AdamW differs from torch.optim.AdamW by {d:.3e}"
-    print(f"worst |fused - torch| over {len(named)} parameters after 3 steps: {worst:.3e}")
+        if d > 2e-6:
+            bad.append((n, f"{d:.3e}"))
+    assert not bad, f"fused clip + AdamW differs from the reference rule on {len(bad)}/{len(named)} parameters: {bad[:10]}"
+    print(f"worst |fused - reference rule| over {len(named)} parameters after 3 steps: {worst:.3e}")
     # the temperature is fed by plain autograd (AccumulateGrad into the arena view) and survives optimizer.zero_grad()
     assert float((m.temp.detach() - params0["temp"]).abs()) > 0 and m.temp.grad is m.temp._xfm_grad
     w = m.fusion_encoder.roberta.encoder.layer[0].intermediate.dense.weight

@@ -528,18 +528,19 @@ def _pretrain_cfg(meta):
             "learnable_temp": True, "max_temp": 0.5, "min_temp": 0.001, "vision_depth": meta.get("vit_depth", 12)}
 
 
-def _pretrain(name, tol=None, cos_tol=None, batch_passes=True):
+def _pretrain(name, tol=None, cos_tol=None, batch_passes=True, packed=False):
     from xfm_amd.model_pretrain import XFM
     z, meta = load(name)
     B = meta["B"]
     m = XFM(dict(_pretrain_cfg(meta), batch_passes=batch_passes))
     _load_into(m, meta["spec"])
     m.cuda().finalize().eval()
-    b = {k: v.cuda() for k, v in syn.pretrain_batch(B, seed=1234).items()}
+    hb = syn.pretrain_batch(B, seed=1234)
+    b = {k: v.cuda() for k, v in hb.items()}
     masks = syn.mim_block_mask(B, 14, 75, seed=1234)
     losses = m(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"], masked_pos=b["masked_pos"],
                masked_ids=b["masked_ids"], ret_mim_loss=True, data_source="image", ids_mask=masks,
-               neg_idx=(meta["image_neg_idx"], meta["text_neg_idx"]))
+               neg_idx=(meta["image_neg_idx"], meta["text_neg_idx"]), text_lens=hb["text_atts"].sum(1) if packed else None)
     total, ref_total = 0, 0.0
     report = {}
     for k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim"):
@@ -570,6 +571,11 @@ def test_pretrain_step_small_vs_golden():
 def test_pretrain_step_small_reference_call_order_vs_golden():
     """batch_passes=False: the reference's own sequence of tower calls (2 ViT passes, ITM and MLM fusion passes apart)."""
     _pretrain("pretrain_small", batch_passes=False)
+
+
+def test_pretrain_step_small_packed_rows_vs_golden():
+    """Unpadded token rows in the text / fusion towers (xfm_amd.packing) against the REAL reference's padded step."""
+    _pretrain("pretrain_small", packed=True)
 
 
 def test_pretrain_step_full_depth_vs_golden():

@@ -50,7 +50,8 @@ class AttnArgs(ctypes.Structure):
                 ("dout", c_void_p), ("do_rs", c_long), ("dq", c_void_p), ("dq_rs", c_long), ("dk", c_void_p),
                 ("dk_rs", c_long), ("dv", c_void_p), ("dv_rs", c_long), ("delta", c_void_p), ("dbias", c_void_p),
                 ("stat_ld", c_long), ("bias_t", c_void_p), ("bias_t_ld", c_long), ("kv_index", c_void_p),
-                ("grp_start", c_void_p), ("grp_rows", c_void_p), ("n_groups", c_int)]
+                ("grp_start", c_void_p), ("grp_rows", c_void_p), ("n_groups", c_int),
+                ("q_start", c_void_p), ("q_len", c_void_p), ("k_start", c_void_p), ("k_len", c_void_p)]
 
 
 class EmbedArgs(ctypes.Structure):
@@ -58,7 +59,8 @@ class EmbedArgs(ctypes.Structure):
                 ("b", c_void_p), ("y", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("pos_ids", c_void_p),
                 ("B", c_int), ("T", c_int), ("pad_id", c_int), ("eps", c_float),
                 ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32),
-                ("dy", c_void_p), ("dword", c_void_p), ("dpos", c_void_p), ("partial", c_void_p), ("pos_mode", c_int)]
+                ("dy", c_void_p), ("dword", c_void_p), ("dpos", c_void_p), ("partial", c_void_p), ("pos_mode", c_int),
+                ("row_map", c_void_p)]
 
 
 class AdamWArgs(ctypes.Structure):
@@ -106,6 +108,8 @@ SIGNATURES = {
     "xfm_ce_bwd": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p]),
     "xfm_adamw": (c_int, [ctypes.POINTER(AdamWArgs), c_void_p]),
     "xfm_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "xfm_rows_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "xfm_rows_scatter_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -113,6 +113,19 @@ __device__ __forceinline__ float group4_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
+// Packed (unpadded) token rows: batch entry b's queries are rows q_start[b] .. q_start[b] + q_len[b] of q / o / dout / dq (q_len <= Sq,
+// Sq stays the padded length: statistics, dropout counters and grids are laid out for it); the same for keys / values through
+// k_start / k_len.  NULL = dense [B, S] rows.  Keys past k_len are excluded exactly (probability 0), which is what the additive
+// -10000 mask of a padded batch gives in fp32 (xroberta.py:751-807), so a prefix-masked batch needs no key_keep when packed.
+__device__ __forceinline__ void q_seq(const AttnArgs& a, int b, long& base, int& len) {
+  if (a.q_start != nullptr) { base = a.q_start[b]; len = a.q_len[b]; }
+  else { base = (long)b * a.Sq; len = a.Sq; }
+}
+__device__ __forceinline__ void k_seq(const AttnArgs& a, int b, long& base, int& len) {
+  if (a.k_start != nullptr) { base = a.k_start[b]; len = a.k_len[b]; }
+  else { base = (long)b * a.Sk; len = a.Sk; }
+}
+
 // Score post-processing shared by forward and dQ: s = raw*scale + bias (+ MASK_NEG when the key is masked or causally hidden),
 // EXCL_NEG past the last key.  Branch-free: the key-keep flags of a chunk are fetched up front with the bias (16 dwords in
 // flight, one wait) and every condition becomes a select; chunks with nothing to mask (`plain`) are a bare FMA.
@@ -126,10 +139,10 @@ __device__ __forceinline__ void load_keep(const AttnArgs& a, int kvb, int kc, in
       kk[t][r] = row[kj < a.Sk ? kj : a.Sk - 1];
     }
 }
-__device__ __forceinline__ float score_masked(const AttnArgs& a, float raw, float biasv, bool has_mask, int keep, bool causal, int qi, int kj) {
+__device__ __forceinline__ float score_masked(const AttnArgs& a, float raw, float biasv, bool has_mask, int keep, bool causal, int qi, int kj, int sk) {
   const bool masked = (has_mask & (keep == 0)) | (causal & (kj > qi));
   const float s = fmaf(raw, a.scale, biasv) + (masked ? MASK_NEG : 0.f);
-  return kj >= a.Sk ? EXCL_NEG : s;
+  return kj >= sk ? EXCL_NEG : s;
 }
 
 // dropout decision of score (b, h, qi, kj): row = the query row, column = the key.  `drop_key` is loop-invariant wherever a
@@ -159,36 +172,40 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
   const int lr = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
+  long qbase, kbase;
+  int sq, sk;
+  q_seq(a, b, qbase, sq);
   const int q0 = (blockIdx.x * (nthreads >> 6) + w) * 16;
-  const bool wave_active = q0 < a.Sq;
+  const bool wave_active = q0 < sq;
   const int qi = q0 + lr;
-  const int qc = qi < a.Sq ? qi : a.Sq - 1;
+  const int qc = qi < sq ? qi : sq - 1;
   const uint32_t dkey = drop_key(a, b, h, qi);
-  const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
+  const bf16* qp = a.q + (qbase + qc) * a.q_rs + h * 64;
   const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
   const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
   const int kvb = a.kv_index ? a.kv_index[b] : b;  // several query rows may share one key/value source (deduplicated images)
-  const bf16* kb = a.k + (long)kvb * a.Sk * a.k_rs + h * 64;
-  const bf16* vb = a.v + (long)kvb * a.Sk * a.v_rs + h * 64;
+  k_seq(a, kvb, kbase, sk);
+  const bf16* kb = a.k + kbase * a.k_rs + h * 64;
+  const bf16* vb = a.v + kbase * a.v_rs + h * 64;
 
   f32x4 oacc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = EXCL_NEG, l_run = 0.f;
 
-  const int nchunks = (a.Sk + 63) / 64;
+  const int nchunks = (sk + 63) / 64;
   constexpr bool resident = RES;  // all chunks of this (b,h) staged once, one barrier (host: Sk <= 256, >= 4 waves)
   const int nw = nthreads >> 6;
   if (resident) {
-    for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, a.Sk, w, nw, lane);
+    for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, sk, w, nw, lane);
     stage_wait();
   } else {
-    stage_slot(lds, kb, a.k_rs, vb, a.v_rs, 0, a.Sk, w, nw, lane);
+    stage_slot(lds, kb, a.k_rs, vb, a.v_rs, 0, sk, w, nw, lane);
   }
   for (int kc = 0; kc < nchunks; ++kc) {
     if (!resident) {  // double buffer: chunk kc has landed, everyone is done with chunk kc-1 -> refill its slot
       stage_wait();
-      if (kc + 1 < nchunks) stage_slot(lds + ((kc + 1) & 1) * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, (kc + 1) * 64, a.Sk, w, nw, lane);
+      if (kc + 1 < nchunks) stage_slot(lds + ((kc + 1) & 1) * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, (kc + 1) * 64, sk, w, nw, lane);
     }
     const char* sK = lds + (resident ? kc : (kc & 1)) * ATTN_SLOT;
     const char* sV = sK + ATTN_TILE;
@@ -197,7 +214,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnArgs a) {
     int kk[PLAIN ? 1 : 4][4];
     const bool has_mask = !PLAIN && a.key_keep != nullptr;
     const bool causal = !PLAIN && a.causal != 0;
-    const bool plain = !has_mask && !causal && kc * 64 + 64 <= a.Sk;  // wave-uniform: nothing to mask in this chunk
+    const bool plain = !has_mask && !causal && kc * 64 + 64 <= sk;  // wave-uniform: nothing to mask in this chunk
     load_bias(a, h, qc, kc, lg, bvs);  // bias (and key-keep) loads first: their L2 latency hides under the QK^T MFMAs
     if constexpr (!PLAIN) {
       if (has_mask) load_keep(a, kvb, kc, lg, kk);
@@ -222,7 +239,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnArgs a) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          st[t][r] = score_masked(a, st[t][r], bvs[t][r], has_mask, has_mask ? kk[PLAIN ? 0 : t][r] : 1, causal, qi, kc * 64 + t * 16 + 4 * lg + r);
+          st[t][r] = score_masked(a, st[t][r], bvs[t][r], has_mask, has_mask ? kk[PLAIN ? 0 : t][r] : 1, causal, qi, kc * 64 + t * 16 + 4 * lg + r, sk);
           mx = fmaxf(mx, st[t][r]);
         }
     }
@@ -259,9 +276,9 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnArgs a) {
         oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sV, 32 * s, 32 * s + 16, dt * 16, lr, lg), pf, oacc[dt], 0, 0, 0);
     }
   }
-  if (!wave_active || qi >= a.Sq) return;
+  if (!wave_active || qi >= sq) return;
   const float inv = 1.0f / l_run;
-  bf16* op = a.o + ((long)b * a.Sq + qi) * a.o_rs + h * 64;
+  bf16* op = a.o + (qbase + qi) * a.o_rs + h * 64;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     bf16x4 ov;
@@ -288,11 +305,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
   const int lr = lane & 15, lg = lane >> 4;
   const int h = blockIdx.y;
   const int q0 = (blockIdx.x * (nthreads >> 6) + w) * 16;
-  const bool wave_active = q0 < a.Sq;
   const int qi = q0 + lr;
-  const bool qvalid = qi < a.Sq;
-  const int qc = qvalid ? qi : a.Sq - 1;
-  const int nchunks = (a.Sk + 63) / 64;
   constexpr bool resident = RES;
 
   f32x4 dsacc[NACC][4];
@@ -304,9 +317,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
   for (int bi = 0; bi < nb_per_block; ++bi) {
     const int b = blockIdx.z * nb_per_block + bi;
     if (b >= a.B) break;
+    long qbase, kbase;
+    int sq, sk;
+    q_seq(a, b, qbase, sq);
+    const bool wave_active = q0 < sq;
+    const bool qvalid = qi < sq;
+    const int qc = qvalid ? qi : sq - 1;
     const uint32_t dkey = drop_key(a, b, h, qi);
-    const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
-    const bf16* dop = a.dout + ((long)b * a.Sq + qc) * a.do_rs + h * 64;
+    const bf16* qp = a.q + (qbase + qc) * a.q_rs + h * 64;
+    const bf16* dop = a.dout + (qbase + qc) * a.do_rs + h * 64;
     const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
     const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
     const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop + 8 * lg);
@@ -314,23 +333,25 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
     const long stat_idx = ((long)b * a.H + h) * a.stat_ld + qc;
     const float lse = a.lse[stat_idx];
     const int kvb = a.kv_index ? a.kv_index[b] : b;
-    const bf16* kb = a.k + (long)kvb * a.Sk * a.k_rs + h * 64;
-    const bf16* vb = a.v + (long)kvb * a.Sk * a.v_rs + h * 64;
+    k_seq(a, kvb, kbase, sk);
+    const int nchunks = (sk + 63) / 64;
+    const bf16* kb = a.k + kbase * a.k_rs + h * 64;
+    const bf16* vb = a.v + kbase * a.v_rs + h * 64;
 
     const int nw = nthreads >> 6;
     if (resident) {
       __syncthreads();  // previous batch entry's readers are done
-      for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, a.Sk, w, nw, lane);
+      for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, sk, w, nw, lane);
       stage_wait();
     }
     // streaming mode: double-buffered slots; `first` issues chunk 0 of a pass, `next` waits for chunk kc and refills
     auto stream_first = [&]() {
       __syncthreads();
-      stage_slot(lds, kb, a.k_rs, vb, a.v_rs, 0, a.Sk, w, nw, lane);
+      stage_slot(lds, kb, a.k_rs, vb, a.v_rs, 0, sk, w, nw, lane);
     };
     auto stream_next = [&](int kc) {
       stage_wait();
-      if (kc + 1 < nchunks) stage_slot(lds + ((kc + 1) & 1) * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, (kc + 1) * 64, a.Sk, w, nw, lane);
+      if (kc + 1 < nchunks) stage_slot(lds + ((kc + 1) & 1) * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, (kc + 1) * 64, sk, w, nw, lane);
     };
     // probabilities P (recomputed from the forward's log-sum-exp) and dropped dP = (dO . V^T) * keep/(1-p) of one chunk
     auto probs = [&](int kc, f32x4 (&st)[4], f32x4 (&dp)[4]) {
@@ -340,7 +361,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
       int kk[PLAIN ? 1 : 4][4];
       const bool has_mask = !PLAIN && a.key_keep != nullptr;
       const bool causal = !PLAIN && a.causal != 0;
-      const bool plain = !has_mask && !causal && kc * 64 + 64 <= a.Sk;
+      const bool plain = !has_mask && !causal && kc * 64 + 64 <= sk;
       load_bias(a, h, qc, kc, lg, bvs);
       if constexpr (!PLAIN) {
         if (has_mask) load_keep(a, kvb, kc, lg, kk);
@@ -365,7 +386,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r)  // excluded keys: exp(EXCL_NEG - lse) = 0
-            st[t][r] = __expf(score_masked(a, st[t][r], bvs[t][r], has_mask, has_mask ? kk[PLAIN ? 0 : t][r] : 1, causal, qi, kc * 64 + t * 16 + 4 * lg + r) - lse_q);
+            st[t][r] = __expf(score_masked(a, st[t][r], bvs[t][r], has_mask, has_mask ? kk[PLAIN ? 0 : t][r] : 1, causal, qi, kc * 64 + t * 16 + 4 * lg + r, sk) - lse_q);
       }
       if (!PLAIN && a.drop_thresh != 0u) {
 #pragma unroll
@@ -415,7 +436,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
           const int kj = kj0 + r;
           const float ds = st[t][r] * (dp[t][r] - delta);
           st[t][r] = ds;
-          if (!DBIAS && a.dbias != nullptr && kj < a.Sk && qvalid) atomicAdd(a.dbias + ((long)h * a.Sq + qi) * a.bias_ld + kj, ds);
+          if (!DBIAS && a.dbias != nullptr && kj < sk && qvalid) atomicAdd(a.dbias + ((long)h * a.Sq + qi) * a.bias_ld + kj, ds);
         }
       }
       if (DBIAS) {  // static register indices only: a wave-uniform compare selects the chunk's accumulator
@@ -436,7 +457,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
       }
     }
     if (wave_active && qvalid) {
-      bf16* dqp = a.dq + ((long)b * a.Sq + qi) * a.dq_rs + h * 64;
+      bf16* dqp = a.dq + (qbase + qi) * a.dq_rs + h * 64;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         bf16x4 ov;
@@ -447,7 +468,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
     }
   }
 
-  if (DBIAS) {
+  if (DBIAS) {  // (dense rows only: the launcher never pairs the bias-gradient variant with packed rows)
+    const bool wave_active = q0 < a.Sq;
+    const int nchunks = (a.Sk + 63) / 64;
     float* fl = reinterpret_cast<float*>(lds + w * 4096);  // wave-private [16 q][64 keys], aliases the K/V slots (done with)
 #pragma unroll
     for (int kc = 0; kc < NACC; ++kc) {
@@ -478,20 +501,26 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
   const int lr = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int k0 = (blockIdx.x * (nthreads >> 6) + w) * 16;
-  const bool wave_active = k0 < a.Sk;
-  const int kj = k0 + lr;
-  const bool kvalid = kj < a.Sk;
-  const int kcl = kvalid ? kj : a.Sk - 1;
   const int kvb = a.kv_index ? a.kv_index[b] : b;
-  const bf16* kp = a.k + ((long)kvb * a.Sk + kcl) * a.k_rs + h * 64;
-  const bf16* vp = a.v + ((long)kvb * a.Sk + kcl) * a.v_rs + h * 64;
+  long qbase, kbase, kout;
+  int sq, sk, sk_unused;
+  q_seq(a, b, qbase, sq);
+  k_seq(a, kvb, kbase, sk);
+  k_seq(a, b, kout, sk_unused);  // dk / dv rows belong to the QUERY batch entry (kv_index folds them afterwards)
+  const int k0 = (blockIdx.x * (nthreads >> 6) + w) * 16;
+  const bool wave_active = k0 < sk;
+  const int kj = k0 + lr;
+  const bool kvalid = kj < sk;
+  const int kcl = kvalid ? kj : sk - 1;
+  const bf16* kp = a.k + (kbase + kcl) * a.k_rs + h * 64;
+  const bf16* vp = a.v + (kbase + kcl) * a.v_rs + h * 64;
+  (void)sk_unused;
   const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp + 8 * lg);
   const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + 32 + 8 * lg);
   const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vp + 8 * lg);
   const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vp + 32 + 8 * lg);
-  const bf16* qb = a.q + (long)b * a.Sq * a.q_rs + h * 64;
-  const bf16* db = a.dout + (long)b * a.Sq * a.do_rs + h * 64;
+  const bf16* qb = a.q + qbase * a.q_rs + h * 64;
+  const bf16* db = a.dout + qbase * a.do_rs + h * 64;
   const float* lse_b = a.lse + ((long)b * a.H + h) * a.stat_ld;
   const float* del_b = a.delta + ((long)b * a.H + h) * a.stat_ld;
   bool key_masked = false;
@@ -502,7 +531,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  const int nchunks = (a.Sq + 63) / 64;
+  const int nchunks = (sq + 63) / 64;
   constexpr bool resident = RES;
   const int nw = nthreads >> 6;
   // row statistics / transposed bias of this lane's 4 consecutive queries in 32-query step `step`: 16-B loads
@@ -519,15 +548,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
   };
   if (resident) {
-    for (int qc = 0; qc < nchunks; ++qc) stage_slot(lds + qc * ATTN_SLOT, qb, a.q_rs, db, a.do_rs, qc * 64, a.Sq, w, nw, lane);
+    for (int qc = 0; qc < nchunks; ++qc) stage_slot(lds + qc * ATTN_SLOT, qb, a.q_rs, db, a.do_rs, qc * 64, sq, w, nw, lane);
     stage_wait();
   } else {
-    stage_slot(lds, qb, a.q_rs, db, a.do_rs, 0, a.Sq, w, nw, lane);
+    stage_slot(lds, qb, a.q_rs, db, a.do_rs, 0, sq, w, nw, lane);
   }
   _Pragma("unroll 1") for (int qc = 0; qc < nchunks; ++qc) {
     if (!resident) {
       stage_wait();
-      if (qc + 1 < nchunks) stage_slot(lds + ((qc + 1) & 1) * ATTN_SLOT, qb, a.q_rs, db, a.do_rs, (qc + 1) * 64, a.Sq, w, nw, lane);
+      if (qc + 1 < nchunks) stage_slot(lds + ((qc + 1) & 1) * ATTN_SLOT, qb, a.q_rs, db, a.do_rs, (qc + 1) * 64, sq, w, nw, lane);
     }
     const char* sQ = lds + (resident ? qc : (qc & 1)) * ATTN_SLOT;
     const char* sD = sQ + ATTN_TILE;
@@ -558,7 +587,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
           }
       }
       const float key_add = key_masked ? MASK_NEG : 0.f;
-      const bool tail = qc * 64 + 64 > a.Sq;  // wave-uniform: this chunk holds rows past the last query
+      const bool tail = qc * 64 + 64 > sq;  // wave-uniform: this chunk holds rows past the last query
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int qi0 = qc * 64 + (2 * s2 + u) * 16 + 4 * lg;
@@ -569,9 +598,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
           if (!PLAIN) sc += (causal & (kj > qi)) ? MASK_NEG : key_add;  // masked once, whichever reason (xroberta.py:772-807)
           float pv = __expf(sc - lsev[u][r]);
           float dl = delv[u][r];
-          if (tail) {  // the statistics past Sq are unwritten padding: select, never multiply
-            pv = qi < a.Sq ? pv : 0.f;
-            dl = qi < a.Sq ? dl : 0.f;
+          if (tail) {  // the statistics past the last query are unwritten padding: select, never multiply
+            pv = qi < sq ? pv : 0.f;
+            dl = qi < sq ? dl : 0.f;
           }
           pv = kvalid ? pv : 0.f;
           delv[u][r] = dl;
@@ -601,8 +630,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
   }
   if (!wave_active || !kvalid) return;
-  bf16* dkp = a.dk + ((long)b * a.Sk + kj) * a.dk_rs + h * 64;
-  bf16* dvp = a.dv + ((long)b * a.Sk + kj) * a.dv_rs + h * 64;
+  bf16* dkp = a.dk + (kout + kj) * a.dk_rs + h * 64;
+  bf16* dvp = a.dv + (kout + kj) * a.dv_rs + h * 64;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     bf16x4 ok_, ov_;
@@ -643,8 +672,10 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
   if (PACK) {
     for (int jj = 0; jj < nrows; ++jj) {
       const int src = a.kv_index ? a.kv_index[rstart + jj] : rstart + jj;
-      stage_slot(lds + jj * ATTN_SLOT, a.k + (long)src * a.Sk * a.k_rs + h * 64, a.k_rs, a.v + (long)src * a.Sk * a.v_rs + h * 64, a.v_rs,
-                 0, a.Sk, w, nw, lane);
+      long kbase;
+      int sk;
+      k_seq(a, src, kbase, sk);
+      stage_slot(lds + jj * ATTN_SLOT, a.k + kbase * a.k_rs + h * 64, a.k_rs, a.v + kbase * a.v_rs + h * 64, a.v_rs, 0, sk, w, nw, lane);
     }
   } else {
     const bf16* kb = a.k + (long)g * a.Sk * a.k_rs + h * 64;
@@ -659,10 +690,14 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
   for (int j = jr; j < nrows; j += rpp) {
     const int b = PACK ? rstart + j : a.grp_rows[rstart + j];
     const int kvb = PACK ? (a.kv_index ? a.kv_index[b] : b) : g;
+    long qbase, kbase_unused;
+    int sq, sk = a.Sk;
+    q_seq(a, b, qbase, sq);
+    if (PACK) k_seq(a, kvb, kbase_unused, sk);
     const int qi = tile * 16 + lr;
-    const int qc = qi < a.Sq ? qi : a.Sq - 1;
+    const int qc = qi < sq ? qi : sq - 1;
     const uint32_t dkey = drop_key(a, b, h, qi);
-    const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
+    const bf16* qp = a.q + (qbase + qc) * a.q_rs + h * 64;
     const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
     const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
     f32x4 oacc[4];
@@ -686,7 +721,7 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          st[t][r] = score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, causal, qi, kc * 64 + t * 16 + 4 * lg + r);
+          st[t][r] = score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, causal, qi, kc * 64 + t * 16 + 4 * lg + r, sk);
           mx = fmaxf(mx, st[t][r]);
         }
       mx = group4_max(mx);
@@ -722,9 +757,9 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
           oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sV, 32 * s2, 32 * s2 + 16, dt * 16, lr, lg), pf, oacc[dt], 0, 0, 0);
       }
     }
-    if (qi < a.Sq) {
+    if (qi < sq) {
       const float inv = 1.0f / l_run;
-      bf16* op = a.o + ((long)b * a.Sq + qi) * a.o_rs + h * 64;
+      bf16* op = a.o + (qbase + qi) * a.o_rs + h * 64;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         bf16x4 ov;
@@ -756,12 +791,15 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
   if (jr >= rpp) return;
   for (int j = jr; j < nrows; j += rpp) {
     const int b = a.grp_rows[rstart + j];
+    long qbase;
+    int sq;
+    q_seq(a, b, qbase, sq);
     const int qi = tile * 16 + lr;
-    const bool qvalid = qi < a.Sq;
-    const int qc = qvalid ? qi : a.Sq - 1;
+    const bool qvalid = qi < sq;
+    const int qc = qvalid ? qi : sq - 1;
     const uint32_t dkey = drop_key(a, b, h, qi);
-    const bf16* qp = a.q + ((long)b * a.Sq + qc) * a.q_rs + h * 64;
-    const bf16* dop = a.dout + ((long)b * a.Sq + qc) * a.do_rs + h * 64;
+    const bf16* qp = a.q + (qbase + qc) * a.q_rs + h * 64;
+    const bf16* dop = a.dout + (qbase + qc) * a.do_rs + h * 64;
     const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
     const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
     const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop + 8 * lg);
@@ -786,7 +824,7 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          st[t][r] = __expf(score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, false, qi, kc * 64 + t * 16 + 4 * lg + r) - lse_q);
+          st[t][r] = __expf(score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, false, qi, kc * 64 + t * 16 + 4 * lg + r, a.Sk) - lse_q);
       if (a.drop_thresh != 0u) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -825,7 +863,7 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
       }
     }
     if (qvalid) {
-      bf16* dqp = a.dq + ((long)b * a.Sq + qi) * a.dq_rs + h * 64;
+      bf16* dqp = a.dq + (qbase + qi) * a.dq_rs + h * 64;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         bf16x4 ov;
@@ -867,8 +905,10 @@ __global__ __launch_bounds__(512, 4) void xattn_dkv_kernel(AttnArgs a) {
     __syncthreads();  // readers of the previous batch are done
     for (int jj = 0; jj < nb; ++jj) {
       const int b = a.grp_rows[rstart + j0 + jj];
-      stage_slot(lds + jj * ATTN_SLOT, a.q + (long)b * a.Sq * a.q_rs + h * 64, a.q_rs, a.dout + (long)b * a.Sq * a.do_rs + h * 64, a.do_rs,
-                 0, a.Sq, w, nw, lane);
+      long qbase;
+      int sq;
+      q_seq(a, b, qbase, sq);
+      stage_slot(lds + jj * ATTN_SLOT, a.q + qbase * a.q_rs + h * 64, a.q_rs, a.dout + qbase * a.do_rs + h * 64, a.do_rs, 0, sq, w, nw, lane);
     }
     stage_wait();
     if (!wave_active) continue;
@@ -878,6 +918,7 @@ __global__ __launch_bounds__(512, 4) void xattn_dkv_kernel(AttnArgs a) {
       const char* sD = sQ + ATTN_TILE;
       const float* lse_b = a.lse + ((long)b * a.H + h) * a.stat_ld;
       const float* del_b = a.delta + ((long)b * a.H + h) * a.stat_ld;
+      const int sq = a.q_len != nullptr ? a.q_len[b] : a.Sq;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         if (s2 * 32 >= a.Sq) continue;  // uniform: no query in this half (Sq = 30 lives in the first)
@@ -906,7 +947,7 @@ __global__ __launch_bounds__(512, 4) void xattn_dkv_kernel(AttnArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int qi = (2 * s2 + u) * 16 + 4 * lg + r;
-            const bool ok = qi < a.Sq && kvalid;
+            const bool ok = qi < sq && kvalid;
             float pv = __expf(fmaf(st[u][r], a.scale, key_add) - lsev[u][r]);
             pv = ok ? pv : 0.f;
             const float dl = ok ? delv[u][r] : 0.f;
@@ -947,6 +988,9 @@ static int attn_check(const AttnArgs& a, bool bwd) {
   XFM_REQUIRE(a.B <= 65535 && a.H <= 65535, "attention: B/H exceed grid limits");
   XFM_REQUIRE(a.stat_ld >= a.Sq && a.stat_ld % 4 == 0 && ((uintptr_t)a.lse % 16) == 0, "attention: stat_ld must be a multiple of 4 and >= Sq, lse 16-byte aligned");
   XFM_REQUIRE(a.bias_t == nullptr || (a.bias != nullptr && a.bias_t_ld % 4 == 0 && a.bias_t_ld >= a.Sq), "attention: bad transposed bias");
+  XFM_REQUIRE((a.q_start == nullptr) == (a.q_len == nullptr) && (a.k_start == nullptr) == (a.k_len == nullptr), "attention: packed rows need both start and len");
+  XFM_REQUIRE((a.q_start == nullptr && a.k_start == nullptr) || (a.bias == nullptr && a.dbias == nullptr && a.kv_index == nullptr),
+              "attention: packed rows take no additive bias and no kv_index");
   if (bwd) {
     XFM_REQUIRE(a.dout && a.dq && a.dk && a.dv && a.delta && a.lse, "attention bwd: missing buffers");
     XFM_REQUIRE(a.do_rs % 8 == 0 && a.dq_rs % 4 == 0 && a.dk_rs % 4 == 0 && a.dv_rs % 4 == 0, "attention bwd: bad strides");

@@ -165,6 +165,15 @@ int xfm_embed_ln_bwd(const xfm_embed_args* a, int D, float* dgamma, float* dbeta
   return xfm_emb_bwd_impl(*a, D, dgamma, dbeta, dtype, workspace, workspace_bytes, ST(stream));
 }
 
+int xfm_rows_gather(const xfm_bf16* src, const int* index, int R, int D, xfm_bf16* dst, void* stream) {
+  XFM_REQUIRE(src && index && dst, "rows_gather: null operand");
+  return xfm_rows_gather_impl(src, index, R, D, dst, ST(stream));
+}
+int xfm_rows_scatter_add(const xfm_bf16* src, const int* index, int R, int D, float* dst32, void* stream) {
+  XFM_REQUIRE(src && index && dst32, "rows_scatter_add: null operand");
+  return xfm_rows_scatter_add_impl(src, index, R, D, dst32, ST(stream));
+}
+
 int xfm_ce_fwd(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, void* stream) {
   XFM_REQUIRE(logits && labels && lse && loss, "ce_fwd: null operand");
   return xfm_ce_fwd_impl(logits, ld, R, V, labels, lse, loss, ST(stream));

@@ -305,6 +305,8 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs p) {
   const int rows = p.B * p.T;
   for (int row = wave; row < rows; row += nwaves) {
     const int b = row / p.T, t = row % p.T;
+    const int orow = p.row_map != nullptr ? p.row_map[row] : row;  // packed output row (wave-uniform)
+    if (orow < 0) continue;
     const uint32_t rkey = rng_row_key(p.seed_lo, p.seed_hi, (uint32_t)row);
     const int64_t* ids_row = p.ids + (long)b * p.T;
     const int pid = p.pos_mode ? t : roberta_pos(ids_row, t, p.pad_id, lane);
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs p) {
         }
         o[j] = f2bf(yv);
       }
-      *reinterpret_cast<bf16x4*>(p.y + (long)row * D + e) = o;
+      *reinterpret_cast<bf16x4*>(p.y + (long)orow * D + e) = o;
     }
   }
 }
@@ -363,6 +365,8 @@ __global__ __launch_bounds__(256) void emb_bwd_kernel(EmbArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[s][i][j] = 0.f;
   for (int row = wave; row < rows; row += nwaves) {
+    const int orow = p.row_map != nullptr ? p.row_map[row] : row;
+    if (orow < 0) continue;
     const uint32_t rkey = rng_row_key(p.seed_lo, p.seed_hi, (uint32_t)row);
     const long wid = p.ids[row];
     const int pid = p.pos_ids[row];
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256) void emb_bwd_kernel(EmbArgs p) {
       const f32x4 c = *reinterpret_cast<const f32x4*>(p.pos + (long)pid * D + e);
       const f32x4 d = *reinterpret_cast<const f32x4*>(p.type + e);
       const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.w + e);
-      const bf16x4 g = *reinterpret_cast<const bf16x4*>(p.dy + (long)row * D + e);
+      const bf16x4 g = *reinterpret_cast<const bf16x4*>(p.dy + (long)orow * D + e);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float gv = bf2f(g[j]);
@@ -602,4 +606,43 @@ int xfm_sumsq_impl(const float* x, long n, float* out, float* workspace, hipStre
   if (rc != XFM_OK) return rc;
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, workspace, grid, out);
   return xfm_check_launch("sumsq_final");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row gather / scatter-add on bf16 rows (packed token rows: [CLS] and masked-position gathers, fusion batch assembly).
+// One 16-B chunk per thread; index < 0 -> zero row (gather) / skipped (scatter).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_gather_kernel(const bf16* __restrict__ src, const int* __restrict__ index, int R, int D,
+                                                          bf16* __restrict__ dst) {
+  const int cpr = D >> 3;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)R * cpr) return;
+  const int r = (int)(t / cpr), c = (int)(t % cpr);
+  const int s = index[r];
+  u32x4 v = u32x4{0, 0, 0, 0};
+  if (s >= 0) v = *reinterpret_cast<const u32x4*>(src + (long)s * D + c * 8);
+  *reinterpret_cast<u32x4*>(dst + (long)r * D + c * 8) = v;
+}
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(const bf16* __restrict__ src, const int* __restrict__ index, int R, int D,
+                                                               float* __restrict__ dst) {
+  const int cpr = D >> 3;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)R * cpr) return;
+  const int r = (int)(t / cpr), c = (int)(t % cpr);
+  const int s = index[r];
+  if (s < 0) return;
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (long)r * D + c * 8);
+  float* d = dst + (long)s * D + c * 8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) atomicAdd(d + i, bf2f(v[i]));
+}
+int xfm_rows_gather_impl(const bf16* src, const int* index, int R, int D, bf16* dst, hipStream_t st) {
+  XFM_REQUIRE(R > 0 && D > 0 && D % 8 == 0, "rows_gather: bad shape R=%d D=%d", R, D);
+  hipLaunchKernelGGL(rows_gather_kernel, dim3(cdiv((long)R * (D >> 3), 256)), dim3(256), 0, st, src, index, R, D, dst);
+  return xfm_check_launch("rows_gather");
+}
+int xfm_rows_scatter_add_impl(const bf16* src, const int* index, int R, int D, float* dst, hipStream_t st) {
+  XFM_REQUIRE(R > 0 && D > 0 && D % 8 == 0, "rows_scatter_add: bad shape R=%d D=%d", R, D);
+  hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(cdiv((long)R * (D >> 3), 256)), dim3(256), 0, st, src, index, R, D, dst);
+  return xfm_check_launch("rows_scatter_add");
 }

@@ -239,9 +239,14 @@ def attn_grouped_ok(Sq, Sk):
     return Sq <= 64 and Sk <= 256
 
 
-def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t=None, kv_index=None, groups=None):
+def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t=None, kv_index=None, groups=None,
+               q_pack=None, k_pack=None):
     for t in (q, k, v, o):
         assert t.dtype == BF16 and t.stride(-1) == 1 and t.dim() == 2
+    for pk in (q_pack, k_pack):
+        if pk is not None:  # (start, len) int32 [B]: packed (unpadded) token rows, see xfm_amd.packing
+            assert bias is None and kv_index is None
+            assert all(t.dtype == torch.int32 and t.numel() == B and t.is_contiguous() for t in pk)
     assert lse.shape[-1] == _stat_ld(Sq)
     if kv_index is not None:
         assert kv_index.dtype == torch.int32 and kv_index.numel() == B and kv_index.is_contiguous()
@@ -257,28 +262,36 @@ def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, dro
                     q=q.data_ptr(), q_rs=q.stride(0), k=k.data_ptr(), k_rs=k.stride(0), v=v.data_ptr(), v_rs=v.stride(0),
                     o=o.data_ptr(), o_rs=o.stride(0), lse=lse.data_ptr(), bias=_ptr(bias),
                     bias_ld=0 if bias is None else bias.stride(1), key_keep=_ptr(key_keep), B=B, H=H, Sq=Sq, Sk=Sk,
-                    scale=scale, causal=int(causal), drop_thresh=drop[0], drop_scale=drop[1], seed_lo=drop[2], seed_hi=drop[3])
+                    scale=scale, causal=int(causal), drop_thresh=drop[0], drop_scale=drop[1], seed_lo=drop[2], seed_hi=drop[3],
+                    q_start=_ptr(q_pack[0]) if q_pack else 0, q_len=_ptr(q_pack[1]) if q_pack else 0,
+                    k_start=_ptr(k_pack[0]) if k_pack else 0, k_len=_ptr(k_pack[1]) if k_pack else 0)
 
 
-def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0), kv_index=None, groups=None):
+def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0), kv_index=None, groups=None,
+             q_pack=None, k_pack=None):
     """q [B*Sq, >=H*64] / k, v [B*Sk, ...] are 2-D (possibly strided column slices of fused projection buffers).
     bias: dense fp32 [H,Sq,ld]; key_keep: int32 [B,Sk].  Returns (o [B*Sq, H*64] bf16, lse [B,H,Sq]).
     groups = kv_groups(...): grouped mode, k / v / key_keep hold one entry per SOURCE."""
     _dev(q)
-    o = torch.empty((B * Sq, H * 64), dtype=BF16, device=q.device)
+    if q_pack is not None:  # one output row per packed query row; rows outside every sequence stay zero (finite for what follows)
+        o = torch.zeros((q.shape[0], H * 64), dtype=BF16, device=q.device)
+    else:
+        o = torch.empty((B * Sq, H * 64), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, _stat_ld(Sq)), dtype=F32, device=q.device)
     if key_keep is not None:
         assert key_keep.dtype == torch.int32 and key_keep.is_contiguous()
-    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, kv_index=kv_index, groups=groups)
+    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, kv_index=kv_index, groups=groups,
+                   q_pack=q_pack, k_pack=k_pack)
     check(_lib.load().xfm_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
     return o, lse
 
 
 def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, dbias=None, key_keep=None, causal=False,
-             drop=(0, 1.0, 0, 0), bias_t=None, kv_index=None, groups=None):
+             drop=(0, 1.0, 0, 0), bias_t=None, kv_index=None, groups=None, q_pack=None, k_pack=None):
     """Writes dq/dk/dv (2-D bf16 views with the same addressing convention as q/k/v); dbias (fp32 [H,Sq,ld]) += .
-    Grouped mode: dk/dv are per SOURCE ([n_groups*Sk] rows), summed over each group's rows."""
-    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t, kv_index, groups)
+    Grouped mode: dk/dv are per SOURCE ([n_groups*Sk] rows), summed over each group's rows.
+    Packed rows: only the rows of real tokens are written -- pass zero-initialised dq (/ dk / dv)."""
+    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t, kv_index, groups, q_pack, k_pack)
     delta = torch.empty((B, H, lse.shape[-1]), dtype=F32, device=q.device)  # the kernels never use its padding entries
     assert dout.dtype == BF16 and dout.stride(-1) == 1
     a.dout, a.do_rs = dout.data_ptr(), dout.stride(0)
@@ -391,31 +404,59 @@ def _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop, pos_mode=0):
                      seed_lo=drop[2], seed_hi=drop[3])
 
 
-def embed_ln_fwd(ids, word, pos, typ, w, b, eps, pad_id, drop=(0, 1.0, 0, 0), pos_mode=0):
+def embed_ln_fwd(ids, word, pos, typ, w, b, eps, pad_id, drop=(0, 1.0, 0, 0), pos_mode=0, row_map=None, out_rows=None):
+    """row_map (int32 [B*T], -1 = skip) + out_rows: write the tokens to packed rows of a [out_rows, D] output."""
     _dev(ids)
     assert ids.dtype == torch.int64 and ids.is_contiguous()
     B, T = ids.shape
     D = word.shape[1]
-    y = torch.empty((B * T, D), dtype=BF16, device=ids.device)
+    if row_map is not None:
+        assert row_map.dtype == torch.int32 and row_map.numel() == B * T and row_map.is_contiguous()
+        y = torch.zeros((out_rows, D), dtype=BF16, device=ids.device)
+    else:
+        y = torch.empty((B * T, D), dtype=BF16, device=ids.device)
     mean = torch.empty(B * T, dtype=F32, device=ids.device)
     rstd = torch.empty(B * T, dtype=F32, device=ids.device)
     pos_ids = torch.empty(B * T, dtype=torch.int32, device=ids.device)
     a = _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop, pos_mode)
+    a.row_map = _ptr(row_map)
     a.y, a.mean, a.rstd, a.pos_ids = y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), pos_ids.data_ptr()
     check(_lib.load().xfm_embed_ln_fwd(ctypes.byref(a), D, _stream()), "embed_ln_fwd")
     return y, mean, rstd, pos_ids
 
 
 def embed_ln_bwd(dy, ids, word, pos, typ, w, b, eps, pad_id, mean, rstd, pos_ids, dword, dpos, dtype_, dgamma, dbeta,
-                 drop=(0, 1.0, 0, 0), pos_mode=0):
+                 drop=(0, 1.0, 0, 0), pos_mode=0, row_map=None):
     D = word.shape[1]
     a = _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop, pos_mode)
+    a.row_map = _ptr(row_map)
     a.mean, a.rstd, a.pos_ids = mean.data_ptr(), rstd.data_ptr(), pos_ids.data_ptr()
     a.dy, a.dword, a.dpos = dy.data_ptr(), dword.data_ptr(), dpos.data_ptr()
     lib = _lib.load()
     ws = workspace(lib.xfm_embed_ln_bwd_workspace(a.B * a.T, D), dy.device)
     check(lib.xfm_embed_ln_bwd(ctypes.byref(a), D, _ptr(dgamma), _ptr(dbeta), _ptr(dtype_), ws.data_ptr(), ws.numel() * 4,
                                _stream()), "embed_ln_bwd")
+
+
+def rows_gather(src, index, out=None):
+    """out[r, :] = src[index[r], :] (zero row where index[r] < 0); src bf16 [*, D] contiguous, index int32 [R]."""
+    _dev(src)
+    assert src.dtype == BF16 and src.dim() == 2 and src.is_contiguous() and index.dtype == torch.int32 and index.is_contiguous()
+    R, D = index.numel(), src.shape[1]
+    if out is None:
+        out = torch.empty((R, D), dtype=BF16, device=src.device)
+    check(_lib.load().xfm_rows_gather(src.data_ptr(), index.data_ptr(), R, D, out.data_ptr(), _stream()), "rows_gather")
+    return out
+
+
+def rows_scatter_add(src, index, dst32):
+    """dst32[index[r], :] += src[r, :] (fp32 accumulation, rows with index[r] < 0 skipped): the adjoint of rows_gather."""
+    _dev(src)
+    assert src.dtype == BF16 and src.dim() == 2 and src.is_contiguous() and dst32.dtype == F32 and dst32.is_contiguous()
+    assert index.dtype == torch.int32 and index.is_contiguous() and index.numel() == src.shape[0] and dst32.shape[1] == src.shape[1]
+    check(_lib.load().xfm_rows_scatter_add(src.data_ptr(), index.data_ptr(), src.shape[0], src.shape[1], dst32.data_ptr(), _stream()),
+          "rows_scatter_add")
+    return dst32
 
 
 def ce_fwd(logits, V, labels):

@@ -6,6 +6,7 @@ import torch
 from .xfm import XFMBase
 
 _TEXT_STREAM_ON = os.environ.get("XFM_TEXT_STREAM", "1") != "0"
+_PACK_ROWS = os.environ.get("XFM_PACK_ROWS", "1") != "0"  # A/B knob: `text_lens` given -> unpadded token rows in the text / fusion towers
 _SIDE_STREAMS = {}
 
 
@@ -35,6 +36,8 @@ class _JoinAfterBackward(torch.autograd.Function):
 
 
 class XFM(XFMBase):
+    accepts_text_lens = True  # forward_multimodal(text_lens=...): see there
+
     def __init__(self, config, load_vision_params=False, load_text_params=False):
         super().__init__(config, load_vision_params=load_vision_params, load_text_params=load_text_params,
                          use_contrastive_loss=True, use_matching_loss=True, use_mlm_loss=True, use_bbox_loss=True,
@@ -52,7 +55,10 @@ class XFM(XFMBase):
                            text_ids_2=None, text_atts_2=None, text_ids_masked_2=None, masked_pos_2=None, masked_ids_2=None,
                            image_atts=None, idx_to_group_img=None, target_bbox=None, is_image=None, ret_mim_loss=False,
                            ret_bbox_loss=False, ret_match_loss=True, ret_mlm_loss=True, ret_bbox_giou=False,
-                           ret_itc_loss=True, data_source=None, ids_mask=None, neg_idx=None):
+                           ret_itc_loss=True, data_source=None, ids_mask=None, neg_idx=None, text_lens=None):
+        """`text_lens` (extension; host-side lengths of the prefix masks `text_atts`, e.g. `text_atts.sum(1)` taken BEFORE the batch
+        was uploaded): run the text and fusion towers on unpadded token rows (xfm_amd.packing).  Same values on every token that
+        any loss reads; None = the reference's padded computation."""
         if ret_bbox_loss or ret_bbox_giou:
             raise NotImplementedError("bbox / region losses (model_pretrain.py:39-41,81-85) are outside the hot-path scope")
         if self.learnable_temp:
@@ -66,13 +72,19 @@ class XFM(XFMBase):
         # node's backward on the stream of its forward, so the two backward chains overlap the same way.
         text_stream = None
         mlm_embeds = text_embeds = None
+        both_passes = ret_match_loss and ret_mlm_loss and self.detach_text_forMLM and text_ids_masked is not None
+        pack = None
+        if text_lens is not None and self.batch_passes and both_passes and data_source != 'imagenet' and _PACK_ROWS:
+            from .packing import Pack
+            lens = [int(x) for x in (text_lens.tolist() if torch.is_tensor(text_lens) else text_lens)]
+            pack = Pack.from_lens(lens + lens, text_ids.shape[1], image.device)   # 2B sequences: clean | masked
         if data_source != 'imagenet' and self.batch_passes and image.is_cuda and _TEXT_STREAM_ON:
             main = torch.cuda.current_stream(image.device)
             text_stream = _side_stream(image.device)
             text_stream.wait_stream(main)
             with torch.cuda.stream(text_stream):
-                if ret_match_loss and ret_mlm_loss and self.detach_text_forMLM and text_ids_masked is not None:
-                    text_embeds, mlm_embeds = self.get_text_embeds_with_masked(text_ids, text_atts, text_ids_masked)
+                if both_passes:
+                    text_embeds, mlm_embeds = self.get_text_embeds_with_masked(text_ids, text_atts, text_ids_masked, pack=pack)
                 else:
                     text_embeds = self.get_text_embeds(text_ids, text_atts)
         if self.batch_passes and do_mim and self.do_image_mask:
@@ -96,11 +108,16 @@ class XFM(XFMBase):
                         t.record_stream(main)
                 if text_embeds.requires_grad:
                     text_embeds = _JoinAfterBackward.apply(text_embeds, main, text_stream)
-            elif self.batch_passes and ret_match_loss and ret_mlm_loss and self.detach_text_forMLM and text_ids_masked is not None:
-                text_embeds, mlm_embeds = self.get_text_embeds_with_masked(text_ids, text_atts, text_ids_masked)
+            elif self.batch_passes and both_passes:
+                text_embeds, mlm_embeds = self.get_text_embeds_with_masked(text_ids, text_atts, text_ids_masked, pack=pack)
             else:
                 text_embeds = self.get_text_embeds(text_ids, text_atts)
-            image_feat, text_feat = self.get_features(image_embeds, text_embeds)
+            if pack is not None:  # text_embeds holds packed rows: the [CLS] row of sequence b is row pack.start[b]
+                from .packing import rows_gather
+                text_cls = rows_gather(text_embeds, pack.start[:image.shape[0]]).unsqueeze(1)
+                image_feat, text_feat = self.get_features(image_embeds, text_cls)
+            else:
+                image_feat, text_feat = self.get_features(image_embeds, text_embeds)
         loss_itc = loss_itm = loss_mlm = loss_mim = zero
         if ret_itc_loss and data_source != 'imagenet':
             loss_itc = self.get_contrastive_loss(image_feat, text_feat)
@@ -109,7 +126,7 @@ class XFM(XFMBase):
         if self.batch_passes and ret_match_loss and ret_mlm_loss and data_source != 'imagenet':
             loss_itm, loss_mlm = self.get_matching_and_fuse_mlm_loss(image_embeds, image_atts, image_feat, text_ids, text_atts,
                                                                      text_feat, text_embeds, text_ids_masked, masked_pos,
-                                                                     masked_ids, neg_idx=neg_idx, mlm_embeds=mlm_embeds)
+                                                                     masked_ids, neg_idx=neg_idx, mlm_embeds=mlm_embeds, pack=pack)
             if w is not None:
                 loss_itm, loss_mlm = loss_itm * w, loss_mlm * w
         else:

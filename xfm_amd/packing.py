@@ -1,0 +1,138 @@
+"""Unpadded ("packed") token rows for the text and fusion towers.
+
+The reference pads every caption to the batch's longest one (dataset/pretrain_dataset.py:264-312, max_tokens = 30) and pushes the
+padding through every Linear / LayerNorm / attention of the text tower (2B sequences) and the fusion tower (4B sequences); nothing
+ever reads those rows (ITC / ITM take the [CLS] row, MLM the masked positions, padded keys are masked out).  With caption lengths
+U[8, 30] that is 37 % of the token rows.  Here the towers can run on the real tokens only: a `Pack` describes where each sequence's
+rows live inside a [cap, D] row buffer, the GEMM / LayerNorm kernels simply see fewer rows, and the attention kernels take the
+(start, length) arrays (xfm_attn_args.q_start ...).  Values on every real token are what the padded computation gives: a padded
+key contributes probability exp(-10000 + ...) == 0 in fp32, exactly like a key that is not there.
+
+Lengths must be known on the HOST (they size buffers and grids) -- callers pass `text_lens`, computed from the CPU batch before it
+is uploaded (xfm_amd.pretrain_loop) -- except for sequences picked by a device-side index (the hard-negative texts of ITM,
+xfm.py:717-746): those get worst-case room (`cap` > rows in use) and their offsets are computed on the device, no sync.  Slack
+rows hold zeros, stay finite through the towers, receive zero gradient and so add nothing to any weight gradient.
+Attention masks are assumed to be prefix masks (ones then zeros), which is what tokenisers produce.
+"""
+import numpy as np
+import torch
+
+from . import functional as Fx
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class Pack:
+    def __init__(self, start, lens, T, cap, lens_host=None):
+        self.start, self.lens = start.contiguous(), lens.contiguous()   # int32 [B] on the device
+        self.B, self.T, self.cap = int(start.numel()), int(T), int(cap)
+        self.lens_host = None if lens_host is None else [int(x) for x in lens_host]
+        self._row_map = None
+
+    @property
+    def pair(self):
+        return (self.start, self.lens)
+
+    @classmethod
+    def from_lens(cls, lens_host, T, device):
+        """Exact packing of sequences whose lengths the host knows."""
+        lh = np.asarray(lens_host, dtype=np.int64).reshape(-1)
+        if lh.size == 0 or lh.min() < 1 or lh.max() > T:
+            raise ValueError(f"packed sequences need 1 <= length <= {T}")
+        start = np.concatenate([[0], np.cumsum(lh)[:-1]]).astype(np.int32)
+        both = torch.from_numpy(np.stack([start, lh.astype(np.int32)])).to(device, non_blocking=True)
+        return cls(both[0], both[1], T, int(lh.sum()), lens_host=lh.tolist())
+
+    @classmethod
+    def concat(cls, blocks, T):
+        """blocks: list of (lens int32 device [n], cap int, lens_host or None).  Each block starts at the sum of the caps before it;
+        inside a block the sequences are contiguous (device-side cumulative sum: no sync when lens is device data)."""
+        starts, lens, host, base = [], [], [], 0
+        for ln, cap, lh in blocks:
+            ln = ln.to(torch.int32)
+            starts.append((torch.cumsum(ln, 0, dtype=torch.int32) - ln) + base)
+            lens.append(ln)
+            host = None if (host is None or lh is None) else host + [int(x) for x in lh]
+            base += int(cap)
+        return cls(torch.cat(starts), torch.cat(lens), T, base, lens_host=host)
+
+    def head(self, n):
+        """The first n sequences (their rows are a prefix of the buffer)."""
+        rows = sum(self.lens_host[:n]) if self.lens_host is not None else None
+        p = Pack(self.start[:n], self.lens[:n], self.T, rows if rows is not None else self.cap,
+                 None if self.lens_host is None else self.lens_host[:n])
+        return p
+
+    def rows_of_head(self, n):
+        if self.lens_host is None:
+            raise ValueError("row count of a sequence prefix needs host-known lengths")
+        return sum(self.lens_host[:n])
+
+    def row_map(self):
+        """int32 [B*T]: packed row of token (b, t), -1 for padding."""
+        if self._row_map is None:
+            ar = torch.arange(self.T, device=self.start.device, dtype=torch.int32)
+            m = self.start[:, None] + ar[None, :]
+            self._row_map = torch.where(ar[None, :] < self.lens[:, None], m, torch.full_like(m, -1)).reshape(-1).contiguous()
+        return self._row_map
+
+    def gather_index(self, src, seq_src=None):
+        """int32 [cap]: for every row of THIS layout the row of layout `src` it copies (sequence j <- src sequence seq_src[j], same
+        token offset), -1 on slack rows.  Device-side, no sync."""
+        dev = self.start.device
+        ar = torch.arange(self.T, device=dev, dtype=torch.int32)
+        s_start = src.start if seq_src is None else src.start.index_select(0, seq_src.long())
+        vals = (s_start[:, None] + ar[None, :])
+        dest = (self.start[:, None] + ar[None, :]).long()
+        valid = ar[None, :] < self.lens[:, None]
+        dest = torch.where(valid, dest, torch.full_like(dest, self.cap))          # invalid tokens land in a dummy slot
+        out = torch.full((self.cap + 1,), -1, dtype=torch.int32, device=dev)
+        out.scatter_(0, dest.reshape(-1), vals.reshape(-1).to(torch.int32))
+        return out[:self.cap].contiguous()
+
+
+class _RowsGatherFn(torch.autograd.Function):
+    """out[r] = rows[index[r]] (zeros where index < 0); backward = scatter-add in fp32."""
+
+    @staticmethod
+    def forward(ctx, rows, index):
+        rows = rows.contiguous()
+        ctx.n, ctx.dtype = rows.shape[0], rows.dtype
+        ctx.index = index
+        return Fx.rows_gather(rows if rows.dtype == BF16 else rows.to(BF16), index)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = (dy if dy.dtype == BF16 else dy.to(BF16)).contiguous()
+        acc = torch.zeros((ctx.n, dy.shape[1]), dtype=F32, device=dy.device)
+        Fx.rows_scatter_add(dy, ctx.index, acc)
+        return acc.to(ctx.dtype), None
+
+
+def rows_gather(rows, index):
+    """Differentiable row gather: rows bf16 [n, D], index int32 [R] (device) -> [R, D]."""
+    return _RowsGatherFn.apply(rows, index.to(torch.int32).contiguous())
+
+
+def unpack(rows, pack):
+    """Packed rows [cap, D] -> the reference's padded layout [B, T, D] (zeros at padding)."""
+    return rows_gather(rows, pack.row_map()).view(pack.B, pack.T, rows.shape[-1])
+
+
+def pack_rows(x, pack):
+    """Padded [B, T, D] -> packed rows [cap, D] (slack rows zero)."""
+    dense = Pack(torch.arange(pack.B, device=x.device, dtype=torch.int32) * pack.T, pack.lens, pack.T, pack.B * pack.T)
+    return rows_gather(x.reshape(pack.B * pack.T, x.shape[-1]), pack.gather_index(dense))
+
+
+def lens_from_mask(text_atts):
+    """Host-side lengths of a CPU prefix mask [B, T] (raises when the mask is not a prefix mask)."""
+    m = text_atts if not text_atts.is_cuda else None
+    if m is None:
+        raise ValueError("lens_from_mask wants the CPU copy of the mask (a device mask would cost a sync)")
+    m = m.to(torch.int64)
+    lens = m.sum(1)
+    T = m.shape[1]
+    if not bool((m == (torch.arange(T)[None, :] < lens[:, None]).to(torch.int64)).all()):
+        raise ValueError("attention mask is not a prefix mask: packed rows need ones followed by zeros")
+    return lens

@@ -51,8 +51,10 @@ def create_optimizer(args, model):
           {"params": [params[n] for n in g[1]], "weight_decay": 0.0, "lr": lr},
           {"params": [params[n] for n in g[2]], "weight_decay": wd, "lr": lr * lr_mult},
           {"params": [params[n] for n in g[3]], "weight_decay": 0.0, "lr": lr * lr_mult}]
-    # transformers' AdamW of the reference = decoupled weight decay, bias correction on: torch.optim.AdamW is the same update;
-    # RCCLDDPAccelerator runs it as one fused kernel over the flat arena
+    # transformers' AdamW of the reference = decoupled weight decay applied after the Adam update, bias correction on, eps added to
+    # sqrt(v) before the correction.  RCCLDDPAccelerator runs exactly that rule as one fused kernel over the flat arena
+    # (csrc/elementwise.hip adamw_kernel); this torch.optim.AdamW object carries the groups / hyper-parameters / state_dict and is
+    # the stepping rule only where the fused path is off (CPU): there eps enters after the correction (differs for |g| ~ 1e-8)
     return torch.optim.AdamW(pg, lr=lr, eps=1e-8, betas=(0.9, 0.98))
 
 
@@ -119,10 +121,17 @@ def run_image_iter(model, image_batch, optimizer, accelerator, metric_logger, de
                    ret_match_loss=True, ret_mlm_loss=True, ret_itc_loss=True, do_optm=False):
     """Pretrain.py:61-91."""
     image = _to(device, image_batch[0])
+    extra = {}
+    base = model.module if hasattr(model, 'module') else model
+    if getattr(base, 'accepts_text_lens', False) and torch.is_tensor(image_batch[2]) and not image_batch[2].is_cuda:
+        # caption lengths, read off the CPU batch before it is uploaded: the towers then run on unpadded token rows
+        # (xfm_amd.packing) without ever asking the device for a size
+        from .packing import lens_from_mask
+        extra['text_lens'] = lens_from_mask(image_batch[2])
     text_ids, text_atts, text_ids_masked, masked_pos, masked_ids = (_to(device, t) for t in image_batch[1:])
     loss = model(image, text_ids, text_atts, text_ids_masked=text_ids_masked, masked_pos=masked_pos, masked_ids=masked_ids,
                  ret_match_loss=ret_match_loss, ret_mim_loss=ret_mim_loss, ret_mlm_loss=ret_mlm_loss, ret_itc_loss=ret_itc_loss,
-                 data_source=data_source)
+                 data_source=data_source, **extra)
     _backward(accelerator, loss['loss_itc'] + loss['loss_itm'] + loss['loss_mlm'] + loss['loss_mim'], optimizer, do_optm)
     if do_optm:
         accelerator.optimizer_step(optimizer, model)

@@ -327,13 +327,19 @@ class XFMBase(nn.Module):
         return encoder(text_ids, attention_mask=text_atts, encoder_hidden_states=None, encoder_attention_mask=None,
                        return_dict=True).last_hidden_state
 
-    def get_text_embeds_with_masked(self, text_ids, text_atts, text_ids_masked):
+    def get_text_embeds_with_masked(self, text_ids, text_atts, text_ids_masked, pack=None):
         """get_text_embeds(text_ids) and the DETACHED get_text_embeds(text_ids_masked) of get_fuse_mlm_loss (xfm.py:648-649) as one
         2B-row pass through the text tower: same arithmetic per row, GEMMs twice as tall; the backward only walks the first B
-        sequences (`grad_batch`).  Returns (text_embeds, mlm_embeds.detach())."""
+        sequences (`grad_batch`).  Returns (text_embeds, mlm_embeds.detach()).
+        `pack` (xfm_amd.packing.Pack over the 2B sequences: clean | masked): the tower runs on unpadded token rows and the result is
+        (rows [pack.cap, D], None) -- sequences 0..B-1 are the text embeddings (with gradient), B..2B-1 the masked-text ones."""
         assert self.detach_text_forMLM
         self._ready()
         bs = text_ids.shape[0]
+        if pack is not None:
+            rows = self.text_encoder.bert(torch.cat([text_ids, text_ids_masked], dim=0), attention_mask=None, encoder_hidden_states=None,
+                                          encoder_attention_mask=None, return_dict=True, grad_batch=bs, pack=pack).last_hidden_state
+            return rows, None
         both = self.text_encoder.bert(torch.cat([text_ids, text_ids_masked], dim=0), attention_mask=torch.cat([text_atts, text_atts], dim=0),
                                       encoder_hidden_states=None, encoder_attention_mask=None, return_dict=True,
                                       grad_batch=bs).last_hidden_state
@@ -448,12 +454,51 @@ class XFMBase(nn.Module):
             return loss, cross[:bs]
         return loss
 
+    def _matching_and_fuse_mlm_packed(self, image_embeds, image_atts, image_feat, text_feat, text_rows, pack, masked_pos, masked_ids,
+                                      idx=None, neg_idx=None):
+        """The 4B-row fusion pass on UNPADDED token rows (xfm_amd.packing).  `text_rows` / `pack`: the text tower's packed output over
+        2B sequences (clean | masked).  The fusion layout is four blocks of B sequences: positives, (negative image, text),
+        (image, negative text), MLM inputs; the lengths of the third block follow the device-side draw of the hard negatives, so it
+        gets worst-case room and device-computed offsets (no host sync)."""
+        from .ops import lm_head_ce
+        from .packing import Pack, rows_gather
+        if neg_idx is None:
+            image_neg_idx, text_neg_idx = self.get_hard_negatives(image_feat, text_feat, idx=idx)
+        else:
+            image_neg_idx = torch.as_tensor(neg_idx[0], dtype=torch.long, device=image_embeds.device)
+            text_neg_idx = torch.as_tensor(neg_idx[1], dtype=torch.long, device=image_embeds.device)
+        bs = image_feat.size(0)
+        dev = image_embeds.device
+        lens, lh = pack.lens[:bs], pack.lens_host[:bs]
+        n_rows, t_max = sum(lh), max(lh)
+        fpack = Pack.concat([(lens, n_rows, lh), (lens, n_rows, lh), (lens.index_select(0, text_neg_idx), bs * t_max, None),
+                             (lens, n_rows, lh)], pack.T)
+        ar = torch.arange(bs, device=dev)
+        seq_src = torch.cat([ar, ar, text_neg_idx, ar + bs])             # sequence of the text tower's pack each fusion row copies
+        text_all = rows_gather(text_rows.detach(), fpack.gather_index(pack, seq_src))   # is_pretrain: the text states are detached
+        enc_index = torch.cat([ar, image_neg_idx, ar, ar]).to(torch.int32)
+        self._ready()
+        seq = self.fusion_encoder.bert(encoder_embeds=text_all, attention_mask=None, encoder_hidden_states=image_embeds,
+                                       encoder_attention_mask=image_atts, return_dict=True, encoder_batch_index=enc_index,
+                                       pack=fpack).last_hidden_state
+        output = self.itm_head(rows_gather(seq, fpack.start[:3 * bs]))
+        itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
+        loss_itm = F.cross_entropy(output, itm_labels)
+        mlm_index = (fpack.start[3 * bs:, None] + masked_pos.to(torch.int32)).reshape(-1)   # gather_seq_out_by_pos (xroberta.py:1215-1216)
+        mlm_seq = rows_gather(seq, mlm_index)
+        loss_mlm, _ = lm_head_ce(mlm_seq, self.fusion_encoder.lm_head, masked_ids.reshape(-1), "mean")
+        return loss_itm, loss_mlm
+
     def get_matching_and_fuse_mlm_loss(self, image_embeds, image_atts, image_feat, text_ids, text_atts, text_feat, text_embeds,
                                        text_ids_masked, masked_pos, masked_ids, idx=None, is_pretrain=True, neg_idx=None,
-                                       mlm_embeds=None):
+                                       mlm_embeds=None, pack=None):
         """get_matching_loss (xfm.py:749-802) and get_fuse_mlm_loss (xfm.py:638-656) through ONE 4B-row fusion pass:
         rows [0,3B) are the ITM positives / negatives, rows [3B,4B) the masked-text MLM inputs.  Same arithmetic per
         row as the two separate calls (no op couples rows); larger GEMMs and a third fewer launches."""
+        if pack is not None:
+            assert is_pretrain, "the packed 4B pass feeds detached text states (pre-training)"
+            return self._matching_and_fuse_mlm_packed(image_embeds, image_atts, image_feat, text_feat, text_embeds, pack, masked_pos,
+                                                      masked_ids, idx=idx, neg_idx=neg_idx)
         if neg_idx is None:
             image_neg_idx, text_neg_idx = self.get_hard_negatives(image_feat, text_feat, idx=idx)
         else:

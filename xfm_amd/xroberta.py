@@ -80,17 +80,19 @@ class RobertaEmbeddings(nn.Module):
 
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, emb, input_ids, drop, owner):
+    def forward(ctx, anchor, emb, input_ids, drop, owner, pack=None):
         ids = input_ids.contiguous()
         ctx.owner = owner if ctx.needs_input_grad[0] else None
         if ctx.owner is not None:
             arena_note_use(owner)
         ln = emb.LayerNorm
+        row_map = None if pack is None else pack.row_map()  # packed (unpadded) output rows, xfm_amd.packing
         y, mean, rstd, pos_ids = Fx.embed_ln_fwd(ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
                                                  emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps,
-                                                 emb.padding_idx, drop, getattr(emb, "pos_mode", 0))
-        ctx.emb, ctx.saved, ctx.drop = emb, (ids, mean, rstd, pos_ids), drop
-        return y.view(ids.shape[0], ids.shape[1], -1)
+                                                 emb.padding_idx, drop, getattr(emb, "pos_mode", 0), row_map=row_map,
+                                                 out_rows=None if pack is None else pack.cap)
+        ctx.emb, ctx.saved, ctx.drop, ctx.row_map = emb, (ids, mean, rstd, pos_ids), drop, row_map
+        return y if pack is not None else y.view(ids.shape[0], ids.shape[1], -1)
 
     @staticmethod
     def backward(ctx, dy):
@@ -102,10 +104,10 @@ class _EmbedFn(torch.autograd.Function):
                         emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps, emb.padding_idx, mean, rstd, pos_ids,
                         grad_view(emb.word_embeddings.weight), grad_view(emb.position_embeddings.weight),
                         grad_view(emb.token_type_embeddings.weight).view(-1), grad_view(ln.weight), grad_view(ln.bias), ctx.drop,
-                        getattr(emb, "pos_mode", 0))
+                        getattr(emb, "pos_mode", 0), row_map=ctx.row_map)
         if ctx.owner is not None:
             arena_note_grad(ctx.owner)
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class RobertaSelfAttention(nn.Module):
@@ -212,7 +214,7 @@ class _EncoderFn(torch.autograd.Function):
     """Layers [lo, hi) of a RobertaEncoder.  x: bf16 [B*T, D]; enc: bf16 [B*N, D] or None."""
 
     @staticmethod
-    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index, grad_batch=None):
+    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index, grad_batch=None, pack=None):
         cfg = model.config
         D, H = cfg.hidden_size, cfg.num_attention_heads
         scale = 1.0 / math.sqrt(D // H)
@@ -221,6 +223,9 @@ class _EncoderFn(torch.autograd.Function):
         need_dx, need_denc = x.requires_grad, (enc is not None and enc.requires_grad)
         saved = []
         x = x.contiguous()
+        qp = None if pack is None else pack.pair  # packed token rows: x is [pack.cap, D], sequences at (start, len)
+        if pack is not None and (key_keep is not None or causal):
+            raise ValueError("packed rows take neither a key mask (lengths say it all) nor the causal mask")
         groups = None
         if enc is not None:
             enc = enc.contiguous()
@@ -233,7 +238,7 @@ class _EncoderFn(torch.autograd.Function):
             d_att, d_h1 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
             qkv = Fx.gemm_nt(x, s["qkv"].wb, s["qkv"].b)
             c1, lse1 = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep,
-                                          causal=causal, drop=d_att)
+                                          causal=causal, drop=d_att, q_pack=qp, k_pack=qp)
             h1 = Fx.gemm_nt(c1, s["o"].wb, s["o"].b)
             ln1 = att.output.LayerNorm
             y1, z1, m1, r1 = Fx.ln_post_fwd(h1, x, ln1.weight, ln1.bias, ln1.eps, d_h1)
@@ -245,7 +250,11 @@ class _EncoderFn(torch.autograd.Function):
                 q2 = Fx.gemm_nt(y1, s["q2"].wb, s["q2"].b)
                 kv = Fx.gemm_nt(enc, s["kv2"].wb, s["kv2"].b)
                 if groups is not None:  # one workgroup per (image, head): K/V staged once for every row that reads it
-                    c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, groups=groups)
+                    c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, groups=groups,
+                                           q_pack=qp)
+                elif pack is not None:
+                    raise NotImplementedError("packed rows with cross-attention need the grouped kernels (T <= 64, N <= 256) and "
+                                              "an encoder_batch_index")
                 else:
                     c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, kv_index=enc_index)
                 h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
@@ -264,6 +273,7 @@ class _EncoderFn(torch.autograd.Function):
         if grad_batch is not None and (enc is not None or not 0 < grad_batch <= B):
             raise ValueError("grad_batch is for self-attention-only passes: 0 < grad_batch <= batch")
         ctx.meta = (lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index, groups, grad_batch)
+        ctx.pack = pack
         ctx.noted = need_dx or need_denc
         if ctx.noted:
             arena_note_use(model)
@@ -279,17 +289,23 @@ class _EncoderFn(torch.autograd.Function):
         dy_a, dy_b = dy.contiguous(), None
         wg = _WgradStream(dy.device)
         B_full = B
+        pack = ctx.pack
+        rows_full = dy_a.shape[0]
         if grad_batch is not None and grad_batch < B:
             # only the first `grad_batch` sequences carry gradient (the rest of the pass was a detached forward that shared the
             # GEMMs): every op is per token / per sequence, so the backward runs on the row prefix of the saved activations
             B = grad_batch
-            G = B * T
+            G = B * T if pack is None else pack.rows_of_head(B)
+            if pack is not None:
+                pack = pack.head(B)
             dy_a = dy_a[:G]
             key_keep = None if key_keep is None else key_keep[:B]
             for rec in ctx.saved:
                 for k, v in list(rec.items()):
                     if torch.is_tensor(v):
                         rec[k] = v[:B] if k.startswith("lse") else v[:G]
+        qp = None if pack is None else pack.pair
+        new_grad = torch.zeros_like if pack is not None else torch.empty_like  # packed: the kernels only write real-token rows
         denc32 = None
         # gradient w.r.t. the shared image states = sum over the cross-attention layers of dKV_l @ Wkv_l: with the grouped
         # kernels every layer's dKV is [images*Nenc, 2D], so the layers write column blocks of ONE buffer and a single GEMM
@@ -317,7 +333,7 @@ class _EncoderFn(torch.autograd.Function):
                 wg.gemm_tn(dh2, r["c2"], s["o2"].dw)
                 dc2 = Fx.gemm_nt(dh2, s["o2"].wt, n=s["o2"].K)
                 kv = r["kv"]
-                dq2 = torch.empty_like(r["q2"])
+                dq2 = new_grad(r["q2"])
                 if groups is not None:  # dK/dV accumulated over each image's rows in registers, written once per image
                     if concat_k:
                         j = cross_layers.index(li)
@@ -325,7 +341,7 @@ class _EncoderFn(torch.autograd.Function):
                     else:
                         dkv = torch.empty((enc.shape[0], 2 * D), dtype=BF16, device=dq2.device)
                     Fx.attn_bwd(dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc,
-                                scale, key_keep=enc_keep, drop=r["d_att2"], groups=groups)
+                                scale, key_keep=enc_keep, drop=r["d_att2"], groups=groups, q_pack=qp)
                 else:
                     dkv = torch.empty((B * Nenc, 2 * D), dtype=BF16, device=dq2.device)  # per query row
                     Fx.attn_bwd(dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc,
@@ -343,16 +359,16 @@ class _EncoderFn(torch.autograd.Function):
             wg.gemm_tn(dh1, r["c1"], s["o"].dw)
             dc1 = Fx.gemm_nt(dh1, s["o"].wt, n=s["o"].K)
             qkv = r["qkv"]
-            dqkv = torch.empty_like(qkv)
+            dqkv = new_grad(qkv)
             Fx.attn_bwd(dc1, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], r["c1"], r["lse1"], dqkv[:, :D], dqkv[:, D:2 * D],
-                        dqkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep, causal=causal, drop=r["d_att"])
+                        dqkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep, causal=causal, drop=r["d_att"], q_pack=qp, k_pack=qp)
             wg.gemm_tn(dqkv, r["x"], s["qkv"].dw, dbias=s["qkv"].db)
             if li > lo or need_dx:
                 dy_a, dy_b = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K), dres1
             ctx.saved[li - lo] = None
         dx = (dy_a.float() + dy_b.float()).to(BF16) if need_dx else None
         if dx is not None and B < B_full:
-            dx = torch.cat([dx, torch.zeros(((B_full - B) * T, dx.shape[1]), dtype=dx.dtype, device=dx.device)], dim=0)
+            dx = torch.cat([dx, torch.zeros((rows_full - dx.shape[0], dx.shape[1]), dtype=dx.dtype, device=dx.device)], dim=0)
         denc = None
         if concat_k:
             wt_cat = torch.cat([model.encoder.layer[li]._s["kv2"].wt[:, :2 * D] for li in cross_layers], dim=1)  # [D_enc, layers*2D]
@@ -362,7 +378,7 @@ class _EncoderFn(torch.autograd.Function):
         wg.join()  # the weight gradients are complete in main-stream order before the tower's all-reduce / the optimizer
         if ctx.noted:
             arena_note_grad(model)
-        return (dx, denc) + (None,) * 12
+        return (dx, denc) + (None,) * 13
 
 
 class RobertaModel(nn.Module):
@@ -392,11 +408,13 @@ class RobertaModel(nn.Module):
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
                 inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
-                is_decoder=False, mode='multi_modal', encoder_batch_index=None, grad_batch=None):
+                is_decoder=False, mode='multi_modal', encoder_batch_index=None, grad_batch=None, pack=None):
         """`encoder_batch_index` (extension, default None = reference behaviour): int tensor [B] mapping every text row to the
         row of `encoder_hidden_states` it attends to, so duplicated images are projected to K/V once per layer.
         `grad_batch` (extension): only the first grad_batch sequences of the batch propagate gradient through the layer stack
-        (a detached pass batched behind a differentiable one, e.g. the masked-text pass of get_fuse_mlm_loss)."""
+        (a detached pass batched behind a differentiable one, e.g. the masked-text pass of get_fuse_mlm_loss).
+        `pack` (extension, xfm_amd.packing.Pack): run on unpadded token rows -- `attention_mask` is then implied by the pack's lengths,
+        `encoder_embeds` is a 2-D [pack.cap, D] row buffer and `last_hidden_state` comes back in the same packed layout."""
         if any(v is not None for v in (token_type_ids, position_ids, head_mask, inputs_embeds, past_key_values)):
             raise NotImplementedError("token_type_ids/position_ids/head_mask/inputs_embeds/past_key_values are not used on the XFM path")
         if isinstance(encoder_hidden_states, (list, tuple)):
@@ -404,15 +422,24 @@ class RobertaModel(nn.Module):
         if self._arena is None:
             raise RuntimeError("RobertaModel is not attached to a parameter arena; build it through XFMBase or call finalize()")
         cfg = self.config
+        if pack is not None and is_decoder:
+            raise NotImplementedError("packed rows are for the bidirectional towers")
         if encoder_embeds is None:
             if input_ids is None:
                 raise ValueError("You have to specify either input_ids or inputs_embeds")
             B, T = input_ids.shape
             drop = Fx.drop_params(cfg.hidden_dropout_prob if self.training else 0.0, _next_seed())
-            x = _EmbedFn.apply(self.embeddings.word_embeddings.weight, self.embeddings, input_ids, drop, self)
+            x = _EmbedFn.apply(self.embeddings.word_embeddings.weight, self.embeddings, input_ids, drop, self, pack)
         else:
-            B, T = encoder_embeds.shape[:2]
+            if pack is not None:
+                assert encoder_embeds.dim() == 2 and encoder_embeds.shape[0] == pack.cap, "packed encoder_embeds are [pack.cap, D] rows"
+                B, T = pack.B, pack.T
+            else:
+                B, T = encoder_embeds.shape[:2]
             x = encoder_embeds if encoder_embeds.dtype == BF16 else encoder_embeds.to(BF16)
+        if pack is not None:
+            assert (B, T) == (pack.B, pack.T)
+            attention_mask = None  # implied by the lengths: keys past a sequence's end do not exist
         dev = x.device
         key_keep = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int32).contiguous()
         enc, enc_keep, Nenc = None, None, 0
@@ -433,11 +460,11 @@ class RobertaModel(nn.Module):
             lo, hi = 0, cfg.num_hidden_layers
         else:
             raise ValueError(f"mode {mode} is not supported")
-        y = x.reshape(B * T, -1)
+        y = x.reshape(B * T, -1) if pack is None else x
         if hi > lo:
             y = _EncoderFn.apply(y, enc, self, key_keep, enc_keep, lo, hi, bool(is_decoder), B, T, Nenc, self.training,
-                                 encoder_batch_index if enc is not None else None, grad_batch)
-        return SimpleNamespace(last_hidden_state=y.view(B, T, -1), pooler_output=None, past_key_values=None,
+                                 encoder_batch_index if enc is not None else None, grad_batch, pack)
+        return SimpleNamespace(last_hidden_state=y.view(B, T, -1) if pack is None else y, pooler_output=None, past_key_values=None,
                                hidden_states=None, attentions=None, cross_attentions=None)
 
 
