@@ -106,6 +106,19 @@ class LinearSlot:
         return self._wt
 
 
+class OwnsArena:
+    """Mixin for modules that can build their own ParamArena (stand-alone towers): `zero_grad()` must zero the arena and keep every
+    .grad attached to it (nn.Module.zero_grad defaults to set_to_none=True, which would drop the views and leave the arena dirty)."""
+    _own_arena = False
+
+    def zero_grad(self, set_to_none=False):
+        arena = getattr(self, "_arena", None)
+        if arena is not None and self._own_arena:
+            arena.zero_grad()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+
 def grad_of(p):
     """Gradient view of a parameter inside its arena (re-attached if a caller dropped .grad); marks the parameter live -- every
     kernel launch site that accumulates a parameter gradient gets its destination through here or through slot.dw / slot.db."""
@@ -264,6 +277,8 @@ class ParamArena:
         for p in plist:
             if not isinstance(p, int):
                 self.touch(p)
+                if p.grad is not p._xfm_grad:  # a caller's zero_grad(set_to_none=True) dropped the view: the gradient lives here
+                    p.grad = p._xfm_grad
 
     def is_live(self, p):
         return self.live[self._unit_of[id(p)]]

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fx
-from .arena import LinearSlot, ParamArena
+from .arena import LinearSlot, OwnsArena, ParamArena
 from .ops import linear_slot
 
 
@@ -297,7 +297,7 @@ def arena_note_grad(mod):
         hook(mod, -1)
 
 
-class VisionTransformer(nn.Module):
+class VisionTransformer(OwnsArena, nn.Module):
     """Drop-in for models.beit2.VisionTransformer (BEiT-v2 configuration used by XFM)."""
     _pool_tail = True  # forward_avgpool (beit2.py:455-466): the trunk node replaces the cls row by the mean of the patch rows
 

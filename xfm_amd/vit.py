@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fx
-from .arena import LinearSlot, ParamArena
+from .arena import LinearSlot, OwnsArena, ParamArena
 from .beit2 import PatchEmbed, _Affine, _Dense, _TrunkFn
 from .ops import linear_slot
 
@@ -48,7 +48,7 @@ class Block(nn.Module):
         self.drop_path_prob = float(drop_path)
 
 
-class VisionTransformer(nn.Module):
+class VisionTransformer(OwnsArena, nn.Module):
     """Drop-in for models.vit.VisionTransformer (vit.py:106-219)."""
 
     _rel_pos = False

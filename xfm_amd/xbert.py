@@ -14,7 +14,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn as nn
 
-from .arena import LinearSlot, ParamArena
+from .arena import LinearSlot, OwnsArena, ParamArena
 from .beit2 import _Affine
 from .ops import lm_head_ce, lm_head_logits
 from .xroberta import RobertaModel, _Emb, _Lin
@@ -90,7 +90,7 @@ class BertOnlyMLMHead(nn.Module):
         self.predictions = BertLMPredictionHead(config)
 
 
-class BertForMaskedLM(nn.Module):
+class BertForMaskedLM(OwnsArena, nn.Module):
     def __init__(self, config):
         super().__init__()
         self.config = config
@@ -108,6 +108,7 @@ class BertForMaskedLM(nn.Module):
     def finalize(self, device=None):
         device = device or self.cls.predictions.bias.device
         self.attach(ParamArena(self, self.linear_slots(), device))
+        self._own_arena = True
         return self
 
     def gather_seq_out_by_pos(self, seq, pos):

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fx
-from .arena import LinearSlot, ParamArena
+from .arena import LinearSlot, OwnsArena, ParamArena
 from .beit2 import _Affine, arena_note_grad, arena_note_use
 from .ops import grad_view, lm_head_ce, lm_head_logits
 
@@ -484,7 +484,7 @@ class RobertaLMHead(nn.Module):
         return [self._slot_dense, self._slot_decoder]
 
 
-class RobertaForMaskedLM(nn.Module):
+class RobertaForMaskedLM(OwnsArena, nn.Module):
     def __init__(self, config):
         super().__init__()
         self.config = config
@@ -504,6 +504,7 @@ class RobertaForMaskedLM(nn.Module):
     def finalize(self, device=None):
         device = device or self.lm_head.bias.device
         self.attach(ParamArena(self, self.linear_slots(), device))
+        self._own_arena = True
         return self
 
     def bert(self, input_ids=None, **kw):  # accepts the reference's keywords plus `encoder_batch_index`
@@ -537,7 +538,7 @@ class RobertaForMaskedLM(nn.Module):
         return SimpleNamespace(loss=loss, logits=logits[:, :V].view(Bq, Tq, V), hidden_states=None, attentions=None)
 
 
-class RobertaForCausalLM(nn.Module):
+class RobertaForCausalLM(OwnsArena, nn.Module):
     """Causal decoder with cross-attention to encoder states (the VQA answer decoder): mirrors models/xroberta.py:963-1153 --
     `roberta` + `lm_head`, causal self-attention mask, next-token shift, `reduction='none'` CE summed per sequence
     (:1107-1114)."""
@@ -559,6 +560,7 @@ class RobertaForCausalLM(nn.Module):
     def finalize(self, device=None):
         device = device or self.lm_head.bias.device
         self.attach(ParamArena(self, self.linear_slots(), device))
+        self._own_arena = True
         return self
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
