@@ -151,6 +151,10 @@ typedef struct {
      is needed.  Rows of o / dq / dk / dv outside every sequence are not written.  No bias, no kv_index in this mode; in grouped
      mode only the query side may be packed. */
   const int* q_start; const int* q_len; const int* k_start; const int* k_len;
+  /* xfm_attn_bwd only: 0 = both kernels; 1 = the dQ kernel alone (writes dq and the row statistics `delta`); 2 = the dK/dV kernel
+     alone (reads the `delta` a phase-1 call left) -- lets a caller put dK/dV, which in cross-attention only feed weight gradients,
+     on another stream than the activation-gradient chain. */
+  int bwd_phase;
 } xfm_attn_args;
 
 int xfm_attn_fwd(const xfm_attn_args* a, void* stream);

@@ -51,7 +51,8 @@ class AttnArgs(ctypes.Structure):
                 ("dk_rs", c_long), ("dv", c_void_p), ("dv_rs", c_long), ("delta", c_void_p), ("dbias", c_void_p),
                 ("stat_ld", c_long), ("bias_t", c_void_p), ("bias_t_ld", c_long), ("kv_index", c_void_p),
                 ("grp_start", c_void_p), ("grp_rows", c_void_p), ("n_groups", c_int),
-                ("q_start", c_void_p), ("q_len", c_void_p), ("k_start", c_void_p), ("k_len", c_void_p)]
+                ("q_start", c_void_p), ("q_len", c_void_p), ("k_start", c_void_p), ("k_len", c_void_p),
+                ("bwd_phase", c_int)]
 
 
 class EmbedArgs(ctypes.Structure):

@@ -670,13 +670,20 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
   if (nrows <= 0) return;  // uniform: before any barrier
   const int nchunks = PACK ? 1 : (a.Sk + 63) / 64;
   if (PACK) {
-    for (int jj = 0; jj < nrows; ++jj) {
-      const int src = a.kv_index ? a.kv_index[rstart + jj] : rstart + jj;
-      long kbase;
-      int sk;
-      k_seq(a, src, kbase, sk);
-      stage_slot(lds + jj * ATTN_SLOT, a.k + kbase * a.k_rs + h * 64, a.k_rs, a.v + kbase * a.v_rs + h * 64, a.v_rs, 0, sk, w, nw, lane);
+    // the (start, length) pairs of the <= ATTN_RES_MAX rows first, so their scalar loads overlap instead of one load -> stage
+    // chain per row
+    long kb_[ATTN_RES_MAX];
+    int sk_[ATTN_RES_MAX];
+#pragma unroll
+    for (int jj = 0; jj < ATTN_RES_MAX; ++jj) {
+      const int row = rstart + (jj < nrows ? jj : 0);
+      const int src = a.kv_index ? a.kv_index[row] : row;
+      k_seq(a, src, kb_[jj], sk_[jj]);
     }
+#pragma unroll
+    for (int jj = 0; jj < ATTN_RES_MAX; ++jj)
+      if (jj < nrows)
+        stage_slot(lds + jj * ATTN_SLOT, a.k + kb_[jj] * a.k_rs + h * 64, a.k_rs, a.v + kb_[jj] * a.v_rs + h * 64, a.v_rs, 0, sk_[jj], w, nw, lane);
   } else {
     const bf16* kb = a.k + (long)g * a.Sk * a.k_rs + h * 64;
     const bf16* vb = a.v + (long)g * a.Sk * a.v_rs + h * 64;
@@ -992,6 +999,7 @@ static int attn_check(const AttnArgs& a, bool bwd) {
   XFM_REQUIRE((a.q_start == nullptr && a.k_start == nullptr) || (a.bias == nullptr && a.dbias == nullptr && a.kv_index == nullptr),
               "attention: packed rows take no additive bias and no kv_index");
   if (bwd) {
+    XFM_REQUIRE(a.bwd_phase >= 0 && a.bwd_phase <= 2, "attention bwd: bwd_phase must be 0, 1 or 2");
     XFM_REQUIRE(a.dout && a.dq && a.dk && a.dv && a.delta && a.lse, "attention bwd: missing buffers");
     XFM_REQUIRE(a.do_rs % 8 == 0 && a.dq_rs % 4 == 0 && a.dk_rs % 4 == 0 && a.dv_rs % 4 == 0, "attention bwd: bad strides");
   }
@@ -1096,9 +1104,11 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
     rc = attn_check_grouped(a);
     if (rc != XFM_OK) return rc;
     attn_grouped_lds();
-    hipLaunchKernelGGL(xattn_dq_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)cdiv(a.Sk, 64) * ATTN_SLOT, st, a);
-    rc = xfm_check_launch("xattn_dq");
-    if (rc != XFM_OK) return rc;
+    if (a.bwd_phase != 2) {
+      hipLaunchKernelGGL(xattn_dq_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)cdiv(a.Sk, 64) * ATTN_SLOT, st, a);
+      rc = xfm_check_launch("xattn_dq");
+      if (rc != XFM_OK || a.bwd_phase == 1) return rc;
+    }
     int knw, kblocks;
     attn_geom(a.Sk, knw, kblocks);
     hipLaunchKernelGGL(xattn_dkv_kernel, dim3(kblocks, a.H, a.n_groups), dim3(knw * 64), (size_t)ATTN_RES_MAX * ATTN_SLOT, st, a);
@@ -1108,7 +1118,9 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
   attn_geom(a.Sq, nw, blocks);
   const bool res = attn_resident(a.Sk, nw);
   const bool plain = attn_plain(a);
-  if (a.dbias != nullptr && res && plain) {
+  if (a.bwd_phase == 2) {
+    // dK/dV alone: `delta` was written by an earlier phase-1 call
+  } else if (a.dbias != nullptr && res && plain) {
     // batch entries whose dS one workgroup sums before touching HBM.  The kernel holds 230+ VGPRs (sum_b dS of four chunks), i.e.
     // one workgroup per CU: of 4 and 8 entries take the one with fewer (rounds of 256 workgroups) x entries, ties to 8
     // (half the atomics) -- B = 64: 192 workgroups x 8 entries beats 384 x 4 (1.5 rounds) by 6 %.
@@ -1129,7 +1141,7 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<0, false, false>), dim3(blocks, a.H, a.B), dim3(nw * 64), attn_lds_bytes(a.Sk, nw, 0), st, a, 1);
   }
   rc = xfm_check_launch("attn_bwd_dq");
-  if (rc != XFM_OK) return rc;
+  if (rc != XFM_OK || a.bwd_phase == 1) return rc;
   attn_geom(a.Sk, nw, blocks);
   const dim3 grid(blocks, a.H, a.B), blk(nw * 64);
   static const bool dkv_res = getenv("XFM_ATTN_DKV_RES") ? atoi(getenv("XFM_ATTN_DKV_RES")) != 0 : true;  // tuning knob

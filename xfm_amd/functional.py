@@ -268,13 +268,14 @@ def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, dro
 
 
 def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0), kv_index=None, groups=None,
-             q_pack=None, k_pack=None):
+             q_pack=None, k_pack=None, zero_fill=True):
     """q [B*Sq, >=H*64] / k, v [B*Sk, ...] are 2-D (possibly strided column slices of fused projection buffers).
     bias: dense fp32 [H,Sq,ld]; key_keep: int32 [B,Sk].  Returns (o [B*Sq, H*64] bf16, lse [B,H,Sq]).
     groups = kv_groups(...): grouped mode, k / v / key_keep hold one entry per SOURCE."""
     _dev(q)
-    if q_pack is not None:  # one output row per packed query row; rows outside every sequence stay zero (finite for what follows)
-        o = torch.zeros((q.shape[0], H * 64), dtype=BF16, device=q.device)
+    if q_pack is not None:  # one output row per packed query row; rows outside every sequence stay zero (finite for what follows;
+        # zero_fill=False: the caller knows the sequences cover every row)
+        o = (torch.zeros if zero_fill else torch.empty)((q.shape[0], H * 64), dtype=BF16, device=q.device)
     else:
         o = torch.empty((B * Sq, H * 64), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, _stat_ld(Sq)), dtype=F32, device=q.device)
@@ -287,12 +288,16 @@ def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=Fals
 
 
 def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, dbias=None, key_keep=None, causal=False,
-             drop=(0, 1.0, 0, 0), bias_t=None, kv_index=None, groups=None, q_pack=None, k_pack=None):
+             drop=(0, 1.0, 0, 0), bias_t=None, kv_index=None, groups=None, q_pack=None, k_pack=None, phase=0, delta=None):
     """Writes dq/dk/dv (2-D bf16 views with the same addressing convention as q/k/v); dbias (fp32 [H,Sq,ld]) += .
     Grouped mode: dk/dv are per SOURCE ([n_groups*Sk] rows), summed over each group's rows.
-    Packed rows: only the rows of real tokens are written -- pass zero-initialised dq (/ dk / dv)."""
+    Packed rows: only the rows of real tokens are written -- pass zero-initialised dq (/ dk / dv).
+    phase 1 = the dQ kernel alone, phase 2 = the dK/dV kernel alone on the `delta` that the phase-1 call returned.  Returns delta."""
     a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t, kv_index, groups, q_pack, k_pack)
-    delta = torch.empty((B, H, lse.shape[-1]), dtype=F32, device=q.device)  # the kernels never use its padding entries
+    if delta is None:
+        assert phase != 2, "phase 2 needs the row statistics of the phase-1 call"
+        delta = torch.empty((B, H, lse.shape[-1]), dtype=F32, device=q.device)  # the kernels never use its padding entries
+    a.bwd_phase = phase
     assert dout.dtype == BF16 and dout.stride(-1) == 1
     a.dout, a.do_rs = dout.data_ptr(), dout.stride(0)
     a.dq, a.dq_rs = dq.data_ptr(), dq.stride(0)
@@ -300,6 +305,7 @@ def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, 
     a.dv, a.dv_rs = dv.data_ptr(), dv.stride(0)
     a.delta, a.dbias = delta.data_ptr(), _ptr(dbias)
     check(_lib.load().xfm_attn_bwd(ctypes.byref(a), _stream()), "attn_bwd")
+    return delta
 
 
 def rows_index_sum(src, index, U, rows_per_item):

@@ -33,6 +33,11 @@ class Pack:
     def pair(self):
         return (self.start, self.lens)
 
+    @property
+    def exact(self):
+        """Every row of the buffer belongs to a sequence (no slack): kernels that only write real-token rows cover the buffer."""
+        return self.lens_host is not None and sum(self.lens_host) == self.cap
+
     @classmethod
     def from_lens(cls, lens_host, T, device):
         """Exact packing of sequences whose lengths the host knows."""

@@ -204,6 +204,34 @@ class _WgradStream:
         with torch.cuda.stream(self.side):
             Fx.gemm_tn(dy, x, dw, **kw)
 
+    def project(self, x, slot):
+        """x @ slot.W^T + b on the side stream; returns (tensor, event) for take()."""
+        if not self.on:
+            return Fx.gemm_nt(x, slot.wb, slot.b), None
+        with torch.cuda.stream(self.side):
+            y = Fx.gemm_nt(x, slot.wb, slot.b)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        y.record_stream(self.main)  # allocated on the side stream, consumed on the main one
+        return y, ev
+
+    def take(self, pair):
+        y, ev = pair
+        if ev is not None:
+            self.main.wait_event(ev)
+        return y
+
+    def run(self, fn, keep=()):
+        """fn() on the side stream, after everything enqueued on the main stream so far; `keep` = the tensors it touches."""
+        if not self.on:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        self.keep.append(tuple(keep))
+        with torch.cuda.stream(self.side):
+            return fn()
+
     def join(self):
         if self.on:
             self.main.wait_stream(self.side)
@@ -224,6 +252,7 @@ class _EncoderFn(torch.autograd.Function):
         saved = []
         x = x.contiguous()
         qp = None if pack is None else pack.pair  # packed token rows: x is [pack.cap, D], sequences at (start, len)
+        zf = pack is not None and not pack.exact  # slack rows exist: attention outputs must be zero there
         if pack is not None and (key_keep is not None or causal):
             raise ValueError("packed rows take neither a key mask (lengths say it all) nor the causal mask")
         groups = None
@@ -231,6 +260,16 @@ class _EncoderFn(torch.autograd.Function):
             enc = enc.contiguous()
             if enc_index is not None and Fx.attn_grouped_ok(T, Nenc):
                 groups = Fx.kv_groups(enc_index, enc.shape[0] // Nenc)
+        # The K/V projections of the image states depend on no text-side activation (xroberta.py:224-226 recomputes them in every
+        # layer from the same encoder_hidden_states): all layers' projections are enqueued up front on the second stream and run under
+        # the self-attention halves of the layers, off the dependent chain; each cross-attention waits for its own layer's event.
+        kv_ready = {}
+        if enc is not None:
+            pre = _WgradStream(x.device)
+            for li in range(lo, hi):
+                layer = model.encoder.layer[li]
+                if layer.has_cross_attention:
+                    kv_ready[li] = pre.project(enc, layer._s["kv2"])
         for li in range(lo, hi):
             layer = model.encoder.layer[li]
             s = layer._s
@@ -238,7 +277,7 @@ class _EncoderFn(torch.autograd.Function):
             d_att, d_h1 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
             qkv = Fx.gemm_nt(x, s["qkv"].wb, s["qkv"].b)
             c1, lse1 = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, T, T, scale, key_keep=key_keep,
-                                          causal=causal, drop=d_att, q_pack=qp, k_pack=qp)
+                                          causal=causal, drop=d_att, q_pack=qp, k_pack=qp, zero_fill=zf)
             h1 = Fx.gemm_nt(c1, s["o"].wb, s["o"].b)
             ln1 = att.output.LayerNorm
             y1, z1, m1, r1 = Fx.ln_post_fwd(h1, x, ln1.weight, ln1.bias, ln1.eps, d_h1)
@@ -248,10 +287,10 @@ class _EncoderFn(torch.autograd.Function):
                 co = layer.crossattention
                 d_att2, d_h2 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
                 q2 = Fx.gemm_nt(y1, s["q2"].wb, s["q2"].b)
-                kv = Fx.gemm_nt(enc, s["kv2"].wb, s["kv2"].b)
+                kv = pre.take(kv_ready.pop(li))
                 if groups is not None:  # one workgroup per (image, head): K/V staged once for every row that reads it
                     c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, groups=groups,
-                                           q_pack=qp)
+                                           q_pack=qp, zero_fill=zf)
                 elif pack is not None:
                     raise NotImplementedError("packed rows with cross-attention need the grouped kernels (T <= 64, N <= 256) and "
                                               "an encoder_batch_index")
@@ -305,7 +344,8 @@ class _EncoderFn(torch.autograd.Function):
                     if torch.is_tensor(v):
                         rec[k] = v[:B] if k.startswith("lse") else v[:G]
         qp = None if pack is None else pack.pair
-        new_grad = torch.zeros_like if pack is not None else torch.empty_like  # packed: the kernels only write real-token rows
+        # packed rows with slack: the attention kernels only write real-token rows, the rest must be zero gradient
+        new_grad = torch.zeros_like if (pack is not None and not pack.exact) else torch.empty_like
         denc32 = None
         # gradient w.r.t. the shared image states = sum over the cross-attention layers of dKV_l @ Wkv_l: with the grouped
         # kernels every layer's dKV is [images*Nenc, 2D], so the layers write column blocks of ONE buffer and a single GEMM
@@ -340,8 +380,12 @@ class _EncoderFn(torch.autograd.Function):
                         dkv = dkv_all[:, j * 2 * D:(j + 1) * 2 * D]
                     else:
                         dkv = torch.empty((enc.shape[0], 2 * D), dtype=BF16, device=dq2.device)
-                    Fx.attn_bwd(dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc,
-                                scale, key_keep=enc_keep, drop=r["d_att2"], groups=groups, q_pack=qp)
+                    # dQ stays on the activation-gradient chain; dK/dV (they only feed the K/V weight gradient and, after the last
+                    # layer, the gradient of the image states) run next to the weight-gradient GEMMs on the second stream
+                    args = (dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc, scale)
+                    kw = dict(key_keep=enc_keep, drop=r["d_att2"], groups=groups, q_pack=qp)
+                    delta = Fx.attn_bwd(*args, phase=1, **kw)
+                    wg.run(lambda: Fx.attn_bwd(*args, phase=2, delta=delta, **kw), keep=args[:9] + (delta,))
                 else:
                     dkv = torch.empty((B * Nenc, 2 * D), dtype=BF16, device=dq2.device)  # per query row
                     Fx.attn_bwd(dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc,
@@ -351,7 +395,10 @@ class _EncoderFn(torch.autograd.Function):
                 wg.gemm_tn(dq2, r["y1"], s["q2"].dw, dbias=s["q2"].db)
                 wg.gemm_tn(dkv, enc, s["kv2"].dw, dbias=s["kv2"].db)
                 if need_denc and not concat_k:
-                    Fx.gemm_nt(dkv, s["kv2"].wt, epi=Fx.EPI_F32_ACC, out=denc32, n=s["kv2"].K)
+                    if groups is not None:  # dkv is produced on the second stream: its consumer follows it there
+                        wg.run(lambda dkv=dkv, s=s: Fx.gemm_nt(dkv, s["kv2"].wt, epi=Fx.EPI_F32_ACC, out=denc32, n=s["kv2"].K), keep=(dkv,))
+                    else:
+                        Fx.gemm_nt(dkv, s["kv2"].wt, epi=Fx.EPI_F32_ACC, out=denc32, n=s["kv2"].K)
                 d1a, d1b = Fx.gemm_nt(dq2, s["q2"].wt, n=s["q2"].K), dres2
             ln1 = layer.attention.output.LayerNorm
             dh1, dres1 = Fx.ln_post_bwd(d1a, r["z1"], r["m1"], r["r1"], ln1.weight, g(ln1.weight), g(ln1.bias), s["o"].db,
@@ -372,8 +419,10 @@ class _EncoderFn(torch.autograd.Function):
         denc = None
         if concat_k:
             wt_cat = torch.cat([model.encoder.layer[li]._s["kv2"].wt[:, :2 * D] for li in cross_layers], dim=1)  # [D_enc, layers*2D]
+            wg.join()  # the dK/dV blocks were written on the second stream
             denc = Fx.gemm_nt(dkv_all, wt_cat)
         elif need_denc:
+            wg.join()
             denc = denc32.to(BF16)
         wg.join()  # the weight gradients are complete in main-stream order before the tower's all-reduce / the optimizer
         if ctx.noted:
