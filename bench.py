@@ -176,7 +176,8 @@ class FlopCounter:
                 B_, H_, Sq_, Sk_ = args[off:off + 4]
                 rows = args[0].shape[0] / B_ if kw.get("q_pack") is not None else Sq_   # packed: mean real length (incl. slack)
                 keys = rows if (kw.get("k_pack") is not None) else Sk_
-                self.flop += scale_ * 4.0 * B_ * H_ * rows * keys * 64
+                ph = kw.get("phase", 0)
+                self.flop += scale_ * 4.0 * B_ * H_ * rows * keys * 64 * (0.5 if ph in (1, 2) else 1.0)
                 return orig(*args, **kw)
             return f
 
@@ -202,7 +203,8 @@ def fusion_probe(model, B, host_batch, packed, iters=5):
     lens_h = host_batch["text_atts"].sum(1)
     perm = torch.randperm(B, generator=g)
     img = (torch.randn(B, 197, 768, generator=g) * 0.7).to(dev, torch.bfloat16).requires_grad_(True)
-    iatts = torch.ones(B, 197, dtype=torch.long, device=dev)
+    from xfm_amd.xfm import _ones_mask
+    iatts = _ones_mask(img)  # the image mask of xfm.py:566-571 (all ones, tagged: the cross-attention skips it)
     ar = torch.arange(B, device=dev)
     index = torch.cat([ar, torch.randperm(B, generator=g).to(dev), ar, ar]).to(torch.int32)
     lens4 = torch.cat([lens_h, lens_h, lens_h[perm], lens_h])

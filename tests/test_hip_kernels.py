@@ -129,6 +129,30 @@ def test_gemm_tn_exact_integers_catch_layout_errors():
     assert torch.equal(db, dy.float().sum(0))
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(5211, 768, 768, 0), (1296, 2304, 768, 0), (83, 128, 256, 1), (2000, 256, 128, 3), (64, 128, 128, 1)])
+def test_gemm_tn_ring_kernel_ragged_rows_vs_register_staged_kernel(M, N, K, splits):
+    """The 4-slot LDS-ring wgrad kernel (edge-free N, K; any M: packed token rows are not multiples of 32) against fp32 math and
+    against the register-staged kernel it replaces (splits = -5 pins the old one), dW += and bias gradient included; exact on
+    small-integer operands (layout errors cannot hide)."""
+    Fx = _fx()
+    dy, x = _rand((M, N), seed=20), _rand((M, K), seed=21)
+    dw = torch.full((N, K), 0.5, dtype=F32, device="cuda")
+    db = torch.full((N,), 0.25, dtype=F32, device="cuda")
+    Fx.gemm_tn(dy, x, dw, splits=splits, dbias=db)
+    ref = dy.float().t() @ x.float() + 0.5
+    _close(dw, ref, 2e-4, "ring wgrad")
+    _close(db, dy.float().sum(0) + 0.25, 2e-4, "ring bias grad")
+    dw2 = torch.full((N, K), 0.5, dtype=F32, device="cuda")
+    Fx.gemm_tn(dy, x, dw2, splits=-5)
+    _close(dw, dw2, 1e-5, "ring vs register-staged")
+    dyi = ((torch.arange(M * N, device="cuda").reshape(M, N) * 7) % 13 - 6).to(BF16)
+    xi = ((torch.arange(M * K, device="cuda").reshape(M, K) * 5) % 11 - 5).to(BF16)
+    dwi = torch.zeros((N, K), dtype=F32, device="cuda")
+    dbi = torch.zeros((N,), dtype=F32, device="cuda")
+    Fx.gemm_tn(dyi, xi, dwi, splits=1, dbias=dbi)
+    assert torch.equal(dwi, dyi.float().t() @ xi.float()) and torch.equal(dbi, dyi.float().sum(0))
+
+
 def test_cast_transpose_and_colsum():
     Fx = _fx()
     w = _rand((300, 136), dtype=F32, seed=12)

@@ -27,7 +27,7 @@ def is_stale():
 def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Wno-inline-asm",
            os.path.join(CSRC, "capi.hip"), "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

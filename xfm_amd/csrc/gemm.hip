@@ -640,10 +640,20 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
                                 aux ? (void*)((bf16*)aux + (long)rows_a * ldaux) : nullptr, ldaux, M - rows_a, N, K, epi, -1, st);
       }
     }
-    if (M >= 2048 && t256 >= 120) cfg = 5;  // ~half a round of 256x256 tiles already beats the rest
+    // ~half a round of 256x256 tiles already beats the rest on the tall problems (M = 12608 / 25216); on the packed token rows of
+    // the text / fusion towers (M ~ 2600 .. 5300, tools/tune_small.py) it needs ~0.7 of a round, below that 128x128 tiles win
+    // (5248x1536x768: 25.2 -> 17.4 us, 2624x3072x768: 24.0 -> 17.1 us)
+    if (M >= 2048 && (t256 >= 180 || (t256 >= 120 && M >= 8192))) cfg = 5;
+    else if (M >= 2048 && t256 >= 120) cfg = 1;
     else if ((long)cdiv(M, 256) * cdiv(N, 128) >= 768) cfg = 4;  // >= 3 rounds of 256x128 tiles: the 3-slot ring wins on cold operands
     else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 800) cfg = 1;
     else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 512) cfg = 2;
+    else if (K >= 1536 && epi != EPI_F32_ACC && (long)cdiv(M, 64) * cdiv(N, 128) < 300) {
+      // a long K loop against about one 64x128 tile per CU or fewer (the FFN / QKV dgrads of the text tower and of a 2B-sequence
+      // fusion pass): 64x64 tiles double the workgroups and four LDS stages keep three K-tiles in flight
+      // (2624x768x3072: 24.4 -> 21.9 us, 1344x768x3072: 24.2 -> 18.5 us, 1344x768x2304: 19.3 -> 14.5 us)
+      cfg = 8;
+    }
     else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 128 || K >= 1536) {  // under two workgroups per CU (tail-split row blocks, text
       // tower) the 2-stage loop exposes the load latency of every K-step: keep two K-tiles in flight (3-stage 64x128; measured
       // 45.9 -> 31.7 us on 3456x768x3072, 18.9 -> 20.6 us on the 720-tile 7680x768x768 which therefore stays 2-stage)
@@ -830,6 +840,130 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
           if (g.direct) *dst += acc[nt][kt][rgi];  // single split: this workgroup is the element's only writer
           else atomicAdd(dst, acc[nt][kt][rgi]);
         }
+      }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// wgrad, 128 x 128 tile on a 4-slot LDS ring (the mid-size problems: M of a few thousand token rows, the text / fusion towers).
+// The register-staged kernel above keeps ONE K-step in flight, and at two workgroups per CU every 64-row step exposes the
+// load latency (measured 1.7 us per step against 0.22 us of MFMA).  Here a step is 32 rows of M (one MFMA k-slice): two
+// [32 m][128 col] images (256-B rows, swz_t on the SOURCE address) = 16 KB, filled by direct-to-LDS loads issued as inline
+// asm (see gemm_tn_256_kernel: the compiler would drain them in front of every transposed LDS read); THREE steps stay in
+// flight behind a counted s_waitcnt vmcnt(8) and one raw barrier per step.  4 waves as 2 (n) x 2 (k), 64 x 64 each -- the
+// register layout of gemm_tn_kernel, so the split partials go through the same tn_reduce128_kernel.  Rows past the end of a
+// split read a zero row (a wgrad must not see clamped rows).  Needs N % 128 == 0 and K % 128 == 0; the bias gradient rides on
+// the matrix cores (dY fragment x ones) in the k-tile-0 workgroups.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) static const uint32_t g_zero_row[64] = {0};
+
+__global__ __launch_bounds__(256) void gemm_tn_ring_kernel(GemmTN g) {
+  constexpr int IMG = 32 * 256, STG = 2 * IMG, NS = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wn = w >> 1, wk = w & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int tiles_k = g.K / 128, tiles_n = g.N / 128;
+  const int per_split = tiles_k * tiles_n;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = wg / per_split, t = wg % per_split;
+  const int n0 = (t / tiles_k) * 128, k0 = (t % tiles_k) * 128;
+  const int mbeg = split * g.m_per_split;
+  int mend = mbeg + g.m_per_split;
+  mend = mend < g.M ? mend : g.M;
+  const int nsteps = (mend - mbeg + 31) / 32;
+  const bool do_bias = g.dbias != nullptr && k0 == 0 && wk == 0;
+
+  // this wave's 4 loads of a step: blocks {w, w + 4} of the dY image and of the X image (a block = 4 rows x 256 B = 1 KiB)
+  const bf16* zrow = reinterpret_cast<const bf16*>(g_zero_row);
+  int lrow[2], lcol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    lrow[i] = 4 * (i * 4 + w) + (lane >> 4);
+    lcol[i] = ((lane & 15) ^ swz_t(lrow[i])) * 8;  // logical column stored at this lane's 16-B slot
+  }
+  auto issue = [&](int s) {
+    if (s >= nsteps) return;
+    char* base = smem + (s & (NS - 1)) * STG;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mbeg + s * 32 + lrow[i];
+      const bool ok = m < mend;
+      const bf16* sy = ok ? g.dY + (long)m * g.ldy + n0 + lcol[i] : zrow + lcol[i];
+      const bf16* sx = ok ? g.X + (long)m * g.ldx + k0 + lcol[i] : zrow + lcol[i];
+      const unsigned dy_lds = (unsigned)(uintptr_t)LDS_PTR(void, base) + (unsigned)__builtin_amdgcn_readfirstlane((i * 4 + w) * 1024);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(sy), "s"(dy_lds) : "memory", "m0");
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(sx), "s"(dy_lds + (unsigned)IMG) : "memory", "m0");
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = f2bf(1.0f);
+
+  issue(0);
+  issue(1);
+  issue(2);
+  for (int s = 0; s < nsteps; ++s) {
+    // step s has landed (this wave's share); the younger steps s+1, s+2 (4 loads each, where they exist) stay in flight
+    const int younger = nsteps - 1 - s < 2 ? nsteps - 1 - s : 2;
+    if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XFM_BAR();      // every wave's share of step s is in LDS; everyone is done reading step s-1, whose slot step s+3 reuses
+    issue(s + 3);
+    const char* sY = smem + (s & (NS - 1)) * STG;
+    const char* sX = sY + IMG;
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) af[nt] = tr_read_pair(sY, 8 * lg, wn * 64 + nt * 16, lr);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) bfr[kt] = tr_read_pair(sX, 8 * lg, wk * 64 + kt * 16, lr);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], ones, bacc[nt], 0, 0, 0);
+    }
+  }
+
+  if (do_bias && lr == 0) {  // D[i = n][j]: every column j holds the same sum; lane (lg, lr = 0) owns rows 4*lg .. 4*lg+3
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(g.dbias + n0 + wn * 64 + nt * 16 + 4 * lg + i, bacc[nt][i]);
+  }
+  if (g.ws != nullptr) {  // split partial in accumulator-register order (coalesced 16-B stores); tn_reduce128_kernel sums them
+    f32x4* wsp = reinterpret_cast<f32x4*>(g.ws) + ((((long)split * per_split + t) * 4 + w) * 16) * 64 + lane;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) wsp[(nt * 4 + kt) * 64] = acc[nt][kt];
+    return;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = k0 + wk * 64 + kt * 16 + lr;
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi) {
+        const int n = n0 + wn * 64 + nt * 16 + 4 * lg + rgi;
+        float* dst = g.dW + (long)n * g.ldw + k;
+        if (g.direct) *dst += acc[nt][kt][rgi];  // single split: this workgroup is the element's only writer
+        else atomicAdd(dst, acc[nt][kt][rgi]);
       }
     }
 }
@@ -1171,9 +1305,14 @@ int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* d
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), smem, st, g);
+  static const int ring_env = getenv("XFM_TN_RING") ? atoi(getenv("XFM_TN_RING")) : 1;  // A/B knob
+  const bool ring = ring_env && N % 128 == 0 && K % 128 == 0 && splits_hint != -5;
+  if (ring) hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(tiles * splits), dim3(256), smem, st, g);
+  else hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), smem, st, g);
   int rc = xfm_check_launch("gemm_tn");
   if (rc != XFM_OK || !use_ws) return rc;
   const long quads = (long)tiles * 4 * 16 * 64;

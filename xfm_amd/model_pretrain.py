@@ -97,7 +97,8 @@ class XFM(XFMBase):
             both, _, _ = self.get_vision_embeds(image, do_mask=True,
                                                 ids_mask=torch.cat([torch.zeros_like(ids_mask), ids_mask], dim=0))
             image_embeds, image_embeds_masked = both[:B], both[B:]
-            image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
+            from .xfm import _ones_mask
+            image_atts = _ones_mask(image_embeds)
         else:
             image_embeds, image_atts = self.get_vision_embeds(image)
         if data_source != 'imagenet':

@@ -98,6 +98,14 @@ class _DeepMlp(nn.Module):
         return linear_slot(x, self._slots[4], out_fp32=True)
 
 
+def _ones_mask(embeds):
+    """image_atts of xfm.py:566-571: all ones.  The tensor is tagged so that the fusion tower can skip the key mask of its
+    cross-attention altogether (16 mask loads per lane and key chunk, and the masked-score selects) without reading it back."""
+    m = torch.ones(embeds.size()[:-1], dtype=torch.long, device=embeds.device)
+    m._xfm_all_ones = True
+    return m
+
+
 def _read_json(path, default):
     if path and os.path.exists(path):
         with open(path) as f:
@@ -315,11 +323,9 @@ class XFMBase(nn.Module):
         self._ready()
         if do_mask:
             image_embeds, id_masked = self.vision_encoder(image, do_mask=True, ids_mask=ids_mask)
-            image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
-            return image_embeds, image_atts, id_masked
+            return image_embeds, _ones_mask(image_embeds), id_masked
         image_embeds = self.vision_encoder(image)
-        image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
-        return image_embeds, image_atts
+        return image_embeds, _ones_mask(image_embeds)
 
     def get_text_embeds(self, text_ids, text_atts):
         assert text_atts is not None

@@ -496,7 +496,7 @@ class RobertaModel(nn.Module):
             enc = encoder_hidden_states if encoder_hidden_states.dtype == BF16 else encoder_hidden_states.to(BF16)
             Nenc = enc.shape[1]
             enc = enc.reshape(-1, enc.shape[-1])
-            if encoder_attention_mask is not None:
+            if encoder_attention_mask is not None and not getattr(encoder_attention_mask, "_xfm_all_ones", False):
                 enc_keep = encoder_attention_mask.to(device=dev, dtype=torch.int32).contiguous()
             if encoder_batch_index is not None:
                 encoder_batch_index = encoder_batch_index.to(device=dev, dtype=torch.int32).contiguous()
