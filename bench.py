@@ -209,10 +209,14 @@ def fusion_probe(model, B, host_batch, packed, iters=5):
     index = torch.cat([ar, torch.randperm(B, generator=g).to(dev), ar, ar]).to(torch.int32)
     lens4 = torch.cat([lens_h, lens_h, lens_h[perm], lens_h])
     if packed:
+        from xfm_amd.xfm import _PACK_SYNC
         ld = lens_h.to(dev).to(torch.int32)
         n_rows, t_max = int(lens_h.sum()), int(lens_h.max())
-        pack = Pack.concat([(ld, n_rows, lens_h.tolist()), (ld, n_rows, lens_h.tolist()), (ld[perm.to(dev)], B * t_max, None),
-                            (ld, n_rows, lens_h.tolist())], T)
+        if _PACK_SYNC:  # the step's default layout: every block exact (the drawn negatives are read back once per step)
+            pack = Pack.from_lens(lens4.tolist(), T, dev)
+        else:           # no host sync: worst-case room for the negative-text block, offsets computed on the device
+            pack = Pack.concat([(ld, n_rows, lens_h.tolist()), (ld, n_rows, lens_h.tolist()), (ld[perm.to(dev)], B * t_max, None),
+                                (ld, n_rows, lens_h.tolist())], T)
         valid = (pack.gather_index(pack) >= 0).unsqueeze(1)           # slack rows of the negative-text block stay zero
         text = ((torch.randn(pack.cap, 768, generator=g) * 0.7).to(dev, torch.bfloat16) * valid).requires_grad_(True)
         kw = dict(encoder_embeds=text, attention_mask=None, pack=pack)

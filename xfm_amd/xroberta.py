@@ -182,6 +182,7 @@ class _WgradStream:
     re-joined (the caching allocator reuses freed blocks in main-stream order only)."""
     _streams = {}
     enabled = os.environ.get("XFM_WGRAD_STREAM", "1") != "0"
+    priority = int(os.environ.get("XFM_WGRAD_PRIO", "0"))  # HIP stream priority of the second stream (lower number = served first)
 
     def __init__(self, device):
         self.main = torch.cuda.current_stream(device)
@@ -189,7 +190,7 @@ class _WgradStream:
         if self.on:
             key = device.index if device.index is not None else torch.cuda.current_device()
             if key not in _WgradStream._streams:
-                _WgradStream._streams[key] = torch.cuda.Stream(device=device)
+                _WgradStream._streams[key] = torch.cuda.Stream(device=device, priority=_WgradStream.priority)
             self.side = _WgradStream._streams[key]
             self.side.wait_stream(self.main)  # arena state (zeroed grads, earlier kernels) is visible to the side stream
         self.keep = []
