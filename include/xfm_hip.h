@@ -28,7 +28,7 @@ extern "C" {
 #define XFM_E_LAUNCH (-2)
 #define XFM_E_UNSUPPORTED (-3)
 
-#define XFM_ABI_VERSION 2
+#define XFM_ABI_VERSION 3
 
 const char* xfm_last_error(void);
 int xfm_abi_version(void);
@@ -218,6 +218,65 @@ int xfm_embed_ln_bwd(const xfm_embed_args* a, int D, float* dgamma, float* dbeta
  * D % 8 == 0); and its adjoint dst32[index[r],:] += src[r,:] (fp32 accumulation, rows with index < 0 are skipped). ------------- */
 int xfm_rows_gather(const xfm_bf16* src, const int* index, int R, int D, xfm_bf16* dst, void* stream);
 int xfm_rows_scatter_add(const xfm_bf16* src, const int* index, int R, int D, float* dst32, void* stream);
+
+/* ---- One whole RobertaLayer per call (xroberta.py:405-473: self-attention block, optional cross-attention block, FFN block, each
+ * closed by dropout + residual + LayerNorm), forward and backward.  The kernels are the ones above; what this adds is the launch
+ * SEQUENCE on the native side: a host language pays microseconds per launch (Python: 7-24 us per wrapper call against ~3.5 us for
+ * the launch itself), and a text / fusion tower is ~50 launches per layer of 10-30 us kernels -- its time is the host's, not the
+ * GPU's, unless the layer is one call.  All buffers are the caller's: `slab` holds the layer's activations (what the backward
+ * needs), `bslab` the backward's gradient temporaries, both laid out by xfm_rlayer_layout.  The weight-gradient GEMMs and the
+ * cross-attention dK/dV kernel are issued on `side_stream` behind events (NULL: everything on the main stream). ------------------ */
+typedef struct {        /* static per layer: bf16 operand copies ([N,K] and transposed [K,ld]), fp32 biases / LayerNorm affine, and
+                           where their gradients accumulate (fp32, +=) */
+  const xfm_bf16 *wqkv, *wqkv_t, *wo, *wo_t, *wq2, *wq2_t, *wkv2_t, *wo2, *wo2_t, *wi, *wi_t, *wout, *wout_t;
+  long ld_wqkv_t, ld_wo_t, ld_wq2_t, ld_wkv2_t, ld_wo2_t, ld_wi_t, ld_wout_t;
+  const float *bqkv, *bo, *bq2, *bo2, *bi, *bout;
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *ln3_w, *ln3_b;
+  float *dwqkv, *dbqkv, *dwo, *dbo, *dwq2, *dbq2, *dwkv2, *dbkv2, *dwo2, *dbo2, *dwi, *dbi, *dwout, *dbout;
+  float *dln1_w, *dln1_b, *dln2_w, *dln2_b, *dln3_w, *dln3_b;
+  int D, H, FF, has_cross;
+  float eps;
+} xfm_rlayer_params;
+
+typedef struct {        /* geometry + per-call inputs shared by forward and backward */
+  int R, B, T;                                   /* token rows, sequences, padded sequence length */
+  int R_alloc, B_alloc;                          /* geometry slab / bslab were laid out for (0: R, B); a backward over the first
+                                                    sequences of a forward pass (their rows are a prefix) passes the forward's */
+  int Nenc, U;                                   /* cross-attention: image tokens per image, images (0 = no cross-attention input) */
+  const int* seq_start; const int* seq_len;      /* packed rows (xfm_attn_args.q_start / q_len) or NULL */
+  const int* key_keep;                           /* [B,T] or NULL */
+  const int* enc_keep;                           /* [U,Nenc] or NULL */
+  const int* grp_start; const int* grp_rows;     /* grouped cross-attention (required with cross-attention input) */
+  int causal, zero_fill;                         /* zero_fill: attention outputs / gradients of rows outside every sequence */
+  float scale;
+  uint32_t att_thresh; float att_scale; uint32_t hid_thresh; float hid_scale;   /* dropout p as threshold / 1/(1-p); 0 = off */
+  uint32_t seed_hi, seed_ctr;                    /* dropout stream k of the layer uses (seed_hi, seed_ctr + 1 + k) */
+  const xfm_bf16* x;                             /* layer input [R,D] */
+  void* slab;                                    /* forward activations, xfm_rlayer_layout(...).fwd_bytes */
+  const xfm_bf16* kv; long kv_ld;                /* cross: this layer's K|V projection of the image states [U*Nenc, >= 2D] */
+  void* kv_event;                                /* hipEvent_t the main stream waits for before it reads kv (NULL: none) */
+} xfm_rlayer_io;
+
+typedef struct {        /* backward-only */
+  void* bslab;                                   /* gradient temporaries, xfm_rlayer_layout(...).bwd_bytes */
+  const xfm_bf16* dy_a; const xfm_bf16* dy_b;    /* gradient w.r.t. the layer output = dy_a + dy_b (dy_b may be NULL) */
+  const xfm_bf16* enc;                           /* image states [U*Nenc, D] (K/V weight gradient) */
+  xfm_bf16* dkv; long dkv_ld;                    /* out: dK|dV of this layer [U*Nenc, 2D] (possibly a column block) */
+  float* denc32;                                 /* optional fp32 [U*Nenc, D] += dkv @ Wkv (NULL: the caller folds dkv itself) */
+  int need_dprev;                                /* produce the gradient w.r.t. the layer input (dprev_a + dprev_b in bslab) */
+  void* side_stream;
+  float* ws_main; long ws_main_bytes; float* ws_side; long ws_side_bytes;
+} xfm_rlayer_bwd_args;
+
+typedef struct {        /* byte offsets inside slab / bslab (256-byte aligned) */
+  long qkv, c1, lse1, h, z1, m1, r1, y1, q2, c2, lse2, z2, m2, r2, y2, hact, u, z3, m3, r3, y3, fwd_bytes;
+  long dh3, dres3, du, d1a, dh2, dres2, dc2, dq2, delta2, d2a, dh1, dres1, dc1, dqkv, delta1, dprev, bwd_bytes;
+  long ws_main_bytes, ws_side_bytes;             /* workspace the backward wants on each stream */
+} xfm_rlayer_layout_t;
+
+int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int dropout, xfm_rlayer_layout_t* out);
+int xfm_rlayer_fwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, void* stream);
+int xfm_rlayer_bwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, const xfm_rlayer_bwd_args* b, void* stream);
 
 /* ---- Vocabulary cross-entropy, ignore_index -100 (xroberta.py:1296-1297, 1107-1114) ------------------------------ */
 int xfm_ce_fwd(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, void* stream);

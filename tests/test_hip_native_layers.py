@@ -1,0 +1,119 @@
+"""One C-ABI call per RobertaLayer (csrc/encoder.hip, xroberta._EncoderFnNative) against the kernel-by-kernel Python sequence
+(xroberta._EncoderFn): same kernels, same order, same dropout streams -> the forward is bit-identical and the gradients agree to
+the summation-order noise of the weight-gradient reductions.  Dropout ON (training mode): the two paths must consume the same
+counter-based streams."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from xfm_amd import synthetic as syn  # noqa: E402
+from xfm_amd import xroberta as XR  # noqa: E402
+from xfm_amd.packing import Pack, pack_rows  # noqa: E402
+
+BF16 = torch.bfloat16
+
+
+def _model(layers, fusion_layer):
+    torch.manual_seed(0)
+    return XR.RobertaForMaskedLM(XR.RobertaConfig(num_hidden_layers=layers, fusion_layer=fusion_layer, vocab_size=4096)).cuda().finalize()
+
+
+def _run(m, native, fn):
+    old = XR._NATIVE_LAYERS
+    XR._NATIVE_LAYERS = native
+    XR._seed_counter[0] = 1000          # both paths draw the same dropout streams
+    try:
+        m.zero_grad()
+        out = fn()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0}
+        return out, grads
+    finally:
+        XR._NATIVE_LAYERS = old
+
+
+def _cmp(ga, gb, tol=2e-5):
+    assert set(ga) == set(gb), set(ga) ^ set(gb)
+    for n in ga:
+        d = float((ga[n].float() - gb[n].float()).abs().max())
+        ref = float(gb[n].float().abs().max()) + 1e-12
+        assert d <= tol * ref + 1e-7, (n, d, ref)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_text_tower_padded_native_equals_kernel_by_kernel(train):
+    m = _model(3, 3).train(train)
+    B, T = 9, 30
+    b = syn.pretrain_batch(B, seed=41, vocab=4096)
+    ids, atts = b["text_ids"].cuda(), b["text_atts"].cuda()
+    w = torch.randn(B, T, 768, device="cuda")
+
+    def fn():
+        out = m.bert(ids, attention_mask=atts).last_hidden_state
+        (out.float() * w).sum().backward()
+        return out.detach().clone()
+
+    oa, ga = _run(m, False, fn)
+    ob, gb = _run(m, True, fn)
+    assert torch.equal(oa, ob)
+    _cmp(gb, ga)
+
+
+def test_text_tower_packed_with_grad_batch_native_equals_kernel_by_kernel():
+    m = _model(2, 2).train(True)
+    B, T = 10, 30
+    b = syn.pretrain_batch(B, seed=43, vocab=4096)
+    ids = b["text_ids"].cuda()
+    ln = b["text_atts"].sum(1)
+    p = Pack.from_lens(ln.tolist(), T, "cuda")
+    w = torch.randn(p.cap, 768, device="cuda")
+
+    def fn():
+        out = m.bert(ids, attention_mask=None, pack=p, grad_batch=6).last_hidden_state
+        (out.float() * w).sum().backward()
+        return out.detach().clone()
+
+    oa, ga = _run(m, False, fn)
+    ob, gb = _run(m, True, fn)
+    assert torch.equal(oa, ob)
+    _cmp(gb, ga)
+
+
+@pytest.mark.parametrize("slack", [False, True])
+def test_fusion_tower_packed_cross_attention_native_equals_kernel_by_kernel(slack):
+    m = _model(3, 0).train(True)
+    B, T, N = 8, 30, 197
+    b = syn.pretrain_batch(B, seed=47, vocab=4096)
+    ln = b["text_atts"].sum(1)
+    g = torch.Generator().manual_seed(9)
+    sel = torch.randint(0, B, (B,), generator=g)
+    lens2 = torch.cat([ln, ln[sel]])
+    if slack:
+        ld = ln.to(torch.int32).cuda()
+        p = Pack.concat([(ld, int(ln.sum()), ln.tolist()), (ld.index_select(0, sel.cuda()), B * int(ln.max()), None)], T)
+    else:
+        p = Pack.from_lens(lens2.tolist(), T, "cuda")
+    keep = (torch.arange(T)[None, :] < lens2[:, None]).cuda()
+    x = ((torch.randn(2 * B, T, 768, generator=g) * 0.7).cuda() * keep[..., None]).to(BF16)
+    xr = pack_rows(x, p).detach()
+    img = (torch.randn(B, N, 768, generator=g) * 0.7).to(BF16).cuda()
+    iatts = torch.ones(B, N, dtype=torch.long, device="cuda")
+    index = torch.cat([torch.arange(B), torch.randint(0, B, (B,), generator=g)]).to(torch.int32).cuda()
+    w = torch.randn(p.cap, 768, device="cuda") * (p.gather_index(p) >= 0)[:, None]
+
+    def fn():
+        xa = xr.clone().requires_grad_(True)
+        ia = img.clone().requires_grad_(True)
+        out = m.bert(encoder_embeds=xa, attention_mask=None, encoder_hidden_states=ia, encoder_attention_mask=iatts,
+                     encoder_batch_index=index, pack=p).last_hidden_state
+        (out.float() * w).sum().backward()
+        return out.detach().clone(), xa.grad.clone(), ia.grad.clone()
+
+    (oa, dxa, dia), ga = _run(m, False, fn)
+    (ob, dxb, dib), gb = _run(m, True, fn)
+    used = p.gather_index(p) >= 0
+    assert torch.equal(oa[used], ob[used])
+    assert torch.equal(dxa, dxb)
+    assert float((dia.float() - dib.float()).abs().max()) <= 2e-2 * float(dia.float().abs().max())
+    _cmp(gb, ga, tol=5e-5)

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # XFM_HIP_LIB: A/B a differently built library (kernel experiments); the default is the in-tree build.
 LIB_PATH = os.environ.get("XFM_HIP_LIB") or os.path.join(_HERE, "libxfm_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_void_p, c_int, c_long, c_float, c_u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint32
 
@@ -64,6 +64,38 @@ class EmbedArgs(ctypes.Structure):
                 ("row_map", c_void_p)]
 
 
+_P, _L, _I, _F, _U = c_void_p, c_long, c_int, c_float, c_u32
+
+
+class RLayerParams(ctypes.Structure):
+    _fields_ = ([(n, _P) for n in ("wqkv", "wqkv_t", "wo", "wo_t", "wq2", "wq2_t", "wkv2_t", "wo2", "wo2_t", "wi", "wi_t", "wout", "wout_t")]
+                + [(n, _L) for n in ("ld_wqkv_t", "ld_wo_t", "ld_wq2_t", "ld_wkv2_t", "ld_wo2_t", "ld_wi_t", "ld_wout_t")]
+                + [(n, _P) for n in ("bqkv", "bo", "bq2", "bo2", "bi", "bout", "ln1_w", "ln1_b", "ln2_w", "ln2_b", "ln3_w", "ln3_b",
+                                     "dwqkv", "dbqkv", "dwo", "dbo", "dwq2", "dbq2", "dwkv2", "dbkv2", "dwo2", "dbo2", "dwi", "dbi",
+                                     "dwout", "dbout", "dln1_w", "dln1_b", "dln2_w", "dln2_b", "dln3_w", "dln3_b")]
+                + [("D", _I), ("H", _I), ("FF", _I), ("has_cross", _I), ("eps", _F)])
+
+
+class RLayerIO(ctypes.Structure):
+    _fields_ = [("R", _I), ("B", _I), ("T", _I), ("R_alloc", _I), ("B_alloc", _I), ("Nenc", _I), ("U", _I),
+                ("seq_start", _P), ("seq_len", _P), ("key_keep", _P), ("enc_keep", _P), ("grp_start", _P), ("grp_rows", _P),
+                ("causal", _I), ("zero_fill", _I), ("scale", _F),
+                ("att_thresh", _U), ("att_scale", _F), ("hid_thresh", _U), ("hid_scale", _F), ("seed_hi", _U), ("seed_ctr", _U),
+                ("x", _P), ("slab", _P), ("kv", _P), ("kv_ld", _L), ("kv_event", _P)]
+
+
+class RLayerBwd(ctypes.Structure):
+    _fields_ = [("bslab", _P), ("dy_a", _P), ("dy_b", _P), ("enc", _P), ("dkv", _P), ("dkv_ld", _L), ("denc32", _P),
+                ("need_dprev", _I), ("side_stream", _P), ("ws_main", _P), ("ws_main_bytes", _L), ("ws_side", _P), ("ws_side_bytes", _L)]
+
+
+class RLayerLayout(ctypes.Structure):
+    _fields_ = [(n, _L) for n in ("qkv", "c1", "lse1", "h", "z1", "m1", "r1", "y1", "q2", "c2", "lse2", "z2", "m2", "r2", "y2", "hact", "u",
+                                  "z3", "m3", "r3", "y3", "fwd_bytes",
+                                  "dh3", "dres3", "du", "d1a", "dh2", "dres2", "dc2", "dq2", "delta2", "d2a", "dh1", "dres1", "dc1", "dqkv",
+                                  "delta1", "dprev", "bwd_bytes", "ws_main_bytes", "ws_side_bytes")]
+
+
 class AdamWArgs(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("group", c_void_p),
                 ("lr", c_float * 4), ("wd", c_float * 4),
@@ -109,6 +141,9 @@ SIGNATURES = {
     "xfm_ce_bwd": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p]),
     "xfm_adamw": (c_int, [ctypes.POINTER(AdamWArgs), c_void_p]),
     "xfm_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "xfm_rlayer_layout": (c_int, [c_int] * 10 + [ctypes.POINTER(RLayerLayout)]),
+    "xfm_rlayer_fwd": (c_int, [ctypes.POINTER(RLayerParams), ctypes.POINTER(RLayerIO), c_void_p]),
+    "xfm_rlayer_bwd": (c_int, [ctypes.POINTER(RLayerParams), ctypes.POINTER(RLayerIO), ctypes.POINTER(RLayerBwd), c_void_p]),
     "xfm_rows_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "xfm_rows_scatter_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }

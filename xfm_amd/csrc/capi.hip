@@ -27,6 +27,7 @@ int xfm_check_launch(const char* what) {
 #include "layernorm.hip"
 #include "attention.hip"
 #include "elementwise.hip"
+#include "encoder.hip"
 
 #define ST(s) ((hipStream_t)(s))
 #define NOTNULL(p, name) XFM_REQUIRE((p) != nullptr, "%s: null argument struct", name)
@@ -172,6 +173,18 @@ int xfm_rows_gather(const xfm_bf16* src, const int* index, int R, int D, xfm_bf1
 int xfm_rows_scatter_add(const xfm_bf16* src, const int* index, int R, int D, float* dst32, void* stream) {
   XFM_REQUIRE(src && index && dst32, "rows_scatter_add: null operand");
   return xfm_rows_scatter_add_impl(src, index, R, D, dst32, ST(stream));
+}
+
+int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int dropout, xfm_rlayer_layout_t* out) {
+  return xfm_rlayer_layout_impl(R, B, T, D, H, FF, has_cross, Nenc, U, dropout, out);
+}
+int xfm_rlayer_fwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, void* stream) {
+  XFM_REQUIRE(p != nullptr && io != nullptr, "rlayer_fwd: null argument struct");
+  return xfm_rlayer_fwd_impl(*p, *io, ST(stream));
+}
+int xfm_rlayer_bwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, const xfm_rlayer_bwd_args* b, void* stream) {
+  XFM_REQUIRE(p != nullptr && io != nullptr && b != nullptr, "rlayer_bwd: null argument struct");
+  return xfm_rlayer_bwd_impl(*p, *io, *b, ST(stream));
 }
 
 int xfm_ce_fwd(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, void* stream) {

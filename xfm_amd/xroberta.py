@@ -164,6 +164,7 @@ class RobertaLayer(nn.Module):
             s["kv2"] = LinearSlot(prefix + "kv2", [c.self.key.weight, c.self.value.weight], [c.self.key.bias, c.self.value.bias])
             s["o2"] = LinearSlot(prefix + "o2", [c.output.dense.weight], [c.output.dense.bias])
         self._s = s
+        self._rlp = None  # (cached native-call pointers belong to the previous arena)
         return list(s.values())
 
 
@@ -431,6 +432,246 @@ class _EncoderFn(torch.autograd.Function):
         return (dx, denc) + (None,) * 13
 
 
+
+_NATIVE_LAYERS = os.environ.get("XFM_NATIVE_LAYERS", "1") != "0"  # A/B knob: one C-ABI call per RobertaLayer (csrc/encoder.hip)
+
+
+def _rlayer_params(layer, cfg):
+    """The layer's static pointers for xfm_rlayer_fwd / _bwd (cached: operand copies and arena views are allocated once)."""
+    P = getattr(layer, "_rlp", None)
+    if P is not None:
+        return P
+    from ._lib import RLayerParams
+    s = layer._s
+    for slot in s.values():
+        slot._alloc()
+    P = RLayerParams()
+
+    def put(name, slot, fwd=True):
+        if fwd:
+            setattr(P, "w" + name, slot._wb.data_ptr())
+            setattr(P, "b" + name, slot.b.data_ptr())
+        setattr(P, "w" + name + "_t", slot._wt.data_ptr())
+        setattr(P, "ld_w" + name + "_t", slot._wt.stride(0))
+        setattr(P, "dw" + name, slot._dw.data_ptr())
+        setattr(P, "db" + name, slot._db.data_ptr())
+
+    put("qkv", s["qkv"]); put("o", s["o"]); put("i", s["i"]); put("out", s["out"])
+    lns = [layer.attention.output.LayerNorm, None, layer.output.LayerNorm]
+    if layer.has_cross_attention:
+        put("q2", s["q2"]); put("kv2", s["kv2"], fwd=False); put("o2", s["o2"])
+        lns[1] = layer.crossattention.output.LayerNorm
+    for k, ln in enumerate(lns):
+        if ln is not None:
+            setattr(P, f"ln{k + 1}_w", ln.weight.data_ptr()); setattr(P, f"ln{k + 1}_b", ln.bias.data_ptr())
+            setattr(P, f"dln{k + 1}_w", ln.weight._xfm_grad.data_ptr()); setattr(P, f"dln{k + 1}_b", ln.bias._xfm_grad.data_ptr())
+    P.D, P.H, P.FF, P.has_cross, P.eps = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size, int(layer.has_cross_attention), \
+        layer.output.LayerNorm.eps
+    layer._rlp = P
+    arena = s["qkv"]._arena
+    own = [p for k in ("qkv", "o", "i", "out") for plist in (s[k].weights, s[k].biases) for p in plist if not isinstance(p, int)]
+    own += [lns[0].weight, lns[0].bias, lns[2].weight, lns[2].bias]
+    cross = []
+    if layer.has_cross_attention:
+        cross = [p for k in ("q2", "kv2", "o2") for plist in (s[k].weights, s[k].biases) for p in plist if not isinstance(p, int)]
+        cross += [lns[1].weight, lns[1].bias]
+    layer._rl_params = (own, cross)
+    layer._rl_units = (sorted({arena._unit_of[id(p)] for p in own}), sorted({arena._unit_of[id(p)] for p in cross}))
+    return P
+
+
+def _rl_touch(layer, arena, cross):
+    """Mark the layer's parameters live (their gradients are written by the native backward) -- a unit-flag check per layer once
+    they all are."""
+    live = arena.live
+    for units, params in zip(layer._rl_units[:2 if cross else 1], layer._rl_params):
+        for u in units:
+            if not live[u]:
+                arena.touch_all(params)
+                break
+
+
+def _view(slab, off, rows, cols, dtype=BF16):
+    n = rows * cols * (2 if dtype == BF16 else 4)
+    return slab[off:off + n].view(dtype).view(rows, cols)
+
+
+class _EncoderFnNative(torch.autograd.Function):
+    """Layers [lo, hi) of a RobertaEncoder with ONE C-ABI call per layer and direction (csrc/encoder.hip sequences the kernels of
+    the layer on the native side).  Same kernels, same order, same dropout streams as _EncoderFn -- results are bit-identical --
+    but the host spends ~15 us per layer instead of ~200 us of per-kernel wrapper work, so a tower of 10-30 us kernels stops
+    being bound by the Python interpreter.  Cross-attention goes through the grouped kernels (encoder_batch_index required)."""
+
+    @staticmethod
+    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index, grad_batch=None, pack=None):
+        from . import _lib
+        from ._lib import RLayerIO, RLayerLayout, check
+        import ctypes
+        lib = _lib.load()
+        cfg = model.config
+        D, H, FF = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size
+        p_att = cfg.attention_probs_dropout_prob if training else 0.0
+        p_hid = cfg.hidden_dropout_prob if training else 0.0
+        need_dx, need_denc = x.requires_grad, (enc is not None and enc.requires_grad)
+        x = x.contiguous()
+        R = x.shape[0]
+        if pack is not None and (key_keep is not None or causal):
+            raise ValueError("packed rows take neither a key mask (lengths say it all) nor the causal mask")
+        if grad_batch is not None and (enc is not None or not 0 < grad_batch <= B):
+            raise ValueError("grad_batch is for self-attention-only passes: 0 < grad_batch <= batch")
+        groups, U = None, 0
+        if enc is not None:
+            enc = enc.contiguous()
+            U = enc.shape[0] // Nenc
+            groups = Fx.kv_groups(enc_index, U)
+        layers = [model.encoder.layer[li] for li in range(lo, hi)]
+        arena = layers[0]._s["qkv"]._arena
+        ver = arena._manual_ver
+        for layer in layers:           # bf16 operand copies up to date (one batched cast launch when the arena version moved)
+            for slot in layer._s.values():
+                if slot._ver != ver:
+                    slot.wb
+        if arena._batch_event is not None:
+            arena._batch_wait()
+        d_att, d_hid = Fx.drop_params(p_att, 1), Fx.drop_params(p_hid, 1)
+        io = RLayerIO()
+        io.R, io.B, io.T, io.Nenc, io.U = R, B, T, Nenc if enc is not None else 0, U
+        if pack is not None:
+            io.seq_start, io.seq_len = pack.start.data_ptr(), pack.lens.data_ptr()
+            io.zero_fill = int(not pack.exact)
+        io.key_keep, io.enc_keep = Fx._ptr(key_keep), Fx._ptr(enc_keep)
+        if groups is not None:
+            io.grp_start, io.grp_rows = groups[0].data_ptr(), groups[1].data_ptr()
+        io.causal, io.scale = int(causal), 1.0 / math.sqrt(D // H)
+        io.att_thresh, io.att_scale, io.hid_thresh, io.hid_scale = d_att[0], d_att[1], d_hid[0], d_hid[1]
+        io.seed_hi = torch.initial_seed() & 0xFFFFFFFF
+        layouts = {}
+
+        def layout(cross):
+            if cross not in layouts:
+                L = RLayerLayout()
+                check(lib.xfm_rlayer_layout(R, B, T, D, H, FF, int(cross), io.Nenc, U, int(p_hid > 0), ctypes.byref(L)), "rlayer_layout")
+                layouts[cross] = L
+            return layouts[cross]
+
+        kv_ready = {}
+        pre = _WgradStream(x.device)
+        if enc is not None:
+            for layer in layers:
+                if layer.has_cross_attention:
+                    kv_ready[id(layer)] = pre.project(enc, layer._s["kv2"])
+        st = Fx._stream()
+        saved = []
+        for layer in layers:
+            cross = layer.has_cross_attention and enc is not None
+            L = layout(cross)
+            slab = torch.empty(L.fwd_bytes, dtype=torch.uint8, device=x.device)
+            ctr = _seed_counter[0]
+            _seed_counter[0] += 5 if cross else 3
+            io.x, io.slab, io.seed_ctr = x.data_ptr(), slab.data_ptr(), ctr & 0xFFFFFFFF
+            kv = None
+            if cross:
+                kv, ev = kv_ready.pop(id(layer))
+                io.kv, io.kv_ld, io.kv_event = kv.data_ptr(), kv.stride(0), (ev.cuda_event if ev is not None else 0)
+            else:
+                io.kv, io.kv_event = 0, 0
+            check(lib.xfm_rlayer_fwd(ctypes.byref(_rlayer_params(layer, cfg)), ctypes.byref(io), st), "rlayer_fwd")
+            saved.append((slab, x, kv, ctr, cross))
+            x = _view(slab, L.y3, R, D)
+        ctx.saved, ctx.model, ctx.enc, ctx.io, ctx.layouts, ctx.pack = saved, model, enc, io, layouts, pack
+        ctx.meta = (lo, hi, B, T, Nenc, U, key_keep, need_dx, need_denc, groups, grad_batch, p_hid > 0)
+        ctx.noted = need_dx or need_denc
+        if ctx.noted:
+            arena_note_use(model)
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        from ._lib import RLayerBwd, check
+        import ctypes
+        lib = _lib.load()
+        model, enc, io, pack = ctx.model, ctx.enc, ctx.io, ctx.pack
+        lo, hi, B, T, Nenc, U, key_keep, need_dx, need_denc, groups, grad_batch, dropout = ctx.meta
+        cfg = model.config
+        D = cfg.hidden_size
+        layers = [model.encoder.layer[li] for li in range(lo, hi)]
+        arena = layers[0]._s["qkv"]._arena
+        dy_a, dy_b = dy.contiguous(), None
+        if dy_a.dtype != BF16:
+            dy_a = dy_a.to(BF16)
+        rows_full, R = dy_a.shape[0], dy_a.shape[0]
+        if grad_batch is not None and grad_batch < B:
+            # only the first `grad_batch` sequences carry gradient: the backward walks the row prefix of the saved activations
+            R = grad_batch * T if pack is None else pack.rows_of_head(grad_batch)
+            io.R_alloc, io.B_alloc, io.R, io.B = rows_full, B, R, grad_batch
+            dy_a = dy_a[:R]
+            if pack is not None:
+                io.zero_fill = int(not pack.head(grad_batch).exact)
+        wg = _WgradStream(dy.device)
+        cross_layers = [layer for layer in layers if layer.has_cross_attention] if enc is not None else []
+        concat_k = need_denc and len(cross_layers) > 1
+        dkv_all = torch.empty((enc.shape[0], len(cross_layers) * 2 * D), dtype=BF16, device=dy.device) if concat_k else None
+        denc32 = torch.zeros((enc.shape[0], D), dtype=F32, device=dy.device) if (need_denc and not concat_k) else None
+        Lmax = max(ctx.layouts.values(), key=lambda L: L.ws_side_bytes)
+        bw = RLayerBwd()
+        ws_main = Fx.workspace(max(L.ws_main_bytes for L in ctx.layouts.values()), dy.device)
+        bw.ws_main, bw.ws_main_bytes = ws_main.data_ptr(), ws_main.numel() * 4
+        if wg.on:
+            with torch.cuda.stream(wg.side):
+                ws_side = Fx.workspace(Lmax.ws_side_bytes, dy.device)
+            bw.side_stream = wg.side.cuda_stream
+        else:
+            # (single stream: the per-stream workspace is already ws_main -- take a buffer of its own)
+            ws_side = torch.empty(max(Lmax.ws_side_bytes // 4 + 1, 1), dtype=F32, device=dy.device)
+        bw.ws_side, bw.ws_side_bytes = ws_side.data_ptr(), ws_side.numel() * 4
+        if enc is not None:
+            bw.enc = enc.data_ptr()
+        bw.denc32 = Fx._ptr(denc32)
+        st = Fx._stream()
+        keep = [ws_main, ws_side]
+        for k in reversed(range(len(layers))):
+            layer = layers[k]
+            slab, x_in, kv, ctr, cross = ctx.saved[k]
+            L = ctx.layouts[cross]
+            bslab = torch.empty(L.bwd_bytes, dtype=torch.uint8, device=dy.device)
+            keep.append((bslab, slab, x_in, kv, dy_a, dy_b))
+            io.x, io.slab, io.seed_ctr = x_in.data_ptr(), slab.data_ptr(), ctr & 0xFFFFFFFF
+            if cross:
+                io.kv, io.kv_ld, io.kv_event = kv.data_ptr(), kv.stride(0), 0
+                if concat_k:
+                    j = cross_layers.index(layer)
+                    bw.dkv, bw.dkv_ld = dkv_all.data_ptr() + j * 2 * D * 2, dkv_all.stride(0)
+                else:
+                    dkv = torch.empty((enc.shape[0], 2 * D), dtype=BF16, device=dy.device)
+                    keep.append(dkv)
+                    bw.dkv, bw.dkv_ld = dkv.data_ptr(), dkv.stride(0)
+            else:
+                io.kv = 0
+            bw.bslab, bw.dy_a, bw.dy_b = bslab.data_ptr(), dy_a.data_ptr(), Fx._ptr(dy_b)
+            bw.need_dprev = int(k > 0 or need_dx)
+            _rl_touch(layer, arena, cross)
+            check(lib.xfm_rlayer_bwd(ctypes.byref(_rlayer_params(layer, cfg)), ctypes.byref(io), ctypes.byref(bw), st), "rlayer_bwd")
+            dy_a, dy_b = _view(bslab, L.dprev, R, D), _view(bslab, L.dres1, R, D)
+            ctx.saved[k] = None
+        dx = (dy_a.float() + dy_b.float()).to(BF16) if need_dx else None
+        if dx is not None and R < rows_full:
+            dx = torch.cat([dx, torch.zeros((rows_full - R, D), dtype=dx.dtype, device=dx.device)], dim=0)
+        denc = None
+        if concat_k:
+            wt_cat = torch.cat([layer._s["kv2"].wt[:, :2 * D] for layer in cross_layers], dim=1)
+            wg.join()
+            denc = Fx.gemm_nt(dkv_all, wt_cat)
+        elif need_denc:
+            wg.join()
+            denc = denc32.to(BF16)
+        wg.join()
+        del keep
+        if ctx.noted:
+            arena_note_grad(model)
+        return (dx, denc) + (None,) * 13
+
+
 class RobertaModel(nn.Module):
     embeddings_class = RobertaEmbeddings
 
@@ -512,8 +753,11 @@ class RobertaModel(nn.Module):
             raise ValueError(f"mode {mode} is not supported")
         y = x.reshape(B * T, -1) if pack is None else x
         if hi > lo:
-            y = _EncoderFn.apply(y, enc, self, key_keep, enc_keep, lo, hi, bool(is_decoder), B, T, Nenc, self.training,
-                                 encoder_batch_index if enc is not None else None, grad_batch, pack)
+            # one native call per layer whenever cross-attention (if any) can take the grouped kernels; else kernel by kernel
+            native = _NATIVE_LAYERS and y.is_cuda and (enc is None or (encoder_batch_index is not None and Fx.attn_grouped_ok(T, Nenc)))
+            fn = _EncoderFnNative if native else _EncoderFn
+            y = fn.apply(y, enc, self, key_keep, enc_keep, lo, hi, bool(is_decoder), B, T, Nenc, self.training,
+                         encoder_batch_index if enc is not None else None, grad_batch, pack)
         return SimpleNamespace(last_hidden_state=y.view(B, T, -1) if pack is None else y, pooler_output=None, past_key_values=None,
                                hidden_states=None, attentions=None, cross_attentions=None)
 
