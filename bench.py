@@ -212,14 +212,19 @@ def fusion_probe(model, B, host_batch, packed, iters=5):
         from xfm_amd.xfm import _PACK_SYNC
         ld = lens_h.to(dev).to(torch.int32)
         n_rows, t_max = int(lens_h.sum()), int(lens_h.max())
-        if _PACK_SYNC:  # the step's default layout: every block exact (the drawn negatives are read back once per step)
-            pack = Pack.from_lens(lens4.tolist(), T, dev)
+        ranges = None
+        if _PACK_SYNC:  # the step's default layout: every sequence exact (the drawn negatives are read back once per step),
+            # sequences image by image so that each image's queries are contiguous rows (xfm.XFMBase._matching_and_fuse_mlm_packed)
+            from xfm_amd.packing import image_major_layout
+            seq_img = index.tolist()
+            pack, _, _, meta, ranges = image_major_layout(lens4.tolist(), seq_img, B, T, dev, extra=(seq_img,))
+            index = meta[1].contiguous()
         else:           # no host sync: worst-case room for the negative-text block, offsets computed on the device
             pack = Pack.concat([(ld, n_rows, lens_h.tolist()), (ld, n_rows, lens_h.tolist()), (ld[perm.to(dev)], B * t_max, None),
                                 (ld, n_rows, lens_h.tolist())], T)
         valid = (pack.gather_index(pack) >= 0).unsqueeze(1)           # slack rows of the negative-text block stay zero
         text = ((torch.randn(pack.cap, 768, generator=g) * 0.7).to(dev, torch.bfloat16) * valid).requires_grad_(True)
-        kw = dict(encoder_embeds=text, attention_mask=None, pack=pack)
+        kw = dict(encoder_embeds=text, attention_mask=None, pack=pack, encoder_row_ranges=ranges)
         rows = pack.cap
     else:
         text = (torch.randn(4 * B, T, 768, generator=g) * 0.7).to(dev, torch.bfloat16).requires_grad_(True)
@@ -234,8 +239,11 @@ def fusion_probe(model, B, host_batch, packed, iters=5):
 
     for _ in range(2):
         once()
+    import xfm_amd.xroberta as xr
+    native, xr._NATIVE_LAYERS = xr._NATIVE_LAYERS, False   # count kernel by kernel (the native per-layer call launches the same ones)
     with FlopCounter() as fc:
         once()
+    xr._NATIVE_LAYERS = native
     executed = fc.flop
     best = None
     for _ in range(3):  # best of three batches of `iters` back-to-back passes (the stand-alone probe follows other work on the GPU)

@@ -246,7 +246,11 @@ typedef struct {        /* geometry + per-call inputs shared by forward and back
   const int* seq_start; const int* seq_len;      /* packed rows (xfm_attn_args.q_start / q_len) or NULL */
   const int* key_keep;                           /* [B,T] or NULL */
   const int* enc_keep;                           /* [U,Nenc] or NULL */
-  const int* grp_start; const int* grp_rows;     /* grouped cross-attention (required with cross-attention input) */
+  const int* grp_start; const int* grp_rows;     /* grouped cross-attention: rows of each image listed sequence by sequence, or ... */
+  const int* xq_start; const int* xq_len; int xq_max;  /* ... RANGE mode: the sequences are laid out image by image, so the queries of
+                                                    image u are the contiguous rows xq_start[u] .. + xq_len[u] (<= xq_max): cross-attention
+                                                    runs as one ragged problem per image on full 16-row tiles (no per-sequence tiles
+                                                    that are mostly padding), dK/dV come out per image */
   int causal, zero_fill;                         /* zero_fill: attention outputs / gradients of rows outside every sequence */
   float scale;
   uint32_t att_thresh; float att_scale; uint32_t hid_thresh; float hid_scale;   /* dropout p as threshold / 1/(1-p); 0 = off */
@@ -274,7 +278,8 @@ typedef struct {        /* byte offsets inside slab / bslab (256-byte aligned) *
   long ws_main_bytes, ws_side_bytes;             /* workspace the backward wants on each stream */
 } xfm_rlayer_layout_t;
 
-int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int dropout, xfm_rlayer_layout_t* out);
+int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int xq_max, int dropout,
+                      xfm_rlayer_layout_t* out);
 int xfm_rlayer_fwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, void* stream);
 int xfm_rlayer_bwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, const xfm_rlayer_bwd_args* b, void* stream);
 

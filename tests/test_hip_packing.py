@@ -138,6 +138,8 @@ def _roberta(layers, fusion_layer):
     return RobertaForMaskedLM(RobertaConfig(num_hidden_layers=layers, fusion_layer=fusion_layer, vocab_size=4096))
 
 
+# key-bias gradients are analytically zero (softmax is invariant to a per-query constant): what the tensors hold is bf16
+# rounding noise of the dK rows, different on every path -- they are left out of the relative comparisons below
 def _grads(m):
     return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0}
 
@@ -163,7 +165,7 @@ def test_text_tower_packed_equals_padded_forward_and_backward():
     (got.float() * w).sum().backward()
     g_pack = _grads(m)
     assert set(g_pack) == set(g_pad)
-    worst = max((_rel(g_pack[n], g_pad[n]), n) for n in g_pad if float(g_pad[n].float().norm()) > 1e-6)
+    worst = max((_rel(g_pack[n], g_pad[n]), n) for n in g_pad if float(g_pad[n].float().norm()) > 1e-6 and "key.bias" not in n)
     print("text tower, packed vs padded: worst gradient rel-L2", worst)
     assert worst[0] <= 1e-2, worst
     # grad_batch on packed rows: only the first sequences back-propagate
@@ -176,7 +178,7 @@ def test_text_tower_packed_equals_padded_forward_and_backward():
     rows4 = m.bert(ids[:4], attention_mask=None, pack=p4).last_hidden_state
     (unpack(rows4, p4).float() * w[:4]).sum().backward()
     g4 = _grads(m)
-    worst = max((_rel(g_head[n], g4[n]), n) for n in g4 if float(g4[n].float().norm()) > 1e-6)
+    worst = max((_rel(g_head[n], g4[n]), n) for n in g4 if float(g4[n].float().norm()) > 1e-6 and "key.bias" not in n)
     assert worst[0] <= 1e-2, worst
 
 
@@ -215,13 +217,61 @@ def test_fusion_tower_packed_with_slack_block_equals_padded():
     (got.float() * w).sum().backward()
     g_pack = _grads(m)
     assert set(g_pack) == set(g_pad)
-    worst = max((_rel(g_pack[n], g_pad[n]), n) for n in g_pad if float(g_pad[n].float().norm()) > 1e-6)
+    worst = max((_rel(g_pack[n], g_pad[n]), n) for n in g_pad if float(g_pad[n].float().norm()) > 1e-6 and "key.bias" not in n)
     print("fusion tower, packed vs padded: worst gradient rel-L2", worst)
     assert worst[0] <= 1e-2, worst
     assert _rel(img.grad, dimg_pad) <= 1e-2
     assert _rel(unpack(xr.grad, p)[keep], dx_pad[keep]) <= 1e-2
     used = p.gather_index(p) >= 0
     assert float(xr.grad[~used].float().abs().max()) == 0.0, "slack rows must carry exactly zero gradient"
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_fusion_tower_image_major_layout_with_row_ranges_equals_padded(native):
+    """Sequences laid out image by image + cross-attention per image on contiguous query rows (encoder_row_ranges) against the padded
+    tower in the caller's sequence order; both the per-layer native executor and the kernel-by-kernel path."""
+    import xfm_amd.xroberta as XR
+    from xfm_amd.packing import image_major_layout
+    torch.manual_seed(0)
+    m = _roberta(2, 0).cuda().finalize().eval()
+    B, U, T, N = 13, 5, 30, 197
+    ln = _lens(B, T, 6)
+    g = torch.Generator().manual_seed(11)
+    seq_img = torch.randint(0, U, (B,), generator=g)
+    seq_img[0], seq_img[1] = U - 1, U - 1
+    seq_img[seq_img == 2] = 3                       # image 2 has no sequence at all
+    keep = (torch.arange(T)[None, :] < ln[:, None]).cuda()
+    x = ((torch.randn(B, T, 768, generator=g) * 0.7).cuda() * keep[..., None]).to(BF16)
+    img = (torch.randn(U, N, 768, generator=g) * 0.7).to(BF16).cuda()
+    iatts = torch.ones(U, N, dtype=torch.long, device="cuda")
+    w = torch.randn(B, T, 768, device="cuda") * keep[..., None]
+    xa, ia = x.clone().requires_grad_(True), img.clone().requires_grad_(True)
+    out = m.bert(encoder_embeds=xa, attention_mask=keep.long(), encoder_hidden_states=ia, encoder_attention_mask=iatts,
+                 encoder_batch_index=seq_img.to(torch.int32).cuda()).last_hidden_state
+    (out.float() * w).sum().backward()
+    g_pad, dimg_pad, dx_pad = _grads(m), ia.grad.clone(), xa.grad.clone()
+    m.zero_grad()
+    pack, order, pos_of, meta, ranges = image_major_layout(ln.tolist(), seq_img.tolist(), U, T, "cuda", extra=(seq_img.tolist(),))
+    assert int(ranges[1][2]) == 0 and ranges[2] == int(ranges[1].max())
+    xs = pack_rows(x[torch.tensor(order)], pack).detach().requires_grad_(True)
+    ib = img.clone().requires_grad_(True)
+    old = XR._NATIVE_LAYERS
+    XR._NATIVE_LAYERS = native
+    try:
+        rows = m.bert(encoder_embeds=xs, attention_mask=None, encoder_hidden_states=ib, encoder_attention_mask=iatts,
+                      encoder_batch_index=meta[1].contiguous(), pack=pack, encoder_row_ranges=ranges).last_hidden_state
+        got = unpack(rows, pack)[torch.tensor(pos_of)]            # back to the caller's sequence order
+        assert _rel(got[keep], out[keep]) <= 2e-3, _rel(got[keep], out[keep])
+        (got.float() * w).sum().backward()
+    finally:
+        XR._NATIVE_LAYERS = old
+    g_pack = _grads(m)
+    assert set(g_pack) == set(g_pad)
+    worst = max((_rel(g_pack[n], g_pad[n]), n) for n in g_pad if float(g_pad[n].float().norm()) > 1e-6 and "key.bias" not in n)
+    print("fusion tower, image-major ranges vs padded: worst gradient rel-L2", worst)
+    assert worst[0] <= 1e-2, worst
+    assert _rel(ib.grad, dimg_pad) <= 1e-2
+    assert _rel(unpack(xs.grad, pack)[torch.tensor(pos_of)][keep], dx_pad[keep]) <= 1e-2
 
 
 def test_pretrain_step_packed_rows_equals_padded_step():
@@ -254,6 +304,7 @@ def test_pretrain_step_packed_rows_equals_padded_step():
     for k in l_pad:
         assert abs(l_pad[k] - l_pack[k]) <= 2e-3 * max(abs(l_pad[k]), 1.0), (k, l_pad, l_pack)
     assert set(g_pad) == set(g_pack)
+    # (key biases: analytically zero gradients -- softmax ignores a per-query constant -- hold rounding noise only)
     bad = [(n, round(_rel(g_pack[n], g_pad[n]), 4)) for n in g_pad
-           if float(g_pad[n].float().norm()) > 1e-5 and _rel(g_pack[n], g_pad[n]) > 2e-2]
+           if float(g_pad[n].float().norm()) > 1e-5 and "key.bias" not in n and _rel(g_pack[n], g_pad[n]) > 2e-2]
     assert not bad, bad[:10]

@@ -22,20 +22,25 @@ iatts = _ones_mask(img)
 ar = torch.arange(B, device=dev)
 index = torch.cat([ar, torch.randperm(B, generator=g).to(dev), ar, ar]).to(torch.int32)
 lh = lens_h.tolist()
-pack = Pack.from_lens(lh + lh + [lh[int(j)] for j in perm] + lh, T, dev)
+from xfm_amd.packing import image_major_layout
+seq_img = index.tolist()
+pack, _, _, meta, ranges = image_major_layout(lh + lh + [lh[int(j)] for j in perm] + lh, seq_img, B, T, dev, extra=(seq_img,))
+index = meta[1].contiguous()
+if os.environ.get("NO_RANGES"):
+    ranges = None
 text = (torch.randn(pack.cap, 768, generator=g) * 0.7).to(dev, torch.bfloat16).requires_grad_(True)
 
 
 def once():
     seq = model.fusion_encoder.bert(encoder_hidden_states=img, encoder_attention_mask=iatts, return_dict=True, encoder_batch_index=index,
-                                    encoder_embeds=text, attention_mask=None, pack=pack).last_hidden_state
+                                    encoder_embeds=text, attention_mask=None, pack=pack, encoder_row_ranges=ranges).last_hidden_state
     seq.float().square().mean().backward()
 
 
 for _ in range(3):
     once()
 torch.cuda.synchronize()
-for iters in (1, 4, 8):
+for iters in (1, 4, 8, 64):
     t0 = time.perf_counter()
     for _ in range(iters):
         once()

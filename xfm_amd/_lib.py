@@ -79,6 +79,7 @@ class RLayerParams(ctypes.Structure):
 class RLayerIO(ctypes.Structure):
     _fields_ = [("R", _I), ("B", _I), ("T", _I), ("R_alloc", _I), ("B_alloc", _I), ("Nenc", _I), ("U", _I),
                 ("seq_start", _P), ("seq_len", _P), ("key_keep", _P), ("enc_keep", _P), ("grp_start", _P), ("grp_rows", _P),
+                ("xq_start", _P), ("xq_len", _P), ("xq_max", _I),
                 ("causal", _I), ("zero_fill", _I), ("scale", _F),
                 ("att_thresh", _U), ("att_scale", _F), ("hid_thresh", _U), ("hid_scale", _F), ("seed_hi", _U), ("seed_ctr", _U),
                 ("x", _P), ("slab", _P), ("kv", _P), ("kv_ld", _L), ("kv_event", _P)]
@@ -141,7 +142,7 @@ SIGNATURES = {
     "xfm_ce_bwd": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p]),
     "xfm_adamw": (c_int, [ctypes.POINTER(AdamWArgs), c_void_p]),
     "xfm_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
-    "xfm_rlayer_layout": (c_int, [c_int] * 10 + [ctypes.POINTER(RLayerLayout)]),
+    "xfm_rlayer_layout": (c_int, [c_int] * 11 + [ctypes.POINTER(RLayerLayout)]),
     "xfm_rlayer_fwd": (c_int, [ctypes.POINTER(RLayerParams), ctypes.POINTER(RLayerIO), c_void_p]),
     "xfm_rlayer_bwd": (c_int, [ctypes.POINTER(RLayerParams), ctypes.POINTER(RLayerIO), ctypes.POINTER(RLayerBwd), c_void_p]),
     "xfm_rows_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -175,8 +175,9 @@ int xfm_rows_scatter_add(const xfm_bf16* src, const int* index, int R, int D, fl
   return xfm_rows_scatter_add_impl(src, index, R, D, dst32, ST(stream));
 }
 
-int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int dropout, xfm_rlayer_layout_t* out) {
-  return xfm_rlayer_layout_impl(R, B, T, D, H, FF, has_cross, Nenc, U, dropout, out);
+int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int xq_max, int dropout,
+                      xfm_rlayer_layout_t* out) {
+  return xfm_rlayer_layout_impl(R, B, T, D, H, FF, has_cross, Nenc, U, xq_max, dropout, out);
 }
 int xfm_rlayer_fwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, void* stream) {
   XFM_REQUIRE(p != nullptr && io != nullptr, "rlayer_fwd: null argument struct");

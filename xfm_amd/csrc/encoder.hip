@@ -21,16 +21,18 @@ typedef xfm_rlayer_layout_t RLL;
 
 static long al256(long x) { return (x + 255) & ~255L; }
 
-int xfm_rlayer_layout_impl(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int dropout, RLL* o) {
+int xfm_rlayer_layout_impl(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int xq_max, int dropout, RLL* o) {
   XFM_REQUIRE(R > 0 && B > 0 && T > 0 && D > 0 && H > 0 && FF > 0 && o != nullptr, "rlayer_layout: bad geometry");
   const long statld = (T + 3) / 4 * 4;
   const long rd = (long)R * D * 2, stat = (long)B * H * statld * 4, rvec = (long)R * 4;
+  // cross-attention row statistics: per sequence, or per image in range mode
+  const long xstat = xq_max > 0 ? (long)U * H * ((xq_max + 3) / 4 * 4) * 4 : stat;
   long off = 0;
   auto take = [&](long bytes) { const long r = off; off += al256(bytes); return r; };
   o->qkv = take(3 * rd); o->c1 = take(rd); o->lse1 = take(stat); o->h = take(rd);
   o->z1 = take(rd); o->m1 = take(rvec); o->r1 = take(rvec); o->y1 = take(rd);
   if (has_cross) {
-    o->q2 = take(rd); o->c2 = take(rd); o->lse2 = take(stat);
+    o->q2 = take(rd); o->c2 = take(rd); o->lse2 = take(xstat);
     o->z2 = take(rd); o->m2 = take(rvec); o->r2 = take(rvec); o->y2 = take(rd);
   } else {
     o->q2 = o->c2 = o->lse2 = o->z2 = o->m2 = o->r2 = o->y2 = -1;
@@ -43,7 +45,7 @@ int xfm_rlayer_layout_impl(int R, int B, int T, int D, int H, int FF, int has_cr
   o->du = take((long)R * FF * 2); o->d1a = take(rd);
   if (has_cross) {
     o->dh2 = take(rd); o->dres2 = dropout ? take(rd) : o->dh2;
-    o->dc2 = take(rd); o->dq2 = take(rd); o->delta2 = take(stat); o->d2a = take(rd);
+    o->dc2 = take(rd); o->dq2 = take(rd); o->delta2 = take(xstat); o->d2a = take(rd);
   } else {
     o->dh2 = o->dres2 = o->dc2 = o->dq2 = o->delta2 = o->d2a = -1;
   }
@@ -103,6 +105,12 @@ static AttnArgs rl_cross_attn(const RLP& p, const RLIO& io, const RLL& L, char* 
   a.B = io.B; a.H = p.H; a.Sq = io.T; a.Sk = io.Nenc;
   a.scale = io.scale; a.causal = 0;
   rl_drop(io.att_thresh, io.att_scale, io.seed_hi, io.seed_ctr + 3, a.drop_thresh, a.drop_scale, a.seed_lo, a.seed_hi);
+  if (io.xq_start != nullptr) {  // range mode: one ragged problem per image (B = images, queries = the image's contiguous rows)
+    a.B = io.U; a.Sq = io.xq_max;
+    a.stat_ld = (io.xq_max + 3) / 4 * 4;
+    a.q_start = io.xq_start; a.q_len = io.xq_len;
+    return a;
+  }
   a.stat_ld = (io.T + 3) / 4 * 4;
   a.grp_start = io.grp_start; a.grp_rows = io.grp_rows; a.n_groups = io.U;
   a.q_start = io.seq_start; a.q_len = io.seq_len;
@@ -127,7 +135,8 @@ static int rl_check(const RLP& p, const RLIO& io) {
   XFM_REQUIRE(io.R > 0 && io.B > 0 && io.T > 0 && io.x != nullptr && io.slab != nullptr, "rlayer: bad geometry / null buffers");
   XFM_REQUIRE(p.D == p.H * 64, "rlayer: head_dim must be 64");
   XFM_REQUIRE((io.seq_start == nullptr) == (io.seq_len == nullptr), "rlayer: packed rows need both start and len");
-  XFM_REQUIRE(!rl_cross(p, io) || (io.grp_start != nullptr && io.grp_rows != nullptr), "rlayer: cross-attention needs the grouped row lists");
+  XFM_REQUIRE(!rl_cross(p, io) || (io.grp_start != nullptr && io.grp_rows != nullptr) || (io.xq_start != nullptr && io.xq_len != nullptr && io.xq_max > 0),
+              "rlayer: cross-attention needs the grouped row lists or the per-image row ranges");
   return XFM_OK;
 }
 
@@ -136,7 +145,7 @@ int xfm_rlayer_fwd_impl(const RLP& p, const RLIO& io, hipStream_t st) {
   const bool cross = rl_cross(p, io);
   RLL L;
   RL_TRY(xfm_rlayer_layout_impl(io.R_alloc > 0 ? io.R_alloc : io.R, io.B_alloc > 0 ? io.B_alloc : io.B, io.T, p.D, p.H, p.FF, p.has_cross,
-                                io.Nenc, io.U, io.hid_thresh != 0u, &L));
+                                io.Nenc, io.U, io.xq_start != nullptr ? io.xq_max : 0, io.hid_thresh != 0u, &L));
   char* s = reinterpret_cast<char*>(io.slab);
   const int R = io.R, D = p.D, FF = p.FF;
   const bool zf = io.zero_fill && io.seq_start != nullptr;
@@ -202,7 +211,7 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
   XFM_REQUIRE(!cross || (b.enc != nullptr && b.dkv != nullptr), "rlayer_bwd: cross-attention needs enc and dkv");
   RLL L;
   RL_TRY(xfm_rlayer_layout_impl(io.R_alloc > 0 ? io.R_alloc : io.R, io.B_alloc > 0 ? io.B_alloc : io.B, io.T, p.D, p.H, p.FF, p.has_cross,
-                                io.Nenc, io.U, io.hid_thresh != 0u, &L));
+                                io.Nenc, io.U, io.xq_start != nullptr ? io.xq_max : 0, io.hid_thresh != 0u, &L));
   XFM_REQUIRE(b.ws_main_bytes >= L.ws_main_bytes && (L.ws_side_bytes == 0 || (b.ws_side != nullptr && b.ws_side_bytes >= L.ws_side_bytes)),
               "rlayer_bwd: workspaces too small");
   char* s = reinterpret_cast<char*>(io.slab);

@@ -96,6 +96,31 @@ class Pack:
         return out[:self.cap].contiguous()
 
 
+def image_major_layout(seq_len, seq_img, n_images, T, device, extra=()):
+    """Lay sequences out IMAGE BY IMAGE.  seq_len / seq_img: host lists (length and image of every sequence, caller's order).
+    Returns (pack over the re-ordered sequences, order [new position -> caller index], pos_of [caller index -> new position],
+    meta int32 device tensor with rows [pos_of, *extra re-ordered..., image starts (padded), image counts (padded)],
+    ranges = (start int32 [U], count int32 [U], max count) of each image's contiguous query rows).  `extra`: host lists in the
+    caller's order that the caller wants on the device in the NEW order (one upload for everything)."""
+    n = len(seq_len)
+    order = sorted(range(n), key=seq_img.__getitem__)      # stable
+    pos_of = [0] * n
+    for k, j in enumerate(order):
+        pos_of[j] = k
+    pack = Pack.from_lens([seq_len[j] for j in order], T, device)
+    counts = [0] * n_images
+    for j in range(n):
+        counts[seq_img[j]] += seq_len[j]
+    starts = [0] * n_images
+    for u in range(1, n_images):
+        starts[u] = starts[u - 1] + counts[u - 1]
+    pad = [0] * (n - n_images)
+    rows = [pos_of] + [[e[j] for j in order] for e in extra] + [starts + pad, counts + pad]
+    meta = torch.tensor(rows, dtype=torch.int32).to(device, non_blocking=True)
+    ranges = (meta[-2, :n_images].contiguous(), meta[-1, :n_images].contiguous(), max(counts))
+    return pack, order, pos_of, meta, ranges
+
+
 class _RowsGatherFn(torch.autograd.Function):
     """out[r] = rows[index[r]] (zeros where index < 0); backward = scatter-add in fp32."""
 

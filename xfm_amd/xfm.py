@@ -466,11 +466,12 @@ class XFMBase(nn.Module):
     def _matching_and_fuse_mlm_packed(self, image_embeds, image_atts, image_feat, text_feat, text_rows, pack, masked_pos, masked_ids,
                                       idx=None, neg_idx=None):
         """The 4B-row fusion pass on UNPADDED token rows (xfm_amd.packing).  `text_rows` / `pack`: the text tower's packed output over
-        2B sequences (clean | masked).  The fusion layout is four blocks of B sequences: positives, (negative image, text),
-        (image, negative text), MLM inputs; the lengths of the third block follow the device-side draw of the hard negatives, so it
-        gets worst-case room and device-computed offsets (no host sync)."""
+        2B sequences (clean | masked).  The 4B fusion sequences are positives, (negative image, text), (image, negative text), MLM
+        inputs.  Default: the drawn negatives are read back once, the sequences are packed exactly and laid out image by image
+        (cross-attention per image on contiguous rows).  XFM_PACK_SYNC=0: no host sync at all -- four blocks in the reference's
+        order, worst-case room and device-computed offsets for the block whose lengths follow the device-side draw."""
         from .ops import lm_head_ce
-        from .packing import Pack, rows_gather
+        from .packing import Pack, image_major_layout, rows_gather
         if neg_idx is None:
             image_neg_idx, text_neg_idx = self.get_hard_negatives(image_feat, text_feat, idx=idx)
         else:
@@ -480,27 +481,41 @@ class XFMBase(nn.Module):
         dev = image_embeds.device
         lens, lh = pack.lens[:bs], pack.lens_host[:bs]
         n_rows, t_max = sum(lh), max(lh)
-        if _PACK_SYNC and neg_idx is None:
-            # read the drawn negatives back (the one host sync of the step, at the end of the ViT forward): every block is then
-            # packed exactly -- 10-15 % fewer fusion rows than worst-case room for the negative-text block buys more than the
-            # ~50 us the device idles while the host catches up
-            tn = text_neg_idx.cpu().tolist()
-            fpack = Pack.from_lens(lh + lh + [lh[j] for j in tn] + lh, pack.T, dev)
+        ar = torch.arange(bs, device=dev)
+        self._ready()
+        if _PACK_SYNC or neg_idx is not None:
+            # Read the drawn negatives back (the one host sync of the step, at the end of the ViT forward).  Every block is then
+            # packed exactly (10-15 % fewer fusion rows than worst-case room for the negative-text block), and the 4B sequences
+            # are laid out IMAGE BY IMAGE: the queries of one image are contiguous rows, so cross-attention runs as one ragged
+            # problem per image on full 16-row tiles (a 17-token sequence fills 1.06 tiles of the 2 it is given on its own).
+            if neg_idx is not None:   # given by the caller: host data already
+                im, tn = [int(j) for j in neg_idx[0]], [int(j) for j in neg_idx[1]]
+            else:
+                im, tn = torch.stack([image_neg_idx, text_neg_idx]).cpu().tolist()
+            seq_len = lh + lh + [lh[j] for j in tn] + lh                       # the reference's order: pos | neg img | neg txt | mlm
+            seq_img = list(range(bs)) + im + list(range(bs)) + list(range(bs))
+            seq_txt = list(range(bs)) + list(range(bs)) + tn + [bs + j for j in range(bs)]   # sequence of the text tower's pack
+            fpack, _, _, meta, ranges = image_major_layout(seq_len, seq_img, bs, pack.T, dev, extra=(seq_txt, seq_img))
+            pos_dev, seq_src, enc_index = meta[0].long(), meta[1].long(), meta[2].contiguous()
+            text_all = rows_gather(text_rows.detach(), fpack.gather_index(pack, seq_src))
+            seq = self.fusion_encoder.bert(encoder_embeds=text_all, attention_mask=None, encoder_hidden_states=image_embeds,
+                                           encoder_attention_mask=image_atts, return_dict=True, encoder_batch_index=enc_index,
+                                           pack=fpack, encoder_row_ranges=ranges).last_hidden_state
+            start_of = fpack.start.index_select(0, pos_dev)                     # start row of every sequence, reference order
         else:
             fpack = Pack.concat([(lens, n_rows, lh), (lens, n_rows, lh), (lens.index_select(0, text_neg_idx), bs * t_max, None),
                                  (lens, n_rows, lh)], pack.T)
-        ar = torch.arange(bs, device=dev)
-        seq_src = torch.cat([ar, ar, text_neg_idx, ar + bs])             # sequence of the text tower's pack each fusion row copies
-        text_all = rows_gather(text_rows.detach(), fpack.gather_index(pack, seq_src))   # is_pretrain: the text states are detached
-        enc_index = torch.cat([ar, image_neg_idx, ar, ar]).to(torch.int32)
-        self._ready()
-        seq = self.fusion_encoder.bert(encoder_embeds=text_all, attention_mask=None, encoder_hidden_states=image_embeds,
-                                       encoder_attention_mask=image_atts, return_dict=True, encoder_batch_index=enc_index,
-                                       pack=fpack).last_hidden_state
-        output = self.itm_head(rows_gather(seq, fpack.start[:3 * bs]))
+            seq_src = torch.cat([ar, ar, text_neg_idx, ar + bs])             # sequence of the text tower's pack each fusion row copies
+            text_all = rows_gather(text_rows.detach(), fpack.gather_index(pack, seq_src))   # is_pretrain: the text states are detached
+            enc_index = torch.cat([ar, image_neg_idx, ar, ar]).to(torch.int32)
+            seq = self.fusion_encoder.bert(encoder_embeds=text_all, attention_mask=None, encoder_hidden_states=image_embeds,
+                                           encoder_attention_mask=image_atts, return_dict=True, encoder_batch_index=enc_index,
+                                           pack=fpack).last_hidden_state
+            start_of = fpack.start
+        output = self.itm_head(rows_gather(seq, start_of[:3 * bs]))
         itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
         loss_itm = F.cross_entropy(output, itm_labels)
-        mlm_index = (fpack.start[3 * bs:, None] + masked_pos.to(torch.int32)).reshape(-1)   # gather_seq_out_by_pos (xroberta.py:1215-1216)
+        mlm_index = (start_of[3 * bs:, None] + masked_pos.to(torch.int32)).reshape(-1)   # gather_seq_out_by_pos (xroberta.py:1215-1216)
         mlm_seq = rows_gather(seq, mlm_index)
         loss_mlm, _ = lm_head_ce(mlm_seq, self.fusion_encoder.lm_head, masked_ids.reshape(-1), "mean")
         return loss_itm, loss_mlm

@@ -244,7 +244,7 @@ class _EncoderFn(torch.autograd.Function):
     """Layers [lo, hi) of a RobertaEncoder.  x: bf16 [B*T, D]; enc: bf16 [B*N, D] or None."""
 
     @staticmethod
-    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index, grad_batch=None, pack=None):
+    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index, grad_batch=None, pack=None, xq=None):
         cfg = model.config
         D, H = cfg.hidden_size, cfg.num_attention_heads
         scale = 1.0 / math.sqrt(D // H)
@@ -260,7 +260,7 @@ class _EncoderFn(torch.autograd.Function):
         groups = None
         if enc is not None:
             enc = enc.contiguous()
-            if enc_index is not None and Fx.attn_grouped_ok(T, Nenc):
+            if xq is None and enc_index is not None and Fx.attn_grouped_ok(T, Nenc):
                 groups = Fx.kv_groups(enc_index, enc.shape[0] // Nenc)
         # The K/V projections of the image states depend on no text-side activation (xroberta.py:224-226 recomputes them in every
         # layer from the same encoder_hidden_states): all layers' projections are enqueued up front on the second stream and run under
@@ -290,7 +290,10 @@ class _EncoderFn(torch.autograd.Function):
                 d_att2, d_h2 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
                 q2 = Fx.gemm_nt(y1, s["q2"].wb, s["q2"].b)
                 kv = pre.take(kv_ready.pop(li))
-                if groups is not None:  # one workgroup per (image, head): K/V staged once for every row that reads it
+                if xq is not None:  # RANGE mode: sequences laid out image by image -> one ragged problem per image, full query tiles
+                    c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], enc.shape[0] // Nenc, H, xq[2], Nenc, scale, key_keep=enc_keep,
+                                           drop=d_att2, q_pack=(xq[0], xq[1]), zero_fill=zf)
+                elif groups is not None:  # one workgroup per (image, head): K/V staged once for every row that reads it
                     c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, groups=groups,
                                            q_pack=qp, zero_fill=zf)
                 elif pack is not None:
@@ -314,7 +317,7 @@ class _EncoderFn(torch.autograd.Function):
         if grad_batch is not None and (enc is not None or not 0 < grad_batch <= B):
             raise ValueError("grad_batch is for self-attention-only passes: 0 < grad_batch <= batch")
         ctx.meta = (lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index, groups, grad_batch)
-        ctx.pack = pack
+        ctx.pack, ctx.xq = pack, xq
         ctx.noted = need_dx or need_denc
         if ctx.noted:
             arena_note_use(model)
@@ -352,8 +355,10 @@ class _EncoderFn(torch.autograd.Function):
         # gradient w.r.t. the shared image states = sum over the cross-attention layers of dKV_l @ Wkv_l: with the grouped
         # kernels every layer's dKV is [images*Nenc, 2D], so the layers write column blocks of ONE buffer and a single GEMM
         # with K = layers*2D (against the column-concatenated transposed weights) replaces one fp32 read-modify-write GEMM per layer
+        xq = ctx.xq
+        per_image = groups is not None or xq is not None   # dK / dV come out per image (not per query sequence)
         cross_layers = [li for li in range(lo, hi) if model.encoder.layer[li].has_cross_attention] if enc is not None else []
-        concat_k = need_denc and groups is not None and len(cross_layers) > 1
+        concat_k = need_denc and per_image and len(cross_layers) > 1
         dkv_all = torch.empty((enc.shape[0], len(cross_layers) * 2 * D), dtype=BF16, device=dy.device) if concat_k else None
         if need_denc and not concat_k:
             denc32 = torch.zeros((enc.shape[0], D), dtype=F32, device=dy.device)
@@ -376,7 +381,7 @@ class _EncoderFn(torch.autograd.Function):
                 dc2 = Fx.gemm_nt(dh2, s["o2"].wt, n=s["o2"].K)
                 kv = r["kv"]
                 dq2 = new_grad(r["q2"])
-                if groups is not None:  # dK/dV accumulated over each image's rows in registers, written once per image
+                if per_image:  # dK/dV accumulated over each image's rows in registers, written once per image
                     if concat_k:
                         j = cross_layers.index(li)
                         dkv = dkv_all[:, j * 2 * D:(j + 1) * 2 * D]
@@ -384,8 +389,13 @@ class _EncoderFn(torch.autograd.Function):
                         dkv = torch.empty((enc.shape[0], 2 * D), dtype=BF16, device=dq2.device)
                     # dQ stays on the activation-gradient chain; dK/dV (they only feed the K/V weight gradient and, after the last
                     # layer, the gradient of the image states) run next to the weight-gradient GEMMs on the second stream
-                    args = (dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc, scale)
-                    kw = dict(key_keep=enc_keep, drop=r["d_att2"], groups=groups, q_pack=qp)
+                    if xq is not None:
+                        args = (dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], enc.shape[0] // Nenc, H,
+                                xq[2], Nenc, scale)
+                        kw = dict(key_keep=enc_keep, drop=r["d_att2"], q_pack=(xq[0], xq[1]))
+                    else:
+                        args = (dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc, scale)
+                        kw = dict(key_keep=enc_keep, drop=r["d_att2"], groups=groups, q_pack=qp)
                     delta = Fx.attn_bwd(*args, phase=1, **kw)
                     wg.run(lambda: Fx.attn_bwd(*args, phase=2, delta=delta, **kw), keep=args[:9] + (delta,))
                 else:
@@ -397,7 +407,7 @@ class _EncoderFn(torch.autograd.Function):
                 wg.gemm_tn(dq2, r["y1"], s["q2"].dw, dbias=s["q2"].db)
                 wg.gemm_tn(dkv, enc, s["kv2"].dw, dbias=s["kv2"].db)
                 if need_denc and not concat_k:
-                    if groups is not None:  # dkv is produced on the second stream: its consumer follows it there
+                    if per_image:  # dkv is produced on the second stream: its consumer follows it there
                         wg.run(lambda dkv=dkv, s=s: Fx.gemm_nt(dkv, s["kv2"].wt, epi=Fx.EPI_F32_ACC, out=denc32, n=s["kv2"].K), keep=(dkv,))
                     else:
                         Fx.gemm_nt(dkv, s["kv2"].wt, epi=Fx.EPI_F32_ACC, out=denc32, n=s["kv2"].K)
@@ -429,7 +439,7 @@ class _EncoderFn(torch.autograd.Function):
         wg.join()  # the weight gradients are complete in main-stream order before the tower's all-reduce / the optimizer
         if ctx.noted:
             arena_note_grad(model)
-        return (dx, denc) + (None,) * 13
+        return (dx, denc) + (None,) * 14
 
 
 
@@ -503,7 +513,7 @@ class _EncoderFnNative(torch.autograd.Function):
     being bound by the Python interpreter.  Cross-attention goes through the grouped kernels (encoder_batch_index required)."""
 
     @staticmethod
-    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index, grad_batch=None, pack=None):
+    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index, grad_batch=None, pack=None, xq=None):
         from . import _lib
         from ._lib import RLayerIO, RLayerLayout, check
         import ctypes
@@ -523,7 +533,8 @@ class _EncoderFnNative(torch.autograd.Function):
         if enc is not None:
             enc = enc.contiguous()
             U = enc.shape[0] // Nenc
-            groups = Fx.kv_groups(enc_index, U)
+            if xq is None:
+                groups = Fx.kv_groups(enc_index, U)
         layers = [model.encoder.layer[li] for li in range(lo, hi)]
         arena = layers[0]._s["qkv"]._arena
         ver = arena._manual_ver
@@ -542,6 +553,8 @@ class _EncoderFnNative(torch.autograd.Function):
         io.key_keep, io.enc_keep = Fx._ptr(key_keep), Fx._ptr(enc_keep)
         if groups is not None:
             io.grp_start, io.grp_rows = groups[0].data_ptr(), groups[1].data_ptr()
+        if xq is not None:
+            io.xq_start, io.xq_len, io.xq_max = xq[0].data_ptr(), xq[1].data_ptr(), int(xq[2])
         io.causal, io.scale = int(causal), 1.0 / math.sqrt(D // H)
         io.att_thresh, io.att_scale, io.hid_thresh, io.hid_scale = d_att[0], d_att[1], d_hid[0], d_hid[1]
         io.seed_hi = torch.initial_seed() & 0xFFFFFFFF
@@ -550,7 +563,8 @@ class _EncoderFnNative(torch.autograd.Function):
         def layout(cross):
             if cross not in layouts:
                 L = RLayerLayout()
-                check(lib.xfm_rlayer_layout(R, B, T, D, H, FF, int(cross), io.Nenc, U, int(p_hid > 0), ctypes.byref(L)), "rlayer_layout")
+                check(lib.xfm_rlayer_layout(R, B, T, D, H, FF, int(cross), io.Nenc, U, io.xq_max if xq is not None else 0, int(p_hid > 0),
+                                            ctypes.byref(L)), "rlayer_layout")
                 layouts[cross] = L
             return layouts[cross]
 
@@ -579,6 +593,7 @@ class _EncoderFnNative(torch.autograd.Function):
             saved.append((slab, x, kv, ctr, cross))
             x = _view(slab, L.y3, R, D)
         ctx.saved, ctx.model, ctx.enc, ctx.io, ctx.layouts, ctx.pack = saved, model, enc, io, layouts, pack
+        ctx.keep = (groups, xq, key_keep, enc_keep)   # device arrays the io struct points at
         ctx.meta = (lo, hi, B, T, Nenc, U, key_keep, need_dx, need_denc, groups, grad_batch, p_hid > 0)
         ctx.noted = need_dx or need_denc
         if ctx.noted:
@@ -669,7 +684,7 @@ class _EncoderFnNative(torch.autograd.Function):
         del keep
         if ctx.noted:
             arena_note_grad(model)
-        return (dx, denc) + (None,) * 13
+        return (dx, denc) + (None,) * 14
 
 
 class RobertaModel(nn.Module):
@@ -699,13 +714,16 @@ class RobertaModel(nn.Module):
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
                 inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
-                is_decoder=False, mode='multi_modal', encoder_batch_index=None, grad_batch=None, pack=None):
+                is_decoder=False, mode='multi_modal', encoder_batch_index=None, grad_batch=None, pack=None, encoder_row_ranges=None):
         """`encoder_batch_index` (extension, default None = reference behaviour): int tensor [B] mapping every text row to the
         row of `encoder_hidden_states` it attends to, so duplicated images are projected to K/V once per layer.
         `grad_batch` (extension): only the first grad_batch sequences of the batch propagate gradient through the layer stack
         (a detached pass batched behind a differentiable one, e.g. the masked-text pass of get_fuse_mlm_loss).
         `pack` (extension, xfm_amd.packing.Pack): run on unpadded token rows -- `attention_mask` is then implied by the pack's lengths,
-        `encoder_embeds` is a 2-D [pack.cap, D] row buffer and `last_hidden_state` comes back in the same packed layout."""
+        `encoder_embeds` is a 2-D [pack.cap, D] row buffer and `last_hidden_state` comes back in the same packed layout.
+        `encoder_row_ranges` (extension, with `pack`): (start int32 [U], count int32 [U], max count) -- the packed sequences are laid
+        out image by image, so the queries of image u are the contiguous rows start[u] .. + count[u]: cross-attention then runs as one
+        ragged problem per image on full 16-row query tiles instead of per-sequence tiles that are mostly padding."""
         if any(v is not None for v in (token_type_ids, position_ids, head_mask, inputs_embeds, past_key_values)):
             raise NotImplementedError("token_type_ids/position_ids/head_mask/inputs_embeds/past_key_values are not used on the XFM path")
         if isinstance(encoder_hidden_states, (list, tuple)):
@@ -754,10 +772,16 @@ class RobertaModel(nn.Module):
         y = x.reshape(B * T, -1) if pack is None else x
         if hi > lo:
             # one native call per layer whenever cross-attention (if any) can take the grouped kernels; else kernel by kernel
-            native = _NATIVE_LAYERS and y.is_cuda and (enc is None or (encoder_batch_index is not None and Fx.attn_grouped_ok(T, Nenc)))
+            xq = None
+            if encoder_row_ranges is not None and enc is not None:
+                assert pack is not None and Nenc <= 256, "per-image row ranges need packed rows and <= 256 image tokens"
+                xq = (encoder_row_ranges[0].to(device=dev, dtype=torch.int32).contiguous(),
+                      encoder_row_ranges[1].to(device=dev, dtype=torch.int32).contiguous(), int(encoder_row_ranges[2]))
+            native = _NATIVE_LAYERS and y.is_cuda and (enc is None or xq is not None or
+                                                       (encoder_batch_index is not None and Fx.attn_grouped_ok(T, Nenc)))
             fn = _EncoderFnNative if native else _EncoderFn
             y = fn.apply(y, enc, self, key_keep, enc_keep, lo, hi, bool(is_decoder), B, T, Nenc, self.training,
-                         encoder_batch_index if enc is not None else None, grad_batch, pack)
+                         encoder_batch_index if enc is not None else None, grad_batch, pack, xq)
         return SimpleNamespace(last_hidden_state=y.view(B, T, -1) if pack is None else y, pooler_output=None, past_key_values=None,
                                hidden_states=None, attentions=None, cross_attentions=None)
 
