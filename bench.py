@@ -73,22 +73,48 @@ class GemmTimer:
         import xfm_amd.beit2 as b2, xfm_amd.xroberta as xr, xfm_amd.ops as ops
         self.Fx, self.orig = Fx, Fx.gemm_nt
 
-        def timed(a, b, bias=None, epi=0, aux=None, out=None, n=None, tile_hint=0):
+        import ctypes
+        from xfm_amd import _lib
+        lib = _lib.load()
+
+        def plan(M, N, K, epi, hint):
+            cfg, rows_a = ctypes.c_int(0), ctypes.c_int(0)
+            lib.xfm_gemm_nt_plan(M, N, K, epi, hint, ctypes.byref(cfg), ctypes.byref(rows_a))
+            return cfg.value, rows_a.value
+
+        def one(a, b, bias, epi, aux, out, n, hint, cfg):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            r = self.orig(a, b, bias, epi, aux, out, n, tile_hint)
+            r = self.orig(a, b, bias, epi, aux, out, n, hint)
             e.record()
             N = b.shape[0] if n is None else n
             self.records.append((s, e, 2.0 * a.shape[0] * N * a.shape[1]))
-            self.shapes.append(("nt", a.shape[0], N, a.shape[1], epi, s, e))
+            self.shapes.append(("nt", a.shape[0], N, a.shape[1], epi, s, e, cfg))
             return r
+
+        def timed(a, b, bias=None, epi=0, aux=None, out=None, n=None, tile_hint=0):
+            """One event pair per KERNEL: a call that the library's plan splits (whole rounds of 256x256 tiles + the remaining rows on
+            the small-tile kernels, xfm_gemm_nt_plan) is issued here as exactly those two launches."""
+            M, K = a.shape
+            N = b.shape[0] if n is None else n
+            cfg, rows_a = plan(M, N, K, epi, tile_hint)
+            if rows_a == 0:
+                return one(a, b, bias, epi, aux, out, n, tile_hint, cfg)
+            if out is None:
+                out = torch.empty((M, N), dtype=torch.float32 if epi in (1, 4) else torch.bfloat16, device=a.device)
+            if epi == 2 and aux is None:
+                aux = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+            one(a[:rows_a], b, bias, epi, None if aux is None else aux[:rows_a], out[:rows_a], n, 5, 5)
+            cfg_b, _ = plan(M - rows_a, N, K, epi, -1)
+            one(a[rows_a:], b, bias, epi, None if aux is None else aux[rows_a:], out[rows_a:], n, -1, cfg_b)
+            return (out, aux) if epi == 2 else out
 
         def timed_tn(dy, x, dw, n=None, dbias=None, splits=0):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = self.orig_tn(dy, x, dw, n=n, dbias=dbias, splits=splits)
             e.record()
-            self.shapes.append(("tn", dy.shape[0], dy.shape[1] if n is None else n, x.shape[1], int(dbias is not None), s, e))
+            self.shapes.append(("tn", dy.shape[0], dy.shape[1] if n is None else n, x.shape[1], int(dbias is not None), s, e, 0))
             return r
 
         def timed_attn(kind, orig):
@@ -99,7 +125,7 @@ class GemmTimer:
                 e.record()
                 off = 3 if kind == "attn_fwd" else 9  # positional (B, H, Sq, Sk)
                 B_, H_, Sq_, Sk_ = args[off:off + 4]
-                self.shapes.append((kind, B_ * H_, Sq_, Sk_, int(kw.get("kv_index") is not None), s, e))
+                self.shapes.append((kind, B_ * H_, Sq_, Sk_, int(kw.get("kv_index") is not None), s, e, 0))
                 return r
             return f
 
@@ -121,7 +147,7 @@ class GemmTimer:
         """{(kind, M, N, K, epi): [calls, total_ms]} for the instrumented step (XFM_BENCH_GEMM_SHAPES=path dumps it)."""
         torch.cuda.synchronize()
         agg = {}
-        for kind, M, N, K, epi, s, e in self.shapes:
+        for kind, M, N, K, epi, s, e, cfg in self.shapes:
             a = agg.setdefault((kind, M, N, K, epi), [0, 0.0])
             a[0] += 1
             a[1] += s.elapsed_time(e)
@@ -134,15 +160,12 @@ class GemmTimer:
         return len(self.records), ms, fl
 
     def dominant(self):
-        """The calls that run as exactly ONE launch of the dominant kernel, gemm_nt_256_kernel<EPI_BF16> (plain bf16 output,
-        >= 120 tiles of 256x256, no tail split -- the launcher's rule in csrc/gemm.hip): (launches, total ms, total flop)."""
+        """EVERY launch of the dominant kernel, gemm_nt_256_kernel<EPI_BF16> (configuration 5 of the library's plan with the plain bf16
+        epilogue; the whole-round part of a tail-split call included): (launches, total ms, total flop, algorithmic bytes)."""
         torch.cuda.synchronize()
         n, ms, fl, by = 0, 0.0, 0.0, 0.0
-        for kind, M, N, K, epi, s, e in self.shapes:
-            if kind != "nt" or epi != 0 or M < 2048:
-                continue
-            t256 = ((M + 255) // 256) * ((N + 255) // 256)
-            if t256 < 120 or (t256 > 256 and t256 % 256 != 0 and (t256 % 256) * 100 < 35 * 256):
+        for kind, M, N, K, epi, s, e, cfg in self.shapes:
+            if kind != "nt" or epi != 0 or cfg != 5:
                 continue
             n += 1
             ms += s.elapsed_time(e)
@@ -219,6 +242,9 @@ def fusion_probe(model, B, host_batch, packed, iters=5):
             seq_img = index.tolist()
             pack, _, _, meta, ranges = image_major_layout(lens4.tolist(), seq_img, B, T, dev, extra=(seq_img,))
             index = meta[1].contiguous()
+            from xfm_amd.xfm import _XATTN_RANGES
+            if not _XATTN_RANGES:
+                ranges = None
         else:           # no host sync: worst-case room for the negative-text block, offsets computed on the device
             pack = Pack.concat([(ld, n_rows, lens_h.tolist()), (ld, n_rows, lens_h.tolist()), (ld[perm.to(dev)], B * t_max, None),
                                 (ld, n_rows, lens_h.tolist())], T)
@@ -378,10 +404,12 @@ def main():
     # brackets exactly one kernel's execution instead of a stretch of two overlapping chains)
     from xfm_amd.xroberta import _WgradStream
     import xfm_amd.model_pretrain as mp
+    import xfm_amd.xroberta as xr
     _WgradStream.enabled, text_on, mp._TEXT_STREAM_ON = False, mp._TEXT_STREAM_ON, False  # (the text tower's stream as well)
+    native, xr._NATIVE_LAYERS = xr._NATIVE_LAYERS, False  # kernel by kernel, so that the wrappers see every launch (same kernels)
     with GemmTimer() as gt:
         step()
-    _WgradStream.enabled, mp._TEXT_STREAM_ON = os.environ.get("XFM_WGRAD_STREAM", "1") != "0", text_on
+    _WgradStream.enabled, mp._TEXT_STREAM_ON, xr._NATIVE_LAYERS = os.environ.get("XFM_WGRAD_STREAM", "1") != "0", text_on, native
     nlaunch, gemm_ms, gemm_flop = gt.summary()
     dom_n, dom_ms, dom_fl, dom_bytes = gt.dominant()
     dom_tf = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -394,7 +422,9 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     traffic, traffic_note = None, None
-    tpath = os.path.join(ROOT, "profiles", "round1_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "round2_hbm_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "round1_hbm_traffic.json")
     if os.path.exists(tpath):  # PMC passes are separate rocprofv3 runs of this same command (profiles/README.md)
         with open(tpath) as f:
             tj = json.load(f)
@@ -428,7 +458,7 @@ def main():
             "mfma_frac_whole_step": round(B * PAIR_GFLOP / ms_per_step / BF16_DENSE_PEAK_TFLOPS, 4),
             "losses_last_step": loss_vals,
             # the dominant kernel alone (HIP events around its launches in the instrumented step) ...
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256_kernel<EPI_BF16> (forward / dgrad GEMMs that run as one launch of it)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256_kernel<EPI_BF16> (every launch of it in one step: forward / dgrad GEMMs, whole-round parts of tail-split calls included)",
                          "achieved": round(dom_tf, 2), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(dom_tf / BF16_DENSE_PEAK_TFLOPS, 4), "launches": dom_n,
                          "avg_launch_us": round(dom_ms / max(dom_n, 1) * 1e3, 1), "flop_per_launch_avg": dom_fl / max(dom_n, 1),

@@ -45,6 +45,11 @@ enum { XFM_EPI_BF16 = 0, XFM_EPI_F32 = 1, XFM_EPI_GELU = 2, XFM_EPI_DGELU = 3, X
 int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* C, long ldc, const float* bias,
                 xfm_bf16* aux, long ldaux, int M, int N, int K, int epilogue, int tile_hint, void* stream);
 
+/* The launch plan xfm_gemm_nt follows for a shape (profilers / benchmarks attribute a call to its kernels with it): *cfg = tile
+ * configuration (the tile_hint numbering), *rows_a > 0 = tail split: the leading rows_a rows run as whole rounds of 256x256 tiles
+ * (configuration 5), the remaining rows are planned again with tile_hint -1. */
+int xfm_gemm_nt_plan(int M, int N, int K, int epilogue, int tile_hint, int* cfg, int* rows_a);
+
 /* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]   (weight gradient, split over M).
  * dbias (optional, fp32 [N]) += column sums of dY: the bias gradient rides along in the same pass over dY.
  * The split partials are written to `workspace` (xfm_gemm_tn_workspace bytes for splits_hint 0; may be 0) and summed

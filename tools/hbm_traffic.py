@@ -17,6 +17,10 @@ def family(name):
         return "gemm_tn"
     if "attn" in name:
         return "attn"
+    if name.startswith("void ln_") or "reduce_sets" in name or "ln_" in name[:12]:
+        return "layernorm"
+    if "adamw" in name or "sumsq" in name or "cast_transpose" in name:
+        return "optimizer"
     return "other"
 
 

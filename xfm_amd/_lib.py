@@ -110,6 +110,7 @@ SIGNATURES = {
     "xfm_abi_version": (c_int, []),
     "xfm_gemm_nt": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long,
                             c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "xfm_gemm_nt_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "xfm_gemm_tn_workspace": (c_long, [c_int, c_int, c_int]),
     "xfm_gemm_tn": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int,
                             c_void_p, c_long, c_void_p]),

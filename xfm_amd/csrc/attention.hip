@@ -700,6 +700,7 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
     long qbase, kbase_unused;
     int sq, sk = a.Sk;
     q_seq(a, b, qbase, sq);
+    if (tile * 16 >= sq) continue;  // packed rows: this 16-query tile lies past the sequence's end (wave-uniform, no barrier below)
     if (PACK) k_seq(a, kvb, kbase_unused, sk);
     const int qi = tile * 16 + lr;
     const int qc = qi < sq ? qi : sq - 1;
@@ -801,6 +802,7 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
     long qbase;
     int sq;
     q_seq(a, b, qbase, sq);
+    if (tile * 16 >= sq) continue;  // nothing of this tile belongs to the sequence
     const int qi = tile * 16 + lr;
     const bool qvalid = qi < sq;
     const int qc = qvalid ? qi : sq - 1;
@@ -939,15 +941,18 @@ __global__ __launch_bounds__(512, 4) void xattn_dkv_kernel(AttnArgs a) {
             delv[u] = *reinterpret_cast<const f32x4*>(del_b + qi0);
           }
         }
+        if (s2 * 32 >= sq) continue;  // uniform per row: the whole 32-query step lies past the sequence's end
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int t = 2 * s2 + u;
           st[u] = f32x4{0.f, 0.f, 0.f, 0.f};
           dp[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 0, lr, lg), kf0, st[u], 0, 0, 0);
-          st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 1, lr, lg), kf1, st[u], 0, 0, 0);
-          dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 0, lr, lg), vf0, dp[u], 0, 0, 0);
-          dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 1, lr, lg), vf1, dp[u], 0, 0, 0);
+          if (t * 16 < sq) {  // (an empty second tile contributes zero probabilities below: skip its four products)
+            st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 0, lr, lg), kf0, st[u], 0, 0, 0);
+            st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 1, lr, lg), kf1, st[u], 0, 0, 0);
+            dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 0, lr, lg), vf0, dp[u], 0, 0, 0);
+            dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 1, lr, lg), vf1, dp[u], 0, 0, 0);
+          }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u)

@@ -43,6 +43,9 @@ int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* 
   return xfm_gemm_nt_impl(A, lda, B, ldb, C, ldc, bias, aux, ldaux, M, N, K, epilogue, tile_hint, ST(stream));
 }
 
+int xfm_gemm_nt_plan(int M, int N, int K, int epilogue, int tile_hint, int* cfg, int* rows_a) {
+  return xfm_gemm_nt_plan_impl(M, N, K, epilogue, tile_hint, cfg, rows_a);
+}
 long xfm_gemm_tn_workspace(int M, int N, int K) { return xfm_gemm_tn_workspace_impl(M, N, K); }
 
 int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float* dW, long ldw, float* dbias, int M, int N,

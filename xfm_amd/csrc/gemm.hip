@@ -613,16 +613,13 @@ static int launch_nt(const GemmNT& g, int epi, hipStream_t st) {
   return xfm_check_launch("gemm_nt");
 }
 
-int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, long ldc, const float* bias,
-                     void* aux, long ldaux, int M, int N, int K, int epi, int tile_hint, hipStream_t st) {
-  XFM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
-  XFM_REQUIRE(K % 64 == 0, "gemm_nt: K=%d must be a multiple of 64", K);
-  XFM_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm_nt: lda=%ld ldb=%ld must be multiples of 8", lda, ldb);
-  XFM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
-              "gemm_nt: operands must be 16-byte aligned");
-  XFM_REQUIRE((epi != EPI_GELU && epi != EPI_DGELU) || aux != nullptr, "gemm_nt: epilogue %d needs aux", epi);
-  static const int gm_env = getenv("XFM_GEMM_GROUP_M") ? atoi(getenv("XFM_GEMM_GROUP_M")) : 0;  // tuning knob
-  GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K, gm_env > 0 ? gm_env : 8, 1};
+// Launch plan of xfm_gemm_nt for a shape: the tile configuration (1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x128 ring, 5 = 256x256
+// phase pipeline, 7 = 64x128 on 3 LDS stages, 8 = 64x64 on 4) and, for the tail split, the leading rows that run as whole rounds of
+// 256x256 tiles (rows_a > 0: those rows go to configuration 5, the rest is planned again with hint -1).  Exported as
+// xfm_gemm_nt_plan so that a profiler / benchmark can attribute a call to the kernels it launches.
+static int nt_plan(int M, int N, int K, int epi, int tile_hint, int* rows_a_out, int* k_splits_out) {
+  *rows_a_out = 0;
+  *k_splits_out = 1;
   int cfg = tile_hint;
   if (cfg <= 0) {  // measured on MI355X (tools/tune_gemm.py): 128x128 pays from ~3 workgroups per CU, else go smaller
     // Tail split: one workgroup per CU, so T tiles of 256x256 cost ceil(T / 256) rounds.  When the last round would be
@@ -633,11 +630,8 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
     if (split_env && tile_hint == 0 && M >= 2048 && t256 > 256 && t256 % 256 != 0 && (t256 % 256) * 100 < split_env * 256) {
       const int rows_a = (int)((t256 / 256) * 256 / tn256) * 256;  // row tiles that exactly fill the whole rounds
       if (rows_a > 0 && rows_a < M) {
-        int rc = xfm_gemm_nt_impl(A, lda, B, ldb, C, ldc, bias, aux, ldaux, rows_a, N, K, epi, 5, st);
-        if (rc != XFM_OK) return rc;
-        const long esz = (epi == EPI_F32 || epi == EPI_F32_ACC) ? 4 : 2;
-        return xfm_gemm_nt_impl((const bf16*)A + (long)rows_a * lda, lda, B, ldb, (char*)C + (long)rows_a * ldc * esz, ldc, bias,
-                                aux ? (void*)((bf16*)aux + (long)rows_a * ldaux) : nullptr, ldaux, M - rows_a, N, K, epi, -1, st);
+        *rows_a_out = rows_a;
+        return 5;
       }
     }
     // ~half a round of 256x256 tiles already beats the rest on the tall problems (M = 12608 / 25216); on the packed token rows of
@@ -664,11 +658,34 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
       if (epi == EPI_F32_ACC && K >= 8192 && t < 192) {
         int sp = (int)(512 / t);
         if (sp > K / 1024) sp = K / 1024;
-        g.k_splits = sp < 1 ? 1 : sp;
+        *k_splits_out = sp < 1 ? 1 : sp;
       }
     }
     else cfg = 3;
   }
+  return cfg;
+}
+
+int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, long ldc, const float* bias,
+                     void* aux, long ldaux, int M, int N, int K, int epi, int tile_hint, hipStream_t st) {
+  XFM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+  XFM_REQUIRE(K % 64 == 0, "gemm_nt: K=%d must be a multiple of 64", K);
+  XFM_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm_nt: lda=%ld ldb=%ld must be multiples of 8", lda, ldb);
+  XFM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
+              "gemm_nt: operands must be 16-byte aligned");
+  XFM_REQUIRE((epi != EPI_GELU && epi != EPI_DGELU) || aux != nullptr, "gemm_nt: epilogue %d needs aux", epi);
+  static const int gm_env = getenv("XFM_GEMM_GROUP_M") ? atoi(getenv("XFM_GEMM_GROUP_M")) : 0;  // tuning knob
+  GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K, gm_env > 0 ? gm_env : 8, 1};
+  int rows_a = 0, k_splits = 1;
+  const int cfg = nt_plan(M, N, K, epi, tile_hint, &rows_a, &k_splits);
+  if (rows_a > 0) {  // tail split: whole rounds of 256x256 tiles first, the remaining rows on the small-tile kernels
+    int rc = xfm_gemm_nt_impl(A, lda, B, ldb, C, ldc, bias, aux, ldaux, rows_a, N, K, epi, 5, st);
+    if (rc != XFM_OK) return rc;
+    const long esz = (epi == EPI_F32 || epi == EPI_F32_ACC) ? 4 : 2;
+    return xfm_gemm_nt_impl((const bf16*)A + (long)rows_a * lda, lda, B, ldb, (char*)C + (long)rows_a * ldc * esz, ldc, bias,
+                            aux ? (void*)((bf16*)aux + (long)rows_a * ldaux) : nullptr, ldaux, M - rows_a, N, K, epi, -1, st);
+  }
+  g.k_splits = k_splits;
   switch (cfg) {
     case 1: return launch_nt<128, 128, 2>(g, epi, st);
     case 2: return launch_nt<64, 128, 2>(g, epi, st);
@@ -1428,3 +1445,10 @@ int xfm_cast_transpose_impl(const float* w, int N, int K, void* wb, long ldb, vo
   return xfm_check_launch("cast_transpose");
 }
 
+
+int xfm_gemm_nt_plan_impl(int M, int N, int K, int epi, int tile_hint, int* cfg, int* rows_a) {
+  XFM_REQUIRE(M > 0 && N > 0 && K > 0 && cfg != nullptr && rows_a != nullptr, "gemm_nt_plan: bad arguments");
+  int ks = 1;
+  *cfg = nt_plan(M, N, K, epi, tile_hint, rows_a, &ks);
+  return XFM_OK;
+}

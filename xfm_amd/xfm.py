@@ -27,6 +27,9 @@ BF16 = torch.bfloat16
 # packed fusion rows: exact layout of the hard-negative text block through ONE host read-back per step (default; measured 42.8 ->
 # 41.8 ms per step against worst-case room for that block, XFM_PACK_SYNC=0, which needs no sync at all)
 _PACK_SYNC = os.environ.get("XFM_PACK_SYNC", "1") != "0"
+# cross-attention per image on contiguous query rows (the image-major layout makes them so) instead of the grouped kernels: measured
+# the same (9.84 vs 9.67 ms for the fusion encoder's fwd+bwd: the generic kernels size their grid for the fullest image), so off
+_XATTN_RANGES = os.environ.get("XFM_XATTN_RANGES", "0") != "0"
 
 
 class AllGather(torch.autograd.Function):
@@ -500,7 +503,7 @@ class XFMBase(nn.Module):
             text_all = rows_gather(text_rows.detach(), fpack.gather_index(pack, seq_src))
             seq = self.fusion_encoder.bert(encoder_embeds=text_all, attention_mask=None, encoder_hidden_states=image_embeds,
                                            encoder_attention_mask=image_atts, return_dict=True, encoder_batch_index=enc_index,
-                                           pack=fpack, encoder_row_ranges=ranges).last_hidden_state
+                                           pack=fpack, encoder_row_ranges=ranges if _XATTN_RANGES else None).last_hidden_state
             start_of = fpack.start.index_select(0, pos_dev)                     # start row of every sequence, reference order
         else:
             fpack = Pack.concat([(lens, n_rows, lh), (lens, n_rows, lh), (lens.index_select(0, text_neg_idx), bs * t_max, None),
