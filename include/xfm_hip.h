@@ -160,6 +160,11 @@ typedef struct {
      alone (reads the `delta` a phase-1 call left) -- lets a caller put dK/dV, which in cross-attention only feed weight gradients,
      on another stream than the activation-gradient chain. */
   int bwd_phase;
+  /* optional second half of the output, o_lo = bf16(O - bf16(O)) (same addressing as o): the forward writes it when non-NULL; the
+     backward then takes the softmax-gradient row term delta_i = sum_j P_ij dP_ij = dO_i . O_i from dO . (o + o_lo) in its prologue
+     (error ~2^-17 |dO||O| plus the forward's own bf16 rounding of P, below the bf16 noise of dS) instead of recomputing it in a
+     first pass over the keys -- two of the dQ kernel's five matrix products.  NULL = the exact two-pass form. */
+  xfm_bf16* o_lo;
 } xfm_attn_args;
 
 int xfm_attn_fwd(const xfm_attn_args* a, void* stream);
@@ -199,6 +204,14 @@ int xfm_pool_rows_bwd(const xfm_bf16* dy, int B, int N, int D, xfm_bf16* out, vo
 int xfm_mim_loss_fwd(const xfm_bf16* x, const xfm_bf16* t, const uint8_t* mask, int B, int N, int D, float* sums, void* stream);
 int xfm_mim_loss_bwd(const xfm_bf16* x, const xfm_bf16* t, const uint8_t* mask, const float* sums, const float* gout, int cls_term,
                      int B, int N, int D, xfm_bf16* dx, void* stream);
+
+/* ---- Block-wise MIM mask sampler (masking_generator.py:27-105, called once per image and step on the host at beit2.py:432-439):
+ * out[b, p] (bytes, [B, GH*GW]) = 1 on exactly `num` patches per image, drawn by the reference's rejection loop (rectangles of area
+ * U[min_num, remaining], log-uniform aspect in [min_aspect, max_aspect], <= 10 attempts per block, uniform top-up), one wavefront per
+ * image, counter-based generator keyed by (seed, image).  delta_hist (optional, int32 [GH*GW + 1], +=): how many new patches each
+ * accepted block added. */
+int xfm_mim_masks(int B, int GH, int GW, int num, int min_num, float min_aspect, float max_aspect, uint64_t seed, uint8_t* out,
+                  int* delta_hist, void* stream);
 
 /* ---- RoBERTa embeddings + LayerNorm + dropout (xroberta.py:104-137, 1747-1757) ----------------------------------- */
 typedef struct {

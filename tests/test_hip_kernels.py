@@ -442,6 +442,55 @@ def test_attention_fwd_bwd(B, H, Sq, Sk, use_bias, use_keep, causal):
         _close(dkv2[:, D:], vr.grad, 2e-2, "dv (bias_t)")
 
 
+@pytest.mark.parametrize("B,H,Sq,Sk,use_bias,use_keep,drop_p", [(3, 12, 197, 197, True, False, 0.0), (2, 4, 577, 577, True, False, 0.0),
+                                                                  (5, 12, 30, 30, False, True, 0.0), (5, 12, 30, 30, False, True, 0.1),
+                                                                  (4, 12, 30, 197, False, False, 0.1)])
+def test_attention_backward_single_pass_delta_vs_two_pass(B, H, Sq, Sk, use_bias, use_keep, drop_p):
+    """delta_i = sum_j P_ij dP_ij taken from dO . (o + o_lo) (forward output kept as bf16 hi + lo halves) against the exact first
+    pass over the keys: gradients agree to well below the bf16 noise of dS, dropout included (the identity holds for the dropped
+    probabilities too), and both agree with fp32 math."""
+    Fx = _fx()
+    D = H * 64
+    scale = 0.125
+    q, kv = _rand((B * Sq, D), seed=70), _rand((B * Sk, 2 * D), seed=71)
+    k, v = kv[:, :D], kv[:, D:]
+    ld = (Sk + 15) // 16 * 16
+    bias = _rand((H, Sq, ld), 1.0, F32, seed=72) if use_bias else None
+    keep = None
+    if use_keep:
+        keep = torch.ones(B, Sk, dtype=torch.int32, device="cuda")
+        for i in range(1, B):
+            keep[i, Sk - (i * 7) % (Sk - 1):] = 0
+    drop = Fx.drop_params(drop_p, 4242)
+    dout = _rand((B * Sq, D), seed=73)
+    o, lse, o_lo = Fx.attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=bias, key_keep=keep, drop=drop, lo=True)
+    o2, _ = Fx.attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=bias, key_keep=keep, drop=drop)
+    assert torch.equal(o, o2)
+    assert float(o_lo.float().abs().max()) <= float(o.float().abs().max()) * 2 ** -8   # what bf16 lost: below half an ulp of o
+
+    def bwd(lo):
+        dq = torch.empty((B * Sq, D), dtype=BF16, device="cuda")
+        dkv = torch.empty((B * Sk, 2 * D), dtype=BF16, device="cuda")
+        dbias = torch.zeros_like(bias) if use_bias else None
+        Fx.attn_bwd(dout, q, k, v, o, lse, dq, dkv[:, :D], dkv[:, D:], B, H, Sq, Sk, scale, bias=bias, dbias=dbias, key_keep=keep,
+                    drop=drop, o_lo=lo)
+        return dq, dkv, dbias
+
+    dq_a, dkv_a, db_a = bwd(None)
+    dq_b, dkv_b, db_b = bwd(o_lo)
+    for name, x, y in (("dq", dq_b, dq_a), ("dkv", dkv_b, dkv_a)) + ((("dbias", db_b, db_a),) if use_bias else ()):
+        rel = float((x.float() - y.float()).norm() / (y.float().norm() + 1e-30))
+        assert rel <= 6e-3, (name, rel)
+    if drop_p == 0.0:
+        qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+        br = bias.clone().requires_grad_(True) if use_bias else None
+        ref = _attn_ref(qr, kr, vr, B, H, Sq, Sk, scale, br, keep, False)
+        ref.backward(dout.float())
+        _close(dq_b, qr.grad, 2e-2, "dq (single pass)")
+        _close(dkv_b[:, :D], kr.grad, 2e-2, "dk (single pass)")
+        _close(dkv_b[:, D:], vr.grad, 2e-2, "dv (single pass)")
+
+
 def test_attention_dropout_mask_consistency():
     """V = I exposes the dropped probabilities: O = P_dropped.  The same mask must drive the backward."""
     Fx = _fx()

@@ -582,6 +582,50 @@ def test_pretrain_step_full_depth_vs_golden():
     _pretrain("pretrain_full", tol=1.5e-1, cos_tol=0.985)
 
 
+def _chi2_two_sample(a, b, min_count=40):
+    """Two-sample chi-square statistic per degree of freedom over the bins where both histograms together hold >= min_count."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    keep = (a + b) >= min_count
+    a, b = a[keep], b[keep]
+    ka, kb = np.sqrt(b.sum() / a.sum()), np.sqrt(a.sum() / b.sum())
+    return float((((ka * a - kb * b) ** 2) / (a + b)).sum() / max(keep.sum() - 1, 1))
+
+
+def test_device_mim_mask_sampler_matches_the_reference_generators_distribution():
+    """The on-device block-wise mask sampler against statistics of the REAL reference generator (50 000 draws of
+    models/masking_generator.py, tools/oracle/gen_mask_stats.py): per-patch mask frequency, the sizes of the accepted blocks, the
+    number of grid rows a mask touches, neighbour co-occurrence -- not just `75 of 196 set`."""
+    from xfm_amd import functional as Fx
+    z, meta = load("mim_mask_stats")
+    n_ref, grid, num = meta["n"], meta["grid"], meta["num"]
+    n = 20000
+    hist = torch.zeros(grid * grid + 1, dtype=torch.int32, device="cuda")
+    m = Fx.mim_masks(n, grid, num, meta["min_num"], "cuda", seed=987654321, delta_hist=hist)
+    assert m.shape == (n, grid * grid) and bool((m.sum(1) == num).all())
+    m2 = Fx.mim_masks(n, grid, num, meta["min_num"], "cuda", seed=987654321)
+    assert torch.equal(m, m2), "a launch is a pure function of its seed"
+    assert not torch.equal(m, Fx.mim_masks(n, grid, num, meta["min_num"], "cuda", seed=987654322))
+    mf = m.float().view(n, grid, grid)
+    f_dev, f_ref = mf.mean(0).reshape(-1).cpu().numpy(), z["freq"] / n_ref
+    sigma = np.sqrt(f_ref * (1 - f_ref) * (1.0 / n + 1.0 / n_ref))
+    zmax = float(np.abs(f_dev - f_ref).max() / sigma.max()), float((np.abs(f_dev - f_ref) / sigma).max())
+    print("per-patch frequency: worst |z|", zmax)
+    assert zmax[1] < 5.0, zmax
+    c_delta = _chi2_two_sample(hist.cpu().numpy(), z["deltas"])
+    rows_dev = torch.bincount((mf.sum(2) > 0).sum(1).long(), minlength=grid + 1).cpu().numpy()
+    c_rows = _chi2_two_sample(rows_dev, z["rows"])
+    print("chi2/dof: accepted-block sizes", c_delta, " rows touched", c_rows)
+    assert c_delta < 2.0 and c_rows < 2.5, (c_delta, c_rows)
+    pair = np.array([float((mf[:, :, :-1] * mf[:, :, 1:]).mean()), float((mf[:, :-1, :] * mf[:, 1:, :]).mean()),
+                     float((mf[:, :-1, :-1] * mf[:, 1:, 1:]).mean())])
+    assert np.abs(pair - z["pair"]).max() < 3e-3, (pair, z["pair"])
+    # the model's generator object draws on the device and never repeats a batch
+    from xfm_amd.beit2 import BlockMaskGenerator
+    g = BlockMaskGenerator(14, 75, 16, seed=3)
+    a, b = g.batch(8, "cuda"), g.batch(8, "cuda")
+    assert a.is_cuda and a.dtype == torch.bool and bool((a.sum(1) == 75).all()) and not torch.equal(a, b)
+
+
 def test_hard_negative_sampler_and_mask_generator_are_valid_draws():
     from xfm_amd.beit2 import BlockMaskGenerator
     g = BlockMaskGenerator(14, 75, 16, seed=0)

@@ -327,3 +327,23 @@ def test_pretrain_step_full_depth():
     if not os.path.exists(os.path.join(GOLDEN, "pretrain_full.npz")):
         pytest.skip("pretrain_full.npz not generated")
     _pretrain("pretrain_full")
+
+
+def test_host_mim_mask_sampler_matches_the_reference_generators_distribution():
+    """xfm_amd.beit2.BlockMaskGenerator (the numpy sampler used off the GPU) against statistics of the REAL reference generator
+    (tests/golden/mim_mask_stats.npz, 50 000 draws of models/masking_generator.py): per-patch frequency and rows touched."""
+    from xfm_amd.beit2 import BlockMaskGenerator
+    z, meta = load("mim_mask_stats")
+    n, n_ref, grid = 4000, meta["n"], meta["grid"]
+    g = BlockMaskGenerator(grid, meta["num"], meta["min_num"], seed=11)
+    m = g.batch(n).numpy().astype(np.float64).reshape(n, grid, grid)
+    assert (m.sum((1, 2)) == meta["num"]).all()
+    f_dev, f_ref = m.mean(0).reshape(-1), z["freq"] / n_ref
+    sigma = np.sqrt(f_ref * (1 - f_ref) * (1.0 / n + 1.0 / n_ref))
+    assert float((np.abs(f_dev - f_ref) / sigma).max()) < 5.0
+    rows = np.bincount((m.sum(2) > 0).sum(1).astype(np.int64), minlength=grid + 1).astype(np.float64)
+    ref = z["rows"].astype(np.float64)
+    keep = (rows + ref) >= 40
+    ka, kb = np.sqrt(ref[keep].sum() / rows[keep].sum()), np.sqrt(rows[keep].sum() / ref[keep].sum())
+    chi = float((((ka * rows[keep] - kb * ref[keep]) ** 2) / (rows[keep] + ref[keep])).sum() / max(keep.sum() - 1, 1))
+    assert chi < 3.0, chi

@@ -32,3 +32,23 @@ e.record()
 torch.cuda.synchronize()
 print("bwd (dq + dkv) us", s.elapsed_time(e) / iters * 1e3)
 print("checksum", float(o.float().abs().sum()), float(dqkv.float().abs().sum()), float(dbias.abs().sum()))
+# single-pass delta (forward keeps o_lo)
+s.record()
+for it in range(iters):
+    o, lse, o_lo = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, 0.125, bias=bias, lo=True)
+e.record()
+torch.cuda.synchronize()
+print("fwd (+ o_lo) us", s.elapsed_time(e) / iters * 1e3)
+for ph, name in ((1, "dq alone"), (2, "dkv alone"), (0, "dq + dkv")):
+    for lo in (None, o_lo):
+        delta = None
+        if ph == 2:
+            delta = Fx.attn_bwd(dout, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                                B, H, N, N, 0.125, bias=bias, dbias=dbias, phase=1, o_lo=lo)
+        s.record()
+        for it in range(iters):
+            Fx.attn_bwd(dout, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                        B, H, N, N, 0.125, bias=bias, dbias=dbias, phase=ph, delta=delta, o_lo=lo)
+        e.record()
+        torch.cuda.synchronize()
+        print(f"bwd {name:10s} {'single-pass delta' if lo is not None else 'two-pass delta  '} us", s.elapsed_time(e) / iters * 1e3)

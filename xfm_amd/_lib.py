@@ -52,7 +52,7 @@ class AttnArgs(ctypes.Structure):
                 ("stat_ld", c_long), ("bias_t", c_void_p), ("bias_t_ld", c_long), ("kv_index", c_void_p),
                 ("grp_start", c_void_p), ("grp_rows", c_void_p), ("n_groups", c_int),
                 ("q_start", c_void_p), ("q_len", c_void_p), ("k_start", c_void_p), ("k_len", c_void_p),
-                ("bwd_phase", c_int)]
+                ("bwd_phase", c_int), ("o_lo", c_void_p)]
 
 
 class EmbedArgs(ctypes.Structure):
@@ -135,6 +135,7 @@ SIGNATURES = {
     "xfm_pool_rows_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xfm_mim_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xfm_mim_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "xfm_mim_masks": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
     "xfm_embed_ln_fwd": (c_int, [ctypes.POINTER(EmbedArgs), c_int, c_void_p]),
     "xfm_embed_ln_bwd_workspace": (c_long, [c_int, c_int]),
     "xfm_embed_ln_bwd": (c_int, [ctypes.POINTER(EmbedArgs), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long,

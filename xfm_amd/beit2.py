@@ -28,6 +28,7 @@ class BlockMaskGenerator:
         self.min_num = min_num_patches
         self.log_aspect = (math.log(min_aspect), math.log(1.0 / min_aspect))
         self.rng = np.random.default_rng(seed)
+        self._seed0 = 0 if seed is None else int(seed)
 
     def _one(self):
         rng, H, W = self.rng, self.h, self.w
@@ -61,12 +62,15 @@ class BlockMaskGenerator:
         return flat
 
     def batch(self, n, device=None):
-        """[n, h*w] bool.  With `device` the masks go up through pinned memory with a non-blocking copy, so the host thread
-        never waits for the GPU queue to drain (a pageable H2D copy is stream-ordered AND host-blocking)."""
-        m = torch.from_numpy(np.stack([self._one() for _ in range(n)], 0))
+        """[n, h*w] bool.  On a HIP device the masks are DRAWN there (csrc/elementwise.hip mim_masks_kernel: one wavefront per image
+        runs the same rejection loop with a counter-based generator; ~10 us for a batch instead of n Python rejection loops on the
+        thread that also enqueues the step's kernels, beit2.py:432-439 of the reference).  On the CPU: the numpy sampler."""
         if device is not None and torch.device(device).type == "cuda":
-            return m.pin_memory().to(device, non_blocking=True)
-        return m
+            self._draws = getattr(self, "_draws", 0) + 1
+            seed = ((torch.initial_seed() & 0xFFFFFFFF) << 32) | ((self._seed0 + self._draws) & 0xFFFFFFFF)
+            return Fx.mim_masks(n, self.h, self.num, self.min_num, device, seed, min_aspect=math.exp(self.log_aspect[0]),
+                                max_aspect=math.exp(self.log_aspect[1]))
+        return torch.from_numpy(np.stack([self._one() for _ in range(n)], 0))
 
 
 def build_relative_position_index(gh, gw):
@@ -176,7 +180,10 @@ class _TrunkFn(torch.autograd.Function):
             if rel_pos:
                 dense, dense_t = Fx.relpos_gather(blk.attn.relative_position_bias_table, vit._index32, H, N, ld, transposed=True)
             qkv = Fx.gemm_nt(y, s["qkv"].wb, s["qkv"].b)
-            ctxv, lse = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense)
+            if ctx.needs_input_grad[0] and _FAST_DELTA:
+                ctxv, lse, ctxv_lo = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, lo=True)
+            else:
+                (ctxv, lse), ctxv_lo = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense), None
             h1 = Fx.gemm_nt(ctxv, s["proj"].wb, s["proj"].b)
             dp1 = None if dp is None else dp[i, 0]
             dp2 = None if dp is None else dp[i, 1]
@@ -185,7 +192,7 @@ class _TrunkFn(torch.autograd.Function):
             h2 = Fx.gemm_nt(hact, s["fc2"].wb, s["fc2"].b)
             nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else final_norm
             x2, yn, meann, rstdn = Fx.ln_ls_fwd(x1, h2, g2, dp2, N, nxt.weight, nxt.bias, nxt.eps)
-            saved.append((y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t))
+            saved.append((y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t, ctxv_lo))
             x, y = x2, yn
         ctx.saved, ctx.vit, ctx.shape = saved, vit, (B, N, D)
         ctx.noted = bool(ctx.needs_input_grad[0])
@@ -212,7 +219,7 @@ class _TrunkFn(torch.autograd.Function):
         ddense_all = None
         for i in reversed(range(len(blocks))):
             blk, s = blocks[i], vit._slots[i]
-            (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t) = ctx.saved[i]
+            (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t, ctxv_lo) = ctx.saved[i]
             final_norm = vit._final_norm if hasattr(vit, "_final_norm") else vit.fc_norm
             nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else final_norm
             g = _g
@@ -237,7 +244,7 @@ class _TrunkFn(torch.autograd.Function):
                     ddense_all = torch.zeros((len(blocks),) + tuple(dense.shape), dtype=dense.dtype, device=dense.device)
                 ddense = ddense_all[i]
             Fx.attn_bwd(dctx, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ctxv, lse, dqkv[:, :D], dqkv[:, D:2 * D],
-                        dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense, bias_t=dense_t)
+                        dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense, bias_t=dense_t, o_lo=ctxv_lo)
             if dense is not None:
                 Fx.relpos_scatter_sorted(ddense, vit._relpos_order, vit._relpos_start, H, N, ld, g(blk.attn.relative_position_bias_table))
             wg.gemm_tn(dqkv, y, s["qkv"].dw, dbias=s["qkv"].db)
@@ -276,6 +283,10 @@ class _TokensFn(torch.autograd.Function):
         return dtok, None, None, None, None
 
 
+# XFM_ATTN_FAST_DELTA=1: the attention backward takes delta = dO . O from the forward's output (kept as bf16 hi + lo halves) instead of a
+# first pass over the keys: dQ kernel 198 -> 165 us, forward 69 -> 80 us at B = 128 (tools/bench_attn.py), the step unchanged within
+# noise (41.6 vs 41.5 ms, tools/ab.sh) -- off by default, the exact two-pass form costs nothing
+_FAST_DELTA = __import__("os").environ.get("XFM_ATTN_FAST_DELTA", "0") != "0"
 _GRAD_CHUNK_BLOCKS = 4  # the trunk's gradients leave for the all-reduce in chunks of this many blocks (12 blocks: 3 chunks)
 
 

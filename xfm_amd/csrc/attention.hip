@@ -162,6 +162,38 @@ __device__ __forceinline__ void load_bias(const AttnArgs& a, int h, int qc, int 
   }
 }
 
+// Output row of one lane: 4 consecutive columns per d-tile, normalised; o_lo (optional) takes the bf16 of what the bf16 of O lost.
+__device__ __forceinline__ void store_out(const AttnArgs& a, long row, int h, int lg, const f32x4 (&oacc)[4], float inv) {
+  bf16* op = a.o + row * a.o_rs + h * 64;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    bf16x4 ov, ol;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = oacc[dt][r] * inv;
+      ov[r] = f2bf(v);
+      ol[r] = f2bf(v - bf2f(ov[r]));
+    }
+    *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * lg) = ov;
+    if (a.o_lo != nullptr) *reinterpret_cast<bf16x4*>(a.o_lo + row * a.o_rs + h * 64 + dt * 16 + 4 * lg) = ol;
+  }
+}
+// delta_i = dO_i . (O_i + Olo_i) for the query row of lane (lg, lr): each of the 4 lanes sharing lr holds 16 of the 64 columns
+// (the two 8-column fragments it already loaded of dO), so the row sum is one group4_sum.
+__device__ __forceinline__ float delta_from_out(const AttnArgs& a, long row, int h, int lg, const bf16x8& df0, const bf16x8& df1) {
+  const bf16* op = a.o + row * a.o_rs + h * 64;
+  const bf16* lp = a.o_lo + row * a.o_rs + h * 64;
+  const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(op + 8 * lg), o1 = *reinterpret_cast<const bf16x8*>(op + 32 + 8 * lg);
+  const bf16x8 l0 = *reinterpret_cast<const bf16x8*>(lp + 8 * lg), l1 = *reinterpret_cast<const bf16x8*>(lp + 32 + 8 * lg);
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    t = fmaf(bf2f(df0[i]), bf2f(o0[i]) + bf2f(l0[i]), t);
+    t = fmaf(bf2f(df1[i]), bf2f(o1[i]) + bf2f(l1[i]), t);
+  }
+  return group4_sum(t);
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: grid (q blocks, H, B); block = NW waves, wave w owns query rows [qblk*16*NW + 16*w, +16)
 // ---------------------------------------------------------------------------------------------
@@ -277,15 +309,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnArgs a) {
     }
   }
   if (!wave_active || qi >= sq) return;
-  const float inv = 1.0f / l_run;
-  bf16* op = a.o + (qbase + qi) * a.o_rs + h * 64;
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    bf16x4 ov;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ov[r] = f2bf(oacc[dt][r] * inv);
-    *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * lg) = ov;
-  }
+  store_out(a, qbase + qi, h, lg, oacc, 1.0f / l_run);
   if (lg == 0) a.lse[((long)b * a.H + h) * a.stat_ld + qi] = m_run + __logf(l_run);
 }
 
@@ -401,18 +425,23 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
     // fp32 rounding (rowsum(dO*O) with a bf16-rounded O breaks it by ~2^-9 |dO||O| and swamps small dS)
     float delta = 0.f;
     f32x4 st[4], dp[4];
-    if (!resident) stream_first();
-    for (int kc = 0; kc < nchunks; ++kc) {
-      if (!resident) stream_next(kc);
-      if (wave_active) {
-        probs(kc, st, dp);
+    const bool fast_delta = a.o_lo != nullptr;  // delta = dO . (O + Olo): no first pass over the keys (uniform over the launch)
+    if (fast_delta) {
+      delta = delta_from_out(a, qbase + qc, h, lg, df0, df1);
+    } else {
+      if (!resident) stream_first();
+      for (int kc = 0; kc < nchunks; ++kc) {
+        if (!resident) stream_next(kc);
+        if (wave_active) {
+          probs(kc, st, dp);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+          for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) delta += st[t][r] * dp[t][r];
+            for (int r = 0; r < 4; ++r) delta += st[t][r] * dp[t][r];
+        }
       }
+      delta = group4_sum(delta);
     }
-    delta = group4_sum(delta);
     if (wave_active && qvalid && lg == 0) a.delta[stat_idx] = delta;
 
     f32x4 dqacc[4];
@@ -420,9 +449,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
     for (int i = 0; i < 4; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // pass 2: dS, dbias, dQ   (a single-chunk problem keeps pass 1's registers and its staged tile)
-    if (!resident && nchunks > 1) stream_first();
+    if (!resident && (nchunks > 1 || fast_delta)) stream_first();
     for (int kc = 0; kc < nchunks; ++kc) {
-      if (nchunks > 1) {
+      if (nchunks > 1 || fast_delta) {
         if (!resident) stream_next(kc);
         if (wave_active) probs(kc, st, dp);
       }
@@ -766,15 +795,7 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
       }
     }
     if (qi < sq) {
-      const float inv = 1.0f / l_run;
-      bf16* op = a.o + (qbase + qi) * a.o_rs + h * 64;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 ov;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = f2bf(oacc[dt][r] * inv);
-        *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * lg) = ov;
-      }
+      store_out(a, qbase + qi, h, lg, oacc, 1.0f / l_run);
       if (lg == 0) a.lse[((long)b * a.H + h) * a.stat_ld + qi] = m_run + __logf(l_run);
     }
   }
@@ -844,20 +865,25 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
     };
     float delta = 0.f;
     f32x4 st[4], dp[4];
-    for (int kc = 0; kc < nchunks; ++kc) {
-      probs(kc, st, dp);
+    const bool fast_delta = a.o_lo != nullptr;
+    if (fast_delta) {
+      delta = delta_from_out(a, qbase + qc, h, lg, df0, df1);
+    } else {
+      for (int kc = 0; kc < nchunks; ++kc) {
+        probs(kc, st, dp);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) delta += st[t][r] * dp[t][r];
+          for (int r = 0; r < 4; ++r) delta += st[t][r] * dp[t][r];
+      }
+      delta = group4_sum(delta);
     }
-    delta = group4_sum(delta);
     if (qvalid && lg == 0) a.delta[stat_idx] = delta;
     f32x4 dqacc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kc = 0; kc < nchunks; ++kc) {
-      if (nchunks > 1) probs(kc, st, dp);
+      if (nchunks > 1 || fast_delta) probs(kc, st, dp);
       const char* sK = lds + kc * ATTN_SLOT;
 #pragma unroll
       for (int t = 0; t < 4; ++t)

@@ -154,6 +154,11 @@ int xfm_mim_loss_bwd(const xfm_bf16* x, const xfm_bf16* t, const uint8_t* mask, 
   return xfm_mim_loss_bwd_impl(x, t, mask, sums, gout, cls_term, B, N, D, dx, ST(stream));
 }
 
+int xfm_mim_masks(int B, int GH, int GW, int num, int min_num, float min_aspect, float max_aspect, uint64_t seed, uint8_t* out,
+                  int* delta_hist, void* stream) {
+  XFM_REQUIRE(out != nullptr, "mim_masks: null output");
+  return xfm_mim_masks_impl(B, GH, GW, num, min_num, min_aspect, max_aspect, seed, out, delta_hist, ST(stream));
+}
 int xfm_embed_ln_fwd(const xfm_embed_args* a, int D, void* stream) {
   NOTNULL(a, "embed_ln_fwd");
   XFM_REQUIRE(a->ids && a->word && a->pos && a->type && a->w && a->b && a->y && a->mean && a->rstd && a->pos_ids,

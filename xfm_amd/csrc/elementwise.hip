@@ -646,3 +646,97 @@ int xfm_rows_scatter_add_impl(const bf16* src, const int* index, int R, int D, f
   hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(cdiv((long)R * (D >> 3), 256)), dim3(256), 0, st, src, index, R, D, dst);
   return xfm_check_launch("rows_scatter_add");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Block-wise MIM mask sampler on the device (masking_generator.py:27-105 of the reference: MaskingGenerator.__call__ / _mask).
+// The reference draws every image's mask with Python `random` on the host, B times per step (beit2.py:432-439); here one wavefront
+// owns one image and runs the same rejection loop with a counter-based generator (every draw is a pure function of (seed, image,
+// draw index), so a launch is reproducible): rectangles of area U[min, remaining] and log-uniform aspect in [lo, hi], at most ten
+// attempts per block, accepted when they add between 1 and `remaining` new patches; then the uniform top-up to exactly `num`.
+// The patch grid lives in registers, lane l holding patches l, l + 64, ... ; counting a rectangle's overlap is a ballot + popcount.
+// delta_hist (optional, int32 [H*W + 1]): histogram of the new patches each accepted block added (the distribution pin of the tests).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mim_u01(uint32_t seed_lo, uint32_t seed_hi, uint32_t img, uint32_t& ctr) {
+  const uint32_t key = rng_row_key(seed_lo, seed_hi, img);
+  const uint32_t r = rng_u32(key, ctr++);
+  return (float)(r >> 8) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void mim_masks_kernel(int B, int GH, int GW, int num, int min_num, float log_lo, float log_hi,
+                                                         uint32_t seed_lo, uint32_t seed_hi, uint8_t* __restrict__ out,
+                                                         int* __restrict__ delta_hist) {
+  const int lane = threadIdx.x & 63;
+  const int img = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (img >= B) return;  // whole waves leave together
+  const int P = GH * GW;
+  constexpr int MAXW = 16;  // up to 1024 patches (32 x 32 grid)
+  bool m[MAXW];
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) m[i] = false;
+  uint32_t ctr = 0;
+  int count = 0;
+  while (count < num) {
+    const int maxp = num - count;
+    int delta = 0;
+    for (int attempt = 0; attempt < 10 && delta == 0; ++attempt) {
+      const float area = (float)min_num + ((float)maxp - (float)min_num) * mim_u01(seed_lo, seed_hi, img, ctr);
+      const float ar = __expf(log_lo + (log_hi - log_lo) * mim_u01(seed_lo, seed_hi, img, ctr));
+      const int h = (int)rintf(sqrtf(area * ar)), w = (int)rintf(sqrtf(area / ar));
+      // (the two position draws are consumed whether or not the rectangle fits, so the stream stays aligned per attempt)
+      const float ut = mim_u01(seed_lo, seed_hi, img, ctr), ul = mim_u01(seed_lo, seed_hi, img, ctr);
+      if (!(w < GW && h < GH)) continue;
+      int top = (int)(ut * (float)(GH - h + 1)), left = (int)(ul * (float)(GW - w + 1));
+      top = top > GH - h ? GH - h : top;
+      left = left > GW - w ? GW - w : left;
+      int masked = 0;
+      bool in[MAXW];
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i) {
+        const int p = i * 64 + lane, y = p / GW, x = p - y * GW;
+        in[i] = p < P && y >= top && y < top + h && x >= left && x < left + w;
+        masked += __popcll(__ballot(in[i] && m[i]));
+      }
+      const int fresh = h * w - masked;
+      if (fresh > 0 && fresh <= maxp) {
+#pragma unroll
+        for (int i = 0; i < MAXW; ++i) m[i] = m[i] || in[i];
+        delta = fresh;
+      }
+    }
+    if (delta == 0) break;
+    count += delta;
+    if (delta_hist != nullptr && lane == 0) atomicAdd(delta_hist + delta, 1);
+  }
+  // top-up: `num - count` of the free patches, uniformly without replacement (np.random.choice(..., replace=False))
+  int nfree = P - count;
+  while (count < num) {
+    int r = (int)(mim_u01(seed_lo, seed_hi, img, ctr) * (float)nfree);
+    r = r >= nfree ? nfree - 1 : r;
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) {
+      const int p = i * 64 + lane;
+      const bool fr = p < P && !m[i];
+      const unsigned long long bal = __ballot(fr);
+      const int before = __popcll(bal & ((1ull << lane) - 1ull));
+      const int tot = __popcll(bal);
+      if (r >= 0 && r < tot && fr && before == r) m[i] = true;
+      r -= tot;  // (negative once the patch was found in an earlier word: no later word matches)
+    }
+    ++count;
+    --nfree;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int p = i * 64 + lane;
+    if (p < P) out[(long)img * P + p] = m[i] ? 1 : 0;
+  }
+}
+
+int xfm_mim_masks_impl(int B, int GH, int GW, int num, int min_num, float min_aspect, float max_aspect, uint64_t seed, uint8_t* out,
+                       int* delta_hist, hipStream_t st) {
+  XFM_REQUIRE(B > 0 && GH > 0 && GW > 0 && GH * GW <= 1024 && num >= 0 && num <= GH * GW && min_num >= 0, "mim_masks: bad geometry");
+  XFM_REQUIRE(min_aspect > 0.f && max_aspect >= min_aspect, "mim_masks: bad aspect range");
+  hipLaunchKernelGGL(mim_masks_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, B, GH, GW, num, min_num, logf(min_aspect), logf(max_aspect),
+                     (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), out, delta_hist);
+  return xfm_check_launch("mim_masks");
+}

@@ -268,7 +268,7 @@ def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, dro
 
 
 def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0), kv_index=None, groups=None,
-             q_pack=None, k_pack=None, zero_fill=True):
+             q_pack=None, k_pack=None, zero_fill=True, lo=False):
     """q [B*Sq, >=H*64] / k, v [B*Sk, ...] are 2-D (possibly strided column slices of fused projection buffers).
     bias: dense fp32 [H,Sq,ld]; key_keep: int32 [B,Sk].  Returns (o [B*Sq, H*64] bf16, lse [B,H,Sq]).
     groups = kv_groups(...): grouped mode, k / v / key_keep hold one entry per SOURCE."""
@@ -283,12 +283,16 @@ def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=Fals
         assert key_keep.dtype == torch.int32 and key_keep.is_contiguous()
     a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, kv_index=kv_index, groups=groups,
                    q_pack=q_pack, k_pack=k_pack)
+    o_lo = None
+    if lo:  # second half of the output (what bf16 rounding of O lost): lets the backward skip its first pass over the keys
+        o_lo = torch.empty_like(o)
+        a.o_lo = o_lo.data_ptr()
     check(_lib.load().xfm_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
-    return o, lse
+    return (o, lse, o_lo) if lo else (o, lse)
 
 
 def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, dbias=None, key_keep=None, causal=False,
-             drop=(0, 1.0, 0, 0), bias_t=None, kv_index=None, groups=None, q_pack=None, k_pack=None, phase=0, delta=None):
+             drop=(0, 1.0, 0, 0), bias_t=None, kv_index=None, groups=None, q_pack=None, k_pack=None, phase=0, delta=None, o_lo=None):
     """Writes dq/dk/dv (2-D bf16 views with the same addressing convention as q/k/v); dbias (fp32 [H,Sq,ld]) += .
     Grouped mode: dk/dv are per SOURCE ([n_groups*Sk] rows), summed over each group's rows.
     Packed rows: only the rows of real tokens are written -- pass zero-initialised dq (/ dk / dv).
@@ -298,6 +302,9 @@ def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, 
         assert phase != 2, "phase 2 needs the row statistics of the phase-1 call"
         delta = torch.empty((B, H, lse.shape[-1]), dtype=F32, device=q.device)  # the kernels never use its padding entries
     a.bwd_phase = phase
+    if o_lo is not None:  # delta from dO . (o + o_lo): the dQ kernel runs one pass over the keys instead of two
+        assert o_lo.shape == o.shape and o_lo.stride() == o.stride() and o_lo.dtype == BF16
+        a.o_lo = o_lo.data_ptr()
     assert dout.dtype == BF16 and dout.stride(-1) == 1
     a.dout, a.do_rs = dout.data_ptr(), dout.stride(0)
     a.dq, a.dq_rs = dq.data_ptr(), dq.stride(0)
@@ -391,6 +398,14 @@ def mim_loss_bwd(x, t, mask, sums, gout, cls_term):
     check(_lib.load().xfm_mim_loss_bwd(x.data_ptr(), t.data_ptr(), mask.data_ptr(), sums.data_ptr(), gout.data_ptr(), int(cls_term), B, N, D,
                                        dx.data_ptr(), _stream()), "mim_loss_bwd")
     return dx
+
+
+def mim_masks(B, grid, num, min_num, device, seed, min_aspect=0.3, max_aspect=None, delta_hist=None):
+    """[B, grid*grid] bool block-wise MIM masks drawn on the device (masking_generator.py:27-105), exactly `num` patches each."""
+    out = torch.empty((B, grid * grid), dtype=torch.uint8, device=device)
+    check(_lib.load().xfm_mim_masks(B, grid, grid, num, min_num, float(min_aspect), float(max_aspect or 1.0 / min_aspect), int(seed),
+                                    out.data_ptr(), _ptr(delta_hist), _stream()), "mim_masks")
+    return out.view(torch.bool)
 
 
 def patchify(image, patch):
