@@ -102,6 +102,7 @@ typedef struct {
   int rows, rows_per_sample;
   float eps;
   uint32_t drop_thresh; float drop_scale; uint32_t seed_lo, seed_hi;  /* POST: dropout on h (thresh = p * 2^32) */
+  int gelu;                /* y = GELU(LN(..)): the Linear -> LayerNorm -> GELU heads (xfm.py:115-121, model_classification.py:33-48) */
 } xfm_ln_fwd_args;
 
 typedef struct {
@@ -115,6 +116,8 @@ typedef struct {
   float* partial;                                                /* set by the library (workspace) */
   int rows, rows_per_sample;
   uint32_t drop_thresh; float drop_scale; uint32_t seed_lo, seed_hi;
+  const float* gelu_b;     /* non-NULL: the forward applied GELU after the affine; this is the LayerNorm bias (the pre-activation
+                              xhat * w + b is rebuilt and dy is multiplied by gelu'(.) first) */
 } xfm_ln_bwd_args;
 
 int xfm_layernorm_fwd(const xfm_ln_fwd_args* a, int D, int mode, void* stream);
@@ -300,6 +303,22 @@ int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, 
                       xfm_rlayer_layout_t* out);
 int xfm_rlayer_fwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, void* stream);
 int xfm_rlayer_bwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, const xfm_rlayer_bwd_args* b, void* stream);
+
+/* ---- Contrastive / matching glue of XFMBase (xfm.py:614-621, 683-746) as a handful of small kernels instead of a few dozen ATen
+ * launches (matmul through the vendor BLAS, softmax, nll_loss, fills, multinomial):
+ *   rownorm      y = x / max(|x|_2, 1e-12) per row (F.normalize, xfm.py:617-620), fp32 [R, E], E % 64 == 0, E <= 1024; inv = 1 / norm
+ *   itc          logits = I . T^T / temp over N gathered rows; loss = (CE(logits, arange) + CE(logits^T, arange)) / 2 (xfm.py:699-703);
+ *                fwd: lse [2N] (rows of logits, then rows of logits^T), loss_sum[0] += the loss; bwd: dI, dT (fully written) and
+ *                dtemp[0] += for the upstream gradient g[0]
+ *   hard_neg     per row of the LOCAL batch: softmax(sim / temp) + 1e-5, own entry zeroed, ONE categorical draw (xfm.py:727-744:
+ *                torch.multinomial(...).item() per row on the host there); text_neg[i] for image i, image_neg[j] for text j  -------- */
+int xfm_rownorm_fwd(const float* x, int R, int E, float* y, float* inv, void* stream);
+int xfm_rownorm_bwd(const float* dy, const float* y, const float* inv, int R, int E, float* dx, void* stream);
+int xfm_itc_fwd(const float* I, const float* T, const float* temp, int N, int E, float* lse, float* loss_sum, void* stream);
+int xfm_itc_bwd(const float* I, const float* T, const float* temp, const float* lse, const float* g, int N, int E, float* dI, float* dT,
+                float* dtemp, void* stream);
+int xfm_hard_negatives(const float* I, const float* T, const float* temp, int B, int E, uint64_t seed, int64_t* image_neg,
+                       int64_t* text_neg, void* stream);
 
 /* ---- Vocabulary cross-entropy, ignore_index -100 (xroberta.py:1296-1297, 1107-1114) ------------------------------ */
 int xfm_ce_fwd(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, void* stream);

@@ -726,3 +726,116 @@ def test_gemm_nt_split_k_accumulate():
     Fx.gemm_nt(a, b, bias, epi=Fx.EPI_F32_ACC, out=c)
     ref = a.float() @ b.float().t() + bias + 2.0
     _close(c, ref, 1e-4, "split-K fp32 accumulate")
+
+
+# ---- contrastive / matching glue (xfm.py:614-621, 683-746) ---------------------------------------------------------------------
+@pytest.mark.parametrize("R,E", [(64, 256), (7, 768), (300, 64)])
+def test_rownorm_matches_normalize(R, E):
+    from xfm_amd.ops import row_normalize
+    x = _rand((R, E), 3.0, F32, seed=1).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    dy = _rand((R, E), 1.0, F32, seed=2)
+    y = row_normalize(x)
+    ref = torch.nn.functional.normalize(xr, dim=-1)
+    y.backward(dy)
+    ref.backward(dy)
+    _close(y, ref, 1e-6, "normalize")
+    _close(x.grad, xr.grad, 1e-5, "normalize backward")
+
+
+@pytest.mark.parametrize("N,E", [(64, 256), (5, 256), (512, 256), (130, 128)])
+@pytest.mark.parametrize("temp", [0.07, 0.5])
+def test_itc_loss_matches_two_cross_entropies(N, E, temp):
+    """fp32 in, fp32 out: 1e-5 relative on the loss, 1e-4 of max |grad| on the gradients (fast-math exp / log in the kernel)."""
+    from xfm_amd.ops import itc_loss
+    F = torch.nn.functional
+    I = F.normalize(_rand((N, E), 1.0, F32, seed=1), dim=-1).requires_grad_(True)
+    T = F.normalize(_rand((N, E), 1.0, F32, seed=2) + 0.5 * I.detach(), dim=-1).requires_grad_(True)
+    t = torch.tensor(temp, device="cuda", requires_grad=True)
+    Ir, Tr, tr = (v.detach().double().requires_grad_(True) for v in (I, T, t))
+    loss = itc_loss(I, T, t)
+    logits = Ir @ Tr.t() / tr
+    labels = torch.arange(N, device="cuda")
+    ref = (F.cross_entropy(logits, labels) + F.cross_entropy(logits.t(), labels)) / 2
+    (loss * 1.7).backward()
+    (ref * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(abs(float(ref)), 1.0)
+    _close(I.grad, Ir.grad, 1e-4, "d image_feat")
+    _close(T.grad, Tr.grad, 1e-4, "d text_feat")
+    assert t.grad.shape == t.shape
+    assert abs(float(t.grad) - float(tr.grad)) <= 1e-4 * max(abs(float(tr.grad)), 1e-3)
+
+
+def test_hard_negative_draws_follow_the_reference_weights():
+    """Frequencies of 4000 draws per row against softmax(sim / temp) + 1e-5 with the own entry zeroed (xfm.py:727-744); never the
+    own index; chi-square per row at p = 1e-4 (df = B - 2) with the 1e-5 floor entries pooled."""
+    Fx = _fx()
+    F = torch.nn.functional
+    B, E, draws = 8, 256, 4000
+    I = F.normalize(_rand((B, E), 1.0, F32, seed=3), dim=-1)
+    T = F.normalize(_rand((B, E), 1.0, F32, seed=4) + 0.3 * I, dim=-1)
+    temp = torch.tensor([0.25], device="cuda")
+    sim = I @ T.t() / temp
+    w_i2t = F.softmax(sim, dim=1) + 1e-5
+    w_t2i = F.softmax(sim.t(), dim=1) + 1e-5
+    w_i2t.fill_diagonal_(0)
+    w_t2i.fill_diagonal_(0)
+    cnt_t = torch.zeros(B, B, device="cuda")   # text negatives of image i
+    cnt_i = torch.zeros(B, B, device="cuda")   # image negatives of text j
+    ar = torch.arange(B, device="cuda")
+    for s in range(draws):
+        im, tx = Fx.hard_negatives(I, T, temp, (1234 << 32) | s)
+        cnt_i[ar, im] += 1
+        cnt_t[ar, tx] += 1
+    for cnt, w in ((cnt_t, w_i2t), (cnt_i, w_t2i)):
+        assert float(cnt.diagonal().sum()) == 0, "a row drew itself"
+        p = (w / w.sum(1, keepdim=True)).double().cpu()
+        c = cnt.double().cpu()
+        for r in range(B):
+            keep = p[r] * draws >= 5
+            exp = torch.cat([p[r][keep] * draws, (p[r][~keep].sum() * draws).reshape(1)])
+            obs = torch.cat([c[r][keep], c[r][~keep].sum().reshape(1)])
+            m = exp > 0
+            chi2 = float((((obs - exp) ** 2)[m] / exp[m]).sum())
+            assert chi2 < 40.0, f"row {r}: chi2 = {chi2:.1f} over {int(m.sum())} cells"   # chi2(7) at 1e-4 is 29.9
+    # same seed, same draw
+    a = Fx.hard_negatives(I, T, temp, 99)
+    b = Fx.hard_negatives(I, T, temp, 99)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("rows,D", [(24, 1536), (8, 3072), (8, 6144), (100, 768)])
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_layernorm_gelu_head(rows, D, dtype):
+    """GELU(LayerNorm(x)) in one kernel against torch (the Linear -> LayerNorm -> GELU heads, xfm.py:115-121); output bf16."""
+    Fx = _fx()
+    x = _rand((rows, D), 2.0, dtype, seed=1)
+    w, b = _rand((D,), 1.0, F32, seed=2), _rand((D,), 0.5, F32, seed=3)
+    dy = _rand((rows, D), 1.0, BF16, seed=4)
+    y, mean, rstd = Fx.ln_fwd(x, w, b, 1e-5, gelu=True)
+    xr = x.float().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-5))
+    ref.backward(dy.float())
+    _close(y, ref, 6e-3, "ln+gelu fwd")
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx = torch.empty((rows, D), dtype=dtype, device="cuda")
+    Fx.ln_bwd(dy, x, mean, rstd, w, dg, db, gelu_b=b, **({"dx32": dx} if dtype == F32 else {"dx16": dx}))
+    _close(dx, xr.grad, 1e-2, "ln+gelu dx")
+    _close(dg, wr.grad, 5e-3, "ln+gelu dgamma")
+    _close(db, br.grad, 5e-3, "ln+gelu dbeta")
+
+
+@pytest.mark.parametrize("R,C", [(192, 2), (24, 1000), (5, 3)])
+def test_small_ce_matches_cross_entropy(R, C):
+    from xfm_amd.ops import small_ce
+    x = _rand((R, C), 2.0, F32, seed=1).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    g = torch.Generator().manual_seed(5)
+    labels = torch.randint(0, C, (R,), generator=g).cuda()
+    loss = small_ce(x, labels)
+    ref = torch.nn.functional.cross_entropy(xr, labels)
+    (loss * 3).backward()
+    (ref * 3).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(abs(float(ref)), 1.0)
+    _close(x.grad, xr.grad, 8e-3, "ce dlogits (stored as bf16)")

@@ -23,7 +23,7 @@ class LnFwdArgs(ctypes.Structure):
                 ("row_scale", c_void_p), ("w", c_void_p), ("b", c_void_p), ("x_out", c_void_p), ("z_out", c_void_p),
                 ("y", c_void_p), ("y32", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
                 ("rows", c_int), ("rows_per_sample", c_int), ("eps", c_float),
-                ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32)]
+                ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32), ("gelu", c_int)]
 
 
 class LnBwdArgs(ctypes.Structure):
@@ -33,7 +33,7 @@ class LnBwdArgs(ctypes.Structure):
                 ("dh", c_void_p), ("dres", c_void_p), ("dstream", c_void_p),
                 ("h", c_void_p), ("ls_gamma", c_void_p), ("row_scale", c_void_p), ("partial", c_void_p),
                 ("rows", c_int), ("rows_per_sample", c_int),
-                ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32)]
+                ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32), ("gelu_b", c_void_p)]
 
 
 class CastItem(ctypes.Structure):
@@ -147,6 +147,11 @@ SIGNATURES = {
     "xfm_rlayer_layout": (c_int, [c_int] * 11 + [ctypes.POINTER(RLayerLayout)]),
     "xfm_rlayer_fwd": (c_int, [ctypes.POINTER(RLayerParams), ctypes.POINTER(RLayerIO), c_void_p]),
     "xfm_rlayer_bwd": (c_int, [ctypes.POINTER(RLayerParams), ctypes.POINTER(RLayerIO), ctypes.POINTER(RLayerBwd), c_void_p]),
+    "xfm_rownorm_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "xfm_rownorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "xfm_itc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "xfm_itc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xfm_hard_negatives": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
     "xfm_rows_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "xfm_rows_scatter_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }

@@ -28,6 +28,7 @@ int xfm_check_launch(const char* what) {
 #include "attention.hip"
 #include "elementwise.hip"
 #include "encoder.hip"
+#include "losses.hip"
 
 #define ST(s) ((hipStream_t)(s))
 #define NOTNULL(p, name) XFM_REQUIRE((p) != nullptr, "%s: null argument struct", name)
@@ -194,6 +195,29 @@ int xfm_rlayer_fwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, void* st
 int xfm_rlayer_bwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, const xfm_rlayer_bwd_args* b, void* stream) {
   XFM_REQUIRE(p != nullptr && io != nullptr && b != nullptr, "rlayer_bwd: null argument struct");
   return xfm_rlayer_bwd_impl(*p, *io, *b, ST(stream));
+}
+
+int xfm_rownorm_fwd(const float* x, int R, int E, float* y, float* inv, void* stream) {
+  XFM_REQUIRE(x && y && inv, "rownorm_fwd: null operand");
+  return xfm_rownorm_fwd_impl(x, R, E, y, inv, ST(stream));
+}
+int xfm_rownorm_bwd(const float* dy, const float* y, const float* inv, int R, int E, float* dx, void* stream) {
+  XFM_REQUIRE(dy && y && inv && dx, "rownorm_bwd: null operand");
+  return xfm_rownorm_bwd_impl(dy, y, inv, R, E, dx, ST(stream));
+}
+int xfm_itc_fwd(const float* I, const float* T, const float* temp, int N, int E, float* lse, float* loss_sum, void* stream) {
+  XFM_REQUIRE(I && T && temp && lse && loss_sum, "itc_fwd: null operand");
+  return xfm_itc_fwd_impl(I, T, temp, N, E, lse, loss_sum, ST(stream));
+}
+int xfm_itc_bwd(const float* I, const float* T, const float* temp, const float* lse, const float* g, int N, int E, float* dI, float* dT,
+                float* dtemp, void* stream) {
+  XFM_REQUIRE(I && T && temp && lse && g && dI && dT && dtemp, "itc_bwd: null operand");
+  return xfm_itc_bwd_impl(I, T, temp, lse, g, N, E, dI, dT, dtemp, ST(stream));
+}
+int xfm_hard_negatives(const float* I, const float* T, const float* temp, int B, int E, uint64_t seed, int64_t* image_neg,
+                       int64_t* text_neg, void* stream) {
+  XFM_REQUIRE(I && T && temp && image_neg && text_neg, "hard_negatives: null operand");
+  return xfm_hard_negatives_impl(I, T, temp, B, E, seed, image_neg, text_neg, ST(stream));
 }
 
 int xfm_ce_fwd(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, void* stream) {

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 }
 
 int xfm_ce_fwd_impl(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, hipStream_t st) {
-  XFM_REQUIRE(R > 0 && V > 0 && ld >= V && ld % 4 == 0, "ce_fwd: bad shape R=%d V=%d ld=%ld", R, V, ld);
+  XFM_REQUIRE(R > 0 && V > 0 && ld >= V && (ld % 4 == 0 || V < 4), "ce_fwd: bad shape R=%d V=%d ld=%ld", R, V, ld);
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(R), dim3(256), 0, st, logits, ld, V, labels, lse, loss);
   return xfm_check_launch("ce_fwd");
 }

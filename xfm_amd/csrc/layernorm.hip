@@ -93,7 +93,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
       bf16x4 o;
       f32x4 o32;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { o32[j] = (v[i][j] - mu) * rstd * wv[i][j] + bv[i][j]; o[j] = f2bf(o32[j]); }
+      for (int j = 0; j < 4; ++j) {
+        o32[j] = (v[i][j] - mu) * rstd * wv[i][j] + bv[i][j];
+        if (p.gelu) o32[j] = gelu_f(o32[j]);
+        o[j] = f2bf(o32[j]);
+      }
       *reinterpret_cast<bf16x4*>(p.y + base + e) = o;
       if (p.y32 != nullptr) *reinterpret_cast<f32x4*>(p.y32 + base + e) = o32;
     }
@@ -145,7 +149,11 @@ __global__ __launch_bounds__(256) void ln_wide_fwd_kernel(LnFwd p, int D) {
     const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + e), b = *reinterpret_cast<const f32x4*>(p.b + e);
     bf16x4 o;
     f32x4 o32;
-    for (int j = 0; j < 4; ++j) { o32[j] = (v[i][j] - mu) * rstd * w[j] + b[j]; o[j] = f2bf(o32[j]); }
+    for (int j = 0; j < 4; ++j) {
+      o32[j] = (v[i][j] - mu) * rstd * w[j] + b[j];
+      if (p.gelu) o32[j] = gelu_f(o32[j]);
+      o[j] = f2bf(o32[j]);
+    }
     if (p.y != nullptr) *reinterpret_cast<bf16x4*>(p.y + base + e) = o;
     if (p.y32 != nullptr) *reinterpret_cast<f32x4*>(p.y32 + base + e) = o32;
   }
@@ -242,6 +250,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
         const bf16x4 xv = *reinterpret_cast<const bf16x4*>(p.x16 + base + e);
 #pragma unroll
         for (int j = 0; j < 4; ++j) xh[i][j] = (bf2f(xv[j]) - mu) * rstd;
+      }
+      if (p.gelu_b != nullptr) {  // the forward output was GELU(xhat * w + b): back through the activation first
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.gelu_b + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dy[i][j] *= gelu_grad_f(fmaf(xh[i][j], wv[i][j], bb[j]));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -404,6 +417,10 @@ __global__ __launch_bounds__(256) void ln_wide_bwd_kernel(LnBwd p, int D, float*
     } else {
       const bf16x4 x = *reinterpret_cast<const bf16x4*>(p.x16 + base + e);
       for (int j = 0; j < 4; ++j) xh[i][j] = (bf2f(x[j]) - mu) * rstd;
+    }
+    if (p.gelu_b != nullptr) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.gelu_b + e);
+      for (int j = 0; j < 4; ++j) dy[i][j] *= gelu_grad_f(fmaf(xh[i][j], w[j], bb[j]));
     }
     for (int j = 0; j < 4; ++j) {
       const float gw = dy[i][j] * w[j];

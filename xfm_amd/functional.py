@@ -135,15 +135,16 @@ def _ln_out(rows, D, device):
             torch.empty(rows, dtype=F32, device=device))
 
 
-def ln_fwd(x, w, b, eps, y32=False):
-    """PLAIN: x [rows, D] fp32 or bf16 -> (y bf16, mean, rstd[, y fp32])."""
+def ln_fwd(x, w, b, eps, y32=False, gelu=False):
+    """PLAIN: x [rows, D] fp32 or bf16 -> (y bf16, mean, rstd[, y fp32]); gelu: y = GELU(LN(x))."""
     _dev(x)
     rows, D = x.shape
     assert x.is_contiguous()
     y, mean, rstd = _ln_out(rows, D, x.device)
     yf = torch.empty((rows, D), dtype=F32, device=x.device) if y32 else None
     a = LnFwdArgs(x32=_ptr(x) if x.dtype == F32 else 0, x16=_ptr(x) if x.dtype == BF16 else 0, w=w.data_ptr(), b=b.data_ptr(),
-                  y=y.data_ptr(), y32=_ptr(yf), mean=mean.data_ptr(), rstd=rstd.data_ptr(), rows=rows, rows_per_sample=1, eps=eps)
+                  y=y.data_ptr(), y32=_ptr(yf), mean=mean.data_ptr(), rstd=rstd.data_ptr(), rows=rows, rows_per_sample=1, eps=eps,
+                  gelu=int(gelu))
     check(_lib.load().xfm_layernorm_fwd(ctypes.byref(a), D, LN_PLAIN, _stream()), "layernorm_fwd")
     return (y, mean, rstd, yf) if y32 else (y, mean, rstd)
 
@@ -185,12 +186,13 @@ def _ln_bwd_call(a, D, mode, dgamma, dbeta, dbias, dls, device):
                                 ws.numel() * 4, _stream()), "layernorm_bwd")
 
 
-def ln_bwd(dy, x, mean, rstd, w, dgamma, dbeta, dy2=None, dy32=None, dx32=None, dx16=None, dx_accum=False):
-    """PLAIN backward: writes dx32 (optionally accumulating) and/or dx16; dgamma/dbeta += ."""
+def ln_bwd(dy, x, mean, rstd, w, dgamma, dbeta, dy2=None, dy32=None, dx32=None, dx16=None, dx_accum=False, gelu_b=None):
+    """PLAIN backward: writes dx32 (optionally accumulating) and/or dx16; dgamma/dbeta += .  gelu_b: the LayerNorm bias when the
+    forward ran with gelu=True (dy is then the gradient of the activated output)."""
     rows, D = x.shape
     a = LnBwdArgs(dy1=dy.data_ptr(), dy2=_ptr(dy2), dy32=_ptr(dy32), x32=_ptr(x) if x.dtype == F32 else 0,
                   x16=_ptr(x) if x.dtype == BF16 else 0, mean=mean.data_ptr(), rstd=rstd.data_ptr(), w=w.data_ptr(),
-                  dx32=_ptr(dx32), dx16=_ptr(dx16), dx_accum=int(dx_accum), rows=rows, rows_per_sample=1)
+                  dx32=_ptr(dx32), dx16=_ptr(dx16), dx_accum=int(dx_accum), rows=rows, rows_per_sample=1, gelu_b=_ptr(gelu_b))
     _ln_bwd_call(a, D, LN_PLAIN, dgamma, dbeta, None, None, x.device)
 
 
@@ -478,6 +480,59 @@ def rows_scatter_add(src, index, dst32):
     check(_lib.load().xfm_rows_scatter_add(src.data_ptr(), index.data_ptr(), src.shape[0], src.shape[1], dst32.data_ptr(), _stream()),
           "rows_scatter_add")
     return dst32
+
+
+def rownorm_fwd(x):
+    """F.normalize(x, dim=-1) on fp32 rows -> (y, 1 / max(norm, 1e-12))."""
+    _dev(x)
+    assert x.dtype == F32 and x.dim() == 2 and x.is_contiguous()
+    y = torch.empty_like(x)
+    inv = torch.empty(x.shape[0], dtype=F32, device=x.device)
+    check(_lib.load().xfm_rownorm_fwd(x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), inv.data_ptr(), _stream()), "rownorm_fwd")
+    return y, inv
+
+
+def rownorm_bwd(dy, y, inv):
+    assert dy.dtype == F32 and dy.is_contiguous() and dy.shape == y.shape
+    dx = torch.empty_like(y)
+    check(_lib.load().xfm_rownorm_bwd(dy.data_ptr(), y.data_ptr(), inv.data_ptr(), y.shape[0], y.shape[1], dx.data_ptr(), _stream()),
+          "rownorm_bwd")
+    return dx
+
+
+def itc_fwd(image_feat, text_feat, temp):
+    """In-batch contrastive loss over N gathered rows (xfm.py:683-703, idx=None) -> (loss [1], lse [2N])."""
+    _dev(image_feat)
+    N, E = image_feat.shape
+    assert image_feat.dtype == F32 and text_feat.dtype == F32 and image_feat.is_contiguous() and text_feat.is_contiguous()
+    assert text_feat.shape == (N, E) and temp.dtype == F32 and temp.numel() == 1
+    lse = torch.empty(2 * N, dtype=F32, device=image_feat.device)
+    loss = torch.zeros(1, dtype=F32, device=image_feat.device)
+    check(_lib.load().xfm_itc_fwd(image_feat.data_ptr(), text_feat.data_ptr(), temp.data_ptr(), N, E, lse.data_ptr(), loss.data_ptr(),
+                                  _stream()), "itc_fwd")
+    return loss, lse
+
+
+def itc_bwd(image_feat, text_feat, temp, lse, g):
+    """-> (d image_feat, d text_feat, d temp [1]) for the upstream gradient g (fp32 [1])."""
+    N, E = image_feat.shape
+    dI, dT = torch.empty_like(image_feat), torch.empty_like(text_feat)
+    dtemp = torch.zeros(1, dtype=F32, device=image_feat.device)
+    check(_lib.load().xfm_itc_bwd(image_feat.data_ptr(), text_feat.data_ptr(), temp.data_ptr(), lse.data_ptr(), g.data_ptr(), N, E,
+                                  dI.data_ptr(), dT.data_ptr(), dtemp.data_ptr(), _stream()), "itc_bwd")
+    return dI, dT, dtemp
+
+
+def hard_negatives(image_feat, text_feat, temp, seed):
+    """One categorical draw per row from softmax(sim / temp) + 1e-5 with the own entry zeroed (xfm.py:717-746, idx=None)
+    -> (image_neg_idx, text_neg_idx) int64 [B]."""
+    _dev(image_feat)
+    B, E = image_feat.shape
+    assert image_feat.dtype == F32 and text_feat.dtype == F32 and image_feat.is_contiguous() and text_feat.is_contiguous()
+    out = torch.empty((2, B), dtype=torch.int64, device=image_feat.device)
+    check(_lib.load().xfm_hard_negatives(image_feat.data_ptr(), text_feat.data_ptr(), temp.data_ptr(), B, E, int(seed),
+                                         out[0].data_ptr(), out[1].data_ptr(), _stream()), "hard_negatives")
+    return out[0], out[1]
 
 
 def ce_fwd(logits, V, labels):

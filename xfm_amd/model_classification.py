@@ -3,6 +3,7 @@ deep MLP head), text-only GLUE-style classification on the text tower, and the m
 import torch
 import torch.nn.functional as F
 
+from .ops import small_ce
 from .xfm import XFMBase, _DeepMlp, build_mlp
 
 
@@ -42,4 +43,4 @@ class XFMForClassification(XFMBase):
         if prediction.shape[-1] == 1:
             loss = F.mse_loss(prediction.view(-1).float(), targets.view(-1).float())
             return loss if train else prediction
-        return F.cross_entropy(prediction.float(), targets) if train else prediction
+        return small_ce(prediction, targets) if train else prediction

@@ -3,6 +3,7 @@ tower; the two [CLS] states are concatenated into a 2-way head."""
 import torch
 import torch.nn.functional as F
 
+from .ops import small_ce
 from .xfm import XFMBase, build_mlp
 
 
@@ -29,4 +30,4 @@ class XFMForNLVR(XFMBase):
         pair = torch.cat((fused_cls[:n], fused_cls[n:]), dim=-1)   # [B, 2 * width]: (first image | second image)
         assert pair.shape[-1] == self.text_width * 2
         logits = self.cls_head(pair)
-        return F.cross_entropy(logits.float(), targets) if train else logits
+        return small_ce(logits, targets) if train else logits

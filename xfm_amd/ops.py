@@ -59,10 +59,10 @@ def linear_slot(x, slot, x_requires_grad=True, out_fp32=False):
 
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, mod):
+    def forward(ctx, x, mod, gelu):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        y, mean, rstd = Fx.ln_fwd(x2, mod.weight, mod.bias, mod.eps)
-        ctx.mod, ctx.saved, ctx.shape, ctx.dtype = mod, (x2, mean, rstd), x.shape, x.dtype
+        y, mean, rstd = Fx.ln_fwd(x2, mod.weight, mod.bias, mod.eps, gelu=gelu)
+        ctx.mod, ctx.saved, ctx.shape, ctx.dtype, ctx.gelu = mod, (x2, mean, rstd), x.shape, x.dtype, gelu
         return y.view(x.shape)
 
     @staticmethod
@@ -71,18 +71,86 @@ class _LayerNormFn(torch.autograd.Function):
         m = ctx.mod
         dy2 = dy.reshape(x2.shape)
         dy2 = (dy2 if dy2.dtype == BF16 else dy2.to(BF16)).contiguous()
+        gb = m.bias if ctx.gelu else None
         if ctx.dtype == F32:
             dx = torch.empty_like(x2)
-            Fx.ln_bwd(dy2, x2, mean, rstd, m.weight, grad_view(m.weight), grad_view(m.bias), dx32=dx)
+            Fx.ln_bwd(dy2, x2, mean, rstd, m.weight, grad_view(m.weight), grad_view(m.bias), dx32=dx, gelu_b=gb)
         else:
             dx = torch.empty_like(x2)
-            Fx.ln_bwd(dy2, x2, mean, rstd, m.weight, grad_view(m.weight), grad_view(m.bias), dx16=dx)
-        return dx.view(ctx.shape), None
+            Fx.ln_bwd(dy2, x2, mean, rstd, m.weight, grad_view(m.weight), grad_view(m.bias), dx16=dx, gelu_b=gb)
+        return dx.view(ctx.shape), None, None
 
 
-def layer_norm(x, mod):
-    """LayerNorm over the last dim (fp32 or bf16 in, bf16 out) using `mod.weight/bias/eps`."""
-    return _LayerNormFn.apply(x, mod)
+def layer_norm(x, mod, gelu=False):
+    """LayerNorm over the last dim (fp32 or bf16 in, bf16 out) using `mod.weight/bias/eps`; gelu: GELU(LayerNorm(x)) in the same
+    kernel (the Linear -> LayerNorm -> GELU heads, xfm.py:115-121)."""
+    return _LayerNormFn.apply(x, mod, bool(gelu))
+
+
+class _RowNormFn(torch.autograd.Function):
+    """F.normalize(x, dim=-1) on fp32 rows (xfm.py:617-620)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, inv = Fx.rownorm_fwd(x.contiguous())
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        return Fx.rownorm_bwd(dy.float().contiguous(), y, inv)
+
+
+def row_normalize(x):
+    return _RowNormFn.apply(x)
+
+
+class _ItcFn(torch.autograd.Function):
+    """(CE(I T^T / temp, arange) + CE(T I^T / temp, arange)) / 2 (xfm.py:683-703) as one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, image_feat, text_feat, temp):
+        I, T = image_feat.float().contiguous(), text_feat.float().contiguous()
+        tv = temp.detach().float().reshape(1)
+        loss, lse = Fx.itc_fwd(I, T, tv)
+        ctx.save_for_backward(I, T, tv, lse)
+        ctx.temp_shape = temp.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        I, T, tv, lse = ctx.saved_tensors
+        dI, dT, dtemp = Fx.itc_bwd(I, T, tv, lse, g.float().reshape(1).contiguous())
+        return dI, dT, (dtemp.reshape(ctx.temp_shape) if ctx.needs_input_grad[2] else None)
+
+
+def itc_loss(image_feat, text_feat, temp):
+    if not torch.is_tensor(temp):
+        temp = torch.full((1,), float(temp), dtype=F32, device=image_feat.device)
+    return _ItcFn.apply(image_feat, text_feat, temp)
+
+
+class _SmallCEFn(torch.autograd.Function):
+    """Mean cross-entropy over a handful of classes (the 2-way ITM head, xfm.py:795-800) through the vocabulary CE kernels."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        lg = logits.float().contiguous()
+        lse, rows = Fx.ce_fwd(lg, lg.shape[1], labels)
+        ctx.save_for_backward(lg, labels, lse)
+        return rows.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, labels, lse = ctx.saved_tensors
+        R, C = lg.shape
+        d = Fx.ce_bwd(lg, C, labels, lse, (g.float() / R).reshape(1), (C + 7) // 8 * 8)
+        return d[:, :C].float(), None
+
+
+def small_ce(logits, labels):
+    return _SmallCEFn.apply(logits, labels)
 
 
 def gelu_grad(u):

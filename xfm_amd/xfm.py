@@ -4,8 +4,11 @@ Mirrors `models/xfm.py::XFMBase` (:471-853): same constructor keywords, `get_*` 
 state_dict key names, so the reference's task models / train loops drive it unchanged.  Towers are the HIP-backed
 `xfm_amd.beit2.VisionTransformer` and `xfm_amd.xroberta.RobertaForMaskedLM`; all their parameters live in one flat
 arena (xfm_amd.arena).  Deliberate MI355X-first departures, none of which changes a value the reference computes:
-  * hard negatives are drawn with ONE batched device-side torch.multinomial per direction instead of 2B host-synchronous
-    `.item()` draws (xfm.py:736-744) -- same per-row categorical distribution, no pipeline stall;
+  * hard negatives are drawn on the device, one categorical draw per row in ONE kernel (xfm_hard_negatives; a batched
+    torch.multinomial when `idx` groups positives) instead of 2B host-synchronous `.item()` draws (xfm.py:736-744) -- same
+    per-row categorical distribution, no pipeline stall;
+  * ITC (similarity + both cross-entropies), F.normalize, the heads' LayerNorm+GELU and the ITM cross-entropy are single HIP
+    kernels (xfm_itc_*, xfm_rownorm_*, xfm_layernorm_* with gelu, xfm_ce_*): no vendor-BLAS / ATen softmax launches in the step;
   * the ITM positive (B) and negative (2B) fusion passes (xfm.py:788-793) run as one 3B-row pass;
   * the MIM loss masks with a weight tensor instead of boolean indexing (no device->host sync).
 """
@@ -20,7 +23,7 @@ import torch.nn.functional as F
 from . import functional as Fx
 from .arena import LinearSlot, ParamArena
 from .beit2 import _Affine, beit_base_patch16
-from .ops import layer_norm, linear_slot
+from .ops import itc_loss, layer_norm, linear_slot, row_normalize, small_ce
 from .xroberta import RobertaConfig, RobertaForMaskedLM, _Lin
 
 BF16 = torch.bfloat16
@@ -69,8 +72,8 @@ class _Mlp(nn.Module):
         return [self._s0, self._s3]
 
     def forward(self, x):
-        h = layer_norm(linear_slot(x, self._s0), getattr(self, "1"))
-        return linear_slot(F.gelu(h.float()).to(BF16), self._s3, out_fp32=True)
+        h = layer_norm(linear_slot(x, self._s0), getattr(self, "1"), gelu=True)
+        return linear_slot(h, self._s3, out_fp32=True)
 
 
 def build_mlp(input_dim, output_dim):
@@ -98,8 +101,7 @@ class _DeepMlp(nn.Module):
 
     def forward(self, x):
         for j in range(4):
-            h = layer_norm(linear_slot(x, self._slots[j]), getattr(self, str(3 * j + 1)))
-            x = F.gelu(h.float()).to(BF16)
+            x = layer_norm(linear_slot(x, self._slots[j]), getattr(self, str(3 * j + 1)), gelu=True)
         return linear_slot(x, self._slots[4], out_fp32=True)
 
 
@@ -360,9 +362,9 @@ class XFMBase(nn.Module):
     def get_features(self, image_embeds=None, text_embeds=None):
         out = []
         if image_embeds is not None:
-            out.append(F.normalize(linear_slot(image_embeds[:, 0, :], self._s_vproj, out_fp32=True), dim=-1))
+            out.append(row_normalize(linear_slot(image_embeds[:, 0, :], self._s_vproj, out_fp32=True)))
         if text_embeds is not None:
-            out.append(F.normalize(linear_slot(text_embeds[:, 0, :], self._s_tproj, out_fp32=True), dim=-1))
+            out.append(row_normalize(linear_slot(text_embeds[:, 0, :], self._s_tproj, out_fp32=True)))
         return out[0] if len(out) == 1 else tuple(out)
 
     def get_cross_embeds(self, image_embeds, image_atts, text_ids=None, text_embeds=None, text_atts=None, is_pretrain=True):
@@ -409,11 +411,9 @@ class XFMBase(nn.Module):
     def get_contrastive_loss(self, image_feat, text_feat, idx=None):
         assert image_feat.size(-1) == self.embed_dim and text_feat.size(-1) == self.embed_dim
         image_feat_all, text_feat_all = allgather(image_feat), allgather(text_feat)
+        if idx is None:   # in-batch labels: similarity, both cross-entropies and their backward as one kernel each way
+            return itc_loss(image_feat_all, text_feat_all, self.temp)
         logits = image_feat_all @ text_feat_all.t() / self.temp
-        bsz = image_feat_all.shape[0]
-        if idx is None:
-            labels = torch.arange(bsz, device=image_feat.device)
-            return (F.cross_entropy(logits, labels) + F.cross_entropy(logits.t(), labels)) / 2
         idx = idx.view(-1, 1)
         assert idx.size(0) == image_feat.size(0)
         idx_all = allgather(idx)
@@ -425,6 +425,11 @@ class XFMBase(nn.Module):
 
     def get_hard_negatives(self, image_feat, text_feat, idx=None):
         """Returns device index tensors (image_neg_idx, text_neg_idx), each [B] int64."""
+        if idx is None:   # one kernel: similarity row, softmax + 1e-5, own entry zeroed, one inverse-CDF draw per row
+            from .xroberta import _next_seed
+            temp = self.temp.detach().float().reshape(1) if torch.is_tensor(self.temp) else \
+                torch.full((1,), float(self.temp), dtype=torch.float32, device=image_feat.device)
+            return Fx.hard_negatives(image_feat.detach().float().contiguous(), text_feat.detach().float().contiguous(), temp, _next_seed())
         with torch.no_grad():
             sim_i2t = image_feat @ text_feat.t() / self.temp
             weights_i2t = F.softmax(sim_i2t, dim=1) + 1e-5
@@ -461,7 +466,7 @@ class XFMBase(nn.Module):
         output = self.itm_head(cross)
         dev = image_embeds.device  # built on the device: a host tensor + .to(device) is a blocking pageable copy
         itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
-        loss = F.cross_entropy(output, itm_labels)
+        loss = small_ce(output, itm_labels)
         if return_cross_embeds:
             return loss, cross[:bs]
         return loss
@@ -517,7 +522,7 @@ class XFMBase(nn.Module):
             start_of = fpack.start
         output = self.itm_head(rows_gather(seq, start_of[:3 * bs]))
         itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
-        loss_itm = F.cross_entropy(output, itm_labels)
+        loss_itm = small_ce(output, itm_labels)
         mlm_index = (start_of[3 * bs:, None] + masked_pos.to(torch.int32)).reshape(-1)   # gather_seq_out_by_pos (xroberta.py:1215-1216)
         mlm_seq = rows_gather(seq, mlm_index)
         loss_mlm, _ = lm_head_ce(mlm_seq, self.fusion_encoder.lm_head, masked_ids.reshape(-1), "mean")
@@ -558,7 +563,7 @@ class XFMBase(nn.Module):
         output = self.itm_head(seq[:3 * bs, 0, :])
         dev = image_embeds.device  # built on the device: a host tensor + .to(device) is a blocking pageable copy
         itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
-        loss_itm = F.cross_entropy(output, itm_labels)
+        loss_itm = small_ce(output, itm_labels)
         mlm_seq = self.fusion_encoder.gather_seq_out_by_pos(seq[3 * bs:], masked_pos)
         from .ops import lm_head_ce
         loss_mlm, _ = lm_head_ce(mlm_seq.reshape(-1, mlm_seq.shape[-1]), self.fusion_encoder.lm_head, masked_ids.reshape(-1), "mean")
