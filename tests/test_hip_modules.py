@@ -3,10 +3,11 @@
   (b) the CPU oracle run live on the same formula weights and synthetic batches.
 Stated tolerances (bf16 MFMA compute, fp32 accumulate/statistics, vs an fp32 reference):
   tower outputs  rel-L2 <= 2e-2 ;
-  parameter / input gradients  rel-L2 <= 8e-2 and cosine >= 0.996 for the 2-layer towers and the 2+2-layer step;
-                               rel-L2 <= 1.5e-1 and cosine >= 0.985 through the full 12+12+12-layer step (every activation
-                               and inter-kernel gradient is stored in bf16: ~240 independent 2^-9 roundings on the longest
-                               path; the fp32 residual stream of the ViT and fp32 statistics keep it from growing faster);
+  parameter / input gradients  rel-L2 <= 8e-2 and cosine >= 0.996 per tensor, everywhere.  The full-depth fixtures (12-block ViT,
+                               12+12+12-layer step, VQA) also carry the REFERENCE's own mixed-precision floor per tensor (its
+                               bf16-autocast gradient against its fp32 gradient -- the reference trains under apex O1); a tensor
+                               may exceed 8e-2 only up to 1.3 x that floor (cosine: 1.7 x its 1 - cos).  Worst measured: 12.5 %
+                               on fusion layers 0-3, where the reference's autocast gradients are 11-12.5 % from its fp32 ones;
   losses         total loss within 1e-3 rel (north-star bound); ITC/MLM/MIM within 3e-3 each, ITM (12-row 2-way CE) 3e-2.
 """
 import json
@@ -35,10 +36,17 @@ def _check_out(z, prefix, t, tol=OUT_TOL):
     assert err <= tol and cos >= COS_TOL, f"{prefix}: rel-L2 {err:.3e} cos {cos:.5f}"
 
 
-def _check_grads(z, prefix, module, name_prefix="", skip=("self.key.bias",), min_rms=1e-7, tol=None, cos_tol=None, abs_ok=None):
+FLOOR_ERR, FLOOR_COS = 1.3, 1.7
+
+
+def _check_grads(z, prefix, module, name_prefix="", skip=("self.key.bias",), min_rms=1e-7, tol=None, cos_tol=None, abs_ok=None, floor=None):
     """`self.key.bias` is skipped: its gradient is analytically zero (softmax is invariant to the per-query constant
     q.b_k), so the reference holds ~1e-9 rounding noise there and a relative comparison is meaningless; it is bounded
-    in absolute terms against the query-bias gradient instead."""
+    in absolute terms against the query-bias gradient instead.
+    floor: key prefix of the fixture's per-tensor mixed-precision floor (tools/oracle/gen_golden.py amp_floor: the reference's own
+    bf16-autocast gradient against its fp32 gradient, [rel-L2, cosine]).  A tensor may then exceed the global tolerance only as far
+    as the REFERENCE's 16-bit training arithmetic does on that same tensor: rel-L2 <= max(tol, 1.3 x floor), 1 - cos <= max(1 -
+    cos_tol, 1.7 x (1 - floor cos)); the margins cover the 256-entry probe against the floor's whole-tensor figure."""
     bad, n, worst = [], 0, (0.0, 1.0)
     tol, cos_tol = tol or GRAD_TOL, cos_tol or COS_TOL
     params = dict(module.named_parameters())
@@ -67,8 +75,12 @@ def _check_grads(z, prefix, module, name_prefix="", skip=("self.key.bias",), min
         if abs_ok and name in abs_ok and float((g.float().cpu().reshape(-1)[:1] - float(z[f"{prefix}/{name}/probe"][0])).abs()) <= abs_ok[name]:
             continue  # an ill-conditioned scalar (see the caller): held in absolute terms
         worst = (max(worst[0], err), min(worst[1], cos))
-        if err > tol or cos < cos_tol:
-            bad.append((name, round(err, 4), round(cos, 5)))
+        tol_t, cos_t = tol, cos_tol
+        if floor is not None and f"{floor}/{name}" in z.files:
+            fe, fc = (float(v) for v in z[f"{floor}/{name}"])
+            tol_t, cos_t = max(tol, FLOOR_ERR * fe), min(cos_tol, 1.0 - FLOOR_COS * (1.0 - fc))
+        if err > tol_t or cos < cos_t:
+            bad.append((name, round(err, 4), round(cos, 5), round(tol_t, 4)))
     print(f"[{prefix}] {n} gradient tensors, worst rel-L2 {worst[0]:.4f}, worst cosine {worst[1]:.5f}")
     assert n > 0
     assert not bad, f"{len(bad)}/{n} gradients out of tolerance: {bad[:12]}"
@@ -294,17 +306,21 @@ def test_plain_vit_tower_vs_golden():
     _check_grads(z, "grad", m)
 
 
-def test_retrieval_model_vs_golden():
+@pytest.mark.parametrize("fixture", ["retrieval_small", "retrieval_384"])
+def test_retrieval_model_vs_golden(fixture):
     """model_retrieval.XFMForRetrieval: bare RobertaModel text tower (no LM heads), ITC with duplicated idx (soft labels), ITM with
-    is_pretrain=False (the text tower also gets the matching gradient)."""
+    is_pretrain=False (the text tower also gets the matching gradient).  retrieval_384: BASELINE configs[2]'s real shape
+    (configs/xfm-ft/Retrieval_coco.yaml:18 -- 384 px = 577 image tokens, 40 text tokens) at B = 8, from the real reference."""
     from xfm_amd.model_retrieval import XFMForRetrieval
-    z, meta = load("retrieval_small")
+    z, meta = load(fixture)
     m = XFMForRetrieval(_pretrain_cfg(meta))
     ours = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
     assert ours == meta["spec"]
     _load_into(m, meta["spec"])
     m.cuda().finalize().eval()
-    b = {k: v.cuda() for k, v in syn.pretrain_batch(meta["B"], seed=77).items()}
+    b = {k: v.cuda() for k, v in syn.pretrain_batch(meta["B"], seed=77, image_res=meta.get("image_res", 224),
+                                                    max_tokens=meta.get("max_tokens", 30)).items()}
+    assert b["image"].shape[-1] == meta.get("image_res", 224) and b["text_ids"].shape[1] == meta.get("max_tokens", 30)
     idx = torch.tensor(meta["idx"]).cuda()
     itc, itm = m(b["image"], b["text_ids"], b["text_atts"], idx=idx, neg_idx=(meta["image_neg_idx"], meta["text_neg_idx"]))
     ri, rm = float(z["loss_itc"]), float(z["loss_itm"])
@@ -313,7 +329,9 @@ def test_retrieval_model_vs_golden():
     (itc + itm).backward()
     # d loss / d temp = -(1 / temp^2) * sum_ij (p_ij - y_ij) sim_ij: with temp = 0.07 a residual of ~1e-3 between cancelling terms is
     # amplified 204 x, so the bf16 features' 1e-3 similarity error moves this ONE scalar by ~0.02 of 0.21 -- held to 0.05 absolute
-    _check_grads(z, "grad", m, min_rms=1e-6, abs_ok={"temp": 0.05})
+    # d loss / d itm bias = mean_i (p_i - y_i): 3B residuals of O(0.3) cancelling to 7e-3 at 384 px; the bf16 towers move each p_i
+    # by ~1e-2 (the ITM loss itself is held to 3e-2 above), so this 2-vector is held to 2e-3 absolute
+    _check_grads(z, "grad", m, min_rms=1e-6, abs_ok={"temp": 0.05, "itm_head.3.bias": 2e-3})
     # the sampler itself: device-side draws must respect the same-idx exclusion (xfm.py:731-734)
     with torch.no_grad():
         img, _ = m.get_vision_embeds(b["image"])
@@ -330,12 +348,8 @@ def _cls_cfg(meta, **kw):
     return cfg
 
 
-def test_classification_imagenet_branch_vs_golden(tmp_path):
-    """BASELINE configs[1] (ImageNet fine-tune, ViT-only path): XFMForClassification built the reference's way -- vision tower loaded
-    by load_pretrained_beit2 from a checkpoint file -- then cls + mean-patch features through the deep MLP head."""
-    from xfm_amd.model_classification import XFMForClassification
-    z, meta = load("classification_imagenet")
-    spec = meta["spec"]
+def _beit_checkpoint_config(spec, tmp_path):
+    """A BEiT-v2 checkpoint file holding the fixture's vision tower + the vision_config JSON that names it (xfm.py:206-234)."""
     vis = {k[len("vision_encoder."):]: v for k, v in state_from_spec(spec).items() if k.startswith("vision_encoder.")}
     vis["head.weight"], vis["head.bias"] = torch.zeros(1000, 768), torch.zeros(1000)
     ckpt = os.path.join(tmp_path, "beit.pth")
@@ -343,6 +357,16 @@ def test_classification_imagenet_branch_vs_golden(tmp_path):
     vcfg = os.path.join(tmp_path, "config_beit2_base.json")
     with open(vcfg, "w") as f:
         json.dump({"ckpt": ckpt, "vision_width": 768, "patch_size": 16}, f)
+    return vcfg
+
+
+def test_classification_imagenet_branch_vs_golden(tmp_path):
+    """BASELINE configs[1] (ImageNet fine-tune, ViT-only path): XFMForClassification built the reference's way -- vision tower loaded
+    by load_pretrained_beit2 from a checkpoint file -- then cls + mean-patch features through the deep MLP head."""
+    from xfm_amd.model_classification import XFMForClassification
+    z, meta = load("classification_imagenet")
+    spec = meta["spec"]
+    vcfg = _beit_checkpoint_config(spec, tmp_path)
     m = XFMForClassification(_cls_cfg(meta, vision_config=vcfg, task_name="imagenet", num_labels=1000))
     ours = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
     assert ours == spec
@@ -360,7 +384,35 @@ def test_classification_imagenet_branch_vs_golden(tmp_path):
     ref = float(z["loss_imagenet"])
     assert abs(float(loss) - ref) <= 2e-3 * abs(ref), (float(loss), ref)
     loss.backward()
-    _check_grads(z, "grad_imagenet", m, min_rms=1e-6, tol=1.5e-1, cos_tol=0.985)  # 12-block ViT: full-depth tolerance
+    _check_grads(z, "grad_imagenet", m, min_rms=1e-6, floor="floor_imagenet")
+
+
+def test_classification_imagenet_at_batch_128_vs_oracle(tmp_path):
+    """BASELINE configs[1]'s real batch (Imagenet.py:437-492, batch 128 per GPU at 224 px, 12-block tower): predictions and the loss
+    against the CPU oracle's forward on the same formula weights.  (Gradients at full depth are pinned by the B = 4 fixture above.)"""
+    from oracle import xfm_oracle as O
+    from xfm_amd.model_classification import XFMForClassification
+    _, meta = load("classification_imagenet")
+    spec = meta["spec"]
+    m = XFMForClassification(_cls_cfg(meta, vision_config=_beit_checkpoint_config(spec, tmp_path), task_name="imagenet", num_labels=1000))
+    sd = _load_into(m, spec)
+    m.cuda().finalize().eval()
+    B = 128
+    image = syn.gaussian("imagenet128.image", (B, 3, 224, 224))
+    g = torch.Generator().manual_seed(11)
+    targets = torch.randint(0, 1000, (B,), generator=g)
+    with torch.no_grad():
+        pred = m(image.cuda(), None, None, targets.cuda(), train=False).float().cpu()
+        loss = float(m(image.cuda(), None, None, targets.cuda(), train=True))
+        ref = O.classification_forward(sd, O.default_cfg(vit_depth=12), image, None, None, deep_head=True).float()
+    assert pred.shape == ref.shape == (B, 1000)
+    err = float((pred - ref).norm() / ref.norm())
+    assert err <= OUT_TOL, err
+    ref_loss = float(torch.nn.functional.cross_entropy(ref, targets))
+    assert abs(loss - ref_loss) <= 2e-3 * abs(ref_loss), (loss, ref_loss)
+    per_row = ((pred - ref).norm(dim=1) / ref.norm(dim=1)).max()
+    assert float(per_row) <= 2 * OUT_TOL, float(per_row)
+    print(f"ImageNet B=128: logits rel-L2 {err:.4f}, worst row {float(per_row):.4f}, loss {loss:.5f} vs {ref_loss:.5f}")
 
 
 def test_classification_multimodal_and_text_branches_vs_golden(tmp_path):
@@ -384,7 +436,7 @@ def test_classification_multimodal_and_text_branches_vs_golden(tmp_path):
     ref = float(z["loss_mm"])
     assert abs(float(loss) - ref) <= 5e-3 * abs(ref), (float(loss), ref)  # 3-way CE over 4 rows fed by bf16 towers
     loss.backward()
-    _check_grads(z, "grad_mm", m, min_rms=1e-6, tol=1.5e-1, cos_tol=0.985)
+    _check_grads(z, "grad_mm", m, min_rms=1e-6, floor="floor_mm")
     m._arena.zero_grad()
     loss = m(None, b["text_ids"], b["text_atts"], t, train=True)
     ref = float(z["loss_text"])
@@ -393,12 +445,14 @@ def test_classification_multimodal_and_text_branches_vs_golden(tmp_path):
     _check_grads(z, "grad_text", m, min_rms=1e-6)
 
 
-def test_vqa_model_vs_golden():
+@pytest.mark.parametrize("fixture", ["vqa_small", "vqa_480"])
+def test_vqa_model_vs_golden(fixture):
     """BASELINE configs[3] (VQA fine-tune): XFMForVQA -- question through text + fusion towers, answers through the causal decoder that
-    cross-attends to the fused question states; weighted per-answer loss, gradients, and the inference-time answer ranking."""
+    cross-attends to the fused question states; weighted per-answer loss, gradients, and the inference-time answer ranking.
+    vqa_480: the configuration's real resolution (480 px = 901 image tokens, 59 x 59 + 3 relative positions), from the real reference."""
     from types import SimpleNamespace as NS
     from xfm_amd.model_generation import XFMForVQA
-    z, meta = load("vqa_small")
+    z, meta = load(fixture)
     cfg = dict(_pretrain_cfg(meta), pad_token_id=meta["pad_token_id"], decoder_fusion_start_at=meta["dec_fusion_start"],
                num_dec_layers=meta["dec_layers"])
     m = XFMForVQA(cfg)
@@ -406,7 +460,7 @@ def test_vqa_model_vs_golden():
     assert ours == meta["spec"]
     _load_into(m, meta["spec"])
     m.cuda().finalize().eval()
-    x = syn.vqa_inputs()
+    x = syn.vqa_inputs(image_res=meta.get("image_res", 224))
     q = NS(input_ids=x.q_ids.cuda(), attention_mask=x.q_atts.cuda())
     a = NS(input_ids=x.a_ids.cuda(), attention_mask=x.a_atts.cuda())
     c = NS(input_ids=x.c_ids.cuda(), attention_mask=x.c_atts.cuda())
@@ -416,7 +470,7 @@ def test_vqa_model_vs_golden():
     loss.backward()
     # 16 bf16 layers deep (12 ViT + 2 text + 2 fusion) before the decoder: the softmax-sensitive Q/K gradients of the decoder's last
     # cross-attention sit at rel-L2 0.08-0.10 (cos 0.9956) where the shallower tower fixtures hold 0.08 / 0.996
-    _check_grads(z, "grad", m, min_rms=1e-6, tol=1.2e-1, cos_tol=0.993)
+    _check_grads(z, "grad", m, min_rms=1e-6, floor="floor")
     with torch.no_grad():
         ids, probs = m(x.image.cuda(), q, c, k=x.topk, train=False)
     # question 0: the reference's first-token shortlist is decided by a 25 % probability margin -> the bf16 path must pick the same three
@@ -522,13 +576,13 @@ def test_nlvr_model_vs_golden():
 
 
 def _pretrain_cfg(meta):
-    return {"use_beit_v2": True, "image_res": 224, "patch_size": 16, "local_attn_depth": -1, "text_encoder": "roberta-base",
+    return {"use_beit_v2": True, "image_res": meta.get("image_res", 224), "patch_size": 16, "local_attn_depth": -1, "text_encoder": "roberta-base",
             "text_num_hidden_layers": meta["text_layers"], "text_fusion_start_at": meta["text_layers"],
             "fusion_num_hidden_layers": meta["fusion_layers"], "fusion_fusion_start_at": 0, "embed_dim": 256, "temp": 0.07,
             "learnable_temp": True, "max_temp": 0.5, "min_temp": 0.001, "vision_depth": meta.get("vit_depth", 12)}
 
 
-def _pretrain(name, tol=None, cos_tol=None, batch_passes=True, packed=False):
+def _pretrain(name, tol=None, cos_tol=None, batch_passes=True, packed=False, floor=None):
     from xfm_amd.model_pretrain import XFM
     z, meta = load(name)
     B = meta["B"]
@@ -557,7 +611,7 @@ def _pretrain(name, tol=None, cos_tol=None, batch_passes=True, packed=False):
     assert abs(float(total) - ref_total) <= 1e-3 * ref_total, (float(total), ref_total, report)
     total.backward()
     # position 1 of the position table only sees padded tokens; bias-table rows with tiny grads are skipped by min_rms
-    _check_grads(z, "grad", m, min_rms=1e-6, tol=tol, cos_tol=cos_tol)
+    _check_grads(z, "grad", m, min_rms=1e-6, tol=tol, cos_tol=cos_tol, floor=floor)
     unused = set(meta["unused"])
     for n, p in m.named_parameters():
         if n in unused:
@@ -579,7 +633,14 @@ def test_pretrain_step_small_packed_rows_vs_golden():
 
 
 def test_pretrain_step_full_depth_vs_golden():
-    _pretrain("pretrain_full", tol=1.5e-1, cos_tol=0.985)
+    """12 + 12 + 12 layers.  Default tolerance (8e-2 / 0.996) per tensor, relaxed only where -- and only as far as -- the reference's
+    own bf16-autocast gradients leave its fp32 gradients on that tensor (fixture floor/<name>; DESIGN.md has the per-tower table:
+    the lower fusion layers sit at 10-12 % in the reference itself)."""
+    _pretrain("pretrain_full", floor="floor")
+
+
+def test_pretrain_step_full_depth_packed_rows_vs_golden():
+    _pretrain("pretrain_full", floor="floor", packed=True)
 
 
 def _chi2_two_sample(a, b, min_count=40):

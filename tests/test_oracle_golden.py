@@ -168,11 +168,13 @@ def test_plain_vit_tower():
     _check_grads(z, "grad", P)
 
 
-def test_retrieval_model():
-    z, meta = load("retrieval_small")
+@pytest.mark.parametrize("fixture", ["retrieval_small", "retrieval_384"])
+def test_retrieval_model(fixture):
+    """retrieval_384: the fine-tuning shape of BASELINE configs[2] (384 px, 40 tokens, B = 8) from the real reference."""
+    z, meta = load(fixture)
     P = _params(meta["spec"])
     cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"], vit_depth=meta.get("vit_depth", 12))
-    b = syn.pretrain_batch(meta["B"], seed=77)
+    b = syn.pretrain_batch(meta["B"], seed=77, image_res=meta.get("image_res", 224), max_tokens=meta.get("max_tokens", 30))
     idx = torch.tensor(meta["idx"])
     itc, itm = O.retrieval_forward(P, cfg, b, idx, meta["image_neg_idx"], meta["text_neg_idx"], text_prefix="text_encoder.")
     assert abs(float(itc) - float(z["loss_itc"])) < 2e-4 and abs(float(itm) - float(z["loss_itm"])) < 2e-4
@@ -211,13 +213,15 @@ def test_classification_models():
     _check_grads(z, "grad_text", P)
 
 
-def test_vqa_model_loss_and_answer_ranking():
-    """BASELINE configs[3]: XFMForVQA's weighted answer loss + gradients, and rank_answer's re-ranked shortlist."""
-    z, meta = load("vqa_small")
+@pytest.mark.parametrize("fixture", ["vqa_small", "vqa_480"])
+def test_vqa_model_loss_and_answer_ranking(fixture):
+    """BASELINE configs[3]: XFMForVQA's weighted answer loss + gradients, and rank_answer's re-ranked shortlist (vqa_480: at the
+    configuration's 480 px)."""
+    z, meta = load(fixture)
     P = _params(meta["spec"])
     cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"], vit_depth=meta.get("vit_depth", 12))
     cfg.update(dec_layers=meta["dec_layers"], dec_fusion_start=meta["dec_fusion_start"])
-    x = syn.vqa_inputs()
+    x = syn.vqa_inputs(image_res=meta.get("image_res", 224))
     loss = O.vqa_train_loss(P, cfg, x.image, x.q_ids, x.q_atts, x.a_ids, x.a_atts, x.k, x.weights, meta["pad_token_id"])
     assert abs(float(loss) - float(z["loss_vqa"])) < 2e-4 * abs(float(z["loss_vqa"])), (float(loss), float(z["loss_vqa"]))
     loss.backward()

@@ -62,6 +62,28 @@ def grads_of(module, out, prefix="grad"):
             pack(f"{prefix}/{name}", p.grad, out, 256)
 
 
+def amp_floor(module, loss_fn, out, prefix="floor"):
+    """The reference trains in mixed precision (accelerators/apex_ddp_accelerator.py:41-60, apex O1).  How far are the reference's
+    OWN gradients under 16-bit autocast from its fp32 gradients?  Call after the fp32 backward (module.*.grad hold the fp32
+    gradients); loss_fn() re-runs the same forward -- same weights, inputs, masks, negatives -- and returns the scalar loss.
+    Stores <prefix>/<name> = [rel-L2, cosine] of (bf16-autocast gradient) against (fp32 gradient) per tensor, over the whole tensor.
+    The GPU parity tests bound the HIP path's error per tensor by this floor instead of one loose global tolerance."""
+    fp32 = {n: p.grad.detach().double().clone() for n, p in module.named_parameters() if p.grad is not None}
+    module.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        loss = loss_fn()
+    loss.float().backward()
+    for n, p in module.named_parameters():
+        if p.grad is None or n not in fp32:
+            continue
+        g, r = p.grad.detach().double().reshape(-1), fp32[n].reshape(-1)
+        rn = float(r.norm())
+        out[f"{prefix}/{n}"] = np.asarray([float((g - r).norm()) / max(rn, 1e-30), float((g @ r) / max(float(g.norm()) * rn, 1e-30))],
+                                          dtype=np.float32)
+    module.zero_grad()
+    return float(loss)
+
+
 class FixedMasks:
     """Stands in for MaskingGenerator(): returns the rows of a pre-drawn mask tensor one by one (beit2.py:432-435)."""
 
@@ -272,7 +294,7 @@ def gen_xbert(layers=2, B=4):
     save(f"xbert_{layers}L", out, {"spec": spec_of(m), "B": B, "layers": layers, "fusion_layer": 1})
 
 
-def gen_pretrain(name, text_layers, fusion_layers, B=4):
+def gen_pretrain(name, text_layers, fusion_layers, B=4, with_floor=False):
     from models.model_pretrain import XFM
     ref_shim.init_single_process_group()
     torch.manual_seed(0)
@@ -304,6 +326,23 @@ def gen_pretrain(name, text_layers, fusion_layers, B=4):
     total.backward()
     grads_of(m, out)
     unused = [n for n, p in m.named_parameters() if p.grad is None]
+    if with_floor:
+        fixed = (torch.stack([torch.as_tensor(i) for i in captured["image_neg_idx"]]),
+                 torch.stack([torch.as_tensor(i) for i in captured["text_neg_idx"]]))
+        m.get_hard_negatives = lambda *a, **kw: fixed
+        last = {}
+
+        def again():
+            m.vision_encoder.generator = FixedMasks(masks, 14)
+            l2 = m(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"], masked_pos=b["masked_pos"],
+                   masked_ids=b["masked_ids"], ret_mim_loss=True, ret_bbox_loss=False, ret_bbox_giou=False, data_source="image")
+            last.update(l2)
+            return sum(l2[k].float() for k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim"))
+
+        amp_floor(m, again, out)
+        for k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim"):
+            out["floor_" + k] = np.asarray(float(last[k]))
+            print("autocast", k, float(last[k]), flush=True)
     save(name, out, {"spec": spec_of(m), "B": B, "text_layers": text_layers, "fusion_layers": fusion_layers,
                      "image_neg_idx": [int(i) for i in captured["image_neg_idx"]],
                      "text_neg_idx": [int(i) for i in captured["text_neg_idx"]], "unused": unused})
@@ -336,19 +375,20 @@ def shallow_vit(depth=SHALLOW):
         rb.beit_base_patch16 = orig
 
 
-def gen_retrieval(B=4):
+def gen_retrieval(B=4, res=224, T=30, name="retrieval_small"):
     """models/model_retrieval.py XFMForRetrieval: ITC with duplicated `idx` (soft labels, xfm.py:705-713), hard negatives that
-    avoid same-idx pairs (:731-734), ITM with the text gradient kept (is_pretrain=False)."""
+    avoid same-idx pairs (:731-734), ITM with the text gradient kept (is_pretrain=False).  res / T: the fine-tuning shape of
+    configs/xfm-ft/Retrieval_coco.yaml (384 px, 40 tokens) for the `retrieval_384` fixture."""
     from models.model_retrieval import XFMForRetrieval
     ref_shim.init_single_process_group()
     torch.manual_seed(0)
-    cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2)
+    cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2, overrides={"image_res": res, "max_tokens": T, "max_words": T})
     with shallow_vit():
         m = XFMForRetrieval(cfg)
     load_formula(m)
     m.eval()
-    b = syn.pretrain_batch(B, seed=77)
-    idx = torch.tensor([5, 9, 5, 2][:B])
+    b = syn.pretrain_batch(B, seed=77, image_res=res, max_tokens=T)
+    idx = torch.tensor([5, 9, 5, 2, 7, 1, 9, 3][:B])
     captured = {}
     orig = m.get_hard_negatives
 
@@ -364,7 +404,8 @@ def gen_retrieval(B=4):
     (loss_itc + loss_itm).backward()
     grads_of(m, out)
     unused = [n for n, p in m.named_parameters() if p.grad is None]
-    save("retrieval_small", out, {"spec": spec_of(m), "B": B, "text_layers": 2, "fusion_layers": 2, "vit_depth": SHALLOW, "idx": idx.tolist(),
+    save(name, out, {"spec": spec_of(m), "B": B, "text_layers": 2, "fusion_layers": 2, "vit_depth": SHALLOW, "idx": idx.tolist(),
+                                  "image_res": res, "max_tokens": T,
                                   "image_neg_idx": [int(i) for i in captured["image_neg_idx"]],
                                   "text_neg_idx": [int(i) for i in captured["text_neg_idx"]], "unused": unused})
 
@@ -462,6 +503,7 @@ def gen_classification(B=4):
     loss.backward()
     grads_of(m, out, "grad_imagenet")
     unused = [n for n, p in m.named_parameters() if p.grad is None]
+    amp_floor(m, lambda: m(b["image"], None, None, targets, train=True), out, "floor_imagenet")
     save("classification_imagenet", out, {"spec": spec_of(m), "B": B, "targets": targets.tolist(), "unused": unused,
                                           "text_layers": 2, "fusion_layers": 2})
     # multimodal branch (e.g. NLVR / VE style heads): plain 2-layer head on the fused [CLS]
@@ -475,6 +517,7 @@ def gen_classification(B=4):
     out2["loss_mm"] = np.asarray(float(loss2.detach()))
     loss2.backward()
     grads_of(m2, out2, "grad_mm")
+    amp_floor(m2, lambda: m2(b["image"], b["text_ids"], b["text_atts"], t2, train=True), out2, "floor_mm")
     # text-only branch on the same model
     m2.zero_grad()
     loss3 = m2(None, b["text_ids"], b["text_atts"], t2, train=True)
@@ -484,9 +527,10 @@ def gen_classification(B=4):
     save("classification_mm", out2, {"spec": spec_of(m2), "B": B, "targets": t2.tolist(), "text_layers": 2, "fusion_layers": 2})
 
 
-def gen_vqa():
+def gen_vqa(res=224, name="vqa_small"):
     """models/model_generation.py XFMForVQA (BASELINE configs[3]): weighted answer-decoder loss + its gradients, and the
-    inference-time answer ranking (first-token shortlist, sequence log-likelihood re-rank)."""
+    inference-time answer ranking (first-token shortlist, sequence log-likelihood re-rank).  res = 480 (configs/xfm-ft/VQA_480.yaml)
+    for the `vqa_480` fixture."""
     from types import SimpleNamespace as NS
 
     def build_tokenizer(*a, **kw):  # only the captioning classes of model_generation.py call it
@@ -497,12 +541,12 @@ def gen_vqa():
     ref_shim.init_single_process_group()
     torch.manual_seed(0)
     cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2,
-                                   overrides={"pad_token_id": 1, "decoder_fusion_start_at": 0, "num_dec_layers": 2})
+                                   overrides={"pad_token_id": 1, "decoder_fusion_start_at": 0, "num_dec_layers": 2, "image_res": res})
     with shallow_vit():
         m = XFMForVQA(cfg)
     load_formula(m)
     m.eval()
-    x = syn.vqa_inputs()
+    x = syn.vqa_inputs(image_res=res)
     q, a, c = NS(input_ids=x.q_ids, attention_mask=x.q_atts), NS(input_ids=x.a_ids, attention_mask=x.a_atts), \
         NS(input_ids=x.c_ids, attention_mask=x.c_atts)
     out = {}
@@ -512,12 +556,13 @@ def gen_vqa():
     loss.backward()
     grads_of(m, out)
     unused = [n for n, p in m.named_parameters() if p.grad is None]
+    amp_floor(m, lambda: m(x.image, q, a, k=x.k, weights=x.weights, train=True), out)
     with torch.no_grad():
         topk_ids, topk_probs = m(x.image, q, c, k=x.topk, train=False)
     out["topk_ids"] = topk_ids.numpy()
     out["topk_probs"] = topk_probs.numpy()
     print("topk", topk_ids.tolist(), topk_probs.tolist(), flush=True)
-    save("vqa_small", out, {"spec": spec_of(m), "B": 3, "text_layers": 2, "fusion_layers": 2, "vit_depth": SHALLOW, "dec_layers": 2, "dec_fusion_start": 0,
+    save(name, out, {"spec": spec_of(m), "B": 3, "image_res": res, "text_layers": 2, "fusion_layers": 2, "vit_depth": SHALLOW, "dec_layers": 2, "dec_fusion_start": 0,
                             "pad_token_id": 1, "unused": unused})
 
 
@@ -657,9 +702,11 @@ def main():
     torch.set_num_threads(8)
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval, "harness": gen_harness, "checkpoint_vqa": gen_checkpoint_vqa, "grounding": gen_grounding}
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval, "harness": gen_harness, "checkpoint_vqa": gen_checkpoint_vqa, "grounding": gen_grounding,
+            "retrieval_384": lambda: gen_retrieval(B=8, res=384, T=40, name="retrieval_384"),
+            "vqa_480": lambda: gen_vqa(res=480, name="vqa_480")}
     if a.full:
-        jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12)
+        jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12, with_floor=True)
     for k, fn in jobs.items():
         if a.only is None or a.only == k:
             print("==", k, flush=True)

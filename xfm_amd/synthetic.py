@@ -162,11 +162,11 @@ def mim_block_mask(batch_size, grid=14, num_masking=75, seed=1234):
     return torch.from_numpy(out.reshape(B, grid * grid))
 
 
-def vqa_inputs(B=3):
+def vqa_inputs(B=3, image_res=224):
     """VQA fixture inputs shared by the golden generator and the CPU / GPU parity tests: B images + questions, k[b] answers per
     question with annotator weights, and a candidate answer list for the inference-time ranking (top `topk`)."""
     from types import SimpleNamespace as NS
-    b = pretrain_batch(B, seed=91)
+    b = pretrain_batch(B, seed=91, image_res=image_res)
     k = [2, 1, 3][:B]
     ans = pretrain_batch(sum(k), seed=92, max_tokens=7, min_len=3, with_image=False)
     cand = pretrain_batch(5, seed=93, max_tokens=6, min_len=3, with_image=False)
