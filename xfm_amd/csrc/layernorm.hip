@@ -198,12 +198,24 @@ template <int NCH, int MODE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
   constexpr int D = NCH * 256;
   constexpr int NSET = (MODE == LN_PLAIN) ? 2 : (MODE == LN_POST ? 3 : 4);
-  __shared__ float red[4][D];
+  // Column sums (dgamma, dbeta, dbias, dls) live in LDS, one private slice per wave, updated by 16-byte read-modify-writes of the
+  // lane's own slots (no atomics: ds_add_f32 serialises per lane -- measured ~200 clocks per wave instruction, 4x slower kernels):
+  // 12 * NSET fewer VGPRs per lane than register accumulators (LS mode at D = 768: 170 -> under 128, i.e. 4 waves per SIMD
+  // instead of 2, which is what an HBM-bound kernel with a load -> reduce -> load -> store chain per row needs).
+  __shared__ f32x4 colsum[4][NSET][NCH][64];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
+#pragma unroll
+  for (int s = 0; s < NSET; ++s)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) colsum[wib][s][i][lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto col_add4 = [&](int s, int i, const f32x4& v) {
+    f32x4 t = colsum[wib][s][i][lane];
+    t += v;
+    colsum[wib][s][i][lane] = t;
+  };
   float wv[NCH][4], lsg[NCH][4];
-  float acc[NSET][NCH][4];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int e = (i * 64 + lane) * 4;
@@ -215,10 +227,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) lsg[i][j] = g[j];
     }
-#pragma unroll
-    for (int s = 0; s < NSET; ++s)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[s][i][j] = 0.f;
   }
   for (int row = wave; row < p.rows; row += nwaves) {
     const long base = (long)row * D;
@@ -226,6 +234,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
     const float mu = p.mean[row], rstd = p.rstd[row];
     float dy[NCH][4], xh[NCH][4];
     float c1 = 0.f, c2 = 0.f;
+    // LS mode: the stream gradient and the branch output of this row are needed only after the row reductions -- fetch them now,
+    // with everything else (one round trip to HBM per row instead of two)
+    f32x4 ds_in[MODE == LN_LS ? NCH : 1];
+    bf16x4 h_in[MODE == LN_LS ? NCH : 1];
+    if (MODE == LN_LS) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int e = (i * 64 + lane) * 4;
+        ds_in[i] = *reinterpret_cast<const f32x4*>(p.dstream + base + e);
+        h_in[i] = *reinterpret_cast<const bf16x4*>(p.h + base + e);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int e = (i * 64 + lane) * 4;
@@ -261,8 +281,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
         const float g = dy[i][j] * wv[i][j];
         c1 += g;
         c2 += g * xh[i][j];
-        acc[0][i][j] += dy[i][j] * xh[i][j];
-        acc[1][i][j] += dy[i][j];
       }
     }
     c1 = wave_sum(c1) * (1.0f / D);
@@ -273,6 +291,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
     for (int i = 0; i < NCH; ++i) {
       const int e = (i * 64 + lane) * 4;
       float dz[4];
+      asm volatile("" ::: "memory");  // keep the column-sum read-modify-writes of chunk i here (hoisted, they cost 12 * NSET VGPRs)
+      col_add4(0, i, f32x4{dy[i][0] * xh[i][0], dy[i][1] * xh[i][1], dy[i][2] * xh[i][2], dy[i][3] * xh[i][3]});
+      col_add4(1, i, f32x4{dy[i][0], dy[i][1], dy[i][2], dy[i][3]});
 #pragma unroll
       for (int j = 0; j < 4; ++j) dz[j] = rstd * (dy[i][j] * wv[i][j] - c1 - xh[i][j] * c2);
       if (MODE == LN_PLAIN) {
@@ -296,6 +317,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
         }
       } else if (MODE == LN_POST) {
         bf16x4 oh, orr;
+        f32x4 a2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float dhv = dz[j];
@@ -305,39 +327,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
           }
           orr[j] = f2bf(dz[j]);
           oh[j] = f2bf(dhv);
-          acc[2][i][j] += bf2f(oh[j]);
+          a2[j] = bf2f(oh[j]);
         }
+        col_add4(2, i, a2);
         *reinterpret_cast<bf16x4*>(p.dh + base + e) = oh;
         if (p.dres != nullptr && p.dres != p.dh) *reinterpret_cast<bf16x4*>(p.dres + base + e) = orr;
       } else {
-        const f32x4 ds = *reinterpret_cast<const f32x4*>(p.dstream + base + e);
-        const bf16x4 hh = *reinterpret_cast<const bf16x4*>(p.h + base + e);
-        f32x4 o;
+        const f32x4 ds = ds_in[MODE == LN_LS ? i : 0];
+        const bf16x4 hh = h_in[MODE == LN_LS ? i : 0];
+        f32x4 o, a2, a3;
         bf16x4 oh;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           o[j] = ds[j] + dz[j];
           const float dhv = rs * lsg[i][j] * o[j];
           oh[j] = f2bf(dhv);
-          acc[2][i][j] += bf2f(oh[j]);
-          acc[3][i][j] += rs * bf2f(hh[j]) * o[j];
+          a2[j] = bf2f(oh[j]);
+          a3[j] = rs * bf2f(hh[j]) * o[j];
         }
+        col_add4(2, i, a2);
+        col_add4(3, i, a3);
         *reinterpret_cast<f32x4*>(p.dstream + base + e) = o;
         *reinterpret_cast<bf16x4*>(p.dh + base + e) = oh;
       }
     }
   }
-  // block reduction of the column partial sums, one set at a time, then one slab row per block
+  // one slab row per block and set
+  __syncthreads();
+  const float* cs = reinterpret_cast<const float*>(&colsum[0][0][0][0]);  // [wave][set][column]
 #pragma unroll
   for (int s = 0; s < NSET; ++s) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) red[wib][(i * 64 + lane) * 4 + j] = acc[s][i][j];
-    __syncthreads();
     float* dst = p.partial + ((long)s * gridDim.x + blockIdx.x) * D;
-    for (int c = threadIdx.x; c < D; c += 256) dst[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    for (int c = threadIdx.x; c < D; c += 256)
+      dst[c] = (cs[(0 * NSET + s) * D + c] + cs[(1 * NSET + s) * D + c]) + (cs[(2 * NSET + s) * D + c] + cs[(3 * NSET + s) * D + c]);
   }
 }
 
