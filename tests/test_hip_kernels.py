@@ -399,6 +399,10 @@ def _attn_ref(q, k, v, B, H, Sq, Sk, scale, bias=None, keep=None, causal=False, 
     (2, 12, 40, 577, False, True, False),    # cross-attention of 40-token captions onto a 384 px image
     (1, 3, 901, 901, True, False, False),    # 480 px (VQA fine-tuning)
     (1, 1, 2, 3, False, False, False),
+    (9, 12, 197, 197, True, False, False),   # short-sequence backward: three batch entries per workgroup (K double buffer, V prefetch)
+    (5, 12, 100, 256, True, False, False),   # ... 16 key tiles, 7 query tiles
+    (11, 12, 256, 64, False, False, False),  # ... one key tile per key-range wave, no bias
+    (3, 12, 50, 20, True, False, False),     # ... two key tiles: two of the four key-range waves idle
 ])
 def test_attention_fwd_bwd(B, H, Sq, Sk, use_bias, use_keep, causal):
     Fx = _fx()

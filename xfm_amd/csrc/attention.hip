@@ -521,6 +521,272 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward 1/2 for short, dense, unmasked problems (the 224-px ViT: Sq = Sk = 197; any Sk <= 256): dQ, delta, dbias.
+// The kernel above gives a wave 16 queries against ALL keys; with the bias gradient that is 253 VGPRs (one 7-wave workgroup per
+// CU), a bias row segment fetched per key chunk, and two passes over the keys for delta: 202 us per ViT layer, 12 us per (batch,
+// head, query block), against 1 us of MFMA time.  Here a workgroup is (query group of <= 4 tiles, head) and its 16 waves are
+// (query tile, key range): a wave owns 16 queries x <= 64 keys of EVERY batch entry the workgroup walks, so
+//   * its bias tile is loaded once (16 VGPRs, batch-invariant) and its bias-gradient sum is 16 VGPRs, not 64;
+//   * S and dP are computed once: the four key-range waves of a query tile exchange their partial delta through LDS;
+//   * dS crosses LDS once (bf16, 8 B per lane and tile) and the wave with key range w sums d-tile w of dQ over all keys;
+//   * K, V (second LDS buffers) and the Q / dO fragments (registers) of the next entry are fetched while this one computes.
+// LDS: K (2 x 32 KB) | V (2 x 32 KB) | dS exchange (8 KB per query tile) | delta partials.  One workgroup (12 waves) per CU.
+// ---------------------------------------------------------------------------------------------
+#define VB_KBUF (ATTN_RES_MAX * ATTN_TILE)
+#define VB_EXCH(QT) ((QT) * 16 * 512)
+#define VB_LDS(QT) (4 * VB_KBUF + VB_EXCH(QT) + (QT) * 4 * 16 * 4)
+
+// rows [0, nrows) of a [*, 64] bf16 operand into consecutive 64-row tiles (direct-to-LDS, same image as stage_slot's tiles).
+// Issued as inline asm on purpose: when the compiler sees a direct-to-LDS load it drains it (s_waitcnt vmcnt(0)) in front of
+// every later LDS read, which would serialise the prefetch of the next entry with the MFMAs of this one.  The caller waits
+// (s_waitcnt vmcnt) before the barrier that publishes the tiles.
+__device__ __forceinline__ void stage_rows(char* tiles, const bf16* g, long rs, int nrows, int w, int nw, int lane) {
+  const int n = ((nrows + 63) >> 6) * 8;
+  for (int j = w; j < n; j += nw) {
+    const int r = (j & 7) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz_a(r);
+    int gr = (j >> 3) * 64 + r;
+    gr = gr < nrows ? gr : nrows - 1;
+    const bf16* src = g + (long)gr * rs + c * 8;
+    const unsigned dst = (unsigned)(uintptr_t)LDS_PTR(void, tiles) + (unsigned)__builtin_amdgcn_readfirstlane((j >> 3) * ATTN_TILE + (j & 7) * 1024);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+  }
+}
+// tr_frag with the two 16-row halves of the k dimension in (possibly) different tiles
+__device__ __forceinline__ bf16x8 tr_frag2(const char* tileA, int rowA, const char* tileB, int rowB, int col0, int lr, int lg) {
+  const int col = col0 + 4 * (lr & 3);
+  const int ra = rowA + 4 * lg + (lr >> 2), rb = rowB + 4 * lg + (lr >> 2);
+  const int offa = ra * 128 + (((col >> 3) ^ swz_a(ra)) << 4) + (col & 7) * 2;
+  const int offb = rb * 128 + (((col >> 3) ^ swz_a(rb)) << 4) + (col & 7) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tileA + offa));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tileB + offb));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for the prefetch DMA in flight
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int QT, int NP>
+__global__ __launch_bounds__(QT * 256) void attn_bwd_dq_short_kernel(AttnArgs a, int nb_per_block) {
+  constexpr int NW = QT * 4;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int qt = w >> 2, kw = w & 3;
+  const int h = blockIdx.y;
+  const int sk = a.Sk, sq = a.Sq;
+  const int KT = (sk + 15) >> 4;  // key tiles of 16 (<= 2 * NP), dealt to the four key-range waves as evenly as they go
+  const int kbase = KT >> 2, krem = KT & 3;
+  const int nt = kbase + (kw < krem ? 1 : 0);
+  const int kt0 = kw * kbase + (kw < krem ? kw : krem);
+  const int QTILES = (sq + 15) >> 4, G = gridDim.x;  // query tiles dealt to the G groups the same way
+  const int qbase_t = QTILES / G, qrem = QTILES % G;
+  const int nqt = qbase_t + ((int)blockIdx.x < qrem ? 1 : 0);
+  const int q0 = ((int)blockIdx.x * qbase_t + ((int)blockIdx.x < qrem ? (int)blockIdx.x : qrem) + qt) * 16;
+  const bool wave_active = qt < nqt && q0 < sq;
+  const int qi = q0 + lr;
+  const bool qvalid = wave_active && qi < sq;
+  const int qc = qi < sq ? qi : sq - 1;
+
+  char* const sK0 = lds;
+  char* const ex = lds + 4 * VB_KBUF;
+  float* const dred = reinterpret_cast<float*>(ex + VB_EXCH(QT));
+
+  // LDS addressing.  A 16-row tile t of an image starts 2048 B after tile t-1 (four to a 64-row, 8 KB staging tile) and the XOR
+  // swizzle of a row depends on (row >> 1) & 7 only, i.e. not on the tile: every fragment address is ONE per-lane offset plus a
+  // multiple of 2048 -- an immediate -- instead of a register per fragment.
+  const int sw_r = (lr >> 1) & 7;
+  const int rf0 = lr * 128 + ((lg ^ sw_r) << 4), rf1 = lr * 128 + (((4 + lg) ^ sw_r) << 4);  // row fragments, k-steps 0 / 1
+  const int tr_row = 4 * lg + (lr >> 2), tr_col = kw * 16 + 4 * (lr & 3);                   // transposed fragment of d-tile kw
+  const int tro = tr_row * 128 + ((((tr_col >> 3) ^ ((tr_row >> 1) & 7))) << 4) + (tr_col & 7) * 2;
+  const int ex_w = ((qt * 16 + kt0) * 64 + lane) * 8, ex_r = (qt * 16 * 64 + lane) * 8;
+
+  // Softmax in the exponent of 2 with the row constants folded into the accumulator the score MFMAs start from:
+  //   S' = K.q + (bias - lse) / scale,  P = exp2(S' * scale * log2 e)   (no subtraction, no select: keys past Sk carry bias -1e30)
+  const float inv_scale = 1.0f / a.scale, c2 = a.scale * 1.44269504088896341f;
+  f32x4 bvs[4], dsacc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    dsacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kj0 = (kt0 + t) * 16 + 4 * lg;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr && t < nt && kj0 < sk) bv = *reinterpret_cast<const f32x4*>(a.bias + ((long)h * sq + qc) * a.bias_ld + kj0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bvs[t][r] = (kj0 + r < sk ? bv[r] : -1.0e30f) * inv_scale;
+  }
+
+  // batch-invariant per-lane byte offsets; an entry adds one scalar stride to the (scalar) base pointers
+  const int q_off = (int)(((long)qc * a.q_rs + h * 64 + 8 * lg) * 2), do_off = (int)(((long)qc * a.do_rs + h * 64 + 8 * lg) * 2);
+  const int dq_off = (int)(((long)qi * a.dq_rs + h * 64 + kw * 16 + 4 * lg) * 2), stat_off = (int)((long)h * a.stat_ld + qc);
+  const long q_bs = (long)sq * a.q_rs * 2, do_bs = (long)sq * a.do_rs * 2, dq_bs = (long)sq * a.dq_rs * 2, stat_bs = (long)a.H * a.stat_ld;
+  const long k_bs = (long)sk * a.k_rs * 2, v_bs = (long)sk * a.v_rs * 2;
+  // this wave's pieces of a K / V image (<= 3 of the 8-per-chunk direct-to-LDS instructions): source offset per lane, LDS offset
+  // per wave.  At least NP / 2 chunks are staged (rows past Sk repeat the last key) so that every tile the dQ loop reads is finite.
+  int k_off[3], v_off[3];
+  unsigned pc_dst[3];
+  const int chunks = (sk + 63) >> 6;
+  const int n_pc = (chunks > NP / 2 ? chunks : NP / 2) * 8;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = w + i * NW;
+    const int r = (j & 7) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz_a(r);
+    int gr = (j >> 3) * 64 + r;
+    gr = gr < sk ? gr : sk - 1;
+    k_off[i] = (int)(((long)gr * a.k_rs + h * 64 + c * 8) * 2);
+    v_off[i] = (int)(((long)gr * a.v_rs + h * 64 + c * 8) * 2);
+    pc_dst[i] = (unsigned)__builtin_amdgcn_readfirstlane((j >> 3) * ATTN_TILE + (j & 7) * 1024);
+  }
+  auto stage_kv = [&](int b, int buf) {
+    const char* kb = reinterpret_cast<const char*>(a.k) + (long)b * k_bs;
+    const char* vb = reinterpret_cast<const char*>(a.v) + (long)b * v_bs;
+    const unsigned dk = (unsigned)(uintptr_t)LDS_PTR(void, sK0) + (unsigned)buf * VB_KBUF, dv = dk + 2 * VB_KBUF;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (w + i * NW < n_pc) {  // (inline asm: see stage_rows)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(kb + k_off[i]), "s"(dk + pc_dst[i]) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vb + v_off[i]), "s"(dv + pc_dst[i]) : "memory", "m0");
+      }
+    }
+  };
+
+  const int b_begin = blockIdx.z * nb_per_block;
+  int b_end = b_begin + nb_per_block;
+  b_end = b_end < a.B ? b_end : a.B;
+  // Q / dO fragments and the log-sum-exp of the NEXT entry are fetched while the current one computes (a load issued at the top
+  // of an entry and waited for there costs the whole HBM latency per entry: every wave of the CU sits behind the same barrier)
+  bf16x8 qf0, qf1, df0, df1;
+  float lse_n = 0.f;
+  auto fetch_q = [&](int b) {
+    const char* qp = reinterpret_cast<const char*>(a.q) + (long)b * q_bs + q_off;
+    const char* dop = reinterpret_cast<const char*>(a.dout) + (long)b * do_bs + do_off;
+    qf0 = *reinterpret_cast<const bf16x8*>(qp);
+    qf1 = *reinterpret_cast<const bf16x8*>(qp + 64);
+    df0 = *reinterpret_cast<const bf16x8*>(dop);
+    df1 = *reinterpret_cast<const bf16x8*>(dop + 64);
+    lse_n = a.lse[(long)b * stat_bs + stat_off];
+  };
+  if (b_begin < b_end) {
+    stage_kv(b_begin, 0);
+    fetch_q(b_begin);
+  }
+  for (int b = b_begin; b < b_end; ++b) {
+    const int cur = (b - b_begin) & 1;
+    const char* sK = sK0 + cur * VB_KBUF;
+    // everything up to the fetches of this entry must have landed.  (The compiler cannot see this wait: the empty asm makes it place
+    // its own wait for the fetched registers HERE, before this entry's direct-to-LDS loads are issued, rather than at their first
+    // use, where a counted wait would also drain those.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(qf0), "+v"(qf1), "+v"(df0), "+v"(df1), "+v"(lse_n));
+    const float lse_s = (qvalid ? lse_n : 1.0e30f) * inv_scale;  // rows past Sq: P = exp2(-huge) = 0
+    lds_barrier();  // K(b), V(b) have landed; every wave is done with entry b-1 (its K / V buffers, the exchange tiles)
+    if (b + 1 < b_end) stage_kv(b + 1, cur ^ 1);
+
+    f32x4 st[4], dp[4];
+    float dpart = 0.f;
+    if (wave_active) {
+      const char* ka = sK + kt0 * 2048;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[t][r] = bvs[t][r] - lse_s;
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(ka + t * 2048 + rf0), qf0, st[t], 0, 0, 0);
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(ka + t * 2048 + rf1), qf1, st[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(ka + 2 * VB_KBUF + t * 2048 + rf0), df0, dp[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(ka + 2 * VB_KBUF + t * 2048 + rf1), df1, dp[t], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(st[t][r] * c2);
+            st[t][r] = pv;
+            dpart = fmaf(pv, dp[t][r], dpart);
+          }
+        }
+      }
+      dpart = group4_sum(dpart);
+      if (lg == 0) dred[(qt * 4 + kw) * 16 + lr] = dpart;
+    }
+    if (b + 1 < b_end) fetch_q(b + 1);  // (here, not at the top: this entry's fragments are dead now and lend their registers)
+    lds_barrier();  // delta partials are in
+    // delta_i = sum_j P_ij dP_ij from the SAME P and dP that form dS, so that sum_j dS_ij = 0 holds to fp32 rounding
+    const float delta = (dred[(qt * 4 + 0) * 16 + lr] + dred[(qt * 4 + 1) * 16 + lr]) + (dred[(qt * 4 + 2) * 16 + lr] + dred[(qt * 4 + 3) * 16 + lr]);
+    if (wave_active && kw == 0 && lg == 0 && qvalid) a.delta[(long)b * stat_bs + stat_off] = delta;
+    if (wave_active) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < nt) {
+          bf16x4 pk;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ds = st[t][r] * (dp[t][r] - delta);
+            dsacc[t][r] += ds;
+            pk[r] = f2bf(ds);
+          }
+          *reinterpret_cast<bf16x4*>(ex + ex_w + t * 512) = pk;
+        }
+      }
+    }
+    lds_barrier();  // the query tile's dS tiles of all keys are in
+    if (wave_active) {
+      // dQ^T[d, q] = sum_keys K^T[d, key] dS^T[key, q] for d-tile kw, two key tiles per MFMA.  Straight-line over NP pairs (tiles past
+      // the last one contribute zeros) so that the LDS reads of several pairs are in flight together; two chains of dependent MFMAs.
+      const char* kb = sK + tro;
+      f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int s2 = 0; s2 < NP; ++s2) {
+        bf16x4 lo = *reinterpret_cast<const bf16x4*>(ex + ex_r + (2 * s2) * 512);
+        bf16x4 hi = *reinterpret_cast<const bf16x4*>(ex + ex_r + (2 * s2 + 1) * 512);
+        if (2 * s2 >= KT) lo = bf16x4{0, 0, 0, 0};
+        if (2 * s2 + 1 >= KT) hi = bf16x4{0, 0, 0, 0};
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pf[j] = lo[j]; pf[4 + j] = hi[j]; }
+        union { struct { s16x4 a, b; } s; bf16x8 v; } kf;
+        kf.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, kb + (2 * s2) * 2048));
+        kf.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, kb + (2 * s2 + 1) * 2048));
+        acc2[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, pf, acc2[s2 & 1], 0, 0, 0);
+        if ((s2 & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four pairs' fragments in flight at a time
+      }
+      const f32x4 acc = acc2[0] + acc2[1];
+      if (qvalid) {
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = f2bf(acc[r] * a.scale);
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(a.dq) + (long)b * dq_bs + dq_off) = ov;
+      }
+    }
+  }
+
+  if (a.dbias != nullptr) {  // flush sum_b dS: a wave-private LDS transpose makes every atomic wave-instruction one run of keys of one row
+    __syncthreads();
+    float* fl = reinterpret_cast<float*>(lds + w * 4096);  // [16 q][64 keys], aliases the K buffers (done with)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(fl + lr * 64 + t * 16 + 4 * lg) = dsacc[t];
+    __syncthreads();
+    if (wave_active && b_begin < b_end) {
+      const int kj = kt0 * 16 + lane;
+      for (int row = 0; row < 16; ++row) {
+        const int q = q0 + row;
+        if (q < sq && lane < nt * 16 && kj < sk) atomicAdd(a.dbias + ((long)h * sq + q) * a.bias_ld + kj, fl[row * 64 + lane]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward 2/2: dK, dV.  grid (key blocks, H, B); wave w owns keys [kblk*16*NW + 16*w, +16); queries stream in chunks
 // of 64 (Q and dO staged in LDS, read by rows for S / dP and transposed for dK^T / dV^T).
 // ---------------------------------------------------------------------------------------------
@@ -1149,8 +1415,29 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
   attn_geom(a.Sq, nw, blocks);
   const bool res = attn_resident(a.Sk, nw);
   const bool plain = attn_plain(a);
+  static const bool short_env = getenv("XFM_ATTN_SHORT_BWD") ? atoi(getenv("XFM_ATTN_SHORT_BWD")) != 0 : true;  // A/B knob
+  const bool short_dq = short_env && plain && a.Sk <= 64 * ATTN_RES_MAX && a.q_start == nullptr && a.k_start == nullptr &&
+                        a.kv_index == nullptr && (a.bias == nullptr || a.bias_ld >= (long)cdiv(a.Sk, 16) * 16) &&
+                        (a.dbias == nullptr || a.bias_ld >= a.Sk);
   if (a.bwd_phase == 2) {
     // dK/dV alone: `delta` was written by an earlier phase-1 call
+  } else if (short_dq) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_short_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, VB_LDS(3));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_short_kernel<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, VB_LDS(3));
+      attr_set = true;
+    }
+    // (query groups x heads) workgroups per batch slice; slices so that one round of <= 256 workgroups covers the batch
+    // three query tiles (12 waves) per workgroup: four would need 128-VGPR waves (measured: 40 spilled registers) and 161 KB of LDS
+    const int QT = 3;
+    const int groups = cdiv(cdiv(a.Sq, 16), QT);
+    int z = 256 / (groups * a.H);
+    z = z < 1 ? 1 : (z > a.B ? a.B : z);
+    const int nb = cdiv(a.B, z);
+    const dim3 grid(groups, a.H, cdiv(a.B, nb));
+    if (a.Sk <= 128) hipLaunchKernelGGL((attn_bwd_dq_short_kernel<3, 4>), grid, dim3(768), VB_LDS(3), st, a, nb);
+    else hipLaunchKernelGGL((attn_bwd_dq_short_kernel<3, 8>), grid, dim3(768), VB_LDS(3), st, a, nb);
   } else if (a.dbias != nullptr && res && plain) {
     // batch entries whose dS one workgroup sums before touching HBM.  The kernel holds 230+ VGPRs (sum_b dS of four chunks), i.e.
     // one workgroup per CU: of 4 and 8 entries take the one with fewer (rounds of 256 workgroups) x entries, ties to 8
