@@ -787,6 +787,200 @@ __global__ __launch_bounds__(QT * 256) void attn_bwd_dq_short_kernel(AttnArgs a,
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward 2/2 for the same short, dense, unmasked problems: dK, dV.  Mirror image of the kernel above: a workgroup is (group of
+// <= 3 key tiles, head), its 12 waves are (key tile, query range), and it walks batch entries with Q, dO and the row statistics
+// (log-sum-exp, delta) of the NEXT entry landing in second LDS buffers while this one computes.  A wave holds its key tile's K / V
+// fragments as the B operands (fetched one entry ahead), computes S and dP for its <= 4 query tiles once, hands P and dS to its
+// three sibling waves through LDS (bf16, 8 B per lane and tile) and sums d-tile `qw` of dV^T = dO^T P and dK^T = Q^T dS over all
+// queries.  Its bias tile [<= 64 queries x 16 keys] is batch-invariant: 16 VGPRs, loaded once.
+// LDS: Q, dO (2 images of 2 NP tiles each) | P, dS exchange (3 x 2 NP tiles x 512 B each) | statistics (2 x 2 x 1 KB).
+// NP = query-tile pairs the dK / dV loops run over (tiles past the last query hold zeros in the exchange and finite rows in the
+// images): 4 for Sq <= 128, 7 for Sq <= 224 (157 KB of LDS; longer sequences take the general kernel).
+// ---------------------------------------------------------------------------------------------
+#define VK_KT 3
+#define VK_IMG(NP) (2 * (NP) * 2048)
+#define VK_EXCH(NP) (VK_KT * 2 * (NP) * 512)
+#define VK_LDS(NP) (4 * VK_IMG(NP) + 2 * VK_EXCH(NP) + 4 * 1024)
+
+template <int NP>
+__global__ __launch_bounds__(VK_KT * 256) void attn_bwd_dkv_short_kernel(AttnArgs a, int nb_per_block) {
+  constexpr int NW = VK_KT * 4, IMG = VK_IMG(NP), EXCH = VK_EXCH(NP), PIECES = 4 * NP;  // 1-KB (8-row) pieces per image
+  constexpr int NPC = (PIECES + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int ktl = w >> 2, qw = w & 3;
+  const int h = blockIdx.y;
+  const int sk = a.Sk, sq = a.Sq;
+  const int QTILES = (sq + 15) >> 4;  // query tiles (<= 2 NP), dealt to the four query-range waves as evenly as they go
+  const int qb4 = QTILES >> 2, qr4 = QTILES & 3;
+  const int nqt = qb4 + (qw < qr4 ? 1 : 0);
+  const int qt0 = qw * qb4 + (qw < qr4 ? qw : qr4);
+  const int KT = (sk + 15) >> 4, G = gridDim.x;  // key tiles dealt to the G groups the same way
+  const int kb_t = KT / G, kr_t = KT % G;
+  const int nkt = kb_t + ((int)blockIdx.x < kr_t ? 1 : 0);
+  const int k0 = ((int)blockIdx.x * kb_t + ((int)blockIdx.x < kr_t ? (int)blockIdx.x : kr_t) + ktl) * 16;
+  const bool wave_active = ktl < nkt && k0 < sk;
+  const int kj = k0 + lr;
+  const bool kvalid = wave_active && kj < sk;
+  const int kc = kj < sk ? kj : sk - 1;
+
+  char* const sQ0 = lds;                // images: Q0 | Q1 | dO0 | dO1
+  char* const exP = lds + 4 * IMG;      // exchange: P | dS
+  char* const stat0 = exP + 2 * EXCH;   // statistics: [buffer][lse | delta][256]
+
+  // (see the dQ kernel: one per-lane offset per fragment kind, tiles are immediates)
+  const int sw_r = (lr >> 1) & 7;
+  const int rf0 = lr * 128 + ((lg ^ sw_r) << 4), rf1 = lr * 128 + (((4 + lg) ^ sw_r) << 4);
+  const int tr_row = 4 * lg + (lr >> 2), tr_col = qw * 16 + 4 * (lr & 3);
+  const int tro = tr_row * 128 + ((((tr_col >> 3) ^ ((tr_row >> 1) & 7))) << 4) + (tr_col & 7) * 2;
+  const int ex_w = ((ktl * 2 * NP + qt0) * 64 + lane) * 8, ex_r = (ktl * 2 * NP * 64 + lane) * 8;
+
+  for (int i = tid; i < 2 * EXCH / 16; i += NW * 64) reinterpret_cast<u32x4*>(exP)[i] = u32x4{0, 0, 0, 0};  // tiles past the last query stay zero
+
+  const float inv_scale = 1.0f / a.scale, c2 = a.scale * 1.44269504088896341f;
+  f32x4 bvs[4];  // (bias[q, key] / scale; -1e30 past the last key or query) for lane (lg, lr): queries 16 t + 4 lg + r, key lr
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qi = (qt0 + t) * 16 + 4 * lg + r;
+      float bv = 0.f;
+      if (a.bias != nullptr && t < nqt && qi < sq && kj < sk) bv = a.bias[((long)h * sq + qi) * a.bias_ld + kj];
+      bvs[t][r] = (qi < sq && kj < sk ? bv : -1.0e30f) * inv_scale;
+    }
+
+  const int k_off = (int)(((long)kc * a.k_rs + h * 64 + 8 * lg) * 2), v_off = (int)(((long)kc * a.v_rs + h * 64 + 8 * lg) * 2);
+  const int dk_off = (int)(((long)kj * a.dk_rs + h * 64 + qw * 16 + 4 * lg) * 2), dv_off = (int)(((long)kj * a.dv_rs + h * 64 + qw * 16 + 4 * lg) * 2);
+  const long k_bs = (long)sk * a.k_rs * 2, v_bs = (long)sk * a.v_rs * 2, dk_bs = (long)sk * a.dk_rs * 2, dv_bs = (long)sk * a.dv_rs * 2;
+  const long q_bs = (long)sq * a.q_rs * 2, do_bs = (long)sq * a.do_rs * 2, stat_bs = (long)a.H * a.stat_ld;
+  int q_off[NPC], do_off[NPC];
+  unsigned pc_dst[NPC];
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int j = w + i * NW;  // piece j: rows 8 j .. 8 j + 7 of the image
+    const int r = (j & 7) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz_a(r);
+    int gr = (j >> 3) * 64 + r;
+    gr = gr < sq ? gr : sq - 1;
+    q_off[i] = (int)(((long)gr * a.q_rs + h * 64 + c * 8) * 2);
+    do_off[i] = (int)(((long)gr * a.do_rs + h * 64 + c * 8) * 2);
+    pc_dst[i] = (unsigned)__builtin_amdgcn_readfirstlane(j * 1024);
+  }
+  // statistics: waves 0..3 stage 64 log-sum-exps each, waves 4..7 64 deltas each (4 B per lane); rows past Sq repeat the last one
+  const int st_q = (w & 3) * 64 + lane;
+  const int st_src = (int)((long)h * a.stat_ld + (st_q < sq ? st_q : sq - 1)) * 4;
+  const unsigned st_dst = (unsigned)__builtin_amdgcn_readfirstlane(((w >> 2) & 1) * 1024 + (w & 3) * 256);
+  auto stage_q = [&](int b, int buf) {
+    const char* qb = reinterpret_cast<const char*>(a.q) + (long)b * q_bs;
+    const char* db = reinterpret_cast<const char*>(a.dout) + (long)b * do_bs;
+    const unsigned dq = (unsigned)(uintptr_t)LDS_PTR(void, sQ0) + (unsigned)buf * IMG, dd = dq + 2 * IMG;
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      if (w + i * NW < PIECES) {  // (inline asm: see stage_rows)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(qb + q_off[i]), "s"(dq + pc_dst[i]) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(db + do_off[i]), "s"(dd + pc_dst[i]) : "memory", "m0");
+      }
+    }
+    if (w < 8) {
+      const char* sp = reinterpret_cast<const char*>(w < 4 ? a.lse : a.delta) + (long)b * stat_bs * 4 + st_src;
+      const unsigned sd = (unsigned)(uintptr_t)LDS_PTR(void, stat0) + (unsigned)buf * 2048 + st_dst;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(sp), "s"(sd) : "memory", "m0");
+    }
+  };
+
+  const int b_begin = blockIdx.z * nb_per_block;
+  int b_end = b_begin + nb_per_block;
+  b_end = b_end < a.B ? b_end : a.B;
+  bf16x8 kf0, kf1, vf0, vf1;
+  auto fetch_k = [&](int b) {
+    const char* kp = reinterpret_cast<const char*>(a.k) + (long)b * k_bs + k_off;
+    const char* vp = reinterpret_cast<const char*>(a.v) + (long)b * v_bs + v_off;
+    kf0 = *reinterpret_cast<const bf16x8*>(kp);
+    kf1 = *reinterpret_cast<const bf16x8*>(kp + 64);
+    vf0 = *reinterpret_cast<const bf16x8*>(vp);
+    vf1 = *reinterpret_cast<const bf16x8*>(vp + 64);
+  };
+  if (b_begin < b_end) {
+    stage_q(b_begin, 0);
+    fetch_k(b_begin);
+  }
+  for (int b = b_begin; b < b_end; ++b) {
+    const int cur = (b - b_begin) & 1;
+    const char* sQ = sQ0 + cur * IMG;
+    const char* sD = sQ + 2 * IMG;
+    const float* sL = reinterpret_cast<const float*>(stat0 + cur * 2048);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see the dQ kernel)
+    asm volatile("" : "+v"(kf0), "+v"(kf1), "+v"(vf0), "+v"(vf1));
+    lds_barrier();  // Q(b), dO(b), statistics(b) have landed; every wave is done with entry b-1
+    if (b + 1 < b_end) stage_q(b + 1, cur ^ 1);
+
+    f32x4 st[4], dp[4];
+    if (wave_active) {
+      const char* qa = sQ + qt0 * 2048;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < nqt) {
+          const f32x4 lsv = *reinterpret_cast<const f32x4*>(sL + (qt0 + t) * 16 + 4 * lg);
+          dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[t][r] = fmaf(-lsv[r], inv_scale, bvs[t][r]);
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qa + t * 2048 + rf0), kf0, st[t], 0, 0, 0);
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qa + t * 2048 + rf1), kf1, st[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qa + 2 * IMG + t * 2048 + rf0), vf0, dp[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qa + 2 * IMG + t * 2048 + rf1), vf1, dp[t], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < nqt) {
+          const f32x4 dlv = *reinterpret_cast<const f32x4*>(sL + 256 + (qt0 + t) * 16 + 4 * lg);
+          bf16x4 pp, ps;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(st[t][r] * c2);
+            pp[r] = f2bf(pv);
+            ps[r] = f2bf(pv * (dp[t][r] - dlv[r]));
+          }
+          *reinterpret_cast<bf16x4*>(exP + ex_w + t * 512) = pp;
+          *reinterpret_cast<bf16x4*>(exP + EXCH + ex_w + t * 512) = ps;
+        }
+      }
+    }
+    if (b + 1 < b_end) fetch_k(b + 1);  // (this entry's K / V fragments are dead: the next ones take their registers)
+    lds_barrier();  // P and dS of all queries against this key tile are in
+    if (wave_active) {
+      // dV^T[d, key] = sum_q dO^T[d, q] P[q, key],  dK^T[d, key] = sum_q Q^T[d, q] dS[q, key]  for d-tile qw, two query tiles per MFMA
+      const char* qb = sQ + tro;
+      f32x4 av[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, ak[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int s2 = 0; s2 < NP; ++s2) {
+        union { struct { bf16x4 a, b; } s; bf16x8 v; } pf, sf;
+        union { struct { s16x4 a, b; } s; bf16x8 v; } qf, df;
+        pf.s.a = *reinterpret_cast<const bf16x4*>(exP + ex_r + (2 * s2) * 512);
+        pf.s.b = *reinterpret_cast<const bf16x4*>(exP + ex_r + (2 * s2 + 1) * 512);
+        sf.s.a = *reinterpret_cast<const bf16x4*>(exP + EXCH + ex_r + (2 * s2) * 512);
+        sf.s.b = *reinterpret_cast<const bf16x4*>(exP + EXCH + ex_r + (2 * s2 + 1) * 512);
+        df.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, qb + 2 * IMG + (2 * s2) * 2048));
+        df.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, qb + 2 * IMG + (2 * s2 + 1) * 2048));
+        qf.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, qb + (2 * s2) * 2048));
+        qf.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, qb + (2 * s2 + 1) * 2048));
+        av[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df.v, pf.v, av[s2 & 1], 0, 0, 0);
+        ak[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf.v, sf.v, ak[s2 & 1], 0, 0, 0);
+        if ((s2 & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two pairs' fragments in flight at a time
+      }
+      if (kvalid) {
+        bf16x4 ok_, ov_;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ok_[r] = f2bf((ak[0][r] + ak[1][r]) * a.scale); ov_[r] = f2bf(av[0][r] + av[1][r]); }
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(a.dk) + (long)b * dk_bs + dk_off) = ok_;
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(a.dv) + (long)b * dv_bs + dv_off) = ov_;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward 2/2: dK, dV.  grid (key blocks, H, B); wave w owns keys [kblk*16*NW + 16*w, +16); queries stream in chunks
 // of 64 (Q and dO staged in LDS, read by rows for S / dP and transposed for dK^T / dV^T).
 // ---------------------------------------------------------------------------------------------
@@ -1460,6 +1654,22 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
   }
   rc = xfm_check_launch("attn_bwd_dq");
   if (rc != XFM_OK || a.bwd_phase == 1) return rc;
+  if (short_dq && a.Sq <= 224) {  // (same preconditions as the short dQ kernel; Sq bounded by the LDS images)
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_short_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, VK_LDS(4));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_short_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, VK_LDS(7));
+      attr_set = true;
+    }
+    const int groups = cdiv(cdiv(a.Sk, 16), VK_KT);
+    int z = 256 / (groups * a.H);
+    z = z < 1 ? 1 : (z > a.B ? a.B : z);
+    const int nb = cdiv(a.B, z);
+    const dim3 grid(groups, a.H, cdiv(a.B, nb));
+    if (a.Sq <= 128) hipLaunchKernelGGL(attn_bwd_dkv_short_kernel<4>, grid, dim3(VK_KT * 256), VK_LDS(4), st, a, nb);
+    else hipLaunchKernelGGL(attn_bwd_dkv_short_kernel<7>, grid, dim3(VK_KT * 256), VK_LDS(7), st, a, nb);
+    return xfm_check_launch("attn_bwd_dkv_short");
+  }
   attn_geom(a.Sk, nw, blocks);
   const dim3 grid(blocks, a.H, a.B), blk(nw * 64);
   static const bool dkv_res = getenv("XFM_ATTN_DKV_RES") ? atoi(getenv("XFM_ATTN_DKV_RES")) != 0 : true;  // tuning knob
