@@ -14,6 +14,6 @@ for f in glob.glob("gpurun_out/pmc_at_$d/**/*counter_collection.csv", recursive=
     for r in csv.DictReader(open(f)): s.add(r["Counter_Name"])
 print(" ".join(sorted(s)))
 PY
-); do echo "-- $c"; python3 tools/pmc_one.py gpurun_out/pmc_at_$d $c attn_bwd_dq | cut -c1-150; done
+); do echo "-- $c"; python3 tools/pmc_one.py gpurun_out/pmc_at_$d $c attn_bwd_d | cut -c1-150; done
 done
 find gpurun_out/pmc_at_a gpurun_out/pmc_at_b gpurun_out/pmc_at_c -type f -delete

@@ -574,22 +574,25 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <int QT, int NP>
-__global__ __launch_bounds__(QT * 256) void attn_bwd_dq_short_kernel(AttnArgs a, int nb_per_block) {
+__global__ __launch_bounds__(QT * 256) void attn_bwd_dq_short_kernel(AttnArgs a, int nb_per_block, int G) {
   constexpr int NW = QT * 4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int qt = w >> 2, kw = w & 3;
-  const int h = blockIdx.y;
+  // 1-D grid, logical id = group + G * (head + H * batch slice), an XCD takes a contiguous range of logical ids: the G groups of one
+  // (head, batch slice) read the same K / V rows at about the same time and now do so through ONE L2
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int grp = wg % G, h = (wg / G) % a.H, zslice = wg / (G * a.H);
   const int sk = a.Sk, sq = a.Sq;
   const int KT = (sk + 15) >> 4;  // key tiles of 16 (<= 2 * NP), dealt to the four key-range waves as evenly as they go
   const int kbase = KT >> 2, krem = KT & 3;
   const int nt = kbase + (kw < krem ? 1 : 0);
   const int kt0 = kw * kbase + (kw < krem ? kw : krem);
-  const int QTILES = (sq + 15) >> 4, G = gridDim.x;  // query tiles dealt to the G groups the same way
+  const int QTILES = (sq + 15) >> 4;  // query tiles dealt to the G groups the same way
   const int qbase_t = QTILES / G, qrem = QTILES % G;
-  const int nqt = qbase_t + ((int)blockIdx.x < qrem ? 1 : 0);
-  const int q0 = ((int)blockIdx.x * qbase_t + ((int)blockIdx.x < qrem ? (int)blockIdx.x : qrem) + qt) * 16;
+  const int nqt = qbase_t + (grp < qrem ? 1 : 0);
+  const int q0 = (grp * qbase_t + (grp < qrem ? grp : qrem) + qt) * 16;
   const bool wave_active = qt < nqt && q0 < sq;
   const int qi = q0 + lr;
   const bool qvalid = wave_active && qi < sq;
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(QT * 256) void attn_bwd_dq_short_kernel(AttnArgs a,
     }
   };
 
-  const int b_begin = blockIdx.z * nb_per_block;
+  const int b_begin = zslice * nb_per_block;
   int b_end = b_begin + nb_per_block;
   b_end = b_end < a.B ? b_end : a.B;
   // Q / dO fragments and the log-sum-exp of the NEXT entry are fetched while the current one computes (a load issued at the top
@@ -803,23 +806,24 @@ __global__ __launch_bounds__(QT * 256) void attn_bwd_dq_short_kernel(AttnArgs a,
 #define VK_LDS(NP) (4 * VK_IMG(NP) + 2 * VK_EXCH(NP) + 4 * 1024)
 
 template <int NP>
-__global__ __launch_bounds__(VK_KT * 256) void attn_bwd_dkv_short_kernel(AttnArgs a, int nb_per_block) {
+__global__ __launch_bounds__(VK_KT * 256) void attn_bwd_dkv_short_kernel(AttnArgs a, int nb_per_block, int G) {
   constexpr int NW = VK_KT * 4, IMG = VK_IMG(NP), EXCH = VK_EXCH(NP), PIECES = 4 * NP;  // 1-KB (8-row) pieces per image
   constexpr int NPC = (PIECES + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int ktl = w >> 2, qw = w & 3;
-  const int h = blockIdx.y;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);  // (see the dQ kernel: the groups of one (head, batch slice) share an XCD)
+  const int grp = wg % G, h = (wg / G) % a.H, zslice = wg / (G * a.H);
   const int sk = a.Sk, sq = a.Sq;
   const int QTILES = (sq + 15) >> 4;  // query tiles (<= 2 NP), dealt to the four query-range waves as evenly as they go
   const int qb4 = QTILES >> 2, qr4 = QTILES & 3;
   const int nqt = qb4 + (qw < qr4 ? 1 : 0);
   const int qt0 = qw * qb4 + (qw < qr4 ? qw : qr4);
-  const int KT = (sk + 15) >> 4, G = gridDim.x;  // key tiles dealt to the G groups the same way
+  const int KT = (sk + 15) >> 4;  // key tiles dealt to the G groups the same way
   const int kb_t = KT / G, kr_t = KT % G;
-  const int nkt = kb_t + ((int)blockIdx.x < kr_t ? 1 : 0);
-  const int k0 = ((int)blockIdx.x * kb_t + ((int)blockIdx.x < kr_t ? (int)blockIdx.x : kr_t) + ktl) * 16;
+  const int nkt = kb_t + (grp < kr_t ? 1 : 0);
+  const int k0 = (grp * kb_t + (grp < kr_t ? grp : kr_t) + ktl) * 16;
   const bool wave_active = ktl < nkt && k0 < sk;
   const int kj = k0 + lr;
   const bool kvalid = wave_active && kj < sk;
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(VK_KT * 256) void attn_bwd_dkv_short_kernel(AttnArg
     }
   };
 
-  const int b_begin = blockIdx.z * nb_per_block;
+  const int b_begin = zslice * nb_per_block;
   int b_end = b_begin + nb_per_block;
   b_end = b_end < a.B ? b_end : a.B;
   bf16x8 kf0, kf1, vf0, vf1;
@@ -1629,9 +1633,9 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
     int z = 256 / (groups * a.H);
     z = z < 1 ? 1 : (z > a.B ? a.B : z);
     const int nb = cdiv(a.B, z);
-    const dim3 grid(groups, a.H, cdiv(a.B, nb));
-    if (a.Sk <= 128) hipLaunchKernelGGL((attn_bwd_dq_short_kernel<3, 4>), grid, dim3(768), VB_LDS(3), st, a, nb);
-    else hipLaunchKernelGGL((attn_bwd_dq_short_kernel<3, 8>), grid, dim3(768), VB_LDS(3), st, a, nb);
+    const dim3 grid(groups * a.H * cdiv(a.B, nb));
+    if (a.Sk <= 128) hipLaunchKernelGGL((attn_bwd_dq_short_kernel<3, 4>), grid, dim3(768), VB_LDS(3), st, a, nb, groups);
+    else hipLaunchKernelGGL((attn_bwd_dq_short_kernel<3, 8>), grid, dim3(768), VB_LDS(3), st, a, nb, groups);
   } else if (a.dbias != nullptr && res && plain) {
     // batch entries whose dS one workgroup sums before touching HBM.  The kernel holds 230+ VGPRs (sum_b dS of four chunks), i.e.
     // one workgroup per CU: of 4 and 8 entries take the one with fewer (rounds of 256 workgroups) x entries, ties to 8
@@ -1665,9 +1669,9 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
     int z = 256 / (groups * a.H);
     z = z < 1 ? 1 : (z > a.B ? a.B : z);
     const int nb = cdiv(a.B, z);
-    const dim3 grid(groups, a.H, cdiv(a.B, nb));
-    if (a.Sq <= 128) hipLaunchKernelGGL(attn_bwd_dkv_short_kernel<4>, grid, dim3(VK_KT * 256), VK_LDS(4), st, a, nb);
-    else hipLaunchKernelGGL(attn_bwd_dkv_short_kernel<7>, grid, dim3(VK_KT * 256), VK_LDS(7), st, a, nb);
+    const dim3 grid(groups * a.H * cdiv(a.B, nb));
+    if (a.Sq <= 128) hipLaunchKernelGGL(attn_bwd_dkv_short_kernel<4>, grid, dim3(VK_KT * 256), VK_LDS(4), st, a, nb, groups);
+    else hipLaunchKernelGGL(attn_bwd_dkv_short_kernel<7>, grid, dim3(VK_KT * 256), VK_LDS(7), st, a, nb, groups);
     return xfm_check_launch("attn_bwd_dkv_short");
   }
   attn_geom(a.Sk, nw, blocks);
