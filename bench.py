@@ -235,22 +235,30 @@ def fusion_probe(model, B, host_batch, packed, iters=5):
         from xfm_amd.xfm import _PACK_SYNC
         ld = lens_h.to(dev).to(torch.int32)
         n_rows, t_max = int(lens_h.sum()), int(lens_h.max())
-        ranges = None
+        ranges, out_rows = None, None
         if _PACK_SYNC:  # the step's default layout: every sequence exact (the drawn negatives are read back once per step),
             # sequences image by image so that each image's queries are contiguous rows (xfm.XFMBase._matching_and_fuse_mlm_packed)
             from xfm_amd.packing import image_major_layout
             seq_img = index.tolist()
-            pack, _, _, meta, ranges = image_major_layout(lens4.tolist(), seq_img, B, T, dev, extra=(seq_img,))
+            from xfm_amd.xfm import _XATTN_RANGES, _LAST_ROWS
+            mpos = host_batch["masked_pos"]
+            M = mpos.shape[1]
+            sel_off = list(range(3 * B)) + [3 * B + j * M for j in range(B)]
+            sel_len = [1] * (3 * B) + [M] * B
+            pack, _, pos_of, meta, ranges = image_major_layout(lens4.tolist(), seq_img, B, T, dev, extra=(seq_img, sel_off, sel_len))
             index = meta[1].contiguous()
-            from xfm_amd.xfm import _XATTN_RANGES
             if not _XATTN_RANGES:
                 ranges = None
+            if _LAST_ROWS and not _XATTN_RANGES:  # as the step does: the last layer only on the rows ITM ([CLS]) and MLM (masked positions) read
+                start_of = pack.start.index_select(0, meta[0].long())
+                sel_rows = torch.cat([start_of[:3 * B], (start_of[3 * B:, None] + mpos.to(dev, torch.int32)).reshape(-1)])
+                out_rows = (sel_rows, meta[2].contiguous(), meta[3].contiguous(), M)
         else:           # no host sync: worst-case room for the negative-text block, offsets computed on the device
             pack = Pack.concat([(ld, n_rows, lens_h.tolist()), (ld, n_rows, lens_h.tolist()), (ld[perm.to(dev)], B * t_max, None),
                                 (ld, n_rows, lens_h.tolist())], T)
         valid = (pack.gather_index(pack) >= 0).unsqueeze(1)           # slack rows of the negative-text block stay zero
         text = ((torch.randn(pack.cap, 768, generator=g) * 0.7).to(dev, torch.bfloat16) * valid).requires_grad_(True)
-        kw = dict(encoder_embeds=text, attention_mask=None, pack=pack, encoder_row_ranges=ranges)
+        kw = dict(encoder_embeds=text, attention_mask=None, pack=pack, encoder_row_ranges=ranges, output_rows=out_rows)
         rows = pack.cap
     else:
         text = (torch.randn(4 * B, T, 768, generator=g) * 0.7).to(dev, torch.bfloat16).requires_grad_(True)
@@ -286,6 +294,7 @@ def fusion_probe(model, B, host_batch, packed, iters=5):
     tf_ref = 4 * B * FUSION_PASS_GFLOP / ms
     tf_exe = executed / (ms * 1e-3) / 1e12
     return {"ms": round(ms, 3), "sample_passes": 4 * B, "token_rows": rows, "token_rows_padded": 4 * B * T, "packed_rows": bool(packed),
+            "last_layer_rows": (int(kw["output_rows"][0].numel()) if packed and kw.get("output_rows") is not None else rows),
             "achieved_reference_flops": round(tf_ref, 1), "frac_reference_flops": round(tf_ref / BF16_DENSE_PEAK_TFLOPS, 4),
             "achieved_executed_flops": round(tf_exe, 1), "frac_executed_flops": round(tf_exe / BF16_DENSE_PEAK_TFLOPS, 4),
             "unit": "TFLOP/s", "executed_gflop": round(executed / 1e9, 1), "reference_gflop": round(4 * B * FUSION_PASS_GFLOP, 1),

@@ -274,6 +274,57 @@ def test_fusion_tower_image_major_layout_with_row_ranges_equals_padded(native):
     assert _rel(unpack(xs.grad, pack)[torch.tensor(pos_of)][keep], dx_pad[keep]) <= 1e-2
 
 
+def test_last_layer_on_selected_rows_equals_full_tower():
+    """output_rows: the last layer computed on the rows somebody reads ([CLS] of some sequences, M arbitrary positions -- duplicates
+    included -- of the others) against the full packed tower read at those rows: outputs, every parameter gradient, the gradient of
+    the image states and of the input rows (the unselected rows' outputs get no cotangent in either run)."""
+    from xfm_amd.packing import image_major_layout
+    torch.manual_seed(0)
+    m = _roberta(3, 0).cuda().finalize().eval()
+    B, U, T, N, M = 12, 4, 30, 197, 5
+    ln = _lens(B, T, 8, lo=6)
+    g = torch.Generator().manual_seed(5)
+    seq_img = torch.randint(0, U, (B,), generator=g)
+    n_cls = 7                                                   # sequences 0..6 are read at [CLS] only, 7..11 at M positions
+    pos = torch.stack([torch.randint(0, int(ln[n_cls + j]), (M,), generator=g) for j in range(B - n_cls)])
+    pos[0, 1] = pos[0, 0]                                       # a duplicate slot
+    pos[1, :] = 0                                               # all padding slots -> [CLS]
+    sel_off = list(range(n_cls)) + [n_cls + j * M for j in range(B - n_cls)]
+    sel_len = [1] * n_cls + [M] * (B - n_cls)
+    pack, order, pos_of, meta, _ = image_major_layout(ln.tolist(), seq_img.tolist(), U, T, "cuda",
+                                                      extra=(seq_img.tolist(), sel_off, sel_len))
+    keep = torch.arange(T)[None, :] < ln[:, None]
+    x = ((torch.randn(B, T, 768, generator=g) * 0.7) * keep[..., None]).to(BF16).cuda()
+    img = (torch.randn(U, N, 768, generator=g) * 0.7).to(BF16).cuda()
+    iatts = torch.ones(U, N, dtype=torch.long, device="cuda")
+    start_of = pack.start.index_select(0, torch.tensor(pos_of, device="cuda"))
+    rows = torch.cat([start_of[:n_cls], (start_of[n_cls:, None] + pos.cuda().to(torch.int32)).reshape(-1)]).to(torch.int32)
+    S = rows.numel()
+    w = torch.randn(S, 768, device="cuda")
+    xr = pack_rows(x[torch.tensor(order)], pack)
+    res = {}
+    for mode in ("full", "rows"):
+        m.zero_grad()
+        xa, ia = xr.detach().clone().requires_grad_(True), img.clone().requires_grad_(True)
+        kw = dict(encoder_embeds=xa, attention_mask=None, encoder_hidden_states=ia, encoder_attention_mask=iatts,
+                  encoder_batch_index=meta[1].contiguous(), pack=pack)
+        if mode == "full":
+            out = m.bert(**kw).last_hidden_state.index_select(0, rows.long())
+        else:
+            out = m.bert(output_rows=(rows, meta[2].contiguous(), meta[3].contiguous(), M), **kw).last_hidden_state
+        assert out.shape == (S, 768)
+        (out.float() * w).sum().backward()
+        res[mode] = (out.detach().float(), _grads(m), ia.grad.clone(), xa.grad.clone())
+    assert _rel(res["rows"][0], res["full"][0]) <= 2e-3, _rel(res["rows"][0], res["full"][0])
+    gf, gr = res["full"][1], res["rows"][1]
+    assert set(gf) == set(gr)
+    worst = max((_rel(gr[n], gf[n]), n) for n in gf if float(gf[n].float().norm()) > 1e-6 and "key.bias" not in n)
+    print("last layer on selected rows vs full tower: worst gradient rel-L2", worst)
+    assert worst[0] <= 1e-2, worst
+    assert _rel(res["rows"][2], res["full"][2]) <= 1e-2
+    assert _rel(res["rows"][3], res["full"][3]) <= 1e-2
+
+
 def test_pretrain_step_packed_rows_equals_padded_step():
     from xfm_amd.model_pretrain import XFM
     z, meta = load("pretrain_small")

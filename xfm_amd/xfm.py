@@ -32,6 +32,7 @@ BF16 = torch.bfloat16
 _PACK_SYNC = os.environ.get("XFM_PACK_SYNC", "1") != "0"
 # cross-attention per image on contiguous query rows (the image-major layout makes them so) instead of the grouped kernels: measured
 # the same (9.84 vs 9.67 ms for the fusion encoder's fwd+bwd: the generic kernels size their grid for the fullest image), so off
+_LAST_ROWS = os.environ.get("XFM_LAST_LAYER_ROWS", "0") != "0"   # fusion tower: last layer only on the rows ITM / MLM read (measured neutral: off)
 _XATTN_RANGES = os.environ.get("XFM_XATTN_RANGES", "0") != "0"
 
 
@@ -503,13 +504,30 @@ class XFMBase(nn.Module):
             seq_len = lh + lh + [lh[j] for j in tn] + lh                       # the reference's order: pos | neg img | neg txt | mlm
             seq_img = list(range(bs)) + im + list(range(bs)) + list(range(bs))
             seq_txt = list(range(bs)) + list(range(bs)) + tn + [bs + j for j in range(bs)]   # sequence of the text tower's pack
-            fpack, _, _, meta, ranges = image_major_layout(seq_len, seq_img, bs, pack.T, dev, extra=(seq_txt, seq_img))
+            # rows of the last layer that are read afterwards: [CLS] of the 3B matching sequences, the M masked positions of the B MLM
+            # sequences (padding slots point at position 0).  In the S-row result they sit in the reference's order.
+            M = masked_pos.shape[1]
+            prune = _LAST_ROWS and not _XATTN_RANGES and M <= 64
+            sel_off = list(range(3 * bs)) + [3 * bs + j * M for j in range(bs)]
+            sel_len = [1] * (3 * bs) + [M] * bs
+            fpack, _, _, meta, ranges = image_major_layout(seq_len, seq_img, bs, pack.T, dev, extra=(seq_txt, seq_img, sel_off, sel_len))
             pos_dev, seq_src, enc_index = meta[0].long(), meta[1].long(), meta[2].contiguous()
             text_all = rows_gather(text_rows.detach(), fpack.gather_index(pack, seq_src))
+            start_of = fpack.start.index_select(0, pos_dev)                     # start row of every sequence, reference order
+            out_rows = None
+            if prune:
+                sel_rows = torch.cat([start_of[:3 * bs], (start_of[3 * bs:, None] + masked_pos.to(torch.int32)).reshape(-1)])
+                out_rows = (sel_rows, meta[3].contiguous(), meta[4].contiguous(), M)
             seq = self.fusion_encoder.bert(encoder_embeds=text_all, attention_mask=None, encoder_hidden_states=image_embeds,
                                            encoder_attention_mask=image_atts, return_dict=True, encoder_batch_index=enc_index,
-                                           pack=fpack, encoder_row_ranges=ranges if _XATTN_RANGES else None).last_hidden_state
-            start_of = fpack.start.index_select(0, pos_dev)                     # start row of every sequence, reference order
+                                           pack=fpack, encoder_row_ranges=ranges if _XATTN_RANGES else None,
+                                           output_rows=out_rows).last_hidden_state
+            if prune:   # the result IS the gathered rows: 3B [CLS] rows, then B x M masked positions
+                output = self.itm_head(seq[:3 * bs])
+                itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
+                loss_itm = small_ce(output, itm_labels)
+                loss_mlm, _ = lm_head_ce(seq[3 * bs:], self.fusion_encoder.lm_head, masked_ids.reshape(-1), "mean")
+                return loss_itm, loss_mlm
         else:
             fpack = Pack.concat([(lens, n_rows, lh), (lens, n_rows, lh), (lens.index_select(0, text_neg_idx), bs * t_max, None),
                                  (lens, n_rows, lh)], pack.T)

@@ -443,6 +443,128 @@ class _EncoderFn(torch.autograd.Function):
 
 
 
+class _LastLayerRowsFn(torch.autograd.Function):
+    """ONE RobertaLayer computed only on the token rows somebody reads afterwards.
+
+    The consumers of the fusion tower's last layer are the [CLS] rows of the 3B matching sequences (xfm.py:795-797) and the masked
+    positions of the B MLM sequences (xroberta.py:1215-1216): ~1/5 of the token rows.  No op of a layer couples token rows except
+    attention, and there only through the keys: so the last layer projects K / V for every row of a sequence but runs its queries,
+    both attention outputs, the three LayerNorms and the FFN on the selected rows alone (same arithmetic per selected row as the
+    full layer; the other rows' outputs were dead values).  x: [R, D] packed rows (all), `rows`: int32 [S] indices into them
+    (duplicates allowed), `sel` = (start, len) int32 [B] of each sequence's block inside the S-row layout, `Tq` = max block length.
+    Output: [S, D].  Backward: the selected rows' gradients are scatter-added into the full-row gradient, next to dK/dV . W_kv."""
+
+    @staticmethod
+    def forward(ctx, x, enc, model, li, B, T, Nenc, training, enc_index, pack, rows, sel, Tq):
+        cfg = model.config
+        D, H = cfg.hidden_size, cfg.num_attention_heads
+        scale = 1.0 / math.sqrt(D // H)
+        p_att = cfg.attention_probs_dropout_prob if training else 0.0
+        p_hid = cfg.hidden_dropout_prob if training else 0.0
+        layer = model.encoder.layer[li]
+        s = layer._s
+        cross = layer.has_cross_attention and enc is not None
+        x = x.contiguous()
+        kp = pack.pair
+        pre = _WgradStream(x.device)
+        kv_pair = pre.project(enc, s["kv2"]) if cross else None
+        groups = Fx.kv_groups(enc_index, enc.shape[0] // Nenc) if cross else None
+        d_att, d_h1 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
+        wqkv, bqkv = s["qkv"].wb, s["qkv"].b
+        kvs = Fx.gemm_nt(x, wqkv[D:3 * D], bqkv[D:3 * D])                      # K | V of every row
+        xs = Fx.rows_gather(x, rows)
+        qs = Fx.gemm_nt(xs, wqkv[:D], bqkv[:D])                                # Q of the selected rows
+        c1, lse1 = Fx.attn_fwd(qs, kvs[:, :D], kvs[:, D:], B, H, Tq, T, scale, drop=d_att, q_pack=sel, k_pack=kp, zero_fill=False)
+        h1 = Fx.gemm_nt(c1, s["o"].wb, s["o"].b)
+        ln1 = layer.attention.output.LayerNorm
+        y1, z1, m1, r1 = Fx.ln_post_fwd(h1, xs, ln1.weight, ln1.bias, ln1.eps, d_h1)
+        rec = dict(x=x, xs=xs, kvs=kvs, qs=qs, c1=c1, lse1=lse1, z1=z1, m1=m1, r1=r1, y1=y1, d_att=d_att, d_h1=d_h1, cross=cross)
+        y2 = y1
+        if cross:
+            d_att2, d_h2 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
+            q2 = Fx.gemm_nt(y1, s["q2"].wb, s["q2"].b)
+            kv = pre.take(kv_pair)
+            c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, Tq, Nenc, scale, drop=d_att2, groups=groups, q_pack=sel, zero_fill=False)
+            h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
+            ln2 = layer.crossattention.output.LayerNorm
+            y2, z2, m2, r2 = Fx.ln_post_fwd(h2, y1, ln2.weight, ln2.bias, ln2.eps, d_h2)
+            rec.update(q2=q2, kv=kv, c2=c2, lse2=lse2, z2=z2, m2=m2, r2=r2, y2=y2, d_att2=d_att2, d_h2=d_h2)
+        d_h3 = Fx.drop_params(p_hid, _next_seed())
+        hact, u = Fx.gemm_nt(y2, s["i"].wb, s["i"].b, epi=Fx.EPI_GELU)
+        h3 = Fx.gemm_nt(hact, s["out"].wb, s["out"].b)
+        ln3 = layer.output.LayerNorm
+        y3, z3, m3, r3 = Fx.ln_post_fwd(h3, y2, ln3.weight, ln3.bias, ln3.eps, d_h3)
+        rec.update(hact=hact, u=u, z3=z3, m3=m3, r3=r3, d_h3=d_h3)
+        ctx.rec, ctx.model, ctx.enc, ctx.layer = rec, model, enc, layer
+        ctx.meta = (B, T, Nenc, scale, groups, kp, rows, sel, Tq, x.requires_grad, enc is not None and enc.requires_grad)
+        ctx.noted = x.requires_grad or (enc is not None and enc.requires_grad)
+        if ctx.noted:
+            arena_note_use(model)
+        return y3
+
+    @staticmethod
+    def backward(ctx, dy):
+        model, enc, layer, r = ctx.model, ctx.enc, ctx.layer, ctx.rec
+        B, T, Nenc, scale, groups, kp, rows, sel, Tq, need_dx, need_denc = ctx.meta
+        cfg = model.config
+        D, H = cfg.hidden_size, cfg.num_attention_heads
+        g, s = grad_view, layer._s
+        dy_a = dy.contiguous()
+        if dy_a.dtype != BF16:
+            dy_a = dy_a.to(BF16)
+        wg = _WgradStream(dy.device)
+        ln3 = layer.output.LayerNorm
+        dh3, dres3 = Fx.ln_post_bwd(dy_a, r["z3"], r["m3"], r["r3"], ln3.weight, g(ln3.weight), g(ln3.bias), s["out"].db, drop=r["d_h3"])
+        wg.gemm_tn(dh3, r["hact"], s["out"].dw)
+        du = Fx.gemm_nt(dh3, s["out"].wt, epi=Fx.EPI_DGELU, aux=r["u"], n=s["out"].K)
+        y2 = r["y2"] if r["cross"] else r["y1"]
+        wg.gemm_tn(du, y2, s["i"].dw, dbias=s["i"].db)
+        d1a, d1b = Fx.gemm_nt(du, s["i"].wt, n=s["i"].K), dres3
+        denc = None
+        if r["cross"]:
+            ln2 = layer.crossattention.output.LayerNorm
+            dh2, dres2 = Fx.ln_post_bwd(d1a, r["z2"], r["m2"], r["r2"], ln2.weight, g(ln2.weight), g(ln2.bias), s["o2"].db, dy2=d1b,
+                                        drop=r["d_h2"])
+            wg.gemm_tn(dh2, r["c2"], s["o2"].dw)
+            dc2 = Fx.gemm_nt(dh2, s["o2"].wt, n=s["o2"].K)
+            kv = r["kv"]
+            dq2 = torch.empty_like(r["q2"])
+            dkv = torch.empty((enc.shape[0], 2 * D), dtype=BF16, device=dq2.device)
+            args = (dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, Tq, Nenc, scale)
+            kw = dict(drop=r["d_att2"], groups=groups, q_pack=sel)
+            delta = Fx.attn_bwd(*args, phase=1, **kw)
+            wg.run(lambda: Fx.attn_bwd(*args, phase=2, delta=delta, **kw), keep=args[:9] + (delta,))
+            wg.gemm_tn(dq2, r["y1"], s["q2"].dw, dbias=s["q2"].db)
+            wg.gemm_tn(dkv, enc, s["kv2"].dw, dbias=s["kv2"].db)
+            if need_denc:
+                denc = wg.run(lambda: Fx.gemm_nt(dkv, s["kv2"].wt, n=s["kv2"].K), keep=(dkv,))
+            d1a, d1b = Fx.gemm_nt(dq2, s["q2"].wt, n=s["q2"].K), dres2
+        ln1 = layer.attention.output.LayerNorm
+        dh1, dres1 = Fx.ln_post_bwd(d1a, r["z1"], r["m1"], r["r1"], ln1.weight, g(ln1.weight), g(ln1.bias), s["o"].db, dy2=d1b,
+                                    drop=r["d_h1"])
+        wg.gemm_tn(dh1, r["c1"], s["o"].dw)
+        dc1 = Fx.gemm_nt(dh1, s["o"].wt, n=s["o"].K)
+        kvs, qs = r["kvs"], r["qs"]
+        dqs, dkvs = torch.empty_like(qs), torch.empty_like(kvs)
+        Fx.attn_bwd(dc1, qs, kvs[:, :D], kvs[:, D:], r["c1"], r["lse1"], dqs, dkvs[:, :D], dkvs[:, D:], B, H, Tq, T, scale, drop=r["d_att"],
+                    q_pack=sel, k_pack=kp)
+        dw, db = s["qkv"].dw, s["qkv"].db
+        wg.gemm_tn(dqs, r["xs"], dw[:D], dbias=db[:D])
+        wg.gemm_tn(dkvs, r["x"], dw[D:3 * D], dbias=db[D:3 * D])
+        dx = None
+        if need_dx:
+            wt = s["qkv"].wt
+            dx32 = Fx.gemm_nt(dkvs, wt[:, D:3 * D], epi=Fx.EPI_F32, n=s["qkv"].K)           # through K / V: every row
+            Fx.rows_scatter_add(Fx.gemm_nt(dqs, wt[:, :D], n=s["qkv"].K), rows, dx32)     # through Q and the residual: selected rows
+            Fx.rows_scatter_add(dres1, rows, dx32)
+            dx = dx32.to(BF16)
+        wg.join()
+        if ctx.noted:
+            arena_note_grad(model)
+        ctx.rec = None
+        return (dx, denc) + (None,) * 11
+
+
 _NATIVE_LAYERS = os.environ.get("XFM_NATIVE_LAYERS", "1") != "0"  # A/B knob: one C-ABI call per RobertaLayer (csrc/encoder.hip)
 
 
@@ -714,7 +836,8 @@ class RobertaModel(nn.Module):
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
                 inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
-                is_decoder=False, mode='multi_modal', encoder_batch_index=None, grad_batch=None, pack=None, encoder_row_ranges=None):
+                is_decoder=False, mode='multi_modal', encoder_batch_index=None, grad_batch=None, pack=None, encoder_row_ranges=None,
+                output_rows=None):
         """`encoder_batch_index` (extension, default None = reference behaviour): int tensor [B] mapping every text row to the
         row of `encoder_hidden_states` it attends to, so duplicated images are projected to K/V once per layer.
         `grad_batch` (extension): only the first grad_batch sequences of the batch propagate gradient through the layer stack
@@ -723,7 +846,10 @@ class RobertaModel(nn.Module):
         `encoder_embeds` is a 2-D [pack.cap, D] row buffer and `last_hidden_state` comes back in the same packed layout.
         `encoder_row_ranges` (extension, with `pack`): (start int32 [U], count int32 [U], max count) -- the packed sequences are laid
         out image by image, so the queries of image u are the contiguous rows start[u] .. + count[u]: cross-attention then runs as one
-        ragged problem per image on full 16-row query tiles instead of per-sequence tiles that are mostly padding."""
+        ragged problem per image on full 16-row query tiles instead of per-sequence tiles that are mostly padding.
+        `output_rows` (extension, with `pack`): (rows int32 [S], start int32 [B], len int32 [B], max len) -- the caller reads only these
+        token rows of the last layer (sequence b's are the block start[b] .. + len[b] of the S-row result): the last layer then runs
+        its queries / FFN / LayerNorms on them alone (_LastLayerRowsFn) and `last_hidden_state` is the [S, D] result."""
         if any(v is not None for v in (token_type_ids, position_ids, head_mask, inputs_embeds, past_key_values)):
             raise NotImplementedError("token_type_ids/position_ids/head_mask/inputs_embeds/past_key_values are not used on the XFM path")
         if isinstance(encoder_hidden_states, (list, tuple)):
@@ -780,8 +906,18 @@ class RobertaModel(nn.Module):
             native = _NATIVE_LAYERS and y.is_cuda and (enc is None or xq is not None or
                                                        (encoder_batch_index is not None and Fx.attn_grouped_ok(T, Nenc)))
             fn = _EncoderFnNative if native else _EncoderFn
-            y = fn.apply(y, enc, self, key_keep, enc_keep, lo, hi, bool(is_decoder), B, T, Nenc, self.training,
-                         encoder_batch_index if enc is not None else None, grad_batch, pack, xq)
+            if output_rows is not None:
+                assert pack is not None and xq is None and grad_batch is None and not is_decoder and key_keep is None
+                assert enc is None or (encoder_batch_index is not None and Fx.attn_grouped_ok(int(output_rows[3]), Nenc))
+                hi -= 1
+            if hi > lo:
+                y = fn.apply(y, enc, self, key_keep, enc_keep, lo, hi, bool(is_decoder), B, T, Nenc, self.training,
+                             encoder_batch_index if enc is not None else None, grad_batch, pack, xq)
+            if output_rows is not None:
+                rows, sel_start, sel_len, tq = output_rows
+                y = _LastLayerRowsFn.apply(y, enc, self, hi, B, T, Nenc, self.training, encoder_batch_index if enc is not None else None,
+                                           pack, rows.to(torch.int32).contiguous(),
+                                           (sel_start.to(torch.int32).contiguous(), sel_len.to(torch.int32).contiguous()), int(tq))
         return SimpleNamespace(last_hidden_state=y.view(B, T, -1) if pack is None else y, pooler_output=None, past_key_values=None,
                                hidden_states=None, attentions=None, cross_attentions=None)
 
