@@ -59,6 +59,12 @@ int xfm_gemm_nt_plan(int M, int N, int K, int epilogue, int tile_hint, int* cfg,
 long xfm_gemm_tn_workspace(int M, int N, int K);
 int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float* dW, long ldw, float* dbias, int M, int N,
                 int K, int splits_hint, float* workspace, long workspace_bytes, void* stream);
+/* nb (1..4) weight gradients of ONE shape (same M, N, K and leading dimensions; host arrays of device pointers; dbias / its entries may be
+ * NULL) as one launch + one reduce -- the three 768 x 768 projections of a RobertaLayer with cross-attention (xroberta.py:201-304).  Falls
+ * back to nb xfm_gemm_tn calls when N or K is not a multiple of 128 or the workspace is smaller than xfm_gemm_tn_batch_workspace(). */
+long xfm_gemm_tn_batch_workspace(int nb, int M, int N, int K);
+int xfm_gemm_tn_batch(int nb, const void* const* dY, long ldy, const void* const* X, long ldx, float* const* dW, long ldw,
+                      float* const* dbias, int M, int N, int K, float* workspace, long workspace_bytes, void* stream);
 
 /* fp32 master weight [N,K] -> bf16 copy wb[N,ldb] and/or transposed bf16 copy wt[K,ldt] (zero padded). */
 int xfm_cast_transpose(const float* w, int N, int K, xfm_bf16* wb, long ldb, xfm_bf16* wt, long ldt, void* stream);

@@ -843,3 +843,24 @@ def test_small_ce_matches_cross_entropy(R, C):
     (ref * 3).backward()
     assert abs(float(loss) - float(ref)) <= 1e-5 * max(abs(float(ref)), 1.0)
     _close(x.grad, xr.grad, 8e-3, "ce dlogits (stored as bf16)")
+
+
+@pytest.mark.parametrize("M,N,K,nb", [(4388, 768, 768, 3), (1300, 768, 768, 2), (2200, 256, 384, 4), (500, 768, 768, 3), (900, 200, 768, 2)])
+def test_gemm_tn_batch_equals_separate_calls(M, N, K, nb):
+    """Several weight gradients of one shape in one launch (+ bias gradients on some of them) against one xfm_gemm_tn each; the last
+    two shapes take the fallback (single split / N not a multiple of 128)."""
+    Fx = _fx()
+    dys = [_rand((M, N), 1.0, seed=10 + i) for i in range(nb)]
+    xs = [_rand((M, K), 1.0, seed=20 + i) for i in range(nb)]
+    dw_a = [torch.full((N, K), 0.5, dtype=F32, device="cuda") for _ in range(nb)]
+    dw_b = [t.clone() for t in dw_a]
+    db_a = [torch.zeros(N, dtype=F32, device="cuda") if i % 2 == 1 else None for i in range(nb)]
+    db_b = [None if t is None else t.clone() for t in db_a]
+    Fx.gemm_tn_batch(dys, xs, dw_a, db_a)
+    for i in range(nb):
+        Fx.gemm_tn(dys[i], xs[i], dw_b[i], dbias=db_b[i])
+        ref = 0.5 + dys[i].float().t() @ xs[i].float()
+        _close(dw_a[i], ref, 2e-3, f"batched dW[{i}]")
+        _close(dw_a[i], dw_b[i], 1e-5, f"batched vs single dW[{i}]")
+        if db_a[i] is not None:
+            _close(db_a[i], dys[i].float().sum(0), 2e-3, f"batched dbias[{i}]")

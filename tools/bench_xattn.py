@@ -26,7 +26,7 @@ def timeit(fn, iters=20):
     return s.elapsed_time(e) / iters * 1e3
 
 
-for name, kk, p in (("mask+dropout", keep, 0.1), ("mask only", keep, 0.0), ("plain", None, 0.0)):
+for name, kk, p in (("mask+dropout", keep, 0.1), ("dropout only", None, 0.1), ("mask only", keep, 0.0), ("plain", None, 0.0)):
     drop = Fx.drop_params(p, 1234)
     o, lse = Fx.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, Sq, Sk, 0.125, key_keep=kk, groups=groups, drop=drop)
     dq, dkv = torch.empty_like(q), torch.empty((U * Sk, 2 * D), dtype=torch.bfloat16, device="cuda")

@@ -147,6 +147,9 @@ SIGNATURES = {
     "xfm_rlayer_layout": (c_int, [c_int] * 11 + [ctypes.POINTER(RLayerLayout)]),
     "xfm_rlayer_fwd": (c_int, [ctypes.POINTER(RLayerParams), ctypes.POINTER(RLayerIO), c_void_p]),
     "xfm_rlayer_bwd": (c_int, [ctypes.POINTER(RLayerParams), ctypes.POINTER(RLayerIO), ctypes.POINTER(RLayerBwd), c_void_p]),
+    "xfm_gemm_tn_batch_workspace": (c_long, [c_int, c_int, c_int, c_int]),
+    "xfm_gemm_tn_batch": (c_int, [c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_void_p, c_long,
+                                  c_void_p]),
     "xfm_rownorm_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "xfm_rownorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "xfm_itc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -54,6 +54,13 @@ int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float
   XFM_REQUIRE(dY && X && dW, "gemm_tn: null operand");
   return xfm_gemm_tn_impl(dY, ldy, X, ldx, dW, ldw, dbias, M, N, K, splits_hint, workspace, workspace_bytes, ST(stream));
 }
+long xfm_gemm_tn_batch_workspace(int nb, int M, int N, int K) { return xfm_gemm_tn_batch_workspace_impl(nb, M, N, K); }
+int xfm_gemm_tn_batch(int nb, const void* const* dY, long ldy, const void* const* X, long ldx, float* const* dW, long ldw, float* const* dbias,
+                      int M, int N, int K, float* workspace, long workspace_bytes, void* stream) {
+  XFM_REQUIRE(nb >= 1 && nb <= 4 && dY && X && dW, "gemm_tn_batch: 1..4 problems, non-null pointer arrays");
+  for (int i = 0; i < nb; ++i) XFM_REQUIRE(dY[i] && X[i] && dW[i], "gemm_tn_batch: null operand in problem %d", i);
+  return xfm_gemm_tn_batch_impl(nb, dY, ldy, X, ldx, dW, ldw, dbias, M, N, K, workspace, workspace_bytes, ST(stream));
+}
 
 int xfm_cast_transpose_batch(const xfm_cast_item* items, int n_items, long total_tiles, void* stream) {
   return xfm_cast_transpose_batch_impl(items, n_items, total_tiles, ST(stream));

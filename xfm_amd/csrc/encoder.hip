@@ -59,6 +59,7 @@ int xfm_rlayer_layout_impl(int R, int B, int T, int D, int H, int FF, int has_cr
   mx(xfm_gemm_tn_workspace_impl(R, D, D));
   mx(xfm_gemm_tn_workspace_impl(R, 3 * D, D));
   if (has_cross && Nenc > 0 && U > 0) mx(xfm_gemm_tn_workspace_impl(U * Nenc, 2 * D, D));
+  if (has_cross) mx(xfm_gemm_tn_batch_workspace_impl(3, R, D, D));
   o->ws_side_bytes = ws;
   return XFM_OK;
 }
@@ -232,6 +233,11 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
     fork();
     return xfm_gemm_tn_impl(dY, ldy, X, ldx, dW, ldw, db, M, N, K, 0, b.ws_side, b.ws_side_bytes, side);
   };
+  // XFM_TN_BATCH=1: the D x D weight gradients of a cross-attention layer (out-projection of both attention blocks, cross query) go
+  // out as ONE batched launch once the last of their dY exists.  Measured on the step: 1 ms SLOWER than one launch each as their dY
+  // appear (the three then trail the activation-gradient chain in one 432-workgroup lump instead of filling its gaps) -- off.
+  static const bool tn_batch = getenv("XFM_TN_BATCH") ? atoi(getenv("XFM_TN_BATCH")) != 0 : false;
+  const bool batch3 = cross && tn_batch;
   const uint32_t c_att = io.seed_ctr + 1, c_h1 = io.seed_ctr + 2, c_att2 = io.seed_ctr + 3, c_h2 = io.seed_ctr + 4;
   const uint32_t c_h3 = cross ? io.seed_ctr + 5 : io.seed_ctr + 3;
   const bf16* y_in = cross ? S16(L.y2) : S16(L.y1);  // input of the feed-forward block
@@ -250,7 +256,7 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
   if (cross) {
     RL_TRY(xfm_ln_bwd_impl(rl_ln_bwd(io, in_a, in_b, s, L.z2, L.m2, L.r2, p.ln2_w, G16(L.dh2), G16(L.dres2), c_h2), D, LN_POST,
                            p.dln2_w, p.dln2_b, p.dbo2, nullptr, b.ws_main, b.ws_main_bytes, st));
-    RL_TRY(wgrad(G16(L.dh2), D, S16(L.c2), D, p.dwo2, D, nullptr, R, D, D));
+    if (!batch3) RL_TRY(wgrad(G16(L.dh2), D, S16(L.c2), D, p.dwo2, D, nullptr, R, D, D));
     RL_TRY(xfm_gemm_nt_impl(G16(L.dh2), D, p.wo2_t, p.ld_wo2_t, G16(L.dc2), D, nullptr, nullptr, 0, R, D, D, EPI_BF16, 0, st));
     if (zf) (void)hipMemsetAsync(g + L.dq2, 0, (size_t)R * D * 2, st);
     AttnArgs a = rl_cross_attn(p, io, L, s);
@@ -264,7 +270,7 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
     fork();
     a.bwd_phase = 2;
     RL_TRY(xfm_attn_bwd_impl(a, side));
-    RL_TRY(wgrad(G16(L.dq2), D, S16(L.y1), D, p.dwq2, D, p.dbq2, R, D, D));
+    if (!batch3) RL_TRY(wgrad(G16(L.dq2), D, S16(L.y1), D, p.dwq2, D, p.dbq2, R, D, D));
     RL_TRY(xfm_gemm_tn_impl(b.dkv, b.dkv_ld, b.enc, D, p.dwkv2, D, p.dbkv2, io.U * io.Nenc, 2 * D, D, 0, b.ws_side, b.ws_side_bytes, side));
     if (b.denc32 != nullptr)
       RL_TRY(xfm_gemm_nt_impl(b.dkv, b.dkv_ld, p.wkv2_t, p.ld_wkv2_t, b.denc32, D, nullptr, nullptr, 0, io.U * io.Nenc, D, 2 * D, EPI_F32_ACC, 0, side));
@@ -275,7 +281,16 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
   // ---- self-attention block
   RL_TRY(xfm_ln_bwd_impl(rl_ln_bwd(io, in_a, in_b, s, L.z1, L.m1, L.r1, p.ln1_w, G16(L.dh1), G16(L.dres1), c_h1), D, LN_POST,
                          p.dln1_w, p.dln1_b, p.dbo, nullptr, b.ws_main, b.ws_main_bytes, st));
-  RL_TRY(wgrad(G16(L.dh1), D, S16(L.c1), D, p.dwo, D, nullptr, R, D, D));
+  if (batch3) {
+    const void* dys[3] = {G16(L.dh2), G16(L.dq2), G16(L.dh1)};
+    const void* xs[3] = {S16(L.c2), S16(L.y1), S16(L.c1)};
+    float* dws[3] = {p.dwo2, p.dwq2, p.dwo};
+    float* dbs[3] = {nullptr, p.dbq2, nullptr};
+    fork();
+    RL_TRY(xfm_gemm_tn_batch_impl(3, dys, D, xs, D, dws, D, dbs, R, D, D, b.ws_side, b.ws_side_bytes, side));
+  } else {
+    RL_TRY(wgrad(G16(L.dh1), D, S16(L.c1), D, p.dwo, D, nullptr, R, D, D));
+  }
   RL_TRY(xfm_gemm_nt_impl(G16(L.dh1), D, p.wo_t, p.ld_wo_t, G16(L.dc1), D, nullptr, nullptr, 0, R, D, D, EPI_BF16, 0, st));
   if (zf) (void)hipMemsetAsync(g + L.dqkv, 0, (size_t)R * 3 * D * 2, st);
   {

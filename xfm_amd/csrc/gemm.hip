@@ -713,6 +713,19 @@ struct GemmTN {
   int direct; // no workspace: 1 = single split, every dW element has one owner -> plain read-modify-write; 0 = fp32 atomics
 };
 
+// Several weight gradients of ONE shape in one launch (the three 768 x 768 projections of a fusion layer: 36 tiles each would
+// need 9 splits apiece to fill the chip; together they are 108 tiles x 4 splits, one launch and one reduce instead of three).
+#define TN_BATCH_MAX 4
+struct TnBatch {
+  int nb;           // 1 = plain call (the arrays are unused)
+  int wg_per;       // workgroups per problem
+  long ws_stride;   // floats of workspace per problem
+  const bf16* dY[TN_BATCH_MAX];
+  const bf16* X[TN_BATCH_MAX];
+  float* dW[TN_BATCH_MAX];
+  float* dbias[TN_BATCH_MAX];
+};
+
 __device__ __forceinline__ int swz_t(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }  // XOR on the 16-B chunk idx
 
 __device__ __forceinline__ bf16x8 tr_read_pair(const char* tile, int row0, int col0, int lr) {
@@ -875,7 +888,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
 // ---------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(256))) static const uint32_t g_zero_row[64] = {0};
 
-__global__ __launch_bounds__(256) void gemm_tn_ring_kernel(GemmTN g) {
+__global__ __launch_bounds__(256) void gemm_tn_ring_kernel(GemmTN g, TnBatch bt) {
   constexpr int IMG = 32 * 256, STG = 2 * IMG, NS = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -883,7 +896,16 @@ __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(GemmTN g) {
   const int lr = lane & 15, lg = lane >> 4;
   const int tiles_k = g.K / 128, tiles_n = g.N / 128;
   const int per_split = tiles_k * tiles_n;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  int wg = xcd_remap(blockIdx.x, gridDim.x);
+  if (bt.nb > 1) {  // which problem of the batch (wave-uniform: scalar loads from the argument arrays)
+    const int bi = wg / bt.wg_per;
+    wg -= bi * bt.wg_per;
+    g.dY = bt.dY[bi];
+    g.X = bt.X[bi];
+    g.dW = bt.dW[bi];
+    g.dbias = bt.dbias[bi];
+    g.ws += (long)bi * bt.ws_stride;
+  }
   const int split = wg / per_split, t = wg % per_split;
   const int n0 = (t / tiles_k) * 128, k0 = (t % tiles_k) * 128;
   const int mbeg = split * g.m_per_split;
@@ -987,7 +1009,11 @@ __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(GemmTN g) {
 
 // dW += sum over splits of the 128 x 128 partial tiles (register order of gemm_tn_kernel), fixed summation order.
 __global__ __launch_bounds__(256) void tn_reduce128_kernel(const float* __restrict__ ws, float* __restrict__ dW, long ldw, int N, int K,
-                                                           int tiles_k, int per_split, int splits) {
+                                                           int tiles_k, int per_split, int splits, TnBatch bt) {
+  if (bt.nb > 1) {  // grid.y = problem
+    ws += (long)blockIdx.y * bt.ws_stride;
+    dW = bt.dW[blockIdx.y];
+  }
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (tile t, wave w, quad q = nt*4+kt, lane)
   const int lane = (int)(idx & 63), q = (int)((idx >> 6) & 15), w = (int)((idx >> 10) & 3);
   const int t = (int)(idx >> 12);
@@ -1328,14 +1354,76 @@ int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* d
   }
   static const int ring_env = getenv("XFM_TN_RING") ? atoi(getenv("XFM_TN_RING")) : 1;  // A/B knob
   const bool ring = ring_env && N % 128 == 0 && K % 128 == 0 && splits_hint != -5;
-  if (ring) hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(tiles * splits), dim3(256), smem, st, g);
+  TnBatch one{};
+  one.nb = 1;
+  if (ring) hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(tiles * splits), dim3(256), smem, st, g, one);
   else hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), smem, st, g);
   int rc = xfm_check_launch("gemm_tn");
   if (rc != XFM_OK || !use_ws) return rc;
   const long quads = (long)tiles * 4 * 16 * 64;
   hipLaunchKernelGGL(tn_reduce128_kernel, dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, st, workspace, dW, ldw, N, K, cdiv(K, 128), tiles,
-                     splits);
+                     splits, one);
   return xfm_check_launch("gemm_tn_reduce128");
+}
+
+// nb (<= TN_BATCH_MAX) weight gradients of one shape and one set of leading dimensions in ONE launch of the ring kernel + ONE reduce.
+// Falls back to nb plain calls when the shape is not the ring kernel's (N, K multiples of 128) or the workspace is too small.
+long xfm_gemm_tn_batch_workspace_impl(int nb, int M, int N, int K) {
+  if (nb <= 0 || M <= 0 || N <= 0 || K <= 0) return 0;
+  int splits, mps;
+  const long single = xfm_gemm_tn_workspace_impl(M, N, K);
+  if (nb == 1 || nb > TN_BATCH_MAX || N % 128 != 0 || K % 128 != 0) return single;
+  const int tiles = cdiv(N, 128) * cdiv(K, 128);
+  int hint = (432 + nb * tiles / 2) / (nb * tiles);
+  hint = hint < 1 ? 1 : hint;
+  tn128_plan(M, N, K, hint, splits, mps);
+  const long need = (long)nb * splits * tiles * 128 * 128 * 4;
+  return need > single ? need : single;
+}
+int xfm_gemm_tn_batch_impl(int nb, const void* const* dY, long ldy, const void* const* X, long ldx, float* const* dW, long ldw,
+                           float* const* dbias, int M, int N, int K, float* workspace, long workspace_bytes, hipStream_t st) {
+  XFM_REQUIRE(nb >= 1 && dY != nullptr && X != nullptr && dW != nullptr, "gemm_tn_batch: bad arguments");
+  const int tiles = cdiv(N, 128) * cdiv(K, 128);
+  int splits = 1, mps = M;
+  bool batched = nb > 1 && nb <= TN_BATCH_MAX && N % 128 == 0 && K % 128 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && M > 0;
+  if (batched) {
+    int hint = (432 + nb * tiles / 2) / (nb * tiles);  // ~432 workgroups in total, as for a single problem
+    hint = hint < 1 ? 1 : hint;
+    tn128_plan(M, N, K, hint, splits, mps);
+    batched = splits > 1 && workspace != nullptr && workspace_bytes >= (long)nb * splits * tiles * 128 * 128 * 4;
+    for (int i = 0; i < nb && batched; ++i) batched = ((uintptr_t)dY[i] % 16) == 0 && ((uintptr_t)X[i] % 16) == 0;
+  }
+  if (!batched) {
+    for (int i = 0; i < nb; ++i) {
+      int rc = xfm_gemm_tn_impl(dY[i], ldy, X[i], ldx, dW[i], ldw, dbias ? dbias[i] : nullptr, M, N, K, 0, workspace, workspace_bytes, st);
+      if (rc != XFM_OK) return rc;
+    }
+    return XFM_OK;
+  }
+  TnBatch bt{};
+  bt.nb = nb;
+  bt.wg_per = tiles * splits;
+  bt.ws_stride = (long)splits * tiles * 128 * 128;
+  for (int i = 0; i < nb; ++i) {
+    bt.dY[i] = (const bf16*)dY[i];
+    bt.X[i] = (const bf16*)X[i];
+    bt.dW[i] = dW[i];
+    bt.dbias[i] = dbias ? dbias[i] : nullptr;
+  }
+  GemmTN g{bt.dY[0], ldy, bt.X[0], ldx, bt.dW[0], ldw, bt.dbias[0], M, N, K, mps, workspace, 0};
+  const size_t smem = 4 * 64 * 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(nb * tiles * splits), dim3(256), smem, st, g, bt);
+  int rc = xfm_check_launch("gemm_tn_batch");
+  if (rc != XFM_OK) return rc;
+  const long quads = (long)tiles * 4 * 16 * 64;
+  hipLaunchKernelGGL(tn_reduce128_kernel, dim3((unsigned)cdiv(quads, 256), nb), dim3(256), 0, st, workspace, bt.dW[0], ldw, N, K, cdiv(K, 128),
+                     tiles, splits, bt);
+  return xfm_check_launch("gemm_tn_batch_reduce");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -87,6 +87,26 @@ def gemm_tn(dy, x, dw, n=None, splits=0, dbias=None):
                           splits, _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream()), "gemm_tn")
 
 
+def gemm_tn_batch(dys, xs, dws, dbiases=None):
+    """dws[i][N,K] (fp32) += dys[i][M,N]^T @ xs[i][M,K] for up to four problems of one shape in one launch (+ one reduce)."""
+    nb = len(dys)
+    assert 1 <= nb <= 4 and len(xs) == nb and len(dws) == nb
+    M, N = dys[0].shape
+    K = xs[0].shape[1]
+    for dy, x, dw in zip(dys, xs, dws):
+        assert dy.dtype == BF16 and x.dtype == BF16 and dw.dtype == F32 and dy.shape == (M, N) and x.shape == (M, K)
+        assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(-1) == 1 and dw.shape[0] >= N and dw.shape[1] == K
+        assert dy.stride(0) == dys[0].stride(0) and x.stride(0) == xs[0].stride(0) and dw.stride(0) == dws[0].stride(0)
+    lib = _lib.load()
+    need = lib.xfm_gemm_tn_batch_workspace(nb, M, N, K)
+    ws = workspace(need, dys[0].device) if need > 0 else None
+    arr = lambda ts: (ctypes.c_void_p * nb)(*[0 if t is None else t.data_ptr() for t in ts])
+    a_dy, a_x, a_dw = arr(dys), arr(xs), arr(dws)
+    a_db = arr(dbiases) if dbiases is not None else None
+    check(lib.xfm_gemm_tn_batch(nb, a_dy, dys[0].stride(0), a_x, xs[0].stride(0), a_dw, dws[0].stride(0), a_db, M, N, K, _ptr(ws),
+                                0 if ws is None else ws.numel() * 4, _stream()), "gemm_tn_batch")
+
+
 def cast_table(entries, device):
     """Device-resident xfm_cast_item table for cast_transpose_batch.  entries: (w fp32 [N,K], wb bf16 [N,ldb] | None,
     wt bf16 [K,ldt] | None).  Returns (table uint8 tensor, n_items, total_tiles)."""
