@@ -16,12 +16,14 @@ sched = create_scheduler(AttrDict(sched="linear", num_warmup_steps=0.1, num_trai
 acc = RCCLDDPAccelerator({"RNG_SEED": 42, "CLIP_GRAD_NORM": 1.0, "GRAD_ACCUMULATE_STEPS": 1})
 wrapped, optimizer, _ = acc.set_up(model, optimizer, None, 0, 1, 0)
 model.train(True)
-batches = [{k: v.to(device) for k, v in syn.pretrain_batch(64, seed=100 + i).items()} for i in range(4)]
+host = [syn.pretrain_batch(64, seed=100 + i) for i in range(4)]
+batches = [{k: v.to(device) for k, v in hb.items()} for hb in host]
+lens = [hb["text_atts"].sum(1) for hb in host]   # host-side caption lengths: the text / fusion towers run on unpadded rows
 t0 = time.perf_counter()
 for s in range(steps):
     b = batches[s % 4]
     losses = wrapped(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"], masked_pos=b["masked_pos"],
-                     masked_ids=b["masked_ids"], ret_mim_loss=True, data_source="image")
+                     masked_ids=b["masked_ids"], ret_mim_loss=True, data_source="image", text_lens=lens[s % 4])
     total = losses["loss_itc"] + losses["loss_itm"] + losses["loss_mlm"] + losses["loss_mim"]
     acc.backward_step(total, optimizer)
     acc.optimizer_step(optimizer, model)
