@@ -403,6 +403,10 @@ def _attn_ref(q, k, v, B, H, Sq, Sk, scale, bias=None, keep=None, causal=False, 
     (5, 12, 100, 256, True, False, False),   # ... 16 key tiles, 7 query tiles
     (11, 12, 256, 64, False, False, False),  # ... one key tile per key-range wave, no bias
     (3, 12, 50, 20, True, False, False),     # ... two key tiles: two of the four key-range waves idle
+    (1, 1, 16, 16, True, False, False),      # ... one tile each way, one batch entry
+    (2, 3, 224, 224, True, False, False),    # ... the longest query side the short dK/dV kernel takes (14 query tiles)
+    (2, 2, 300, 256, True, False, False),    # ... short dQ kernel (16 key tiles) + general dK/dV kernel (Sq > 224)
+    (70, 1, 33, 197, False, False, False),   # ... more batch entries than one round of workgroups: long per-workgroup loops
 ])
 def test_attention_fwd_bwd(B, H, Sq, Sk, use_bias, use_keep, causal):
     Fx = _fx()
