@@ -149,6 +149,51 @@ def test_several_backward_steps_before_one_optimizer_step_world2():
     assert any(a <= lo and hi <= b or (a < hi and lo < b) for a, b in r0["live"]), (r0["live"], r0["text_range"])
 
 
+def _bf16_exchange_worker(rank, world, init_file, out, dtype):
+    """GRAD_EXCHANGE_DTYPE = bf16 and one exchange per optimizer step (sync=False on all but the last source)."""
+    from xfm_amd.accelerators import ACCELERATOR_MAP
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    model = Tiny()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    acc = ACCELERATOR_MAP["RCCLDDP"]({"RNG_SEED": 1, "CLIP_GRAD_NORM": 0.0, "GRAD_ACCUMULATE_STEPS": 1, "GRAD_EXCHANGE_DTYPE": dtype})
+    wrapped, opt, _ = acc.set_up(model, opt, None, local_rank=rank, world_size=world, rank=rank)
+    assert acc.takes_sync_hint
+    xs, local = [], None
+    for k in range(3):
+        torch.manual_seed(77 * k + rank)
+        x = torch.randn(4, 8)
+        xs.append(x)
+        acc.backward_step(wrapped(x).pow(2).mean(), opt, sync=(k == 2))
+        if k == 1:   # nothing has been exchanged yet: the arena holds this rank's own sum
+            local = model._arena.grad.detach().clone()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    acc.optimizer_step(opt, model)
+    torch.save({"xs": xs, "grads": grads, "local": local, "arena": model._arena.data.detach().clone()}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_one_exchange_per_step_in_bf16_or_fp32_keeps_replicas_identical_world2(dtype):
+    r0, r1 = _spawn(_bf16_exchange_worker, dtype)
+    ref = Tiny()
+    per_rank = []
+    for r in (r0, r1):
+        ref.zero_grad()
+        for x in r["xs"]:
+            ref(x).pow(2).mean().backward()
+        per_rank.append({n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None})
+    # before the last source the arenas differ (no exchange yet) ...
+    assert not torch.equal(r0["local"], r1["local"])
+    # ... after it every rank holds the mean of the ranks' summed gradients: exactly in fp32, to bf16 resolution otherwise
+    tol = 1e-6 if dtype == "fp32" else 1e-2
+    for n in per_rank[0]:
+        want = (per_rank[0][n] + per_rank[1][n]) / 2
+        scale = float(want.abs().max()) + 1e-12
+        assert float((r0["grads"][n] - want).abs().max()) <= tol * scale, n
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), f"{n}: replicas must hold bit-identical exchanged gradients"
+    assert torch.equal(r0["arena"], r1["arena"]), "parameters must stay bit-identical across ranks"
+
+
 def _itc_worker(rank, world, init_file, out):
     from xfm_amd.xfm import allgather
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
