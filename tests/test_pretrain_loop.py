@@ -136,3 +136,15 @@ def test_train_loop_aux_source_and_checkpoint_schedule():
     # (global_step + 1) % 3 == 0 at global_step 2 and 5 -> epoch checkpoints with optimizer / scheduler state; (gs + 1) % 4 == 0 at 3
     assert saved == [(0, None, ["config", "epoch", "lr_scheduler", "model", "optimizer"]), (1, 3, ["config", "model"]),
                      (1, None, ["config", "epoch", "lr_scheduler", "model", "optimizer"])]
+
+
+def test_train_loop_resumed_run_stops_at_max_epoch():
+    """utils.MetricLogger.log_every (driven from Pretrain.py:205-209) ends a run after (max_epoch - start_epoch) * step_per_epoch
+    batches: resumed at epoch 1 of 2 with 3 steps per epoch, exactly 3 more steps run even when the loader holds more."""
+    log = []
+    m, acc = _Model(log), _Acc(log)
+    opt = torch.optim.SGD([{"params": [m.p], "lr": 0.5}, {"params": [], "lr": 0.5}, {"params": [], "lr": 1.0}, {"params": [], "lr": 1.0}])
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)
+    cfg = {"train_dataset_size": 6, "batch_size": 2, "ckpt_frequent": 10 ** 9, "ckpt_frequent_step": 10 ** 9}
+    PL.train(m, _batches(6), (None, None, None, None, None), opt, (1, 2), "cpu", sch, cfg, acc)
+    assert sum(1 for e in log if e == ("opt",)) == 3

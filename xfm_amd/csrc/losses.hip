@@ -39,14 +39,16 @@ __device__ __forceinline__ float block_add256(float v, float* red) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-#define XFM_LOSS_MAXN 2048
+// the logits row lives in dynamic LDS (N floats + 4 reduction slots): 16000 rows = 62.5 KiB, inside the default 64 KiB dynamic limit.
+// The gathered row count is world_size * B (the reference pre-trains at 128 x 24 = 3072).
+#define XFM_LOSS_MAXN 16000
 
 // blocks [0, N): rows of logits (image i against every text); blocks [N, 2N): rows of logits^T.  loss_sum += (lse - logit[r, r]) / (2N)
 template <int EPL>
 __global__ __launch_bounds__(256) void itc_fwd_kernel(const float* __restrict__ I, const float* __restrict__ T, const float* __restrict__ temp,
                                                        int N, int E, float* __restrict__ lse, float* __restrict__ loss_sum) {
-  __shared__ float lg[XFM_LOSS_MAXN];
-  __shared__ float red[4];
+  extern __shared__ float lg[];
+  float* red = lg + N;
   const int r = blockIdx.x < N ? blockIdx.x : blockIdx.x - N;
   const bool rows = blockIdx.x < N;
   const float inv_temp = 1.0f / temp[0];
@@ -70,8 +72,8 @@ template <int EPL>
 __global__ __launch_bounds__(256) void itc_bwd_kernel(const float* __restrict__ I, const float* __restrict__ T, const float* __restrict__ temp,
                                                        const float* __restrict__ lse, const float* __restrict__ g, int N, int E,
                                                        float* __restrict__ dI, float* __restrict__ dT, float* __restrict__ dtemp) {
-  __shared__ float lg[XFM_LOSS_MAXN];
-  __shared__ float red[4];
+  extern __shared__ float lg[];
+  float* red = lg + N;
   const int r = blockIdx.x < N ? blockIdx.x : blockIdx.x - N;
   const bool rows = blockIdx.x < N;
   const float tv = temp[0], inv_temp = 1.0f / tv, gs = g[0] / (2.0f * N);
@@ -105,8 +107,8 @@ template <int EPL>
 __global__ __launch_bounds__(256) void hard_neg_kernel(const float* __restrict__ I, const float* __restrict__ T, const float* __restrict__ temp,
                                                         int B, int E, uint32_t seed_lo, uint32_t seed_hi, int64_t* __restrict__ image_neg,
                                                         int64_t* __restrict__ text_neg) {
-  __shared__ float lg[XFM_LOSS_MAXN];
-  __shared__ float red[4];
+  extern __shared__ float lg[];
+  float* red = lg + B;
   const int r = blockIdx.x < B ? blockIdx.x : blockIdx.x - B;
   const bool rows = blockIdx.x < B;
   row_logits<EPL>((rows ? I : T) + (long)r * E, rows ? T : I, B, E, 1.0f / temp[0], lg);
@@ -195,14 +197,14 @@ int xfm_rownorm_bwd_impl(const float* dy, const float* y, const float* inv, int 
 int xfm_itc_fwd_impl(const float* I, const float* T, const float* temp, int N, int E, float* lse, float* loss_sum, hipStream_t st) {
   int rc = loss_check(N, E);
   if (rc != XFM_OK) return rc;
-  XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((itc_fwd_kernel<EPL>), dim3(2 * N), dim3(256), 0, st, I, T, temp, N, E, lse, loss_sum));
+  XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((itc_fwd_kernel<EPL>), dim3(2 * N), dim3(256), (N + 4) * sizeof(float), st, I, T, temp, N, E, lse, loss_sum));
   return xfm_check_launch("itc_fwd");
 }
 int xfm_itc_bwd_impl(const float* I, const float* T, const float* temp, const float* lse, const float* g, int N, int E, float* dI,
                      float* dT, float* dtemp, hipStream_t st) {
   int rc = loss_check(N, E);
   if (rc != XFM_OK) return rc;
-  XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((itc_bwd_kernel<EPL>), dim3(2 * N), dim3(256), 0, st, I, T, temp, lse, g, N, E, dI, dT, dtemp));
+  XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((itc_bwd_kernel<EPL>), dim3(2 * N), dim3(256), (N + 4) * sizeof(float), st, I, T, temp, lse, g, N, E, dI, dT, dtemp));
   return xfm_check_launch("itc_bwd");
 }
 int xfm_hard_negatives_impl(const float* I, const float* T, const float* temp, int B, int E, uint64_t seed, int64_t* image_neg,
@@ -210,7 +212,7 @@ int xfm_hard_negatives_impl(const float* I, const float* T, const float* temp, i
   int rc = loss_check(B, E);
   if (rc != XFM_OK) return rc;
   XFM_REQUIRE(B >= 2, "hard_negatives: a batch of one has no negative");
-  XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((hard_neg_kernel<EPL>), dim3(2 * B), dim3(256), 0, st, I, T, temp, B, E, (uint32_t)(seed & 0xFFFFFFFFu),
+  XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((hard_neg_kernel<EPL>), dim3(2 * B), dim3(256), (B + 4) * sizeof(float), st, I, T, temp, B, E, (uint32_t)(seed & 0xFFFFFFFFu),
                                          (uint32_t)(seed >> 32), image_neg, text_neg));
   return xfm_check_launch("hard_negatives");
 }

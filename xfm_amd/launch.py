@@ -16,8 +16,32 @@ def free_port():
         return s.getsockname()[1]
 
 
+def _visible_filter(n):
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [t for t in v.split(",") if t.strip() != ""]
+            return min(n, len(ids))
+    return n
+
+
 def visible_gpu_count():
-    """Number of GPUs without initialising the runtime (device_count() does not create a context on ROCm builds of torch)."""
+    """Number of GPUs WITHOUT loading the HIP runtime: the KFD topology lists one node per agent, and GPU nodes are the ones with
+    SIMDs (`simd_count` > 0 in .../nodes/N/properties); *_VISIBLE_DEVICES narrows it.  Falls back to torch's device_count() (which
+    does not create a context on this ROCm build of torch) only where the topology is not readable."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count"):
+                        n += int(line.split()[1]) > 0
+                        break
+        if n > 0:
+            return _visible_filter(n)
+    except OSError:
+        pass
     try:
         import torch
         return int(torch.cuda.device_count())
@@ -41,7 +65,7 @@ def launch(script, script_args, nproc, master_port=None, env=None, visible_devic
     e = dict(os.environ)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
     e.setdefault("OMP_NUM_THREADS", "4")
-    e["MASTER_ADDR"] = "127.0.0.1" if "--master-addr" not in kw else e.get("MASTER_ADDR", "127.0.0.1")
+    e["MASTER_ADDR"] = kw.get("master_addr", "127.0.0.1")  # torchrun re-exports it to the ranks from --master-addr
     if visible_devices is not None:
         e["HIP_VISIBLE_DEVICES"] = visible_devices
         e["CUDA_VISIBLE_DEVICES"] = visible_devices

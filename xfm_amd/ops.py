@@ -132,25 +132,40 @@ def itc_loss(image_feat, text_feat, temp):
 
 
 class _SmallCEFn(torch.autograd.Function):
-    """Mean cross-entropy over a handful of classes (the 2-way ITM head, xfm.py:795-800) through the vocabulary CE kernels."""
+    """Mean cross-entropy over a handful of classes (the 2-way ITM head, xfm.py:795-800; the classification heads,
+    model_classification.py:67) through the vocabulary CE kernels.  F.cross_entropy semantics: labels of -100 are ignored and
+    the mean is over the VALID rows.  Any class count: the kernels read rows of 4-column granularity, so a logits buffer
+    whose width is not a multiple of 4 is copied into a padded one (ld is passed separately from C)."""
 
     @staticmethod
-    def forward(ctx, logits, labels):
+    def forward(ctx, logits, labels, n_valid):
         lg = logits.float().contiguous()
-        lse, rows = Fx.ce_fwd(lg, lg.shape[1], labels)
-        ctx.save_for_backward(lg, labels, lse)
-        return rows.mean()
+        R, C = lg.shape
+        if C >= 4 and C % 4:
+            padded = torch.empty((R, (C + 3) // 4 * 4), dtype=F32, device=lg.device)
+            padded[:, :C] = lg
+            lg = padded
+        labels = labels.reshape(-1).contiguous()
+        lse, rows = Fx.ce_fwd(lg, C, labels)
+        if n_valid is None:
+            nvalid = (labels != -100).sum().clamp(min=1).to(F32)
+        else:   # the caller built the labels itself (ITM: ones | zeros) -- no counting kernels on the step's critical path
+            nvalid = torch.full((), float(n_valid), dtype=F32, device=lg.device)
+        ctx.save_for_backward(lg, labels, lse, nvalid)
+        ctx.C = C
+        return rows.sum() / nvalid
 
     @staticmethod
     def backward(ctx, g):
-        lg, labels, lse = ctx.saved_tensors
-        R, C = lg.shape
-        d = Fx.ce_bwd(lg, C, labels, lse, (g.float() / R).reshape(1), (C + 7) // 8 * 8)
-        return d[:, :C].float(), None
+        lg, labels, lse, nvalid = ctx.saved_tensors
+        C = ctx.C
+        d = Fx.ce_bwd(lg, C, labels, lse, (g.float() / nvalid).reshape(1), (C + 7) // 8 * 8)
+        return d[:, :C].float(), None, None
 
 
-def small_ce(logits, labels):
-    return _SmallCEFn.apply(logits, labels)
+def small_ce(logits, labels, n_valid=None):
+    """n_valid: the number of labels != -100 when the caller knows it (skips the count)."""
+    return _SmallCEFn.apply(logits, labels, n_valid)
 
 
 def gelu_grad(u):

@@ -161,7 +161,7 @@ def train(model, image_loader, data_loaders, optimizer, epoch_info, device, sche
     image_loader_aux, image_loader_web, image_loader_imagenet, region_loader, text_loader = data_loaders
     if region_loader is not None:
         raise NotImplementedError("region batches (run_region_iter, Pretrain.py:94-121) are outside the hot-path scope")
-    start_epoch, _ = epoch_info
+    start_epoch, max_epoch = epoch_info
     metric_logger = LossMeters()
     step_per_epoch = math.ceil(config['train_dataset_size'] / (config['batch_size'] * world_size))
     assert step_per_epoch > 1
@@ -172,7 +172,12 @@ def train(model, image_loader, data_loaders, optimizer, epoch_info, device, sche
     iters = {name: (iter(ld) if ld is not None else None)
              for name, ld in (('web', image_loader_web), ('imagenet', image_loader_imagenet), ('text', text_loader),
                               ('aux', image_loader_aux))}
+    # utils.MetricLogger.log_every stops after (end_epoch - start_epoch) * step_per_epoch batches (Pretrain.py:205-209): a run resumed at
+    # epoch k trains the REMAINING epochs, whatever the loader's length
+    total_steps = (max_epoch - start_epoch) * step_per_epoch if max_epoch is not None else None
     for i, batch in enumerate(image_loader):
+        if total_steps is not None and i >= total_steps:
+            break
         gates = dict(ret_mim_loss=global_step < stop_mim, ret_match_loss=global_step < stop_itm, ret_mlm_loss=global_step < stop_mlm,
                      ret_itc_loss=global_step < stop_itc)
         if iters['text'] is not None:

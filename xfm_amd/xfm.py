@@ -467,7 +467,7 @@ class XFMBase(nn.Module):
         output = self.itm_head(cross)
         dev = image_embeds.device  # built on the device: a host tensor + .to(device) is a blocking pageable copy
         itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
-        loss = small_ce(output, itm_labels)
+        loss = small_ce(output, itm_labels, n_valid=itm_labels.numel())
         if return_cross_embeds:
             return loss, cross[:bs]
         return loss
@@ -525,7 +525,7 @@ class XFMBase(nn.Module):
             if prune:   # the result IS the gathered rows: 3B [CLS] rows, then B x M masked positions
                 output = self.itm_head(seq[:3 * bs])
                 itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
-                loss_itm = small_ce(output, itm_labels)
+                loss_itm = small_ce(output, itm_labels, n_valid=itm_labels.numel())
                 loss_mlm, _ = lm_head_ce(seq[3 * bs:], self.fusion_encoder.lm_head, masked_ids.reshape(-1), "mean")
                 return loss_itm, loss_mlm
         else:
@@ -540,7 +540,7 @@ class XFMBase(nn.Module):
             start_of = fpack.start
         output = self.itm_head(rows_gather(seq, start_of[:3 * bs]))
         itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
-        loss_itm = small_ce(output, itm_labels)
+        loss_itm = small_ce(output, itm_labels, n_valid=itm_labels.numel())
         mlm_index = (start_of[3 * bs:, None] + masked_pos.to(torch.int32)).reshape(-1)   # gather_seq_out_by_pos (xroberta.py:1215-1216)
         mlm_seq = rows_gather(seq, mlm_index)
         loss_mlm, _ = lm_head_ce(mlm_seq, self.fusion_encoder.lm_head, masked_ids.reshape(-1), "mean")
@@ -581,7 +581,7 @@ class XFMBase(nn.Module):
         output = self.itm_head(seq[:3 * bs, 0, :])
         dev = image_embeds.device  # built on the device: a host tensor + .to(device) is a blocking pageable copy
         itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
-        loss_itm = small_ce(output, itm_labels)
+        loss_itm = small_ce(output, itm_labels, n_valid=itm_labels.numel())
         mlm_seq = self.fusion_encoder.gather_seq_out_by_pos(seq[3 * bs:], masked_pos)
         from .ops import lm_head_ce
         loss_mlm, _ = lm_head_ce(mlm_seq.reshape(-1, mlm_seq.shape[-1]), self.fusion_encoder.lm_head, masked_ids.reshape(-1), "mean")
