@@ -30,21 +30,49 @@ FULL_CFG = {"use_beit_v2": True, "image_res": 224, "patch_size": 16, "local_attn
             "max_temp": 0.5, "min_temp": 0.001, "max_tokens": 30, "max_masks": 15}
 
 
+# BASELINE.json configs -> bench workloads.  `gflop`: algorithmic fwd+bwd GFLOP per unit as the REFERENCE executes it, None
+# where the survey gives no figure (only the executed count is reported then).
+WORKLOADS = {
+    "pretrain": dict(batch=64, cpu_batch=8, unit="pairs/s", gflop=376.1,
+                     metric="image-text pairs/sec fwd+bwd, XFM-base 224px/30tok",
+                     desc="Pretrain.py full multimodal step (ITC+ITM+MLM+MIM), XFM-base, synthetic 224px images + 30-token captions, random init"),
+    "imagenet": dict(batch=128, cpu_batch=8, unit="images/s", gflop=105.4,
+                     metric="images/sec fwd+bwd, ImageNet-1k fine-tune (ViT-only path), 224px",
+                     desc="Imagenet.py:437-492 step: XFMForClassification image-only branch (BEiT-v2 base + 5-Linear head, 1000 classes), synthetic 224px images, random init"),
+    "retrieval": dict(batch=32, cpu_batch=4, unit="pairs/s", gflop=580.0,
+                      metric="image-text pairs/sec fwd+bwd, COCO retrieval fine-tune, 384px/40tok",
+                      desc="Retrieval.py:35-74 step: XFMForRetrieval (ITC with idx soft labels + ITM with hard negatives), synthetic 384px images + 40-token captions, random init"),
+    "vqa": dict(batch=24, cpu_batch=2, unit="questions/s", gflop=None,
+                metric="questions/sec fwd+bwd, VQA fine-tune, 480px/40tok, k~U[1,10] answers",
+                desc="VQA.py:35-72 step: XFMForVQA (ViT + text + fusion towers, 12-layer causal answer decoder, weighted answer loss), synthetic 480px images, random init"),
+    "glue": dict(batch=32, cpu_batch=32, unit="sequences/s", gflop=None,
+                 metric="sequences/sec fwd+bwd, GLUE MRPC fine-tune (text-only), T=128",
+                 desc="run_glue.py:347-365 step: XFMForClassification text-only branch on the xbert text encoder (12 layers, 3 labels), synthetic 128-token sequences, random init"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU (north-star: 64)")
+    ap.add_argument("--batch", type=int, default=0, help="units per GPU (0 = the workload's configured batch; pre-train: 64, the north-star's)")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward(+all-reduce) only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fusion-probe", action="store_true", help="skip the stand-alone fusion-encoder fwd+bwd measurement (profiling runs)")
-    ap.add_argument("--cpu-batch", type=int, default=8, help="pairs per CPU-baseline step (SURVEY 8d: B = 8, 1 warm-up + 3 timed)")
+    ap.add_argument("--cpu-batch", type=int, default=0, help="units per CPU-baseline step (0 = the workload's bounded sample; pre-train: 8, SURVEY 8d)")
     ap.add_argument("--padded-rows", action="store_true", help="push the padding rows of the 30-token captions through the text / fusion "
                     "towers like the reference does (default: unpadded token rows, xfm_amd.packing)")
     ap.add_argument("--pool", type=int, default=4, help="distinct device-resident batches rotated through the steps")
     ap.add_argument("--eval-mode", action="store_true", help="disable dropout / drop-path (not the headline setting)")
-    return ap.parse_args()
+    ap.add_argument("--workload", default="pretrain", choices=sorted(WORKLOADS),
+                    help="pretrain = BASELINE configs[4] shape, the headline line (default); imagenet / retrieval / vqa / glue = "
+                         "configs[1] / [2] / [3] / [0] at their real shapes (secondary lines, same JSON shape)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU leg (0 = short sweep over 8/16/32/64/128)")
+    a = ap.parse_args()
+    if a.batch <= 0:
+        a.batch = WORKLOADS[a.workload]["batch"]
+    return a
 
 
 def build_model(device):
@@ -303,10 +331,7 @@ def fusion_probe(model, B, host_batch, packed, iters=5):
                                "GEMM launched + attention, K/V projected once per image" + (", unpadded token rows" if packed else "")}
 
 
-def cpu_baseline(model, batch_size):
-    """The CPU oracle on the same architecture, same synthetic batch generator; bounded sample."""
-    from oracle import xfm_oracle as O
-    from xfm_amd import synthetic as syn
+def _oracle_params(model):
     P = {k: (v.detach().float() if v.dtype.is_floating_point else v.detach()).cpu().clone() for k, v in model.state_dict().items()}
     for k in list(P):
         if k.endswith("decoder.bias"):
@@ -314,22 +339,210 @@ def cpu_baseline(model, batch_size):
     for v in P.values():
         if v.dtype.is_floating_point:
             v.requires_grad_(True)
-    cfg = O.default_cfg(12, 12, 12)
-    b = syn.pretrain_batch(batch_size, seed=1234)
-    masks = syn.mim_block_mask(batch_size, 14, 75, seed=1234)
-    times = []
-    for it in range(4):
+    return P
+
+
+def cpu_baseline(model, wl, batch_size, threads=0):
+    """The CPU oracle (a port, not the reference itself) on the same architecture and synthetic batch generator; bounded sample.
+    The thread count is chosen by a short sweep on a quarter-size sample (the GPU box shows 128 hardware threads but a job's CPU
+    share can be far smaller: over-subscription halves the rate) and stated in `cores`."""
+    from oracle import xfm_oracle as O
+    P = _oracle_params(model)
+    one = wl["cpu_step"]
+
+    def timed(bs, n):
         t0 = time.time()
-        out = O.pretrain_forward(P, cfg, b, ids_mask=masks)
-        total = out["loss_itc"] + out["loss_itm"] + out["loss_mlm"] + out["loss_mim"]
-        total.backward()
-        for v in P.values():
-            v.grad = None
-        times.append(time.time() - t0)
-    best = min(times[1:])
-    return {"value": round(batch_size / best, 4), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32 full pre-train step fwd+bwd, B={batch_size}, 1 warm-up + 3 timed steps, best of 3 "
-                      f"({best:.2f} s/step, {batch_size * PAIR_GFLOP / best / 1000:.3f} TFLOP/s)"}
+        for _ in range(n):
+            one(O, P, bs)
+            for v in P.values():
+                v.grad = None
+        return (time.time() - t0) / n
+
+    ncpu = os.cpu_count() or 8
+    sweep = {}
+    if threads <= 0:
+        cands = [c for c in (8, 16, 32, 64, 128) if c <= ncpu] or [ncpu]
+        small = max(batch_size // 4, 1)
+        torch.set_num_threads(cands[0])
+        timed(small, 1)  # warm-up (allocator, first-touch)
+        for c in cands:
+            torch.set_num_threads(c)
+            sweep[c] = round(small / timed(small, 1), 4)
+        threads = max(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    timed(batch_size, 1)
+    best = min(timed(batch_size, 1) for _ in range(2))
+    gf = wl.get("gflop")
+    return {"value": round(batch_size / best, 4), "unit": wl["unit"], "cores": threads, "kind": "port",
+            "host_hw_threads": ncpu, "thread_sweep_quarter_sample": sweep,
+            "sample": f"oracle fp32 {wl['name']} step fwd+bwd, B={batch_size}, 1 warm-up + 2 timed steps, best of 2 ({best:.2f} s/step"
+                      + (f", {batch_size * gf / best / 1000:.3f} TFLOP/s)" if gf else ")"),
+            "reference_cross_check": "the reference itself (unmodified models/, fp32, 8 vCPU Xeon 2.1 GHz build container): 1.02 pairs/s on the "
+                                     "pre-train step at B=8 (BASELINE.md section 2)" if wl["name"] == "pretrain" else None}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# workloads: each returns (model, forward(batch_index) -> scalar loss, cpu_step(O, P, bs), extra config keys)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _vision_ckpt_config(image_res):
+    """XFMForClassification loads its vision tower from a checkpoint file (xfm.py:230-232): write a random-init one."""
+    import tempfile
+    from xfm_amd.beit2 import VisionTransformer
+    d = tempfile.mkdtemp(prefix="xfm_bench_")
+    torch.manual_seed(1234)
+    v = VisionTransformer(img_size=image_res, depth=12, drop_path_rate=0.1)
+    sd = dict(v.state_dict())
+    sd["head.weight"], sd["head.bias"] = torch.zeros(1000, 768), torch.zeros(1000)
+    torch.save({"model": sd}, os.path.join(d, "beit.pth"))
+    with open(os.path.join(d, "config_beit2_base.json"), "w") as f:
+        json.dump({"ckpt": os.path.join(d, "beit.pth"), "vision_width": 768, "patch_size": 16}, f)
+    return os.path.join(d, "config_beit2_base.json")
+
+
+def _ft_cfg(image_res, **kw):
+    c = dict(FULL_CFG, image_res=image_res)
+    c.update(kw)
+    return c
+
+
+def wl_pretrain(args, device, rank):
+    from xfm_amd import synthetic as syn
+    model = build_model(device)
+    B = args.batch
+    host = [syn.pretrain_batch(B, seed=1234 + rank + 7919 * j) for j in range(args.pool)]
+    batches = [{k: v.to(device) for k, v in hb.items()} for hb in host]
+    # caption lengths are host-side facts of a batch (the data loader's collate knows them): the towers run on unpadded token rows
+    lens = [None if args.padded_rows else hb["text_atts"].sum(1) for hb in host]
+
+    def forward(wrapped, j):
+        batch = batches[j]
+        losses = wrapped(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
+                         masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], ret_mim_loss=True,
+                         data_source="image", text_lens=lens[j])
+        return losses["loss_itc"] + losses["loss_itm"] + losses["loss_mlm"] + losses["loss_mim"], \
+            {k: losses[k] for k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim")}
+
+    def cpu_step(O, P, bs):
+        b = syn.pretrain_batch(bs, seed=1234)
+        out = O.pretrain_forward(P, O.default_cfg(12, 12, 12), b, ids_mask=syn.mim_block_mask(bs, 14, 75, seed=1234))
+        (out["loss_itc"] + out["loss_itm"] + out["loss_mlm"] + out["loss_mim"]).backward()
+
+    return model, forward, cpu_step, {"image_res": 224, "max_tokens": 30}, host
+
+
+def wl_imagenet(args, device, rank):
+    from xfm_amd import synthetic as syn
+    from xfm_amd.model_classification import XFMForClassification
+    torch.manual_seed(1234)
+    model = XFMForClassification(_ft_cfg(224, vision_config=_vision_ckpt_config(224), task_name="imagenet", num_labels=1000,
+                                         text_num_hidden_layers=0, text_fusion_start_at=0, fusion_num_hidden_layers=0)).to(device)
+    B = args.batch
+    g = torch.Generator().manual_seed(5 + rank)
+    pool = [(syn.gaussian(f"imagenet{rank}.{j}", (B, 3, 224, 224)).to(device), torch.randint(0, 1000, (B,), generator=g).to(device))
+            for j in range(args.pool)]
+
+    def forward(wrapped, j):
+        loss = wrapped(pool[j][0], None, None, pool[j][1], train=True)
+        return loss, {"loss": loss}
+
+    def cpu_step(O, P, bs):
+        image = syn.gaussian("imagenet.cpu", (bs, 3, 224, 224))
+        logits = O.classification_forward(P, O.default_cfg(vit_depth=12), image, None, None, deep_head=True)
+        torch.nn.functional.cross_entropy(logits, torch.arange(bs) % 1000).backward()
+
+    return model, forward, cpu_step, {"image_res": 224, "num_labels": 1000}, None
+
+
+def wl_retrieval(args, device, rank):
+    from xfm_amd import synthetic as syn
+    from xfm_amd.model_retrieval import XFMForRetrieval
+    torch.manual_seed(1234)
+    model = XFMForRetrieval(_ft_cfg(384)).to(device)
+    B = args.batch
+    pool = []
+    for j in range(args.pool):
+        b = syn.pretrain_batch(B, seed=384 + rank + 7919 * j, image_res=384, max_tokens=40)
+        pool.append(({k: v.to(device) for k, v in b.items()}, (torch.arange(B) + 1000 * j).to(device)))
+
+    def forward(wrapped, j):
+        b, idx = pool[j]
+        itc, itm = wrapped(b["image"], b["text_ids"], b["text_atts"], idx=idx)
+        return itc + itm, {"loss_itc": itc, "loss_itm": itm}
+
+    def cpu_step(O, P, bs):
+        b = syn.pretrain_batch(bs, seed=384, image_res=384, max_tokens=40)
+        itc, itm = O.retrieval_forward(P, O.default_cfg(12, 12, 12), b, torch.arange(bs), [(i + 1) % bs for i in range(bs)],
+                                       [(i + 2) % bs for i in range(bs)])
+        (itc + itm).backward()
+
+    return model, forward, cpu_step, {"image_res": 384, "max_tokens": 40}, None
+
+
+def wl_vqa(args, device, rank):
+    from types import SimpleNamespace as NS
+    from xfm_amd import synthetic as syn
+    from xfm_amd.model_generation import XFMForVQA
+    torch.manual_seed(1234)
+    model = XFMForVQA(dict(_ft_cfg(480), pad_token_id=1, decoder_fusion_start_at=0, num_dec_layers=12)).to(device)
+    B = args.batch
+    pool = []
+    for j in range(args.pool):
+        x = syn.vqa_batch(B, seed=480 + rank + 7919 * j, image_res=480)
+        pool.append((x.image.to(device), NS(input_ids=x.q_ids.to(device), attention_mask=x.q_atts.to(device)),
+                     NS(input_ids=x.a_ids.to(device), attention_mask=x.a_atts.to(device)), x.k, x.weights.to(device)))
+
+    def forward(wrapped, j):
+        image, q, a, k, w = pool[j]
+        loss = wrapped(image, q, a, k=k, weights=w, train=True)
+        return loss, {"loss": loss}
+
+    def cpu_step(O, P, bs):
+        x = syn.vqa_batch(bs, seed=480, image_res=480)
+        cfg = dict(O.default_cfg(12, 12, 12), dec_layers=12, dec_fusion_start=0)
+        O.vqa_train_loss(P, cfg, x.image, x.q_ids, x.q_atts, x.a_ids, x.a_atts, x.k, x.weights, 1).backward()
+
+    return model, forward, cpu_step, {"image_res": 480, "max_tokens": 40, "answers_per_question": "U[1,10]", "answer_len": 8}, None
+
+
+def wl_glue(args, device, rank):
+    from xfm_amd import synthetic as syn
+    from xfm_amd.model_classification import XFMForClassification
+    torch.manual_seed(1234)
+    model = XFMForClassification(_ft_cfg(224, text_encoder="bert-base-uncased", vision_config=_vision_ckpt_config(224), task_name="mrpc",
+                                         num_labels=3, fusion_num_hidden_layers=0)).to(device)
+    B, T = args.batch, 128
+    vocab = model.text_encoder.config.vocab_size
+
+    def batch(seed, bs):
+        b = syn.pretrain_batch(bs, seed=seed, max_tokens=T, min_len=12, vocab=vocab, with_image=False)
+        ids = b["text_ids"].clone()
+        ids[b["text_atts"] == 0] = 0
+        return ids, b["text_atts"], torch.arange(bs) % 3
+
+    pool = [tuple(t.to(device) for t in batch(128 + rank + 7919 * j, B)) for j in range(args.pool)]
+
+    def forward(wrapped, j):
+        ids, atts, y = pool[j]
+        loss = wrapped(None, ids, atts, y, train=True)
+        return loss, {"loss": loss}
+
+    def cpu_step(O, P, bs):
+        ids, atts, y = batch(128, bs)
+        feat = O.bert_model(P, "text_encoder.", ids, atts, num_layers=12, fusion_layer=12)[:, 0, :]
+        torch.nn.functional.cross_entropy(O.build_mlp_forward(P, "cls_head.", feat), y).backward()
+
+    return model, forward, cpu_step, {"max_length": 128, "num_labels": 3, "text_encoder": "xbert (bert-base-uncased shape)"}, None
+
+
+BUILDERS = {"pretrain": wl_pretrain, "imagenet": wl_imagenet, "retrieval": wl_retrieval, "vqa": wl_vqa, "glue": wl_glue}
+
+
+def device_identity(device):
+    p = torch.cuda.get_device_properties(device)
+    for attr in ("uuid",):
+        if hasattr(p, attr):
+            return str(getattr(p, attr))
+    return f"{getattr(p, 'pci_domain_id', 0)}:{getattr(p, 'pci_bus_id', -1)}:{getattr(p, 'pci_device_id', -1)}:{device.index}"
 
 
 def main():
@@ -352,42 +565,39 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    backend = os.environ.get("XFM_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("XFM_BENCH_BACKEND", "nccl"), world_size=world, rank=rank)
+        dist.init_process_group(backend, world_size=world, rank=rank)
 
-    from xfm_amd import synthetic as syn
     from xfm_amd.accelerators import RCCLDDPAccelerator
 
-    model = build_model(device)
+    wl = dict(WORKLOADS[args.workload], name=args.workload)
+    pretrain = args.workload == "pretrain"
+    model, forward, cpu_step, cfg_extra, host = BUILDERS[args.workload](args, device, rank)
+    wl["cpu_step"] = cpu_step
     optimizer = make_optimizer(model)
     acc = RCCLDDPAccelerator({"RNG_SEED": 42 + rank, "CLIP_GRAD_NORM": 1.0, "GRAD_ACCUMULATE_STEPS": 1})
     wrapped, optimizer, _ = acc.set_up(model, optimizer, None, local_rank, world, rank)
     model.train(not args.eval_mode)
 
     B = args.batch
-    # a small pool of distinct device-resident batches, rotated step by step (inputs are in HBM before the timed region; one batch
-    # replayed for the whole run would be trained to convergence on, e.g. an ITC loss of 0.01 after 25 steps)
-    host = [syn.pretrain_batch(B, seed=1234 + rank + 7919 * j) for j in range(args.pool)]
-    batches = [{k: v.to(device) for k, v in hb.items()} for hb in host]
-    # caption lengths are host-side facts of a batch (the data loader's collate knows them): the towers run on unpadded token rows
-    lens = [None if args.padded_rows else hb["text_atts"].sum(1) for hb in host]
     counter = [0]
+    comm_events = []
 
-    def step():
-        j = counter[0] % len(batches)
-        batch = batches[j]
+    def step(timed_comm=False):
+        j = counter[0] % args.pool
         counter[0] += 1
-        losses = wrapped(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
-                         masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], ret_mim_loss=True,
-                         data_source="image", text_lens=lens[j])
-        total = losses["loss_itc"] + losses["loss_itm"] + losses["loss_mlm"] + losses["loss_mim"]
+        total, parts = forward(wrapped, j)
+        if timed_comm and world > 1:  # end of backward -> gradient all-reduce complete, on the launch stream
+            acc.timing = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            comm_events.append(acc.timing)
         acc.backward_step(total, optimizer)
         if args.no_optimizer:
             model.zero_grad()
         else:
             acc.optimizer_step(optimizer, model)
-        return losses
+        return parts
 
     def barrier():
         if world > 1:
@@ -399,26 +609,44 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = step()
+        losses = step(timed_comm=True)
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t)
-    loss_vals = {k: round(float(v.detach()), 4) for k, v in losses.items() if k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim")}
+    acc.timing = None
+    loss_vals = {k: round(float(v.detach()), 4) for k, v in losses.items()}
+    exposed = [a.elapsed_time(b) for a, b in comm_events] if comm_events else []
+    ex_stats = dict(acc.stats)
+
+    # distributed self-description: how many ranks RCCL actually connected and on how many distinct devices
+    rccl = None
+    if world > 1:
+        ids = [None] * world
+        dist.all_gather_object(ids, device_identity(device))
+        rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "distinct_devices": len(set(ids)),
+                "exchange_dtype": acc.exchange_dtype, "exchange_bytes": ex_stats["exchange_bytes"],
+                "exchange_calls": ex_stats["exchange_calls"], "overlapped_bytes": ex_stats["overlapped_bytes"],
+                "exposed_comm_ms": round(sum(exposed) / max(len(exposed), 1), 3),
+                "exposed_comm_note": "HIP events on the launch stream: end of this rank's backward -> its last gradient all-reduce has "
+                                     "landed (mean over the timed steps, rank 0); the overlapped part of the exchange ran under backward"}
 
     # one instrumented step (outside the timed region): HIP events around every gemm_nt launch on the launch stream
     # (weight-gradient GEMMs normally run on a second stream; for this step they stay on the launch stream so that an event pair
-    # brackets exactly one kernel's execution instead of a stretch of two overlapping chains)
+    # brackets exactly one kernel's execution instead of a stretch of two overlapping chains); the same step counts the MFMA work the
+    # launched kernels execute (2MNK per GEMM + attention)
     from xfm_amd.xroberta import _WgradStream
     import xfm_amd.model_pretrain as mp
     import xfm_amd.xroberta as xr
     _WgradStream.enabled, text_on, mp._TEXT_STREAM_ON = False, mp._TEXT_STREAM_ON, False  # (the text tower's stream as well)
     native, xr._NATIVE_LAYERS = xr._NATIVE_LAYERS, False  # kernel by kernel, so that the wrappers see every launch (same kernels)
-    with GemmTimer() as gt:
-        step()
+    with FlopCounter() as fc:
+        with GemmTimer() as gt:
+            step()
     _WgradStream.enabled, mp._TEXT_STREAM_ON, xr._NATIVE_LAYERS = os.environ.get("XFM_WGRAD_STREAM", "1") != "0", text_on, native
+    executed_flop = fc.flop
     nlaunch, gemm_ms, gemm_flop = gt.summary()
     dom_n, dom_ms, dom_fl, dom_bytes = gt.dominant()
     dom_tf = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -431,56 +659,64 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     traffic, traffic_note = None, None
-    tpath = os.path.join(ROOT, "profiles", "round2_hbm_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "round1_hbm_traffic.json")
-    if os.path.exists(tpath):  # PMC passes are separate rocprofv3 runs of this same command (profiles/README.md)
-        with open(tpath) as f:
-            tj = json.load(f)
-        dk = tj["families"].get("kernel:gemm_nt_256_kernel<0>")
-        fam = tj["families"].get("gemm_nt")
-        if dk and dk["launches_per_step"] > 0:  # the dominant kernel's own launches (its average launch, like `achieved`)
-            traffic = dk["hbm_bytes_per_step_corrected"] / dk["launches_per_step"]
-            traffic_note = f"bytes beyond L2 per launch of gemm_nt_256_kernel<0>, averaged over its {dk['launches_per_step']:.0f} launches per step " \
-                           "(tail-split row blocks included), from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes " \
-                           "(2 x FETCH_SIZE + WRITE_SIZE, KB; tools/pmc_traffic.sh); Infinity-Cache hits are counted; algorithmic bytes " \
-                           f"per launch (A + B + C once) average {dom_bytes / max(dom_n, 1):.3e}"
-        elif fam and fam["launches_per_step"] >= nlaunch:  # kernel launches >= host calls: a call may split into two launches
-            traffic = fam["hbm_bytes_per_step_corrected"]
-            traffic_note = f"bytes beyond L2 per STEP over all gemm_nt kernels ({fam['launches_per_step']:.0f} launches for the family's {nlaunch} calls), " \
-                           "from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (2 x FETCH_SIZE + WRITE_SIZE, KB; tools/pmc_traffic.sh); " \
-                           "Infinity-Cache hits are counted"
+    if pretrain:
+        for name in ("round3_hbm_traffic.json", "round2_hbm_traffic.json", "round1_hbm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tpath):
+                break
+        if os.path.exists(tpath):  # PMC passes are separate rocprofv3 runs of this same command (profiles/README.md)
+            with open(tpath) as f:
+                tj = json.load(f)
+            dk = tj["families"].get("kernel:gemm_nt_256_kernel<0>")
+            if dk and dk["launches_per_step"] > 0:  # the dominant kernel's own launches (its average launch, like `achieved`)
+                traffic = dk["hbm_bytes_per_step_corrected"] / dk["launches_per_step"]
+                traffic_note = f"bytes beyond L2 per launch of gemm_nt_256_kernel<0>, averaged over its {dk['launches_per_step']:.0f} launches per step " \
+                               f"(tail-split row blocks included), from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in profiles/{name} " \
+                               "(2 x FETCH_SIZE + WRITE_SIZE, KB; tools/pmc_traffic.sh); Infinity-Cache hits are counted; algorithmic bytes " \
+                               f"per launch (A + B + C once) average {dom_bytes / max(dom_n, 1):.3e}"
     if rank == 0:
+        gf = wl["gflop"]
+        step_tf_exec = executed_flop / (ms_per_step * 1e-3) / 1e12
+        if dom_n > 0:
+            roof = {"bound": "mfma", "kernel": "gemm_nt_256_kernel<EPI_BF16> (every launch of it in one step: forward / dgrad GEMMs, whole-round parts of tail-split calls included)",
+                    "achieved": round(dom_tf, 2), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(dom_tf / BF16_DENSE_PEAK_TFLOPS, 4), "launches": dom_n,
+                    "avg_launch_us": round(dom_ms / max(dom_n, 1) * 1e3, 1), "flop_per_launch_avg": dom_fl / max(dom_n, 1),
+                    "traffic": traffic, "traffic_note": traffic_note}
+        else:  # no launch of the 256 x 256 kernel at this size: the whole forward / dgrad GEMM family stands in
+            roof = {"bound": "mfma", "kernel": "gemm_nt family (every forward / dgrad GEMM of one step; the 256 x 256 kernel is not selected at these sizes)",
+                    "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "launches": nlaunch, "traffic": None}
+        # ... and the whole gemm_nt family (every forward + dgrad GEMM of the step, small tiles included)
+        roof["family_gemm_nt"] = {"achieved": round(achieved, 2), "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4),
+                                  "calls": nlaunch, "kernel_ms_per_step": round(gemm_ms, 3), "flop_per_step": gemm_flop}
         out = {
-            "metric": "image-text pairs/sec fwd+bwd, XFM-base 224px/30tok",
+            "metric": wl["metric"],
             "value": round(B * world * args.steps / elapsed, 2),
-            "unit": "pairs/s",
+            "unit": wl["unit"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Pretrain.py full multimodal step (ITC+ITM+MLM+MIM), XFM-base, synthetic 224px images + 30-token captions, random init",
-                       "pairs_per_gpu": B, "global_batch": B * world, "image_res": 224, "max_tokens": 30,
-                       "dropout": not args.eval_mode, "optimizer_step_in_timed_region": not args.no_optimizer,
-                       "grad_allreduce": world > 1, "parallelism": f"dp{world}"},
-            "step_tflops_per_gpu": round(B * PAIR_GFLOP / ms_per_step, 2),
-            "mfma_frac_whole_step": round(B * PAIR_GFLOP / ms_per_step / BF16_DENSE_PEAK_TFLOPS, 4),
+            "config": dict({"workload": wl["desc"], "units_per_gpu": B, "global_batch": B * world,
+                            "dropout": not args.eval_mode, "optimizer_step_in_timed_region": not args.no_optimizer,
+                            "grad_allreduce": world > 1, "parallelism": f"dp{world}"}, **cfg_extra),
+            # throughput credit: the FLOPs the REFERENCE spends on this step over our time -- NOT hardware utilisation
+            "step_tflops_per_gpu_reference_count": round(B * gf / ms_per_step, 2) if gf else None,
+            "mfma_frac_whole_step": round(B * gf / ms_per_step / BF16_DENSE_PEAK_TFLOPS, 4) if gf else None,
+            # hardware utilisation: 2MNK of every GEMM launched (forward, dgrad, wgrad) + attention, over the timed step
+            "step_tflops_per_gpu_executed": round(step_tf_exec, 2),
+            "mfma_frac_whole_step_executed": round(step_tf_exec / BF16_DENSE_PEAK_TFLOPS, 4),
+            "executed_gflop_per_step": round(executed_flop / 1e9, 1),
             "losses_last_step": loss_vals,
-            # the dominant kernel alone (HIP events around its launches in the instrumented step) ...
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256_kernel<EPI_BF16> (every launch of it in one step: forward / dgrad GEMMs, whole-round parts of tail-split calls included)",
-                         "achieved": round(dom_tf, 2), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(dom_tf / BF16_DENSE_PEAK_TFLOPS, 4), "launches": dom_n,
-                         "avg_launch_us": round(dom_ms / max(dom_n, 1) * 1e3, 1), "flop_per_launch_avg": dom_fl / max(dom_n, 1),
-                         "traffic": traffic, "traffic_note": traffic_note,
-                         # ... and the whole gemm_nt family (every forward + dgrad GEMM of the step, small tiles included)
-                         "family_gemm_nt": {"achieved": round(achieved, 2), "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4),
-                                            "calls": nlaunch, "kernel_ms_per_step": round(gemm_ms, 3), "flop_per_step": gemm_flop}},
+            "roofline": roof,
         }
-        if not args.no_fusion_probe and world == 1:  # single-rank only: its backward would launch unmatched gradient collectives
+        if rccl is not None:
+            out["distributed"] = rccl
+        if pretrain and not args.no_fusion_probe and world == 1:  # single-rank only: its backward would launch unmatched gradient collectives
             out["fusion_encoder_fwd_bwd"] = fusion_probe(model, B, host[0], packed=not args.padded_rows)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
-
-            out["cpu_baseline"] = cpu_baseline(model, args.cpu_batch)
+            out["cpu_baseline"] = cpu_baseline(model, wl, args.cpu_batch or wl["cpu_batch"], args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,81 @@
+"""Worker of test_hip_accelerator.test_collectives_through_rccl_in_a_group_of_one (run as a child process with a time limit, so that
+an RCCL bring-up problem cannot hang the test process).  Three runs of the same three pre-training steps on cuda:0:
+  A  no process group (the plain W = 1 path);
+  B  backend 'nccl' (RCCL), world_size 1, FORCE_COLLECTIVES: agreement MAX all-reduce, ITC all_gather with slice backward,
+     arena broadcast, ReduceOp.AVG all-reduces issued from the tower hooks / the ViT chunk hand-over on the communication
+     stream, fp32 exchange;
+  C  the same with the bf16 wire format (pack -> all-reduce -> unpack on the communication stream).
+Mean over one rank is the identity, so B must reproduce A bit for bit; C rounds every exchanged gradient to bf16 once.
+Prints one JSON line."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from golden_util import load, state_from_spec  # noqa: E402
+from xfm_amd import pretrain_loop as PL  # noqa: E402
+from xfm_amd import synthetic as syn  # noqa: E402
+
+
+def run(meta, force, exchange="fp32"):
+    from xfm_amd.accelerators import RCCLDDPAccelerator
+    from xfm_amd.model_pretrain import XFM
+    cfg = {"use_beit_v2": True, "image_res": 224, "patch_size": 16, "local_attn_depth": -1, "text_encoder": "roberta-base",
+           "text_num_hidden_layers": meta["text_layers"], "text_fusion_start_at": meta["text_layers"],
+           "fusion_num_hidden_layers": meta["fusion_layers"], "fusion_fusion_start_at": 0, "embed_dim": 256, "temp": 0.07,
+           "learnable_temp": True, "max_temp": 0.5, "min_temp": 0.001, "vision_depth": 6}
+    m = XFM(cfg)
+    sd = syn.formula_state_dict(m.state_dict())
+    m.load_state_dict(sd, strict=True)
+    m.cuda()
+    opt = PL.create_optimizer(PL.AttrDict(lr=1e-3, weight_decay=0.05, lr_mult=2), m)
+    acc = RCCLDDPAccelerator({"RNG_SEED": 3, "CLIP_GRAD_NORM": 1.0, "GRAD_ACCUMULATE_STEPS": 1, "FORCE_COLLECTIVES": force,
+                              "GRAD_EXCHANGE_DTYPE": exchange})
+    wrapped, opt, _ = acc.set_up(m, opt, None, 0, 1, 0)
+    m.eval()
+    B = meta["B"]
+    stats, grads = [], None
+    for step in range(3):
+        b = {k: v.cuda() for k, v in syn.pretrain_batch(B, seed=100 + step).items()}
+        masks = syn.mim_block_mask(B, 14, 75, seed=100 + step)
+        losses = wrapped(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"], masked_pos=b["masked_pos"],
+                         masked_ids=b["masked_ids"], ret_mim_loss=True, data_source="image", ids_mask=masks,
+                         neg_idx=([(i + 1) % B for i in range(B)], [(i + 2) % B for i in range(B)]))
+        acc.backward_step(losses["loss_itc"] + losses["loss_itm"] + losses["loss_mlm"] + losses["loss_mim"], opt)
+        stats.append(dict(acc.stats, overlapped_ranges=len(getattr(acc, "overlapped_ranges", []))))
+        if step == 2:
+            grads = m._arena.grad.clone()
+        acc.optimizer_step(opt, m)
+    torch.cuda.synchronize()
+    return m._arena.data.clone(), grads, stats, str(acc._op), sum(b_ - a for a, b_ in acc.live_ranges())
+
+
+def main():
+    torch.cuda.set_device(0)
+    _, meta = load("pretrain_small")
+    pa, ga, _, _, live = run(meta, False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29653")
+    dist.init_process_group("nccl", world_size=1, rank=0)
+    pb, gb, sb, op, _ = run(meta, True)
+    pc, gc, sc, _, _ = run(meta, True, "bf16")
+    dist.barrier()
+    dist.destroy_process_group()
+    out = {"backend": "nccl", "op": op, "live_elems": live,
+           "fp32_params_equal": bool(torch.equal(pa, pb)), "fp32_grads_equal": bool(torch.equal(ga, gb)),
+           "fp32_max_abs_param_diff": float((pa - pb).abs().max()),
+           "bf16_grad_rel_l2": float((gc - ga).norm() / ga.norm()),
+           "bf16_grads_are_bf16_of_fp32": bool(torch.equal(gc, ga.to(torch.bfloat16).float())),
+           "bf16_param_rel_l2": float((pc - pa).norm() / pa.norm()),
+           "stats_fp32": sb, "stats_bf16": sc}
+    print("NCCL_W1 " + json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

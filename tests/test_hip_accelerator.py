@@ -242,3 +242,32 @@ def test_resume_from_optimizer_state_dict_is_bit_identical():
     b = third_step(m2, opt2, acc2)
     for n in a:
         assert torch.equal(a[n], b[n]), f"{n} differs after resume"
+
+
+def test_collectives_through_rccl_in_a_group_of_one():
+    """The N > 1 branches on hardware before a multi-GPU node is available: a process group of ONE rank on backend 'nccl' (= RCCL)
+    with FORCE_COLLECTIVES, three pre-training steps (tests/nccl_w1_worker.py).  The live-set agreement, the arena broadcast, the
+    ITC all_gather, ReduceOp.AVG, async all-reduces launched from the tower hooks and the ViT trunk's chunk hand-over on the
+    communication stream, and the bf16 pack / unpack all run through ProcessGroupNCCL; the mean over one rank is the identity, so
+    parameters and gradients must equal the run without any collective BIT FOR BIT (fp32 exchange), and the bf16 exchange must
+    deliver exactly the bf16 rounding of the fp32 gradients (ddp_accelerator.py:34-98, apex_ddp_accelerator.py:77-110)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_w1_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=420, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("NCCL_W1 ")][-1]
+    out = json.loads(line[len("NCCL_W1 "):])
+    print(line)
+    assert "AVG" in out["op"]
+    assert out["fp32_params_equal"] and out["fp32_grads_equal"], out
+    # from the step after the live set is agreed, ranges leave for the all-reduce from INSIDE backward (tower hooks + ViT chunks)
+    s3 = out["stats_fp32"][2]
+    assert s3["overlapped_ranges"] >= 3 and s3["overlapped_bytes"] > 0.5 * s3["exchange_bytes"], s3
+    assert s3["exchange_bytes"] == 4 * out["live_elems"], (s3, out["live_elems"])   # every live element exactly once, fp32
+    assert out["stats_bf16"][2]["exchange_bytes"] == 2 * out["live_elems"]
+    # bf16 wire format: one rounding of each exchanged gradient
+    assert out["bf16_grad_rel_l2"] < 4e-3 and out["bf16_param_rel_l2"] < 1e-3, out

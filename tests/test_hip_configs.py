@@ -1,0 +1,197 @@
+"""BASELINE.json configs[0..3] at their REAL shapes on a MI355X, one optimisation-step's forward + backward each, against the CPU oracle
+run live on the same formula weights and synthetic batch:
+
+  configs[0]  GLUE text-only classification (run_glue.py:347-365 -> model_classification.py:52-55): B = 32, T = 128, 12 layers, on the
+              xbert text encoder AND on the xroberta one (configs/xfm-ft/glue_mrpc.yaml names roberta-base; BASELINE names the xbert path)
+              -- loss within 1e-3 rel, every gradient by the module tests' rule (rel-L2 <= 8e-2, cosine >= 0.996);
+  configs[2]  retrieval fine-tune (Retrieval.py:35-74 -> model_retrieval.py:25-36): B = 32, 384 px (577 image tokens), T = 40,
+              12-block ViT + 12 text + 12 fusion layers -- ITC / ITM against the oracle's forward; finite, complete gradients;
+  configs[3]  VQA fine-tune (VQA.py:35-72 -> model_generation.py:96-133): B = 24, 480 px (901 image tokens), k ~ U[1, 10] answers per
+              question through the 12-layer causal decoder -- weighted loss against the oracle's forward; finite, complete gradients.
+(configs[1], ImageNet at B = 128, is test_hip_modules.test_classification_imagenet_at_batch_128_vs_oracle.)
+The full-depth GRADIENTS of the towers are pinned by the reference fixtures (pretrain_full, classification_*, vqa_*, retrieval_*);
+here the oracle's backward is only run where it takes seconds (the text-only model)."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from xfm_amd import synthetic as syn  # noqa: E402
+
+GRAD_TOL, COS_TOL = 8e-2, 0.996
+
+
+def _cfg(image_res, text_layers, fusion_layers, vit_depth, **kw):
+    c = {"use_beit_v2": True, "image_res": image_res, "patch_size": 16, "local_attn_depth": -1, "text_encoder": "roberta-base",
+         "text_num_hidden_layers": text_layers, "text_fusion_start_at": text_layers, "fusion_num_hidden_layers": fusion_layers,
+         "fusion_fusion_start_at": 0, "embed_dim": 256, "temp": 0.07, "learnable_temp": True, "max_temp": 0.5, "min_temp": 0.001,
+         "vision_depth": vit_depth}
+    c.update(kw)
+    return c
+
+
+def _formula(model):
+    sd = syn.formula_state_dict(model.state_dict())
+    model.load_state_dict(sd, strict=True)
+    return sd
+
+
+def _oracle_params(sd, grad=False):
+    P = {k: v.clone() for k, v in sd.items()}
+    for k in list(P):
+        if k.endswith("decoder.bias"):
+            P[k] = P[k[:-len("decoder.bias")] + "bias"]
+    if grad:
+        for v in P.values():
+            if v.dtype.is_floating_point:
+                v.requires_grad_(True)
+    return P
+
+
+def _vision_checkpoint(tmp_path, depth, image_res):
+    """XFMForClassification loads its vision tower from a checkpoint file (xfm.py:230-232): write one (formula weights)."""
+    from xfm_amd.beit2 import VisionTransformer
+    v = VisionTransformer(img_size=image_res, depth=depth, drop_path_rate=0.1)
+    vis = syn.formula_state_dict({"vision_encoder." + k: t for k, t in v.state_dict().items()})
+    vis = {k[len("vision_encoder."):]: t for k, t in vis.items()}
+    vis["head.weight"], vis["head.bias"] = torch.zeros(1000, 768), torch.zeros(1000)
+    ckpt = os.path.join(tmp_path, "beit.pth")
+    torch.save({"model": vis}, ckpt)
+    vcfg = os.path.join(tmp_path, "config_beit2_base.json")
+    with open(vcfg, "w") as f:
+        json.dump({"ckpt": ckpt, "vision_width": 768, "patch_size": 16}, f)
+    return vcfg
+
+
+@pytest.mark.parametrize("encoder", ["bert-base-uncased", "roberta-base"])
+def test_glue_text_classification_at_config_shape_vs_oracle(encoder, tmp_path):
+    """configs[0]: `loss = model(image=None, text_ids=input_ids, text_atts=attention_mask, targets=labels)` (run_glue.py:355-358) with
+    per_device_train_batch_size 32, max_length 128, num_labels 3 (configs/xfm-ft/glue_mrpc.yaml), 12-layer text encoder."""
+    from oracle import xfm_oracle as O
+    from xfm_amd.model_classification import XFMForClassification
+    B, T, L, C = 32, 128, 12, 3
+    bert = "roberta" not in encoder
+    cfg = _cfg(224, L, 0, 1, text_encoder=encoder, vision_config=_vision_checkpoint(tmp_path, 1, 224), task_name="mrpc", num_labels=C)
+    m = XFMForClassification(cfg)
+    assert type(m.text_encoder).__module__.endswith("xbert" if bert else "xroberta")
+    sd = _formula(m)
+    m.cuda().finalize().eval()
+    vocab = m.text_encoder.config.vocab_size
+    b = syn.pretrain_batch(B, seed=2024, max_tokens=T, min_len=12, vocab=vocab, with_image=False)
+    ids, atts = b["text_ids"].clone(), b["text_atts"]
+    assert ids.shape == (B, T) and int(atts.sum(1).max()) > 100
+    if bert:   # [PAD] = 0 in the BERT vocabulary
+        ids[atts == 0] = 0
+    targets = torch.tensor([(7 * i + i // 3) % C for i in range(B)])
+    loss = m(None, ids.cuda(), atts.cuda(), targets.cuda(), train=True)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    P = _oracle_params(sd, grad=True)
+    if bert:
+        feat = O.bert_model(P, "text_encoder.", ids, atts, num_layers=L, fusion_layer=L)[:, 0, :]
+    else:
+        feat = O.roberta_model(P, "text_encoder.", input_ids=ids, att=atts, num_layers=L, fusion_layer=L)[:, 0, :]
+    ref = torch.nn.functional.cross_entropy(O.build_mlp_forward(P, "cls_head.", feat), targets)
+    ref.backward()
+    got, want = float(loss), float(ref)
+    assert abs(got - want) <= 1e-3 * abs(want), (got, want)
+    # gradients: every parameter the oracle differentiates, by the module tests' rule; tensors whose oracle gradient is below 1 % of
+    # the median rms (saturated Q/K weights) are held in absolute terms
+    named = dict(m.named_parameters())
+    rms = sorted(float(v.grad.pow(2).mean().sqrt()) for k, v in P.items() if v.requires_grad and v.grad is not None and k in named)
+    floor = 1e-2 * rms[len(rms) // 2]
+    worst, n, bad = (0.0, 1.0), 0, []
+    for k, v in P.items():
+        if not v.dtype.is_floating_point or v.grad is None or k not in named or k.endswith("self.key.bias"):
+            continue
+        g, r = named[k].grad.float().cpu().double().reshape(-1), v.grad.double().reshape(-1)
+        if float(r.pow(2).mean().sqrt()) < floor:
+            assert float((g - r).abs().max()) <= 4 * floor, k
+            continue
+        err = float((g - r).norm() / r.norm())
+        cos = float((g @ r) / (g.norm() * r.norm()))
+        if k.endswith("word_embeddings.weight") or k.endswith("position_embeddings.weight"):
+            pass  # row-sparse, compared whole like every other tensor (the oracle's gradient is dense here)
+        n += 1
+        worst = (max(worst[0], err), min(worst[1], cos))
+        if err > GRAD_TOL or cos < COS_TOL:
+            bad.append((k, round(err, 4), round(cos, 5)))
+    print(f"GLUE {encoder} B={B} T={T}: loss {got:.5f} vs oracle {want:.5f}; {n} gradients, worst rel-L2 {worst[0]:.4f}, cosine {worst[1]:.5f}")
+    assert n >= 12 * 16 and not bad, bad[:10]
+    # the vision tower took no part
+    assert all(float(p._xfm_grad.abs().max()) == 0.0 for k, p in named.items() if k.startswith("vision_encoder.") and hasattr(p, "_xfm_grad"))
+
+
+def _finite_and_complete(model, expect_zero=()):
+    """Every parameter outside `expect_zero` prefixes received a finite, non-zero gradient (the live set of the step)."""
+    dead, nonfinite = [], []
+    for k, p in model.named_parameters():
+        g = p.grad if p.grad is not None else getattr(p, "_xfm_grad", None)
+        if any(k.startswith(z) or z in k for z in expect_zero):
+            continue
+        if g is None or float(g.abs().max()) == 0.0:
+            dead.append(k)
+        elif not bool(torch.isfinite(g).all()):
+            nonfinite.append(k)
+    assert not nonfinite, nonfinite[:8]
+    return dead
+
+
+def test_retrieval_step_at_config_shape_vs_oracle():
+    """configs[2]: `loss_itc, loss_itm = model(image, text_ids, text_atts, idx=idx)` (Retrieval.py:50-58), batch_size_train 32, image_res
+    384, max_tokens 40, full depth (configs/xfm-ft/Retrieval_coco.yaml)."""
+    from oracle import xfm_oracle as O
+    from xfm_amd.model_retrieval import XFMForRetrieval
+    B, R, T = 32, 384, 40
+    m = XFMForRetrieval(_cfg(R, 12, 12, 12))
+    sd = _formula(m)
+    m.cuda().finalize().eval()
+    b = syn.pretrain_batch(B, seed=384, image_res=R, max_tokens=T)
+    idx = torch.tensor([i if i % 8 else max(i - 1, 0) for i in range(B)])   # a few captions share an image id (soft labels, xfm.py:705-713)
+    neg_i = [(i + 5) % B if idx[(i + 5) % B] != idx[i] else (i + 7) % B for i in range(B)]
+    neg_t = [(i + 11) % B if idx[(i + 11) % B] != idx[i] else (i + 13) % B for i in range(B)]
+    torch.cuda.reset_peak_memory_stats()
+    itc, itm = m(b["image"].cuda(), b["text_ids"].cuda(), b["text_atts"].cuda(), idx=idx.cuda(), neg_idx=(neg_i, neg_t))
+    (itc + itm).backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    with torch.no_grad():
+        ri, rm = O.retrieval_forward(_oracle_params(sd), O.default_cfg(12, 12, 12), b, idx, neg_i, neg_t)
+    ri, rm = float(ri), float(rm)
+    print(f"retrieval B={B} {R}px T={T}: itc {float(itc):.5f} vs {ri:.5f}, itm {float(itm):.5f} vs {rm:.5f}, peak {peak:.1f} GiB")
+    assert abs(float(itc) - ri) <= 3e-3 * max(abs(ri), 1.0) and abs(float(itm) - rm) <= 3e-2 * max(abs(rm), 1.0)
+    assert abs(float(itc + itm) - (ri + rm)) <= 2e-3 * (ri + rm)
+    dead = _finite_and_complete(m, expect_zero=("vision_encoder.mask_token", "self.key.bias", "crossattention.self.key.bias"))
+    # the text tower (layers 0-11 of its own stack) has no cross-attention; everything else trains
+    assert all("crossattention" in k and k.startswith("text_encoder.") for k in dead), dead[:8]
+
+
+def test_vqa_step_at_config_shape_vs_oracle():
+    """configs[3]: `loss = model(image, question_input, answer_input, train=True, k=n, weights=weights)` (VQA.py:50), batch_size_train
+    24, image_res 480, max_tokens 40, 12 + 12 + 12-layer decoder (configs/xfm-ft/VQA.yaml); k ~ U[1, 10] answers per question."""
+    from types import SimpleNamespace as NS
+    from oracle import xfm_oracle as O
+    from xfm_amd.model_generation import XFMForVQA
+    B, R = 24, 480
+    m = XFMForVQA(dict(_cfg(R, 12, 12, 12), pad_token_id=1, decoder_fusion_start_at=0, num_dec_layers=12))
+    sd = _formula(m)
+    m.cuda().finalize().eval()
+    x = syn.vqa_batch(B, seed=480, image_res=R)
+    q = NS(input_ids=x.q_ids.cuda(), attention_mask=x.q_atts.cuda())
+    a = NS(input_ids=x.a_ids.cuda(), attention_mask=x.a_atts.cuda())
+    torch.cuda.reset_peak_memory_stats()
+    loss = m(x.image.cuda(), q, a, k=x.k, weights=x.weights.cuda(), train=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    cfg = dict(O.default_cfg(12, 12, 12), dec_layers=12, dec_fusion_start=0)
+    with torch.no_grad():
+        ref = float(O.vqa_train_loss(_oracle_params(sd), cfg, x.image, x.q_ids, x.q_atts, x.a_ids, x.a_atts, x.k, x.weights, 1))
+    print(f"VQA B={B} {R}px answers={sum(x.k)}: loss {float(loss):.5f} vs oracle {ref:.5f}, peak {peak:.1f} GiB")
+    assert abs(float(loss) - ref) <= 5e-3 * abs(ref), (float(loss), ref)
+    dead = _finite_and_complete(m, expect_zero=("vision_encoder.mask_token", "key.bias"))
+    assert all(("crossattention" in k and k.startswith("text_encoder.")) or "lm_cap_head" in k or "position_ids" in k for k in dead), dead[:8]

@@ -76,7 +76,14 @@ class RCCLDDPAccelerator(Accelerator):
         # xGMI bytes: chunks are packed to bf16, averaged by RCCL and unpacked on the communication stream)
         self.exchange_dtype = str(g("GRAD_EXCHANGE_DTYPE", os.environ.get("XFM_GRAD_EXCHANGE", "fp32"))).lower()
         assert self.exchange_dtype in ("fp32", "bf16"), self.exchange_dtype
+        # FORCE_COLLECTIVES (test / bring-up knob, also XFM_DDP_FORCE=1): run every collective of the N > 1 path -- the agreement
+        # all-reduce, the overlapped arena all-reduces on the communication stream, the bf16 pack / unpack, the chunked ViT hand-over
+        # -- in a process group of ONE rank, so that they execute through ProcessGroupNCCL (RCCL) on a single-GPU box; the result
+        # must equal the no-collective run (mean over one rank)
+        self.force = bool(g("FORCE_COLLECTIVES", os.environ.get("XFM_DDP_FORCE", "0") == "1"))
         self.world_size, self.rank = 1, 0
+        self._dist = False         # collectives on: world_size > 1, or forced in an initialised group
+        self.stats = {"exchange_bytes": 0, "exchange_calls": 0, "overlapped_bytes": 0}   # of the last synchronising backward
         self.model = None
         self.arena = None
         self._pending = []
@@ -94,6 +101,7 @@ class RCCLDDPAccelerator(Accelerator):
         self._done_ranges = []
         self._use = {}
         self._op = dist.ReduceOp.SUM
+        self.timing = None         # (start, end) torch.cuda.Event pair a caller installs to time the exposed part of the exchange
 
     # ------------------------------------------------------------------------------------------ set-up
     def set_seed(self):
@@ -112,14 +120,18 @@ class RCCLDDPAccelerator(Accelerator):
             model = model.cuda()
         if world_size > 1 and not dist.is_initialized():
             dist.init_process_group(backend="nccl" if use_cuda else "gloo", world_size=world_size, rank=rank)
+        self._dist = world_size > 1 or (self.force and dist.is_available() and dist.is_initialized())
+        if self.force and self._dist:
+            from .. import xfm as _xfm
+            _xfm.FORCE_COLLECTIVES = True
         # RCCL averages in the collective itself (no extra pass over the 1.4 GB of live gradients)
-        self._op = dist.ReduceOp.AVG if (world_size > 1 and dist.get_backend() == "nccl") else dist.ReduceOp.SUM
+        self._op = dist.ReduceOp.AVG if (self._dist and dist.get_backend() == "nccl") else dist.ReduceOp.SUM
         if hasattr(model, "finalize"):
             model.finalize()
         self.model = model
         arena = getattr(model, "_arena", None)
         self.arena = arena
-        if world_size > 1:
+        if self._dist:
             self.broadcast()
         if arena is not None:
             self._towers = self._tower_ranges(model)
@@ -146,7 +158,7 @@ class RCCLDDPAccelerator(Accelerator):
     def _agree(self):
         """Bring the live-parameter set up to date (and identical on every rank)."""
         arena = self.arena
-        if self.world_size > 1:
+        if self._dist:
             flags = torch.tensor(arena.live, dtype=torch.uint8).to(arena.grad.device).to(torch.int32)
             dist.all_reduce(flags, op=dist.ReduceOp.MAX)
             merged = flags.cpu().numpy().astype(bool).tolist()
@@ -209,6 +221,8 @@ class RCCLDDPAccelerator(Accelerator):
     def _exchange(self, a, b, async_ok=True):
         """All-reduce (mean) of arena.grad[a:b] on the current stream."""
         g = self.arena.grad[a:b]
+        self.stats["exchange_calls"] += 1
+        self.stats["exchange_bytes"] += (b - a) * (2 if self.exchange_dtype == "bf16" else 4)
         if self.exchange_dtype == "bf16":
             buf = g.to(torch.bfloat16)
             w = dist.all_reduce(buf, op=self._op, async_op=True)
@@ -227,6 +241,7 @@ class RCCLDDPAccelerator(Accelerator):
         with torch.cuda.stream(self._comm_stream):
             for a, b in _clip(self._ranges, *rng):
                 self._exchange(a, b)
+                self.stats["overlapped_bytes"] += (b - a) * (2 if self.exchange_dtype == "bf16" else 4)
         self._done_ranges.append(rng)
 
     # ------------------------------------------------------------------------------------------ step
@@ -240,12 +255,18 @@ class RCCLDDPAccelerator(Accelerator):
         arena = self.arena
         if arena is not None:
             arena.reattach()  # a caller's optimizer.zero_grad(set_to_none=True) must not detach .grad from the arena
-        self._overlap_ok = (self.world_size > 1 and self._sync_now and arena is not None and self._comm_stream is not None
+        self._overlap_ok = (self._dist and self._sync_now and arena is not None and self._comm_stream is not None
                             and arena.live_ver == self._agreed_ver and self._agreed_ver >= 0)
+        if self._sync_now:
+            self.stats = {"exchange_bytes": 0, "exchange_calls": 0, "overlapped_bytes": 0}
         loss.backward()
         self._overlap_ok = False
-        if self.world_size > 1 and self._sync_now:
+        if self._dist and self._sync_now:
+            if self.timing is not None and self._comm_stream is not None:   # bench.py: end of backward -> all-reduce done
+                self.timing[0].record()
             self._finish_allreduce()
+            if self.timing is not None and self._comm_stream is not None:
+                self.timing[1].record()
 
     def _finish_allreduce(self):
         arena = self.arena
@@ -285,7 +306,7 @@ class RCCLDDPAccelerator(Accelerator):
         self._pending = []
         for rec in self._use.values():
             rec[0] = 0
-        if self._op == dist.ReduceOp.SUM:  # gloo has no AVG: scale the exchanged ranges
+        if self._op == dist.ReduceOp.SUM and self.world_size > 1:  # gloo has no AVG: scale the exchanged ranges
             for a, b in self._ranges:
                 arena.grad[a:b].mul_(1.0 / self.world_size)
 

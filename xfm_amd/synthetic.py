@@ -182,3 +182,20 @@ def retrieval_eval_inputs(n_img=5, n_txt=8):
     txt2img = [j % n_img for j in range(n_txt)]
     img2txt = [[j for j in range(n_txt) if txt2img[j] == i] for i in range(n_img)]
     return NS(image=b["image"][:n_img], text_ids=b["text_ids"], text_atts=b["text_atts"], k_test=3, txt2img=txt2img, img2txt=img2txt)
+
+
+def vqa_batch(batch_size, seed=1234, image_res=480, max_tokens=40, max_answers=10, answer_len=8):
+    """BASELINE configs[3] synthetic batch (the collate of dataset/vqa_dataset.py as VQA.py:45-52 consumes it): B images +
+    questions of up to `max_tokens` tokens, k[b] ~ U[1, max_answers] answers per question (<s> ... </s>, up to `answer_len` tokens,
+    pad = 1) and one annotator weight per answer (the weights of a question sum to 1)."""
+    from types import SimpleNamespace as NS
+    b = pretrain_batch(batch_size, seed=seed, image_res=image_res, max_tokens=max_tokens)
+    k = [int(v) for v in (1 + np.floor(uniform01(f"vqa{seed}.k", batch_size) * max_answers)).clip(1, max_answers)]
+    ans = pretrain_batch(sum(k), seed=seed + 1, max_tokens=answer_len, min_len=3, with_image=False)
+    w = uniform01(f"vqa{seed}.w", sum(k)) + 0.1
+    o = 0
+    for n in k:
+        w[o:o + n] /= w[o:o + n].sum()
+        o += n
+    return NS(image=b["image"], q_ids=b["text_ids"], q_atts=b["text_atts"], k=k, a_ids=ans["text_ids"], a_atts=ans["text_atts"],
+              weights=torch.from_numpy(w.astype(np.float32)))

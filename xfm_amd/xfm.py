@@ -51,8 +51,11 @@ class AllGather(torch.autograd.Function):
         return grad_output[ctx.batch_size * ctx.rank: ctx.batch_size * (ctx.rank + 1)], None, None
 
 
+FORCE_COLLECTIVES = False   # set by RCCLDDPAccelerator(FORCE_COLLECTIVES=True): gather even in a group of one rank (hardware bring-up test)
+
+
 def allgather(t):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES):
         return AllGather.apply(t, dist.get_rank(), dist.get_world_size())
     return t
 
