@@ -121,7 +121,7 @@ def test_glue_text_classification_at_config_shape_vs_oracle(encoder, tmp_path):
         if err > GRAD_TOL or cos < COS_TOL:
             bad.append((k, round(err, 4), round(cos, 5)))
     print(f"GLUE {encoder} B={B} T={T}: loss {got:.5f} vs oracle {want:.5f}; {n} gradients, worst rel-L2 {worst[0]:.4f}, cosine {worst[1]:.5f}")
-    assert n >= 12 * 16 and not bad, bad[:10]
+    assert n >= 12 * 12 and not bad, bad[:10]
     # the vision tower took no part
     assert all(float(p._xfm_grad.abs().max()) == 0.0 for k, p in named.items() if k.startswith("vision_encoder.") and hasattr(p, "_xfm_grad"))
 

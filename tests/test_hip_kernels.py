@@ -890,3 +890,54 @@ def test_small_ce_any_class_count_and_ignored_labels(C):
     # dlogits leave the kernel as bf16
     _close(x.grad, xr.grad, 1e-2, "d logits")
     assert float(x.grad[::5].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,H,S,use_bias", [
+    (2, 12, 197, True),     # the 224-px ViT (13 tiles: the seventh key-owner wave holds 5 keys, the last query pair is one tile)
+    (41, 12, 197, True),    # 492 items, two per workgroup: a workgroup whose items straddle two heads flushes its bias gradient twice
+    (3, 5, 197, False),     # models/vit.py: no relative-position bias
+    (2, 3, 208, True),      # every tile full
+    (4, 2, 100, True),      # 7 tiles: four key-owner waves, the rest idle
+    (3, 4, 65, True),       # 5 tiles, one key past the last full tile
+    (1, 1, 80, True),       # a single item
+])
+def test_vit_attention_fused_forward_backward(B, H, S, use_bias):
+    """The batch-walking ViT kernels (csrc/attention_vit.hip: one workgroup per (batch entry, head) problem at a time; forward with the
+    whole score row in registers, backward with S / dP computed once for dQ, dK, dV and the bias gradient) against fp32 math
+    (beit2.py:126-166), and against the general kernels (XFM_ATTN_VIT=0 is their A/B switch) on delta's definition: here
+    delta_i = dO_i . O_i with the bf16 O."""
+    Fx = _fx()
+    D = H * 64
+    scale = 0.125
+    qkv = _rand((B * S, 3 * D), seed=150 + S)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    ld = (S + 15) // 16 * 16
+    bias = bias_t = None
+    if use_bias:
+        bias = torch.full((H, S, ld), float("nan"), dtype=F32, device="cuda")   # the padding of a bias row is never initialised
+        bias[:, :, :S] = _rand((H, S, S), 1.0, F32, seed=152)
+        bias_t = torch.full((H, S, ld), float("nan"), dtype=F32, device="cuda")
+        bias_t[:, :, :S] = bias[:, :, :S].transpose(1, 2)
+    dout = _rand((B * S, D), seed=153)
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    br = bias[:, :, :S].clone().requires_grad_(True) if use_bias else None
+    ref = _attn_ref(qr, kr, vr, B, H, S, S, scale, br)
+    ref.backward(dout.float())
+    o, lse = Fx.attn_fwd(q, k, v, B, H, S, S, scale, bias=bias)
+    _close(o, ref, 1e-2, "attention out")
+    s_ref = (qr.detach().view(B, S, H, 64).permute(0, 2, 1, 3) @ kr.detach().view(B, S, H, 64).permute(0, 2, 3, 1)) * scale
+    if use_bias:
+        s_ref = s_ref + br.detach().unsqueeze(0)
+    assert float((lse[:, :, :S] - s_ref.logsumexp(-1)).abs().max()) <= 2e-2
+    dqkv = torch.full((B * S, 3 * D), float("nan"), dtype=BF16, device="cuda")
+    dbias = torch.zeros_like(bias).nan_to_num(0.0) if use_bias else None
+    delta = Fx.attn_bwd(dout, q, k, v, o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, S, S, scale, bias=bias, dbias=dbias,
+                        bias_t=bias_t)
+    _close(dqkv[:, :D], qr.grad, 2e-2, "dq")
+    _close(dqkv[:, D:2 * D], kr.grad, 2e-2, "dk")
+    _close(dqkv[:, 2 * D:], vr.grad, 2e-2, "dv")
+    want_delta = (dout.float() * o.float()).view(B, S, H, 64).sum(-1).permute(0, 2, 1)
+    _close(delta[:, :, :S], want_delta, 1e-3, "delta")
+    if use_bias:
+        _close(dbias[:, :, :S], br.grad, 2e-2, "dbias")
+        assert float(dbias[:, :, S:].abs().max() if ld > S else 0.0) == 0.0

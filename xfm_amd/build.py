@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libxfm_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "layernorm.hip", "attention.hip", "elementwise.hip", "encoder.hip", "losses.hip", "common.h",
+SOURCES = ["capi.hip", "gemm.hip", "layernorm.hip", "attention.hip", "attention_vit.hip", "elementwise.hip", "encoder.hip", "losses.hip", "common.h",
            os.path.join("..", "..", "include", "xfm_hip.h")]
 
 

@@ -1481,6 +1481,8 @@ __global__ __launch_bounds__(512, 4) void xattn_dkv_kernel(AttnArgs a) {
   }
 }
 
+#include "attention_vit.hip"
+
 static int attn_check(const AttnArgs& a, bool bwd) {
   XFM_REQUIRE(a.B > 0 && a.H > 0 && a.Sq > 0 && a.Sk > 0, "attention: empty problem B=%d H=%d Sq=%d Sk=%d", a.B, a.H, a.Sq, a.Sk);
   XFM_REQUIRE(a.q_rs % 8 == 0 && a.k_rs % 8 == 0 && a.v_rs % 8 == 0 && a.o_rs % 4 == 0, "attention: row strides must be multiples of 8");
@@ -1577,6 +1579,7 @@ int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(xattn_fwd_kernel<true>, dim3(1, a.H, cdiv(a.B, rpb)), dim3(rpb * tq * 64), (size_t)rpb * ATTN_SLOT, st, a);
     return xfm_check_launch("xattn_fwd<pack>");
   }
+  if (attn_vit_shape(a)) return launch_attn_fwd_vit(a, st);
   int nw, blocks;
   static const int fwd_nw = getenv("XFM_ATTN_FWD_NW") ? atoi(getenv("XFM_ATTN_FWD_NW")) : 8;  // tuning knob
   attn_geom(a.Sq, nw, blocks, fwd_nw);
@@ -1609,6 +1612,7 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(xattn_dkv_kernel, dim3(kblocks, a.H, a.n_groups), dim3(knw * 64), (size_t)ATTN_RES_MAX * ATTN_SLOT, st, a);
     return xfm_check_launch("xattn_dkv");
   }
+  if (attn_vit_bwd_shape(a)) return launch_attn_bwd_vit(a, st);
   int nw, blocks;
   attn_geom(a.Sq, nw, blocks);
   const bool res = attn_resident(a.Sk, nw);
