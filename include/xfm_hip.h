@@ -28,7 +28,7 @@ extern "C" {
 #define XFM_E_LAUNCH (-2)
 #define XFM_E_UNSUPPORTED (-3)
 
-#define XFM_ABI_VERSION 3
+#define XFM_ABI_VERSION 4
 
 const char* xfm_last_error(void);
 int xfm_abi_version(void);
@@ -174,10 +174,21 @@ typedef struct {
      (error ~2^-17 |dO||O| plus the forward's own bf16 rounding of P, below the bf16 noise of dS) instead of recomputing it in a
      first pass over the keys -- two of the dQ kernel's five matrix products.  NULL = the exact two-pass form. */
   xfm_bf16* o_lo;
+  /* optional copies of `bias` in the MFMA accumulator layout (xfm_bias_tile), used by the batch-walking kernels of the 224-px ViT
+     shape (Sq == Sk <= 224, no mask / dropout): bias_tiled for the forward, bias_t_tiled (tiles of the transposed bias) for the
+     backward.  One bias tile is then one contiguous 1-KB wave load instead of 16 strided row segments.  NULL = read `bias` /
+     `bias_t`. */
+  const float* bias_tiled; const float* bias_t_tiled;
 } xfm_attn_args;
 
 int xfm_attn_fwd(const xfm_attn_args* a, void* stream);
 int xfm_attn_bwd(const xfm_attn_args* a, void* stream);
+/* dense additive bias [H,S,ld] (fp32) -> two tiled copies, each [H][T][T][64 lanes][4] floats with T = ceil(S / 16), pre-divided by
+ * `scale` (the kernels start the score accumulators from bias / scale):
+ *   tiled  [h][a][b][lane][r] = bias[h][16a + (lane & 15)][16b + 4 (lane >> 4) + r] / scale        (query on the lane: forward)
+ *   tiled_t[h][a][b][lane][r] = bias[h][16b + 4 (lane >> 4) + r][16a + (lane & 15)] / scale        (key on the lane:   backward)
+ * Entries whose key is past S hold -1e30 (probability 0), entries whose query is past S hold 0.  Either output may be NULL. */
+int xfm_bias_tile(const float* bias, int H, int S, long ld, float scale, float* tiled, float* tiled_t, void* stream);
 /* dense[h,i,j] = table[index[i*N+j]*H + h] (beit2.py:139-145), rows padded to ld (dense_t: optional [h,j,i] copy);
  * and its scatter-add gradient. */
 /* dst[u,:] = sum_{r: index[r]==u} src[r,:]  (bf16 rows of `len` elements, fp32 accumulation). */

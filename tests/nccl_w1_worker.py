@@ -5,8 +5,11 @@ an RCCL bring-up problem cannot hang the test process).  Three runs of the same 
      arena broadcast, ReduceOp.AVG all-reduces issued from the tower hooks / the ViT chunk hand-over on the communication
      stream, fp32 exchange;
   C  the same with the bf16 wire format (pack -> all-reduce -> unpack on the communication stream).
-Mean over one rank is the identity, so B must reproduce A bit for bit; C rounds every exchanged gradient to bf16 once.
-Prints one JSON line."""
+Mean over one rank is the identity: every range that leaves through RCCL -- from the tower hooks and the ViT chunk hand-over inside
+backward, or from the sweep after it -- must come back BIT FOR BIT (fp32) or as exactly its bf16 rounding (bf16 wire format); the
+worker snapshots each range on the communication stream right before its collective and compares after the step.  Run-to-run the
+gradients themselves differ in the last bits (float atomics in the small-problem weight-gradient path), so A vs B is held to that
+noise on the first step's gradients, not bitwise.  Prints one JSON line."""
 import json
 import os
 import sys
@@ -41,6 +44,16 @@ def run(meta, force, exchange="fp32"):
     m.eval()
     B = meta["B"]
     stats, grads = [], None
+    snaps, identity = [], {"ranges": 0, "bad": 0}
+    if force:
+        orig = acc._exchange
+
+        def snapshotting(a, b, async_ok=True):   # runs under torch.cuda.stream(comm stream): the clone is ordered before the collective
+            snaps.append((a, b, m._arena.grad[a:b].clone()))
+            return orig(a, b, async_ok)
+
+        acc._exchange = snapshotting
+    first_grads = None
     for step in range(3):
         b = {k: v.cuda() for k, v in syn.pretrain_batch(B, seed=100 + step).items()}
         masks = syn.mim_block_mask(B, 14, 75, seed=100 + step)
@@ -48,31 +61,39 @@ def run(meta, force, exchange="fp32"):
                          masked_ids=b["masked_ids"], ret_mim_loss=True, data_source="image", ids_mask=masks,
                          neg_idx=([(i + 1) % B for i in range(B)], [(i + 2) % B for i in range(B)]))
         acc.backward_step(losses["loss_itc"] + losses["loss_itm"] + losses["loss_mlm"] + losses["loss_mim"], opt)
+        torch.cuda.synchronize()
+        for a_, b_, pre in snaps:   # what came back from RCCL vs what went in
+            post = m._arena.grad[a_:b_]
+            want = pre.to(torch.bfloat16).float() if exchange == "bf16" else pre
+            identity["ranges"] += 1
+            identity["bad"] += int(not torch.equal(post, want))
+        snaps.clear()
+        if step == 0:
+            first_grads = m._arena.grad.clone()
         stats.append(dict(acc.stats, overlapped_ranges=len(getattr(acc, "overlapped_ranges", []))))
         if step == 2:
             grads = m._arena.grad.clone()
         acc.optimizer_step(opt, m)
     torch.cuda.synchronize()
-    return m._arena.data.clone(), grads, stats, str(acc._op), sum(b_ - a for a, b_ in acc.live_ranges())
+    return m._arena.data.clone(), first_grads, stats, str(acc._op), sum(b_ - a for a, b_ in acc.live_ranges()), identity
 
 
 def main():
     torch.cuda.set_device(0)
     _, meta = load("pretrain_small")
-    pa, ga, _, _, live = run(meta, False)
+    pa, ga, _, _, live, _ = run(meta, False)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29653")
     dist.init_process_group("nccl", world_size=1, rank=0)
-    pb, gb, sb, op, _ = run(meta, True)
-    pc, gc, sc, _, _ = run(meta, True, "bf16")
+    pb, gb, sb, op, _, id_fp32 = run(meta, True)
+    pc, gc, sc, _, _, id_bf16 = run(meta, True, "bf16")
     dist.barrier()
     dist.destroy_process_group()
     out = {"backend": "nccl", "op": op, "live_elems": live,
-           "fp32_params_equal": bool(torch.equal(pa, pb)), "fp32_grads_equal": bool(torch.equal(ga, gb)),
-           "fp32_max_abs_param_diff": float((pa - pb).abs().max()),
-           "bf16_grad_rel_l2": float((gc - ga).norm() / ga.norm()),
-           "bf16_grads_are_bf16_of_fp32": bool(torch.equal(gc, ga.to(torch.bfloat16).float())),
-           "bf16_param_rel_l2": float((pc - pa).norm() / pa.norm()),
+           "identity_fp32": id_fp32, "identity_bf16": id_bf16,
+           "first_step_grad_rel_l2_vs_no_collectives": float((gb - ga).norm() / ga.norm()),
+           "first_step_grad_rel_l2_bf16_wire": float((gc - ga).norm() / ga.norm()),
+           "param_rel_l2_after_3_steps": float((pb - pa).norm() / pa.norm()),
            "stats_fp32": sb, "stats_bf16": sc}
     print("NCCL_W1 " + json.dumps(out), flush=True)
 

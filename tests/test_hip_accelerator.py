@@ -249,8 +249,9 @@ def test_collectives_through_rccl_in_a_group_of_one():
     with FORCE_COLLECTIVES, three pre-training steps (tests/nccl_w1_worker.py).  The live-set agreement, the arena broadcast, the
     ITC all_gather, ReduceOp.AVG, async all-reduces launched from the tower hooks and the ViT trunk's chunk hand-over on the
     communication stream, and the bf16 pack / unpack all run through ProcessGroupNCCL; the mean over one rank is the identity, so
-    parameters and gradients must equal the run without any collective BIT FOR BIT (fp32 exchange), and the bf16 exchange must
-    deliver exactly the bf16 rounding of the fp32 gradients (ddp_accelerator.py:34-98, apex_ddp_accelerator.py:77-110)."""
+    every arena range must come back from RCCL BIT FOR BIT (fp32 exchange) or as exactly its bf16 rounding (bf16 wire format), and
+    the first step's gradients must equal those of a run without any collective up to the float-atomics noise of two runs
+    (ddp_accelerator.py:34-98, apex_ddp_accelerator.py:77-110)."""
     import json
     import os
     import subprocess
@@ -263,11 +264,13 @@ def test_collectives_through_rccl_in_a_group_of_one():
     out = json.loads(line[len("NCCL_W1 "):])
     print(line)
     assert "AVG" in out["op"]
-    assert out["fp32_params_equal"] and out["fp32_grads_equal"], out
+    assert out["identity_fp32"]["ranges"] >= 15 and out["identity_fp32"]["bad"] == 0, out["identity_fp32"]
+    assert out["identity_bf16"]["ranges"] >= 15 and out["identity_bf16"]["bad"] == 0, out["identity_bf16"]
+    assert out["first_step_grad_rel_l2_vs_no_collectives"] < 1e-4, out
     # from the step after the live set is agreed, ranges leave for the all-reduce from INSIDE backward (tower hooks + ViT chunks)
     s3 = out["stats_fp32"][2]
     assert s3["overlapped_ranges"] >= 3 and s3["overlapped_bytes"] > 0.5 * s3["exchange_bytes"], s3
     assert s3["exchange_bytes"] == 4 * out["live_elems"], (s3, out["live_elems"])   # every live element exactly once, fp32
     assert out["stats_bf16"][2]["exchange_bytes"] == 2 * out["live_elems"]
     # bf16 wire format: one rounding of each exchanged gradient
-    assert out["bf16_grad_rel_l2"] < 4e-3 and out["bf16_param_rel_l2"] < 1e-3, out
+    assert out["first_step_grad_rel_l2_bf16_wire"] < 4e-3 and out["param_rel_l2_after_3_steps"] < 1e-2, out

@@ -892,6 +892,7 @@ def test_small_ce_any_class_count_and_ignored_labels(C):
     assert float(x.grad[::5].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("tiled", [True, False])
 @pytest.mark.parametrize("B,H,S,use_bias", [
     (2, 12, 197, True),     # the 224-px ViT (13 tiles: the seventh key-owner wave holds 5 keys, the last query pair is one tile)
     (41, 12, 197, True),    # 492 items, two per workgroup: a workgroup whose items straddle two heads flushes its bias gradient twice
@@ -901,11 +902,12 @@ def test_small_ce_any_class_count_and_ignored_labels(C):
     (3, 4, 65, True),       # 5 tiles, one key past the last full tile
     (1, 1, 80, True),       # a single item
 ])
-def test_vit_attention_fused_forward_backward(B, H, S, use_bias):
+def test_vit_attention_fused_forward_backward(B, H, S, use_bias, tiled, monkeypatch):
     """The batch-walking ViT kernels (csrc/attention_vit.hip: one workgroup per (batch entry, head) problem at a time; forward with the
     whole score row in registers, backward with S / dP computed once for dQ, dK, dV and the bias gradient) against fp32 math
     (beit2.py:126-166), and against the general kernels (XFM_ATTN_VIT=0 is their A/B switch) on delta's definition: here
     delta_i = dO_i . O_i with the bf16 O."""
+    monkeypatch.setenv("XFM_ATTN_VIT_BWD", "1")   # (the single-pass backward is an opt-in; read once per process by the library)
     Fx = _fx()
     D = H * 64
     scale = 0.125
@@ -923,7 +925,10 @@ def test_vit_attention_fused_forward_backward(B, H, S, use_bias):
     br = bias[:, :, :S].clone().requires_grad_(True) if use_bias else None
     ref = _attn_ref(qr, kr, vr, B, H, S, S, scale, br)
     ref.backward(dout.float())
-    o, lse = Fx.attn_fwd(q, k, v, B, H, S, S, scale, bias=bias)
+    if tiled and not use_bias:
+        pytest.skip("no bias to tile")
+    tiles = Fx.bias_tiles(bias, S, scale) if tiled else None   # accumulator-layout copies (one contiguous load per tile)
+    o, lse = Fx.attn_fwd(q, k, v, B, H, S, S, scale, bias=bias, bias_tiles=tiles)
     _close(o, ref, 1e-2, "attention out")
     s_ref = (qr.detach().view(B, S, H, 64).permute(0, 2, 1, 3) @ kr.detach().view(B, S, H, 64).permute(0, 2, 3, 1)) * scale
     if use_bias:
@@ -932,7 +937,7 @@ def test_vit_attention_fused_forward_backward(B, H, S, use_bias):
     dqkv = torch.full((B * S, 3 * D), float("nan"), dtype=BF16, device="cuda")
     dbias = torch.zeros_like(bias).nan_to_num(0.0) if use_bias else None
     delta = Fx.attn_bwd(dout, q, k, v, o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, S, S, scale, bias=bias, dbias=dbias,
-                        bias_t=bias_t)
+                        bias_t=None if tiled else bias_t, bias_tiles=tiles)
     _close(dqkv[:, :D], qr.grad, 2e-2, "dq")
     _close(dqkv[:, D:2 * D], kr.grad, 2e-2, "dk")
     _close(dqkv[:, 2 * D:], vr.grad, 2e-2, "dv")

@@ -176,14 +176,18 @@ class _TrunkFn(torch.autograd.Function):
             s = vit._slots[i]
             g1 = blk.gamma_1 if blk.gamma_1 is not None else vit._ones   # ... and no layer scale (gamma = 1, no gradient)
             g2 = blk.gamma_2 if blk.gamma_2 is not None else vit._ones
-            dense = dense_t = None
+            dense = dense_t = tiles = None
             if rel_pos:
                 dense, dense_t = Fx.relpos_gather(blk.attn.relative_position_bias_table, vit._index32, H, N, ld, transposed=True)
+                if 64 < N <= 224:   # the batch-walking ViT-shape kernels (csrc/attention_vit.hip) read accumulator-layout copies
+                    tiles = Fx.bias_tiles(dense, N, blk.attn.scale, fwd=True, bwd=_VIT_FUSED_BWD and ctx.needs_input_grad[0])
             qkv = Fx.gemm_nt(y, s["qkv"].wb, s["qkv"].b)
             if ctx.needs_input_grad[0] and _FAST_DELTA:
-                ctxv, lse, ctxv_lo = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, lo=True)
+                ctxv, lse, ctxv_lo = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, lo=True,
+                                                 bias_tiles=tiles)
             else:
-                (ctxv, lse), ctxv_lo = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense), None
+                (ctxv, lse), ctxv_lo = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense,
+                                                   bias_tiles=tiles), None
             h1 = Fx.gemm_nt(ctxv, s["proj"].wb, s["proj"].b)
             dp1 = None if dp is None else dp[i, 0]
             dp2 = None if dp is None else dp[i, 1]
@@ -192,7 +196,7 @@ class _TrunkFn(torch.autograd.Function):
             h2 = Fx.gemm_nt(hact, s["fc2"].wb, s["fc2"].b)
             nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else final_norm
             x2, yn, meann, rstdn = Fx.ln_ls_fwd(x1, h2, g2, dp2, N, nxt.weight, nxt.bias, nxt.eps)
-            saved.append((y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t, ctxv_lo))
+            saved.append((y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t, ctxv_lo, tiles))
             x, y = x2, yn
         ctx.saved, ctx.vit, ctx.shape = saved, vit, (B, N, D)
         ctx.noted = bool(ctx.needs_input_grad[0])
@@ -219,7 +223,7 @@ class _TrunkFn(torch.autograd.Function):
         ddense_all = None
         for i in reversed(range(len(blocks))):
             blk, s = blocks[i], vit._slots[i]
-            (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t, ctxv_lo) = ctx.saved[i]
+            (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t, ctxv_lo, tiles) = ctx.saved[i]
             final_norm = vit._final_norm if hasattr(vit, "_final_norm") else vit.fc_norm
             nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else final_norm
             g = _g
@@ -244,7 +248,8 @@ class _TrunkFn(torch.autograd.Function):
                     ddense_all = torch.zeros((len(blocks),) + tuple(dense.shape), dtype=dense.dtype, device=dense.device)
                 ddense = ddense_all[i]
             Fx.attn_bwd(dctx, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ctxv, lse, dqkv[:, :D], dqkv[:, D:2 * D],
-                        dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense, bias_t=dense_t, o_lo=ctxv_lo)
+                        dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense, bias_t=dense_t, o_lo=ctxv_lo,
+                        bias_tiles=tiles if _VIT_FUSED_BWD else None)
             if dense is not None:
                 Fx.relpos_scatter_sorted(ddense, vit._relpos_order, vit._relpos_start, H, N, ld, g(blk.attn.relative_position_bias_table))
             wg.gemm_tn(dqkv, y, s["qkv"].dw, dbias=s["qkv"].db)
@@ -287,6 +292,7 @@ class _TokensFn(torch.autograd.Function):
 # first pass over the keys: dQ kernel 198 -> 165 us, forward 69 -> 80 us at B = 128 (tools/bench_attn.py), the step unchanged within
 # noise (41.6 vs 41.5 ms, tools/ab.sh) -- off by default, the exact two-pass form costs nothing
 _FAST_DELTA = __import__("os").environ.get("XFM_ATTN_FAST_DELTA", "0") != "0"
+_VIT_FUSED_BWD = __import__("os").environ.get("XFM_ATTN_VIT_BWD", "0") != "0"   # opt-in single-pass backward (measured slower: DESIGN.md)
 _GRAD_CHUNK_BLOCKS = 4  # the trunk's gradients leave for the all-reduce in chunks of this many blocks (12 blocks: 3 chunks)
 
 

@@ -106,6 +106,9 @@ int xfm_attn_fwd(const xfm_attn_args* a, void* stream) {
   XFM_REQUIRE(a->q && a->k && a->v && a->o && a->lse, "attn_fwd: null operand");
   return xfm_attn_fwd_impl(*a, ST(stream));
 }
+int xfm_bias_tile(const float* bias, int H, int S, long ld, float scale, float* tiled, float* tiled_t, void* stream) {
+  return xfm_bias_tile_impl(bias, H, S, ld, scale, tiled, tiled_t, ST(stream));
+}
 int xfm_attn_bwd(const xfm_attn_args* a, void* stream) {
   NOTNULL(a, "attn_bwd");
   XFM_REQUIRE(a->q && a->k && a->v && a->o && a->lse, "attn_bwd: null operand");

@@ -262,7 +262,7 @@ def attn_grouped_ok(Sq, Sk):
 
 
 def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t=None, kv_index=None, groups=None,
-               q_pack=None, k_pack=None):
+               q_pack=None, k_pack=None, bias_tiles=None):
     for t in (q, k, v, o):
         assert t.dtype == BF16 and t.stride(-1) == 1 and t.dim() == 2
     for pk in (q_pack, k_pack):
@@ -279,7 +279,14 @@ def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, dro
         assert kv_index is None and bias is None and not causal and attn_grouped_ok(Sq, Sk)
         assert g_start.dtype == torch.int32 and g_rows.dtype == torch.int32 and g_start.numel() == n_groups + 1 and g_rows.numel() == B
         assert k.shape[0] == n_groups * Sk
+    tiled = tiled_t = None
+    if bias_tiles is not None:  # (tiled, tiled_t) of bias_tiles(): the accumulator-layout copies the ViT-shape kernels read
+        tiled, tiled_t = bias_tiles
+        T = (Sq + 15) // 16
+        assert bias is not None and Sq == Sk and all(t is None or (t.dtype == F32 and t.is_contiguous() and t.numel() == H * T * T * 256)
+                                                     for t in (tiled, tiled_t))
     return AttnArgs(stat_ld=lse.shape[-1], bias_t=_ptr(bias_t), bias_t_ld=0 if bias_t is None else bias_t.stride(1),
+                    bias_tiled=_ptr(tiled), bias_t_tiled=_ptr(tiled_t),
                     kv_index=_ptr(kv_index), grp_start=_ptr(g_start), grp_rows=_ptr(g_rows), n_groups=n_groups,
                     q=q.data_ptr(), q_rs=q.stride(0), k=k.data_ptr(), k_rs=k.stride(0), v=v.data_ptr(), v_rs=v.stride(0),
                     o=o.data_ptr(), o_rs=o.stride(0), lse=lse.data_ptr(), bias=_ptr(bias),
@@ -289,8 +296,19 @@ def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, dro
                     k_start=_ptr(k_pack[0]) if k_pack else 0, k_len=_ptr(k_pack[1]) if k_pack else 0)
 
 
+def bias_tiles(bias, S, scale, fwd=True, bwd=True):
+    """Dense additive bias fp32 [H, S, ld] -> (tiled, tiled_t): copies in the MFMA accumulator layout, divided by `scale`, that the
+    batch-walking ViT-shape attention kernels read with one contiguous 1-KB load per tile (xfm_bias_tile in include/xfm_hip.h)."""
+    H, T = bias.shape[0], (S + 15) // 16
+    assert bias.dtype == F32 and bias.dim() == 3 and bias.stride(2) == 1 and bias.stride(0) == S * bias.stride(1)
+    tiled = torch.empty(H * T * T * 256, dtype=F32, device=bias.device) if fwd else None
+    tiled_t = torch.empty(H * T * T * 256, dtype=F32, device=bias.device) if bwd else None
+    check(_lib.load().xfm_bias_tile(bias.data_ptr(), H, S, bias.stride(1), float(scale), _ptr(tiled), _ptr(tiled_t), _stream()), "bias_tile")
+    return tiled, tiled_t
+
+
 def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=False, drop=(0, 1.0, 0, 0), kv_index=None, groups=None,
-             q_pack=None, k_pack=None, zero_fill=True, lo=False):
+             q_pack=None, k_pack=None, zero_fill=True, lo=False, bias_tiles=None):
     """q [B*Sq, >=H*64] / k, v [B*Sk, ...] are 2-D (possibly strided column slices of fused projection buffers).
     bias: dense fp32 [H,Sq,ld]; key_keep: int32 [B,Sk].  Returns (o [B*Sq, H*64] bf16, lse [B,H,Sq]).
     groups = kv_groups(...): grouped mode, k / v / key_keep hold one entry per SOURCE."""
@@ -304,7 +322,7 @@ def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=Fals
     if key_keep is not None:
         assert key_keep.dtype == torch.int32 and key_keep.is_contiguous()
     a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, kv_index=kv_index, groups=groups,
-                   q_pack=q_pack, k_pack=k_pack)
+                   q_pack=q_pack, k_pack=k_pack, bias_tiles=bias_tiles)
     o_lo = None
     if lo:  # second half of the output (what bf16 rounding of O lost): lets the backward skip its first pass over the keys
         o_lo = torch.empty_like(o)
@@ -314,12 +332,13 @@ def attn_fwd(q, k, v, B, H, Sq, Sk, scale, bias=None, key_keep=None, causal=Fals
 
 
 def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, dbias=None, key_keep=None, causal=False,
-             drop=(0, 1.0, 0, 0), bias_t=None, kv_index=None, groups=None, q_pack=None, k_pack=None, phase=0, delta=None, o_lo=None):
+             drop=(0, 1.0, 0, 0), bias_t=None, kv_index=None, groups=None, q_pack=None, k_pack=None, phase=0, delta=None, o_lo=None,
+             bias_tiles=None):
     """Writes dq/dk/dv (2-D bf16 views with the same addressing convention as q/k/v); dbias (fp32 [H,Sq,ld]) += .
     Grouped mode: dk/dv are per SOURCE ([n_groups*Sk] rows), summed over each group's rows.
     Packed rows: only the rows of real tokens are written -- pass zero-initialised dq (/ dk / dv).
     phase 1 = the dQ kernel alone, phase 2 = the dK/dV kernel alone on the `delta` that the phase-1 call returned.  Returns delta."""
-    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t, kv_index, groups, q_pack, k_pack)
+    a = _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t, kv_index, groups, q_pack, k_pack, bias_tiles)
     if delta is None:
         assert phase != 2, "phase 2 needs the row statistics of the phase-1 call"
         delta = torch.empty((B, H, lse.shape[-1]), dtype=F32, device=q.device)  # the kernels never use its padding entries
