@@ -187,7 +187,9 @@ int xfm_attn_bwd(const xfm_attn_args* a, void* stream);
  * `scale` (the kernels start the score accumulators from bias / scale):
  *   tiled  [h][a][b][lane][r] = bias[h][16a + (lane & 15)][16b + 4 (lane >> 4) + r] / scale        (query on the lane: forward)
  *   tiled_t[h][a][b][lane][r] = bias[h][16b + 4 (lane >> 4) + r][16a + (lane & 15)] / scale        (key on the lane:   backward)
- * Entries whose key is past S hold -1e30 (probability 0), entries whose query is past S hold 0.  Either output may be NULL. */
+ * Entries whose key is past S hold -1e30 (probability 0), entries whose query is past S hold 0.  tiled_t has T + 1 key-tile rows
+ * ([H][T+1][T][64][4]): the last one is all -1e30, for a kernel wave whose second key tile lies past the sequence.  Either output may be
+ * NULL. */
 int xfm_bias_tile(const float* bias, int H, int S, long ld, float scale, float* tiled, float* tiled_t, void* stream);
 /* dense[h,i,j] = table[index[i*N+j]*H + h] (beit2.py:139-145), rows padded to ld (dense_t: optional [h,j,i] copy);
  * and its scatter-add gradient. */

@@ -44,8 +44,9 @@ def test_pretrain_checkpoint_into_retrieval_model(tmp_path):
 
 
 def test_resolution_change_resamples_relative_position_tables(tmp_path):
-    """224 -> 384 px: every block's table goes from 27 x 27 + 3 to 47 x 47 + 3 entries (beit2.py:763-821).  The reference's interp2d
-    call is gone from SciPy (parity unpinned, see beit2.interpolate_rel_pos_bias); what can be held is checked below."""
+    """224 -> 384 px: every block's table goes from 27 x 27 + 3 to 47 x 47 + 3 entries (beit2.py:763-821).  The values are pinned by
+    tests/test_oracle_relpos_interp.py against the reference's own function; here: the plumbing through load_pretrained and the
+    properties of the resampling (coordinates, exactness on cubics, untouched cls entries)."""
     import numpy as np
     from xfm_amd.beit2 import interpolate_rel_pos_bias, rel_pos_source_coordinates
     from xfm_amd.model_retrieval import XFMForRetrieval

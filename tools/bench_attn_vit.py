@@ -48,5 +48,5 @@ e.record()
 torch.cuda.synchronize()
 tb = s.elapsed_time(e) / iters * 1e3
 gf = 4.0 * B * H * N * N * 64 / 1e9
-print(f"XFM_ATTN_VIT={os.environ.get('XFM_ATTN_VIT', '1')} B={B}: fwd {tf:.1f} us ({gf / tf * 1e3:.0f} TFLOP/s), bwd {tb:.1f} us ({2.5 * gf / tb * 1e3:.0f} TFLOP/s); "
+print(f"XFM_ATTN_VIT={os.environ.get('XFM_ATTN_VIT', '1')} BWD={os.environ.get('XFM_ATTN_VIT_BWD')} B={B}: fwd {tf:.1f} us ({gf / tf * 1e3:.0f} TFLOP/s), bwd {tb:.1f} us ({2.5 * gf / tb * 1e3:.0f} TFLOP/s); "
       f"checksum {float(o.float().abs().sum()):.4e} {float(dqkv.float().abs().sum()):.4e} {float(dbias.abs().sum()) if dbias is not None else 0.0:.4e}")

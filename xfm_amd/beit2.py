@@ -292,7 +292,7 @@ class _TokensFn(torch.autograd.Function):
 # first pass over the keys: dQ kernel 198 -> 165 us, forward 69 -> 80 us at B = 128 (tools/bench_attn.py), the step unchanged within
 # noise (41.6 vs 41.5 ms, tools/ab.sh) -- off by default, the exact two-pass form costs nothing
 _FAST_DELTA = __import__("os").environ.get("XFM_ATTN_FAST_DELTA", "0") != "0"
-_VIT_FUSED_BWD = __import__("os").environ.get("XFM_ATTN_VIT_BWD", "0") != "0"   # opt-in single-pass backward (measured slower: DESIGN.md)
+_VIT_FUSED_BWD = __import__("os").environ.get("XFM_ATTN_VIT_BWD", "0") != "0"   # opt-in single-pass attention backward (measured slower than the split pair: csrc/attention_vit.hip)
 _GRAD_CHUNK_BLOCKS = 4  # the trunk's gradients leave for the all-reduce in chunks of this many blocks (12 blocks: 3 chunks)
 
 
@@ -434,11 +434,11 @@ def interpolate_rel_pos_bias(rel_pos_bias, dst_num_pos, dst_patch_shape):
     beit2.py:763-821: the (2s-1)^2 grid part is resampled from geometric-progression source coordinates to the integer target
     coordinates with a bicubic interpolating spline, the 3 extra (cls) entries are carried over.
 
-    PARITY UNPINNED: the reference calls `scipy.interpolate.interp2d(x, y, z, kind='cubic')`, removed in SciPy 1.14 (this image
-    has 1.15), so no fixture could be taken from it.  `RectBivariateSpline(kx=3, ky=3, s=0)` is the replacement SciPy's own
-    interp2d transition guide gives for rectilinear grids (same FITPACK interpolating spline; the guide states agreement to 1e-14).
-    What the tests do hold: exact reproduction of the source values wherever a target coordinate coincides with a source
-    coordinate (0 and +-1), the untouched extra tokens, and the geometric-progression coordinates themselves."""
+    The reference calls `scipy.interpolate.interp2d(x, y, z, kind='cubic')`, removed in SciPy 1.14 (this image has 1.15); for a regular
+    grid that was FITPACK's interpolating tensor-product spline (`regrid_smth` with s = 0, evaluated by `bispev`), which
+    `RectBivariateSpline(kx=3, ky=3, s=0)` reaches through the same routines.  Pinned by tests/golden/relpos_interp.npz: the
+    reference's own `interpolate_pos_embed` run on a formula table (224 -> 384 / 480 px) with the removed call supplied by a
+    from-source restatement of it (tests/test_oracle_relpos_interp.py holds this function to that fixture at 1e-6)."""
     import numpy as np
     from scipy.interpolate import RectBivariateSpline
     src_num_pos, num_attn_heads = rel_pos_bias.shape
@@ -484,8 +484,8 @@ def rel_pos_source_coordinates(src_size, dst_size):
 
 def load_pretrained_beit2(model, ckpt_rpath):
     """beit2.py:572-660: unwrap `model` / `module`, drop the classification head and the `relative_position_index` buffers, expand
-    a shared relative-position table to every block, resample tables of another grid size (`interpolate_rel_pos_bias`, parity
-    unpinned -- see there), load with strict=False."""
+    a shared relative-position table to every block, resample tables of another grid size (`interpolate_rel_pos_bias`), load with
+    strict=False."""
     checkpoint = torch.load(ckpt_rpath, map_location='cpu')
     checkpoint_model = None
     for model_key in ('model', 'module'):

@@ -1612,7 +1612,7 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(xattn_dkv_kernel, dim3(kblocks, a.H, a.n_groups), dim3(knw * 64), (size_t)ATTN_RES_MAX * ATTN_SLOT, st, a);
     return xfm_check_launch("xattn_dkv");
   }
-  if (attn_vit_bwd_shape(a)) return launch_attn_bwd_vit(a, st);
+  if (attn_vit3_shape(a)) return launch_attn_bwd_vit3(a, st);
   int nw, blocks;
   attn_geom(a.Sq, nw, blocks);
   const bool res = attn_resident(a.Sk, nw);

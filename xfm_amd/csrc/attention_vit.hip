@@ -9,13 +9,10 @@
 //   * forward (attn_fwd_vit_kernel): 7 waves; a wave owns a 16-query tile against ALL keys (<= 14 key tiles = 56 accumulator VGPRs),
 //     two tiles per item; the scores start from bias / scale as the MFMA accumulator, one row maximum, p = exp2(fma), no rescale;
 //     K / V of the NEXT item land in the second LDS buffers while this one computes;
-//   * backward (attn_bwd_vit_kernel): 8 waves; waves 0..6 own 32 keys each ("key on the lane": S = Q K^T and dP = dO V^T leave the
-//     MFMA with the key on the lane, so P and dS are already the B operands of dV^T += dO^T P and dK^T += Q^T dS, whose accumulators
-//     stay in registers for the whole item); only dS crosses LDS (bf16, once) for dQ^T = K^T dS^T, which wave 7 (and wave 6, whose
-//     second key tile is past the sequence) sums over all keys; the bias gradient sum_b dS stays in the owners' registers across the
-//     items of one head (104 VGPRs) and leaves through 128-byte runs of float atomics when the head changes.  5 matrix products, each
-//     (b, h) read from HBM once.
-// Items are (head, batch entry) pairs in head-major order, `ipw` consecutive ones per workgroup: 1536 items = 6 per CU at B = 128.
+//   * backward (attn_bwd_vit3_kernel, opt-in): one pass for dQ, dK, dV, delta and the bias gradient -- see its header for the design and
+//     for why the split dQ + dK/dV kernels of attention.hip remain the default.
+// Items are (head, batch entry) pairs in head-major order, consecutive ones per workgroup: 1536 items = 6 per CU at B = 128.
+#include <type_traits>
 #define VF_MAXT 14                  // 16-row tiles per image (S <= 224)
 #define VF_IMG (VF_MAXT * 2048)     // one [224 x 64] bf16 image
 #define VF_LDS (4 * VF_IMG)         // forward: K | K' | V | V'
@@ -236,11 +233,11 @@ __global__ __launch_bounds__(VF_NW * 64) void attn_fwd_vit_kernel(AttnArgs a, Vi
 // One 64-thread workgroup per (head, tile a, tile b): the tile in the accumulator layout of both kernels (see include/xfm_hip.h).
 __global__ __launch_bounds__(64) void bias_tile_kernel(const float* __restrict__ bias, int S, long ld, float inv_scale, float* __restrict__ tiled,
                                                        float* __restrict__ tiled_t) {
-  const int T = gridDim.x, a_ = blockIdx.y, b_ = blockIdx.x, h = blockIdx.z;
+  const int T = gridDim.x, a_ = blockIdx.y, b_ = blockIdx.x, h = blockIdx.z;   // a_ in [0, T]: tiled_t has one more key-tile row, all -1e30
   const int lane = threadIdx.x, lr = lane & 15, lg = lane >> 4;
   const float* bh = bias + (long)h * S * ld;
   const long tile = (((long)h * T + a_) * T + b_) * 256 + lane * 4;
-  if (tiled != nullptr) {   // query 16a + lr, keys 16b + 4lg + r
+  if (tiled != nullptr && a_ < T) {   // query 16a + lr, keys 16b + 4lg + r
     const int q = a_ * 16 + lr;
     f32x4 v;
 #pragma unroll
@@ -258,7 +255,7 @@ __global__ __launch_bounds__(64) void bias_tile_kernel(const float* __restrict__
       const int q = b_ * 16 + 4 * lg + r;
       v[r] = k < S ? (q < S ? bh[(long)q * ld + k] * inv_scale : 0.f) : -1.0e30f;
     }
-    *reinterpret_cast<f32x4*>(tiled_t + tile) = v;
+    *reinterpret_cast<f32x4*>(tiled_t + (((long)h * (T + 1) + a_) * T + b_) * 256 + lane * 4) = v;
   }
 }
 
@@ -266,7 +263,7 @@ int xfm_bias_tile_impl(const float* bias, int H, int S, long ld, float scale, fl
   XFM_REQUIRE(bias != nullptr && H > 0 && S > 0 && ld >= S && scale > 0.f, "bias_tile: bad arguments");
   XFM_REQUIRE(((uintptr_t)tiled % 16) == 0 && ((uintptr_t)tiled_t % 16) == 0, "bias_tile: outputs must be 16-byte aligned");
   const int T = cdiv(S, 16);
-  hipLaunchKernelGGL(bias_tile_kernel, dim3(T, T, H), dim3(64), 0, st, bias, S, ld, 1.0f / scale, tiled, tiled_t);
+  hipLaunchKernelGGL(bias_tile_kernel, dim3(T, T + 1, H), dim3(64), 0, st, bias, S, ld, 1.0f / scale, tiled, tiled_t);
   return xfm_check_launch("bias_tile");
 }
 
@@ -302,46 +299,54 @@ static int launch_attn_fwd_vit(const AttnArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// backward: dQ, dK, dV, delta and the bias gradient of one (b, h) per step of a workgroup's item walk (see the file header).
-// LDS: Q | dO | K | V images (28 KB each) | dS exchange, two query-tile pairs of [224 keys][16 q] bf16 x 2 | lse / scale and delta
-// (256 floats each) | a 2-KB transposition scratch per owner wave for the bias-gradient flush.
-// delta_i = dO_i . O_i (+ o_lo: what bf16 rounding of O lost): one pass over the keys; the general kernels' exact two-pass delta
-// (sum_j P_ij dP_ij) is what XFM_ATTN_VIT=0 still runs.
+// backward, single pass (S in (192, 208]: 13 tiles, 7 query-tile pairs; opt-in, XFM_ATTN_VIT_BWD=3): dQ, dK, dV, delta and the bias
+// gradient of one (b, h) from ONE evaluation of S and dP -- 5 matrix products instead of the 7 of the split dQ + dK/dV kernels, each
+// problem read from HBM once.  Waves 0..6 own 32 keys each ("key on the lane": S = Q K^T and dP = dO V^T leave the MFMA with the key on
+// the lane, so P and dS are already the B operands of dV^T += dO^T P and dK^T += Q^T dS, whose accumulators stay in registers for the
+// whole item); only dS crosses LDS (bf16, once) for dQ^T = K^T dS^T; the bias gradient sum_b dS stays in the owners' registers across the
+// items of one head (104 VGPRs) and leaves through 128-byte runs of float atomics when the head changes.  delta_i = dO_i . O_i (bf16 O).
+// Nothing of an item is staged while the workgroup waits: K and V images are double-buffered across items; Q, dO and O arrive one
+// query-tile PAIR ahead in a two-slot ring (they are only ever needed pair by pair: row fragments for S / dP, transposed fragments for
+// dV / dK, dO . O for delta); wave 7 issues every direct-to-LDS load, waits for them behind counted vmcnt, turns dO . O into delta and
+// publishes the pair's row statistics before the barrier that opens the pair.  The owner waves issue no LDS-DMA at all, so their own
+// loads (bias tiles, one query tile ahead) never queue behind a prefetch.  dQ of a pair is summed one iteration later, one
+// (query tile, d-tile) unit per wave, the last pair of an item inside the first iteration of the next one.
+// MEASURED (B = 128: 1536 problems, tools/bench_attn_vit.py, tools/pmc_attn_vit.sh): 285 us against 231 us for the split pair, although it
+// issues 17 % fewer VALU instructions and keeps the matrix pipe busy for 30 % fewer cycles: with the bias-gradient sums resident a wave
+// needs 256 VGPRs, so a CU holds 8 waves (the split kernels: 12), and they spend 72 % of their cycles parked (SQ_WAIT_ANY) -- one
+// barrier per query-tile pair whose period is set by wave 7's 22 LDS-DMA issues and their landing, not by the 55 MFMAs of the pair.
+// A variant that staged a whole item at its top (no ring) measured the same 287 us.  Kept as an opt-in with its tests; the default
+// backward is the split pair.
+// LDS: K | K' | V | V' (13 tiles each) | ring: 2 x (Q | dO | O of 32 rows) | exchange: 2 x 2 x [208 keys][16 q] bf16 | statistics.
 // ---------------------------------------------------------------------------------------------------------------------------
-#define VB2_QTM 13                        // query / key tiles (S <= 208): the bias-gradient accumulators are 8 VGPRs per query tile
-#define VB2_NPM 7
-#define VB2_EXQ (VF_MAXT * 16 * 32)       // one query tile of the exchange: [224 keys][16 q] bf16
-#define VB2_EXCH (2 * VB2_EXQ)
-#define VB2_OFF_EX (4 * VF_IMG)
-#define VB2_OFF_ST (VB2_OFF_EX + 2 * VB2_EXCH)
-#define VB2_OFF_SCR (VB2_OFF_ST + 2 * 1024)
-#define VB2_OFF_SINK (VB2_OFF_SCR + 7 * 2048)   // 256 B that the L2-prefetch loads land in (never read)
-#define VB2_LDS (VB2_OFF_SINK + 256)
+#define V3_KT 13
+#define V3_NP 7
+#define V3_IMG (V3_KT * 2048)                 // 26,624
+#define V3_SLOT (3 * 4096)                    // Q | dO | O rows of one pair
+#define V3_EXQ (V3_KT * 16 * 32)              // 6,656: one query tile of the exchange
+#define V3_EXCH (2 * V3_EXQ)
+#define V3_OFF_RING (4 * V3_IMG)
+#define V3_OFF_EX (V3_OFF_RING + 2 * V3_SLOT)
+#define V3_OFF_ST (V3_OFF_EX + 2 * V3_EXCH)    // 2 x { lse / scale [32] | delta [32] }
+#define V3_LDS (V3_OFF_ST + 2 * 256)
 
-template <bool HAS_BIAS, int KTC, bool TILED>
-__global__ __launch_bounds__(512) void attn_bwd_vit_kernel(AttnArgs a, VitMap vm, int dbg) {
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(512) void attn_bwd_vit3_kernel(AttnArgs a, VitMap vm) {
+  constexpr int KT = V3_KT, NP = V3_NP;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: wave-uniform address math stays on the SALU)
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
-  const int S = a.Sq, KT = KTC ? KTC : (S + 15) >> 4, NP = (KT + 1) >> 1;
+  const int S = a.Sq;
   const int wg = blockIdx.x;
   int h, b, hn = 0, bn = 0;
   if (!vit_item(vm, wg, 0, h, b)) return;
 
-  char* const sQ = lds;
-  char* const sD = lds + VF_IMG;
-  char* const sK = lds + 2 * VF_IMG;
-  char* const sV = lds + 3 * VF_IMG;
-  char* const ex = lds + VB2_OFF_EX;
-  float* const sL = reinterpret_cast<float*>(lds + VB2_OFF_ST);   // lse / scale (1e30 past the last query: P = 0)
-  float* const sDl = sL + 256;                                    // delta
-  // key tiles past the sequence are never written by an owner: they must read as zeros in the dQ product
-  for (int i = tid; i < 2 * VB2_EXCH / 16; i += 512) reinterpret_cast<u32x4*>(ex)[i] = u32x4{0, 0, 0, 0};
-
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(void, lds);
+  char* const ring = lds + V3_OFF_RING;
+  char* const ex = lds + V3_OFF_EX;
+  float* const st = reinterpret_cast<float*>(lds + V3_OFF_ST);
   const bool owner = w < 7;
   const int kt0 = 2 * w;
-  int nt = KT - kt0;
-  nt = !owner || nt < 0 ? 0 : (nt > 2 ? 2 : nt);
   const int sw_r = (lr >> 1) & 7;
   const int rf0 = lr * 128 + ((lg ^ sw_r) << 4), rf1 = lr * 128 + (((4 + lg) ^ sw_r) << 4);
   const int tr_row = 4 * lg + (lr >> 2);
@@ -349,220 +354,253 @@ __global__ __launch_bounds__(512) void attn_bwd_vit_kernel(AttnArgs a, VitMap vm
     const int tr_col = dt * 16 + 4 * (lr & 3);
     return tr_row * 128 + (((tr_col >> 3) ^ ((tr_row >> 1) & 7)) << 4) + (tr_col & 7) * 2;
   };
-  constexpr bool tiled = TILED;
-  const int ex_w = (kt0 * 16 + lr) * 32 + lg * 8;              // owner: dS[q = 4 lg .. +3][key = lr] of key tile kt0 (+512 per tile)
-  const int ex_r = (4 * lg + (lr >> 2)) * 32 + (lr & 3) * 8;   // dQ: transposed read of a [4 keys][16 q] block (+512 per key tile)
+  const int ex_w = (kt0 * 16 + lr) * 32 + lg * 8;
+  const int ex_r = (4 * lg + (lr >> 2)) * 32 + (lr & 3) * 8;
   const float inv_scale = 1.0f / a.scale, c2 = a.scale * 1.44269504088896341f;
-  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(void, lds);
-  const long q_bs = (long)S * a.q_rs * 2, k_bs = (long)S * a.k_rs * 2, v_bs = (long)S * a.v_rs * 2, do_bs = (long)S * a.do_rs * 2;
-  const int PC = 4 * NP;  // 1-KB pieces per image (rows past S repeat the last row: finite)
+  const long q_bs = (long)S * a.q_rs * 2, k_bs = (long)S * a.k_rs * 2, v_bs = (long)S * a.v_rs * 2, do_bs = (long)S * a.do_rs * 2,
+             o_bs = (long)S * a.o_rs * 2;
   bool kvalid[2];
-  int keyc[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int key = (kt0 + t) * 16 + lr;
-    kvalid[t] = key < S;
-    keyc[t] = key < S ? key : S - 1;
-  }
+  for (int t = 0; t < 2; ++t) kvalid[t] = (kt0 + t) * 16 + lr < S;
 
-  f32x4 dsacc[VB2_QTM][2];
+  // ---- direct-to-LDS staging (issued by wave 7, except the first item's K / V which every wave shares)
+  // one 1-KB piece: rows r0 .. r0 + 7 (clamped to the last row) of a [S, 64]-per-head operand, swizzled like every image here
+  auto piece = [&](const char* base, long rs2, int hh, int r0, unsigned dst) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int r = r0 + (ln >> 3);
+    const int c = (ln & 7) ^ swz_a(r);
+    const int gr = r < S ? r : S - 1;
+    lds_dma16(base + (long)gr * rs2 + hh * 128 + c * 16, dst);
+  };
+  auto stage_kv_pieces = [&](int hh, int bb, int buf, int j0, int j1) {   // pieces j0 .. j1 - 1 of the 52 (K: 0..25, V: 26..51)
+    const char* kb = reinterpret_cast<const char*>(a.k) + (long)bb * k_bs;
+    const char* vb = reinterpret_cast<const char*>(a.v) + (long)bb * v_bs;
+    for (int j = j0; j < j1; ++j) {
+      const int isv = j >= 26 ? 1 : 0, jj = j - isv * 26;
+      piece(isv ? vb : kb, isv ? a.v_rs * 2 : a.k_rs * 2, hh, jj * 8, lds0 + (unsigned)((isv * 2 + buf) * V3_IMG + jj * 1024));
+    }
+  };
+  // Q | dO | O rows and the log-sum-exps of pair p of item (hh, bb) into ring / statistics slot `slot`: 13 wave-instructions
+  auto stage_pair = [&](int hh, int bb, int p, int slot) {
+    const char* qb = reinterpret_cast<const char*>(a.q) + (long)bb * q_bs;
+    const char* db = reinterpret_cast<const char*>(a.dout) + (long)bb * do_bs;
+    const char* ob = reinterpret_cast<const char*>(a.o) + (long)bb * o_bs;
+    const unsigned dst = lds0 + V3_OFF_RING + slot * V3_SLOT;
 #pragma unroll
-  for (int i = 0; i < VB2_QTM; ++i) dsacc[i][0] = dsacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) {
+      piece(qb, a.q_rs * 2, hh, p * 32 + j * 8, dst + j * 1024);
+      piece(db, a.do_rs * 2, hh, p * 32 + j * 8, dst + 4096 + j * 1024);
+      piece(ob, a.o_rs * 2, hh, p * 32 + j * 8, dst + 8192 + j * 1024);
+    }
+    int row = p * 32 + (lane & 31);
+    row = row < S ? row : S - 1;
+    const char* lp = reinterpret_cast<const char*>(a.lse + ((long)bb * a.H + hh) * a.stat_ld + row);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(lp), "s"(lds0 + V3_OFF_ST + slot * 256) : "memory", "m0");
+  };
+  // after the pair's loads have landed (wave 7's own vmcnt): delta_r = dO_r . O_r, lse_r / scale (1e30 past the last query: P = 0)
+  auto publish_stats = [&](int hh, int bb, int p, int slot) {
+    const char* sl = ring + slot * V3_SLOT;
+    float* ss = st + slot * 64;
+    const int rr = lane >> 1, half = lane & 1;          // row of the pair, half of its 64 columns
+    const char* dp_ = sl + 4096 + (rr >> 4) * 2048 + (rr & 15) * 128 + half * 64;
+    const char* op_ = sl + 8192 + (rr >> 4) * 2048 + (rr & 15) * 128 + half * 64;
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {   // (both rows carry the same chunk swizzle: the dot product pairs the right elements)
+      const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dp_ + c * 16), ov = *reinterpret_cast<const bf16x8*>(op_ + c * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d = fmaf(bf2f(dv[e]), bf2f(ov[e]), d);
+    }
+    d += __shfl_xor(d, 1, 64);
+    const int row = p * 32 + rr;
+    float ls = 0.f;
+    if (lane < 32) ls = ss[lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (half == 0) {
+      ss[32 + rr] = d;
+      if (row < S && a.delta != nullptr) a.delta[((long)bb * a.H + hh) * a.stat_ld + row] = d;
+    }
+    if (lane < 32) ss[lane] = p * 32 + lane < S ? ls * inv_scale : 1.0e30f;
+  };
 
-  // sum_b dS of this wave's 32 keys leaves through a wave-private LDS transpose: every atomic wave-instruction adds two 128-byte
-  // runs (32 keys of two bias rows)
-  auto flush = [&](int h) {
-    if (a.dbias == nullptr || nt == 0 || (dbg & 4)) return;
-    float* scr = reinterpret_cast<float*>(lds + VB2_OFF_SCR + w * 2048);
+  f32x4 dsacc[KT][2];
+#pragma unroll
+  for (int i = 0; i < KT; ++i) dsacc[i][0] = dsacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // sum_b dS of this wave's 32 keys leaves through a wave-private 1-KB transpose in exchange buffer `xs` (idle when this runs)
+  auto flush = [&](int hh, int xs) {
+    if (a.dbias == nullptr || !owner) return;
+    float* scr = reinterpret_cast<float*>(ex + xs * V3_EXCH + w * 1024);
     const int col = lane & 31, key = kt0 * 16 + col;
-    const bool kok = key < S && col < nt * 16;
-    float* const dst0 = a.dbias + (long)h * S * a.bias_ld + key;
+    float* const dst0 = a.dbias + (long)hh * S * a.bias_ld + key;
 #pragma unroll
-    for (int i = 0; i < VB2_QTM; ++i) {
-      if (i < KT) {
+    for (int i = 0; i < KT; ++i) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+      for (int hf = 0; hf < 2; ++hf) {   // query rows 8 hf .. 8 hf + 7 of tile i: lanes with lg >> 1 == hf hold them
+        if ((lg >> 1) == hf) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) scr[(4 * lg + r) * 32 + t * 16 + lr] = dsacc[i][t][r];
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scr[(4 * (lg & 1) + r) * 32 + t * 16 + lr] = dsacc[i][t][r];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
-        for (int step = 0; step < 8; ++step) {   // a real loop: unrolled, the 104 address computations of a flush spill to scratch
+        for (int step = 0; step < 4; ++step) {
           const int row = 2 * step + (lane >> 5);
-          const int q = i * 16 + row;
+          const int q = i * 16 + 8 * hf + row;
           const float v = scr[row * 32 + col];
-          if (kok && q < S) atomicAdd(dst0 + (long)q * a.bias_ld, v);
+          if (key < S && q < S) atomicAdd(dst0 + (long)q * a.bias_ld, v);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
   };
 
-  int cur_h = -1;
+  // ---- prologue: K / V of the first item (all waves), its first pair (wave 7)
+  stage_kv_pieces(h, b, 0, w * 7, w * 7 + 7 < 52 ? w * 7 + 7 : 52);
+  if (w == 7) stage_pair(h, b, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (w == 7) publish_stats(h, b, 0, 0);
+  lds_barrier_v();
+
+  f32x4 dKa[2][4], dVa[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dKa[t][dt] = dVa[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bcur[2];
+  auto load_bias_t = [&](f32x4 (&bv)[2], int hh, int qt) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (HAS_BIAS && owner && qt < KT)
+        bv[t] = *reinterpret_cast<const f32x4*>(a.bias_t_tiled + (((long)hh * (KT + 1) + kt0 + t) * KT + qt) * 256 + lane * 4);
+    }
+  };
+  load_bias_t(bcur, h, 0);
+
+  // dQ^T[d, q] of one (query tile, d-tile) unit of the pair whose dS sits in exchange buffer `xs`, keys from K buffer `kbuf`
+  auto dq_unit = [&](int hh, int bb, int pq, int xs, int kbuf, int un) {
+    const int u = un >> 2, dt = un & 3, qt = 2 * pq + u;
+    if (qt >= KT) return;
+    const int tro = tro_of(dt);
+    const char* xb = ex + xs * V3_EXCH + u * V3_EXQ + ex_r;
+    const char* kb = lds + kbuf * V3_IMG + tro;
+    f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s2 = 0; s2 < NP; ++s2) {
+      union { struct { s16x4 a, b; } s; bf16x8 v; } kf, sf;
+      sf.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, xb + (2 * s2) * 512));
+      kf.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, kb + (2 * s2) * 2048));
+      if (2 * s2 + 1 < KT) {
+        sf.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, xb + (2 * s2 + 1) * 512));
+        kf.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, kb + (2 * s2 + 1) * 2048));
+      } else {   // the 13th key tile has no partner: a zero half
+        sf.s.b = s16x4{0, 0, 0, 0};
+        kf.s.b = kf.s.a;
+      }
+      acc2[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, sf.v, acc2[s2 & 1], 0, 0, 0);
+    }
+    const int qi = qt * 16 + lr;
+    if (qi < S) {
+      bf16x4 ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = f2bf((acc2[0][r] + acc2[1][r]) * a.scale);
+      *reinterpret_cast<bf16x4*>(a.dq + ((long)bb * S + qi) * a.dq_rs + hh * 64 + dt * 16 + 4 * lg) = ov;
+    }
+  };
+
+  int hp = h, bp = b, last_par = 0;   // the item whose last pair still waits for its dQ
+  bool have_prev = false;
   for (int it = 0; it < vm.c; ++it) {
+    const int par = it & 1;
     const bool more = it + 1 < vm.c && vit_item(vm, wg, it + 1, hn, bn);
-    if (h != cur_h) {
-      if (cur_h >= 0) {
-        flush(cur_h);
+    const char* sK = lds + par * V3_IMG;
+    const char* sV = lds + (2 + par) * V3_IMG;
 #pragma unroll
-        for (int i = 0; i < VB2_QTM; ++i) dsacc[i][0] = dsacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      cur_h = h;
-    }
-    // ---- stage Q, dO, K, V of this item (every wave is past the previous item's last barrier)
-    if (!(dbg & 8) || it == 0) {
-      const char* src_b[4] = {reinterpret_cast<const char*>(a.q) + (long)b * q_bs, reinterpret_cast<const char*>(a.dout) + (long)b * do_bs,
-                              reinterpret_cast<const char*>(a.k) + (long)b * k_bs, reinterpret_cast<const char*>(a.v) + (long)b * v_bs};
-      const long rs_b[4] = {a.q_rs * 2, a.do_rs * 2, a.k_rs * 2, a.v_rs * 2};
-#pragma unroll
-      for (int img = 0; img < 4; ++img) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int j = w + i * 8;
-          if (j < PC) {
-            const int r = j * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ swz_a(r);
-            const int gr = r < S ? r : S - 1;
-            lds_dma16(src_b[img] + (long)gr * rs_b[img] + h * 128 + c * 16, lds0 + (unsigned)__builtin_amdgcn_readfirstlane(img * VF_IMG + j * 1024));
-          }
+    for (int p = 0; p < NP; ++p) {
+      const int slot = (p & 1) ^ par, nslot = slot ^ 1;
+      // ---------------- wave 7: the next pair's rows, a share of the next item's K / V, then the pair's statistics
+      if (w == 7) {
+        const bool next_here = p + 1 < NP;
+        if (next_here) stage_pair(h, b, p + 1, nslot);
+        else if (more) stage_pair(hn, bn, 0, nslot);
+        int nkv = 0;
+        if (more && p >= 1) {   // (not in p = 0: the previous item's last dQ still reads the K buffer these pieces overwrite)
+          const int j0 = (p - 1) * 9, j1 = p * 9 < 52 ? p * 9 : 52;
+          stage_kv_pieces(hn, bn, par ^ 1, j0, j1);
+          nkv = j1 - j0;
         }
-      }
-    }
-    // ---- row statistics: thread pair (2 r, 2 r + 1) owns row r: delta_r = dO_r . (O_r + Olo_r), lse_r / scale
-    if (!(dbg & 16) || it == 0) {
-      const int row = tid >> 1, half = tid & 1;
-      float d = 0.f;
-      if (row < S) {
-        const bf16* dp_ = a.dout + ((long)b * S + row) * a.do_rs + h * 64 + half * 32;
-        const bf16* op_ = a.o + ((long)b * S + row) * a.o_rs + h * 64 + half * 32;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dp_ + c * 8), ov = *reinterpret_cast<const bf16x8*>(op_ + c * 8);
-          if (a.o_lo != nullptr) {
-            const bf16x8 lv = *reinterpret_cast<const bf16x8*>(a.o_lo + ((long)b * S + row) * a.o_rs + h * 64 + half * 32 + c * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) d = fmaf(bf2f(dv[e]), bf2f(ov[e]) + bf2f(lv[e]), d);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) d = fmaf(bf2f(dv[e]), bf2f(ov[e]), d);
-          }
+        if (next_here || more) {
+          // the 13 loads of the pair are older than this iteration's K / V pieces: wait for all but those
+          if (nkv == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+          else if (nkv == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (next_here) publish_stats(h, b, p + 1, nslot);
+          else publish_stats(hn, bn, 0, nslot);
         }
+        if (p == NP - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next item's K / V are complete before its first pair
       }
-      d += __shfl_xor(d, 1, 64);
-      if (half == 0) {
-        sDl[row] = d;
-        if (row < S && a.delta != nullptr) a.delta[((long)b * a.H + h) * a.stat_ld + row] = d;
-      } else {
-        sL[row] = row < S ? a.lse[((long)b * a.H + h) * a.stat_ld + row] * inv_scale : 1.0e30f;
-      }
-    }
-    // bias of this wave's keys against the first query tile (transposed dense bias: 4 consecutive queries of one key = 16 bytes)
-    f32x4 bcur[2];
-    auto load_bias_t = [&](f32x4 (&bv)[2], int qt) {
+      // ---------------- owners: S, dP, P, dS of query tiles 2p, 2p+1 against this wave's keys
+      if (owner) {
+        const char* sl = ring + slot * V3_SLOT;
+        const float* ss = st + slot * 64;
+        char* const exb = ex + slot * V3_EXCH;
+        auto body = [&](auto NTc) {
+          constexpr int NT = decltype(NTc)::value;
+          bf16x4 pp[2][2], ps[2][2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        bv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (HAS_BIAS && t < nt && qt < KT) {
-          if (tiled) bv[t] = *reinterpret_cast<const f32x4*>(a.bias_t_tiled + (((long)h * KT + kt0 + t) * KT + qt) * 256 + lane * 4);
-          else bv[t] = *reinterpret_cast<const f32x4*>(a.bias_t + ((long)h * S + keyc[t]) * a.bias_t_ld + qt * 16 + 4 * lg);
-        }
-      }
-    };
-    load_bias_t(bcur, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(bcur[0]), "+v"(bcur[1]));
-    lds_barrier_v();  // images and statistics of this item are in
-
-    f32x4 dKa[2][4], dVa[2][4];
+          for (int u = 0; u < 2; ++u) {
+            const int qt = 2 * p + u;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t) pp[u][t] = ps[u][t] = bf16x4{0, 0, 0, 0};
+            if (qt < KT) {
+              f32x4 bnx[2];
+              if (qt + 1 < KT) load_bias_t(bnx, h, qt + 1);
+              else load_bias_t(bnx, more ? hn : h, 0);   // the first tile of the next item
+              const f32x4 lsv = *reinterpret_cast<const f32x4*>(ss + u * 16 + 4 * lg);
+              const f32x4 dlv = *reinterpret_cast<const f32x4*>(ss + 32 + u * 16 + 4 * lg);
+              const bf16x8 qa0 = *reinterpret_cast<const bf16x8*>(sl + u * 2048 + rf0), qa1 = *reinterpret_cast<const bf16x8*>(sl + u * 2048 + rf1);
+              const bf16x8 da0 = *reinterpret_cast<const bf16x8*>(sl + 4096 + u * 2048 + rf0), da1 = *reinterpret_cast<const bf16x8*>(sl + 4096 + u * 2048 + rf1);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dKa[t][dt] = dVa[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // The images leave no LDS for a second set, so the next item cannot be staged under this one's products.  Wave 7 (the dQ wave: no
-    // loads of its own to wait for) touches one dword of every 128-byte line the next item will stage or read: they are in L2 when
-    // the direct-to-LDS loads ask for them (each lane one line per instruction; the values are never used).
-    if (w == 7 && more && !(dbg & 32)) {
-      const int h2 = hn, b2 = bn;
-      const char* pb[5] = {reinterpret_cast<const char*>(a.q) + (long)b2 * q_bs, reinterpret_cast<const char*>(a.dout) + (long)b2 * do_bs,
-                           reinterpret_cast<const char*>(a.k) + (long)b2 * k_bs, reinterpret_cast<const char*>(a.v) + (long)b2 * v_bs,
-                           reinterpret_cast<const char*>(a.o) + (long)b2 * S * a.o_rs * 2};
-      const long pr[5] = {a.q_rs * 2, a.do_rs * 2, a.k_rs * 2, a.v_rs * 2, a.o_rs * 2};
-#pragma unroll
-      for (int img = 0; img < 5; ++img) {
-#pragma unroll 1
-        for (int r0 = 0; r0 < S; r0 += 64) {
-          const int r = r0 + lane < S ? r0 + lane : S - 1;
-          // (a direct-to-LDS dword: a load into a VGPR would land, some microseconds later, in a register the compiler has reused)
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(pb[img] + (long)r * pr[img] + h2 * 128), "s"(lds0 + VB2_OFF_SINK) : "memory", "m0");
-        }
-      }
-    }
-
-#pragma unroll
-    for (int p = 0; p <= VB2_NPM; ++p) {
-      if (p < NP && nt > 0 && !(dbg & 2)) {
-        // ---- owner: S, dP, P, dS of query tiles 2p, 2p+1 against this wave's keys; dS to the exchange; dV^T, dK^T accumulate
-        char* const exb = ex + (p & 1) * VB2_EXCH;
-        bf16x4 pp[2][2], ps[2][2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int qt = 2 * p + u;
-#pragma unroll
-          for (int t = 0; t < 2; ++t) pp[u][t] = ps[u][t] = bf16x4{0, 0, 0, 0};
-          if (qt < VB2_QTM && qt < KT) {
-            f32x4 bnx[2];
-            load_bias_t(bnx, qt + 1);  // one query tile ahead: its L2 latency hides under this tile's products
-            const f32x4 lsv = *reinterpret_cast<const f32x4*>(sL + qt * 16 + 4 * lg);
-            const f32x4 dlv = *reinterpret_cast<const f32x4*>(sDl + qt * 16 + 4 * lg);
-            const bf16x8 qa0 = *reinterpret_cast<const bf16x8*>(sQ + qt * 2048 + rf0), qa1 = *reinterpret_cast<const bf16x8*>(sQ + qt * 2048 + rf1);
-            const bf16x8 da0 = *reinterpret_cast<const bf16x8*>(sD + qt * 2048 + rf0), da1 = *reinterpret_cast<const bf16x8*>(sD + qt * 2048 + rf1);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              if (t < nt) {
+              for (int t = 0; t < NT; ++t) {
                 const char* kp = sK + (kt0 + t) * 2048;
                 const char* vp = sV + (kt0 + t) * 2048;
-                f32x4 st, dp;
+                f32x4 sc, dp;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  float bv = bcur[t][r];
-                  if (HAS_BIAS && tiled) {   // pre-divided by the scale, -1e30 past the last key, 0 past the last query
-                    st[r] = bv - lsv[r];
-                  } else {
-                    if (HAS_BIAS && qt == KT - 1) bv = qt * 16 + 4 * lg + r < S ? bv : 0.f;   // (the padding of a bias row is not initialised)
-                    bv = kvalid[t] ? bv : -1.0e30f;
-                    st[r] = fmaf(bv, inv_scale, -lsv[r]);
-                  }
+                  if (HAS_BIAS) sc[r] = bcur[t][r] - lsv[r];   // tiled: pre-divided by the scale, -1e30 past the last key
+                  else sc[r] = kvalid[t] ? -lsv[r] : -1.0e30f;
                   dp[r] = -dlv[r];
                 }
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, *reinterpret_cast<const bf16x8*>(kp + rf0), st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, *reinterpret_cast<const bf16x8*>(kp + rf1), st, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, *reinterpret_cast<const bf16x8*>(kp + rf0), sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, *reinterpret_cast<const bf16x8*>(kp + rf1), sc, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da0, *reinterpret_cast<const bf16x8*>(vp + rf0), dp, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da1, *reinterpret_cast<const bf16x8*>(vp + rf1), dp, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  const float pv = __builtin_amdgcn_exp2f(st[r] * c2);
+                  const float pv = __builtin_amdgcn_exp2f(sc[r] * c2);
                   const float ds = pv * dp[r];
-                  dsacc[qt < VB2_QTM ? qt : 0][t][r] += ds;
+                  dsacc[qt < KT ? qt : 0][t][r] += ds;
                   pp[u][t][r] = f2bf(pv);
                   ps[u][t][r] = f2bf(ds);
                 }
-                *reinterpret_cast<bf16x4*>(exb + u * VB2_EXQ + ex_w + t * 512) = ps[u][t];
+                *reinterpret_cast<bf16x4*>(exb + u * V3_EXQ + ex_w + t * 512) = ps[u][t];
               }
+              bcur[0] = bnx[0];
+              bcur[1] = bnx[1];
             }
-            bcur[0] = bnx[0];
-            bcur[1] = bnx[1];
           }
-        }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const int tro = tro_of(dt);
-          union { struct { s16x4 a, b; } s; bf16x8 v; } df, qf;
-          df.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sD + (2 * p) * 2048 + tro));
-          df.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sD + (2 * p + 1) * 2048 + tro));
-          qf.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sQ + (2 * p) * 2048 + tro));
-          qf.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sQ + (2 * p + 1) * 2048 + tro));
+          for (int dt = 0; dt < 4; ++dt) {
+            const int tro = tro_of(dt);
+            union { struct { s16x4 a, b; } s; bf16x8 v; } df, qf;
+            df.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sl + 4096 + tro));
+            df.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sl + 4096 + 2048 + tro));
+            qf.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sl + tro));
+            qf.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sl + 2048 + tro));
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            if (t < nt) {
+            for (int t = 0; t < NT; ++t) {
               union { struct { bf16x4 a, b; } s; bf16x8 v; } pf, sf;
               pf.s.a = pp[0][t]; pf.s.b = pp[1][t];
               sf.s.a = ps[0][t]; sf.s.b = ps[1][t];
@@ -570,49 +608,21 @@ __global__ __launch_bounds__(512) void attn_bwd_vit_kernel(AttnArgs a, VitMap vm
               dKa[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf.v, sf.v, dKa[t][dt], 0, 0, 0);
             }
           }
-        }
+        };
+        if (w == 6) body(std::integral_constant<int, 1>{});   // keys 192 .. 207 only: its second tile is past the sequence
+        else body(std::integral_constant<int, 2>{});
       }
-      if (p >= 1 && p <= NP && w >= 6 && !(dbg & 1)) {
-        // ---- dQ^T[d, q] = sum_keys K^T[d, key] dS^T[key, q] of the PREVIOUS pair: wave 7 takes six (query tile, d-tile) units, wave 6
-        // (at most 16 keys of its own at S = 197) the other two
-        const int pq = p - 1;
-        const char* exb = ex + (pq & 1) * VB2_EXCH;
-        const int u_begin = w == 7 ? 0 : 6, u_end = w == 7 ? 6 : 8;
-#pragma unroll 1
-        for (int un = u_begin; un < u_end; ++un) {
-          const int u = un >> 2, dt = un & 3, qt = 2 * pq + u;
-          if (qt >= KT) continue;
-          const int tro = tro_of(dt);
-          const char* xb = exb + u * VB2_EXQ + ex_r;
-          f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-          for (int s2 = 0; s2 < VB2_NPM; ++s2) {
-            if (s2 < NP) {
-              union { struct { s16x4 a, b; } s; bf16x8 v; } kf, sf;
-              sf.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, xb + (2 * s2) * 512));
-              sf.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, xb + (2 * s2 + 1) * 512));
-              kf.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sK + (2 * s2) * 2048 + tro));
-              kf.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sK + (2 * s2 + 1) * 2048 + tro));
-              acc2[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, sf.v, acc2[s2 & 1], 0, 0, 0);
-            }
-          }
-          const int qi = qt * 16 + lr;
-          if (qi < S) {
-            bf16x4 ov;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = f2bf((acc2[0][r] + acc2[1][r]) * a.scale);
-            *reinterpret_cast<bf16x4*>(a.dq + ((long)b * S + qi) * a.dq_rs + h * 64 + dt * 16 + 4 * lg) = ov;
-          }
-        }
-      }
+      // ---------------- dQ of the previous pair (exchange buffer slot ^ 1): one unit per wave
+      if (p > 0) dq_unit(h, b, p - 1, slot ^ 1, par, w);
+      else if (have_prev) dq_unit(hp, bp, NP - 1, slot ^ 1, par ^ 1, w);
       lds_barrier_v();
     }
-    // ---- dK, dV of this wave's keys
-    if (nt > 0) {
+    // ---- dK, dV of this wave's keys; the bias gradient leaves when the head changes
+    if (owner) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int key = (kt0 + t) * 16 + lr;
-        if (t < nt && key < S) {
+        if (key < S) {
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
             bf16x4 ok_, ov_;
@@ -622,49 +632,40 @@ __global__ __launch_bounds__(512) void attn_bwd_vit_kernel(AttnArgs a, VitMap vm
             *reinterpret_cast<bf16x4*>(a.dv + ((long)b * S + key) * a.dv_rs + h * 64 + dt * 16 + 4 * lg) = ov_;
           }
         }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dKa[t][dt] = dVa[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
+    hp = h; bp = b; have_prev = true; last_par = par;
     if (!more) break;
+    if (hn != h) {
+      // exchange buffer (par ^ 1) ^ 1... : the last pair (p = 6) wrote buffer ((6 & 1) ^ par) = par; its dQ is still pending, so the
+      // transposition scratch takes the other one
+      flush(h, par ^ 1);
+#pragma unroll
+      for (int i = 0; i < KT; ++i) dsacc[i][0] = dsacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      lds_barrier_v();
+    }
     h = hn;
     b = bn;
   }
-  if (cur_h >= 0) flush(cur_h);
+  // ---- drain: dQ of the very last pair (its dS sits in exchange buffer `last_par`, its keys in K buffer `last_par`), then the bias
+  // gradient through the other exchange buffer
+  dq_unit(hp, bp, NP - 1, last_par, last_par, w);
+  flush(hp, last_par ^ 1);
 }
 
-// Measured at B = 128 (1536 problems, tools/bench_attn_vit.py): 271 us against 234 us for the pair of split kernels (dQ + dK/dV).  The
-// single pass does 5 products instead of 7 and reads each problem once, but with the bias-gradient sums resident it needs 256 VGPRs (two
-// waves per SIMD) and its four LDS images leave no room to stage the next item under the current one: 15 us of exposed staging per
-// item round, 40 us of atomics for the bias gradient, owners bound by VALU issue.  Kept as an opt-in (XFM_ATTN_VIT_BWD=1) with its
-// tests; the default backward stays the split pair.
-static bool attn_vit_bwd_shape(const AttnArgs& a) {
+static bool attn_vit3_shape(const AttnArgs& a) {
   const char* e = getenv("XFM_ATTN_VIT_BWD");   // (read per call: the tests switch it inside one process)
-  const bool on = e != nullptr && atoi(e) != 0;
-  return on && attn_vit_shape(a) && a.Sq <= 16 * VB2_QTM && a.bwd_phase == 0 &&
-         (a.bias == nullptr || a.bias_t_tiled != nullptr ||
-          (a.bias_t != nullptr && a.bias_t_ld >= (long)cdiv(a.Sq, 16) * 16 && ((uintptr_t)a.bias_t % 16) == 0)) &&
-         (a.dbias == nullptr || a.bias != nullptr) && a.o != nullptr;
+  const int mode = e != nullptr ? atoi(e) : 0;
+  return mode != 0 && attn_vit_shape(a) && cdiv(a.Sq, 16) == V3_KT && a.bwd_phase == 0 && a.o != nullptr && a.o_lo == nullptr &&
+         (a.bias == nullptr || a.bias_t_tiled != nullptr) && (a.dbias == nullptr || a.bias != nullptr) &&
+         ((uintptr_t)a.dout % 16) == 0 && ((uintptr_t)a.o % 16) == 0 && a.o_rs % 8 == 0;
 }
 
-template <typename K>
-static void vit_launch_bwd(K kernel, dim3 grid, hipStream_t st, const AttnArgs& a, const VitMap& vm, int dbg) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, VB2_LDS);
-  hipLaunchKernelGGL(kernel, grid, dim3(512), VB2_LDS, st, a, vm, dbg);
-}
-
-static int launch_attn_bwd_vit(const AttnArgs& a, hipStream_t st) {
+static int launch_attn_bwd_vit3(const AttnArgs& a, hipStream_t st) {
   const VitMap vm = vit_map(a.B, a.H);
-  const dim3 grid(vm.grid);
-  const bool k13 = cdiv(a.Sq, 16) == 13;
-  static const int dbg = getenv("XFM_VIT_DBG") ? atoi(getenv("XFM_VIT_DBG")) : 0;  // timing experiments only (results are wrong when set)
-  if (a.bias == nullptr) {
-    if (k13) vit_launch_bwd(attn_bwd_vit_kernel<false, 13, false>, grid, st, a, vm, dbg);
-    else vit_launch_bwd(attn_bwd_vit_kernel<false, 0, false>, grid, st, a, vm, dbg);
-  } else if (a.bias_t_tiled != nullptr) {
-    if (k13) vit_launch_bwd(attn_bwd_vit_kernel<true, 13, true>, grid, st, a, vm, dbg);
-    else vit_launch_bwd(attn_bwd_vit_kernel<true, 0, true>, grid, st, a, vm, dbg);
-  } else {
-    if (k13) vit_launch_bwd(attn_bwd_vit_kernel<true, 13, false>, grid, st, a, vm, dbg);
-    else vit_launch_bwd(attn_bwd_vit_kernel<true, 0, false>, grid, st, a, vm, dbg);
-  }
-  return xfm_check_launch("attn_bwd_vit");
+  if (a.bias != nullptr) vit_launch(attn_bwd_vit3_kernel<true>, V3_LDS, dim3(vm.grid), dim3(512), st, a, vm);
+  else vit_launch(attn_bwd_vit3_kernel<false>, V3_LDS, dim3(vm.grid), dim3(512), st, a, vm);
+  return xfm_check_launch("attn_bwd_vit3");
 }

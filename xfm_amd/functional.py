@@ -283,8 +283,8 @@ def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, dro
     if bias_tiles is not None:  # (tiled, tiled_t) of bias_tiles(): the accumulator-layout copies the ViT-shape kernels read
         tiled, tiled_t = bias_tiles
         T = (Sq + 15) // 16
-        assert bias is not None and Sq == Sk and all(t is None or (t.dtype == F32 and t.is_contiguous() and t.numel() == H * T * T * 256)
-                                                     for t in (tiled, tiled_t))
+        assert bias is not None and Sq == Sk and all(t is None or (t.dtype == F32 and t.is_contiguous() and t.numel() == H * (T + e) * T * 256)
+                                                     for t, e in ((tiled, 0), (tiled_t, 1)))
     return AttnArgs(stat_ld=lse.shape[-1], bias_t=_ptr(bias_t), bias_t_ld=0 if bias_t is None else bias_t.stride(1),
                     bias_tiled=_ptr(tiled), bias_t_tiled=_ptr(tiled_t),
                     kv_index=_ptr(kv_index), grp_start=_ptr(g_start), grp_rows=_ptr(g_rows), n_groups=n_groups,
@@ -302,7 +302,7 @@ def bias_tiles(bias, S, scale, fwd=True, bwd=True):
     H, T = bias.shape[0], (S + 15) // 16
     assert bias.dtype == F32 and bias.dim() == 3 and bias.stride(2) == 1 and bias.stride(0) == S * bias.stride(1)
     tiled = torch.empty(H * T * T * 256, dtype=F32, device=bias.device) if fwd else None
-    tiled_t = torch.empty(H * T * T * 256, dtype=F32, device=bias.device) if bwd else None
+    tiled_t = torch.empty(H * (T + 1) * T * 256, dtype=F32, device=bias.device) if bwd else None
     check(_lib.load().xfm_bias_tile(bias.data_ptr(), H, S, bias.stride(1), float(scale), _ptr(tiled), _ptr(tiled_t), _stream()), "bias_tile")
     return tiled, tiled_t
 

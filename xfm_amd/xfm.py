@@ -178,8 +178,8 @@ def load_pretrained(model, ckpt_rpath, config, is_eval=False, load_text=False):
     drop the `relative_position_index` buffers (rebuilt by the model), and -- with `load_text` -- strip the `roberta.` / `bert.`
     level from `text_encoder.*` keys so that a pre-training checkpoint (text tower with LM heads) loads into a fine-tuning model
     (bare encoder).  Returns the state_dict to pass to `load_state_dict(strict=False)`.
-    A change of image resolution resamples the relative-position tables (`beit2.interpolate_rel_pos_bias`; the reference's
-    `scipy.interpolate.interp2d` call, beit2.py:753-821, no longer exists in SciPy >= 1.14, so that one function is parity-unpinned)."""
+    A change of image resolution resamples the relative-position tables (`beit2.interpolate_rel_pos_bias`, beit2.py:753-821; pinned by
+    tests/golden/relpos_interp.npz)."""
     checkpoint = torch.load(ckpt_rpath, map_location='cpu')
     state_dict = checkpoint['model'] if 'model' in checkpoint.keys() else checkpoint
     if is_eval:
