@@ -438,7 +438,7 @@ def interpolate_rel_pos_bias(rel_pos_bias, dst_num_pos, dst_patch_shape):
     grid that was FITPACK's interpolating tensor-product spline (`regrid_smth` with s = 0, evaluated by `bispev`), which
     `RectBivariateSpline(kx=3, ky=3, s=0)` reaches through the same routines.  Pinned by tests/golden/relpos_interp.npz: the
     reference's own `interpolate_pos_embed` run on a formula table (224 -> 384 / 480 px) with the removed call supplied by a
-    from-source restatement of it (tests/test_oracle_relpos_interp.py holds this function to that fixture at 1e-6)."""
+    from-source restatement of it (the CPU suite holds this function to that fixture at 1e-6)."""
     import numpy as np
     from scipy.interpolate import RectBivariateSpline
     src_num_pos, num_attn_heads = rel_pos_bias.shape
