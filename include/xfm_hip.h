@@ -153,7 +153,7 @@ typedef struct {
   const float* bias_t; long bias_t_ld; /* optional transposed copy of bias [H,Sk,bias_t_ld] (vector loads in dK/dV) */
   const int* kv_index;            /* optional [B]: query batch row b reads keys/values (and key_keep) of source kv_index[b];
                                      dk/dv stay per query row (fold them with xfm_rows_index_sum) */
-  /* optional GROUPED mode (Sq <= 64, Sk <= 256, no bias / causal / kv_index): group g = query batch rows
+  /* optional GROUPED mode (Sq <= 64, no bias / causal / kv_index; Sk > 256 streams the keys through LDS): group g = query batch rows
      grp_rows[grp_start[g] .. grp_start[g+1]) and reads key/value source g (k, v, key_keep have n_groups batch entries).
      One workgroup per (source, head) keeps K/V LDS-resident for all of its rows; dk/dv are summed over the group and
      written per SOURCE ([n_groups*Sk] rows). */

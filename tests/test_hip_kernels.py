@@ -692,10 +692,14 @@ def test_attention_shared_kv_sources_and_row_fold():
     _close(folded, ref, 1e-2, "folded dK/dV")
 
 
-@pytest.mark.parametrize("B,U,Sq,Sk,p", [(6, 3, 30, 197, 0.0), (11, 4, 30, 197, 0.1), (5, 5, 40, 64, 0.1), (9, 2, 64, 256, 0.0)])
+@pytest.mark.parametrize("B,U,Sq,Sk,p", [(6, 3, 30, 197, 0.0), (11, 4, 30, 197, 0.1), (5, 5, 40, 64, 0.1), (9, 2, 64, 256, 0.0),
+                                         (11, 4, 40, 577, 0.1),    # 384-px retrieval: streamed keys (10 chunks through a two-slot ring)
+                                         (7, 3, 40, 901, 0.0),     # 480-px VQA: 15 chunks, the last one 5 keys
+                                         (30, 2, 40, 300, 0.1)])   # ~15 rows x 3 tiles per image: three passes of 16 tile slots
 def test_attention_grouped_by_kv_source(B, U, Sq, Sk, p):
-    """Grouped mode (one workgroup per key/value source and head, dK/dV summed over the group's rows in registers) against the
-    kv_index path + row fold: same masks, same dropout stream (keyed by the query batch row), empty groups give zero dK/dV."""
+    """Grouped mode (one workgroup per key/value source and head, dK/dV summed over the group's rows in registers; more than 256 keys
+    stream through LDS) against the kv_index path + row fold: same masks, same dropout stream (keyed by the query batch row), empty
+    groups give zero dK/dV."""
     Fx = _fx()
     H = 4
     D = H * 64

@@ -1481,6 +1481,250 @@ __global__ __launch_bounds__(512, 4) void xattn_dkv_kernel(AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Grouped cross-attention with STREAMED keys (Sk > 256: the 577 image tokens of 384-px retrieval fine-tuning, the 901 of 480-px VQA,
+// model_retrieval.py:25-36, model_generation.py:93-130): the image's K / V no longer fit LDS whole, so the 64-key chunks go through a
+// two-slot ring and the chunk loop is the OUTER one -- every (row, 16-query tile) of the group keeps its running maximum, sum and
+// output (forward) or its dQ (backward) in registers across the chunks, up to XS_SLOTS per wave; a group with more than 8 * XS_SLOTS
+// tiles takes another pass over the chunks.  One workgroup per (source, head), 32 KB of LDS: several workgroups share a CU and cover
+// each other's staging.  dK / dV come from xattn_dkv_kernel above, which already walks any number of keys.
+// ---------------------------------------------------------------------------------------------
+#define XS_SLOTS 2
+__global__ __launch_bounds__(512, 2) void xattn_fwd_stream_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int rstart = a.grp_start[g], nrows = a.grp_start[g + 1] - rstart;
+  if (nrows <= 0) return;
+  const int tq = (a.Sq + 15) / 16, n_slots = nrows * tq, nchunks = (a.Sk + 63) / 64;
+  const bf16* kb = a.k + (long)g * a.Sk * a.k_rs + h * 64;
+  const bf16* vb = a.v + (long)g * a.Sk * a.v_rs + h * 64;
+  const bool has_mask = a.key_keep != nullptr;
+  for (int base = 0; base < n_slots; base += nw * XS_SLOTS) {   // workgroup-uniform: every wave takes the same barriers
+    bf16x8 qf[XS_SLOTS][2];
+    f32x4 oacc[XS_SLOTS][4];
+    float m_run[XS_SLOTS], l_run[XS_SLOTS];
+    int qi_[XS_SLOTS], sq_[XS_SLOTS], b_[XS_SLOTS];
+    long qb_[XS_SLOTS];
+    uint32_t dkey[XS_SLOTS];
+    bool ok[XS_SLOTS];
+#pragma unroll
+    for (int i = 0; i < XS_SLOTS; ++i) {
+      const int s = base + w + nw * i;
+      const int j = s / tq, tile = s - j * tq;
+      ok[i] = s < n_slots;
+      b_[i] = a.grp_rows[rstart + (ok[i] ? j : 0)];
+      q_seq(a, b_[i], qb_[i], sq_[i]);
+      ok[i] = ok[i] && tile * 16 < sq_[i];
+      qi_[i] = tile * 16 + lr;
+      const int qc = qi_[i] < sq_[i] ? qi_[i] : sq_[i] - 1;
+      const bf16* qp = a.q + (qb_[i] + qc) * a.q_rs + h * 64;
+      qf[i][0] = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
+      qf[i][1] = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
+      dkey[i] = drop_key(a, b_[i], h, qi_[i]);
+      m_run[i] = EXCL_NEG;
+      l_run[i] = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oacc[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    stage_slot(lds, kb, a.k_rs, vb, a.v_rs, 0, a.Sk, w, nw, lane);
+    for (int kc = 0; kc < nchunks; ++kc) {
+      stage_wait();  // chunk kc has landed, everyone is done with chunk kc - 1 -> refill its slot
+      if (kc + 1 < nchunks) stage_slot(lds + ((kc + 1) & 1) * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, (kc + 1) * 64, a.Sk, w, nw, lane);
+      const char* sK = lds + (kc & 1) * ATTN_SLOT;
+      const char* sV = sK + ATTN_TILE;
+      int kk[4][4];
+      if (has_mask) load_keep(a, g, kc, lg, kk);
+#pragma unroll
+      for (int i = 0; i < XS_SLOTS; ++i) {
+        if (!ok[i]) continue;   // wave-uniform
+        f32x4 st[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 0, lr, lg), qf[i][0], st[t], 0, 0, 0);
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 1, lr, lg), qf[i][1], st[t], 0, 0, 0);
+        }
+        float mx = EXCL_NEG;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            st[t][r] = score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, false, qi_[i], kc * 64 + t * 16 + 4 * lg + r, a.Sk);
+            mx = fmaxf(mx, st[t][r]);
+          }
+        mx = group4_max(mx);
+        const float m_new = fmaxf(m_run[i], mx);
+        const float alpha = __expf(m_run[i] - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            st[t][r] = __expf(st[t][r] - m_new);
+            psum += st[t][r];
+          }
+        if (a.drop_thresh != 0u) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              st[t][r] = drop_keep(a, dkey[i], kc * 64 + t * 16 + 4 * lg + r) ? st[t][r] * a.drop_scale : 0.f;
+        }
+        psum = group4_sum(psum);
+        l_run[i] = l_run[i] * alpha + psum;
+        m_run[i] = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oacc[i][dt][r] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = pack_pair(st[2 * s2], st[2 * s2 + 1]);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            oacc[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sV, 32 * s2, 32 * s2 + 16, dt * 16, lr, lg), pf, oacc[i][dt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XS_SLOTS; ++i) {
+      if (ok[i] && qi_[i] < sq_[i]) {
+        store_out(a, qb_[i] + qi_[i], h, lg, oacc[i], 1.0f / l_run[i]);
+        if (lg == 0) a.lse[((long)b_[i] * a.H + h) * a.stat_ld + qi_[i]] = m_run[i] + __logf(l_run[i]);
+      }
+    }
+    __syncthreads();  // the next pass refills slot 0
+  }
+}
+
+// dQ (and delta) with streamed keys: two sweeps over the chunks per pass -- delta_i = sum_j P_ij dP_ij first (the exact two-pass form
+// of the kernels above), then dS and dQ -- unless the forward left o_lo (one sweep).
+__global__ __launch_bounds__(512, 2) void xattn_dq_stream_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int rstart = a.grp_start[g], nrows = a.grp_start[g + 1] - rstart;
+  if (nrows <= 0) return;
+  const int tq = (a.Sq + 15) / 16, n_slots = nrows * tq, nchunks = (a.Sk + 63) / 64;
+  const bf16* kb = a.k + (long)g * a.Sk * a.k_rs + h * 64;
+  const bf16* vb = a.v + (long)g * a.Sk * a.v_rs + h * 64;
+  const bool has_mask = a.key_keep != nullptr;
+  const bool fast_delta = a.o_lo != nullptr;
+  for (int base = 0; base < n_slots; base += nw * XS_SLOTS) {
+    bf16x8 qf[XS_SLOTS][2], df[XS_SLOTS][2];
+    f32x4 dqacc[XS_SLOTS][4];
+    float lse_q[XS_SLOTS], delta[XS_SLOTS];
+    int qi_[XS_SLOTS], sq_[XS_SLOTS];
+    long qb_[XS_SLOTS], stat_[XS_SLOTS];
+    uint32_t dkey[XS_SLOTS];
+    bool ok[XS_SLOTS];
+#pragma unroll
+    for (int i = 0; i < XS_SLOTS; ++i) {
+      const int s = base + w + nw * i;
+      const int j = s / tq, tile = s - j * tq;
+      ok[i] = s < n_slots;
+      const int b = a.grp_rows[rstart + (ok[i] ? j : 0)];
+      q_seq(a, b, qb_[i], sq_[i]);
+      ok[i] = ok[i] && tile * 16 < sq_[i];
+      qi_[i] = tile * 16 + lr;
+      const bool qvalid = qi_[i] < sq_[i];
+      const int qc = qvalid ? qi_[i] : sq_[i] - 1;
+      const bf16* qp = a.q + (qb_[i] + qc) * a.q_rs + h * 64;
+      const bf16* dop = a.dout + (qb_[i] + qc) * a.do_rs + h * 64;
+      qf[i][0] = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
+      qf[i][1] = *reinterpret_cast<const bf16x8*>(qp + 32 + 8 * lg);
+      df[i][0] = *reinterpret_cast<const bf16x8*>(dop + 8 * lg);
+      df[i][1] = *reinterpret_cast<const bf16x8*>(dop + 32 + 8 * lg);
+      stat_[i] = ((long)b * a.H + h) * a.stat_ld + qc;
+      lse_q[i] = qvalid ? a.lse[stat_[i]] : 3.0e38f;
+      dkey[i] = drop_key(a, b, h, qi_[i]);
+      delta[i] = 0.f;
+      if (fast_delta && ok[i]) delta[i] = delta_from_out(a, qb_[i] + qc, h, lg, df[i][0], df[i][1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dqacc[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int sweep = fast_delta ? 1 : 0; sweep < 2; ++sweep) {
+      stage_slot(lds, kb, a.k_rs, vb, a.v_rs, 0, a.Sk, w, nw, lane);
+      for (int kc = 0; kc < nchunks; ++kc) {
+        stage_wait();
+        if (kc + 1 < nchunks) stage_slot(lds + ((kc + 1) & 1) * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, (kc + 1) * 64, a.Sk, w, nw, lane);
+        const char* sK = lds + (kc & 1) * ATTN_SLOT;
+        const char* sV = sK + ATTN_TILE;
+        int kk[4][4];
+        if (has_mask) load_keep(a, g, kc, lg, kk);
+#pragma unroll
+        for (int i = 0; i < XS_SLOTS; ++i) {
+          if (!ok[i]) continue;
+          f32x4 st[4], dp[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 0, lr, lg), qf[i][0], st[t], 0, 0, 0);
+            st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 1, lr, lg), qf[i][1], st[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 0, lr, lg), df[i][0], dp[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 1, lr, lg), df[i][1], dp[t], 0, 0, 0);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              st[t][r] = __expf(score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, false, qi_[i], kc * 64 + t * 16 + 4 * lg + r, a.Sk) - lse_q[i]);
+          if (a.drop_thresh != 0u) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                dp[t][r] = drop_keep(a, dkey[i], kc * 64 + t * 16 + 4 * lg + r) ? dp[t][r] * a.drop_scale : 0.f;
+          }
+          if (sweep == 0) {
+            float d = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) d += st[t][r] * dp[t][r];
+            delta[i] += d;
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) st[t][r] = st[t][r] * (dp[t][r] - delta[i]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const bf16x8 pf = pack_pair(st[2 * s2], st[2 * s2 + 1]);
+#pragma unroll
+              for (int dt = 0; dt < 4; ++dt)
+                dqacc[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK, 32 * s2, 32 * s2 + 16, dt * 16, lr, lg), pf, dqacc[i][dt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (sweep == 0) {
+#pragma unroll
+        for (int i = 0; i < XS_SLOTS; ++i) delta[i] = group4_sum(delta[i]);
+      }
+      __syncthreads();  // the next sweep / pass refills slot 0
+    }
+#pragma unroll
+    for (int i = 0; i < XS_SLOTS; ++i) {
+      if (ok[i] && qi_[i] < sq_[i]) {
+        if (lg == 0) a.delta[stat_[i]] = delta[i];
+        bf16* dqp = a.dq + (qb_[i] + qi_[i]) * a.dq_rs + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          bf16x4 ov;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov[r] = f2bf(dqacc[i][dt][r] * a.scale);
+          *reinterpret_cast<bf16x4*>(dqp + dt * 16 + 4 * lg) = ov;
+        }
+      }
+    }
+  }
+}
+
 #include "attention_vit.hip"
 
 static int attn_check(const AttnArgs& a, bool bwd) {
@@ -1543,7 +1787,7 @@ static bool attn_packable(const AttnArgs& a) {
 
 static int attn_check_grouped(const AttnArgs& a) {
   XFM_REQUIRE(a.grp_rows != nullptr && a.n_groups > 0 && a.n_groups <= 65535, "grouped attention: grp_rows / n_groups missing");
-  XFM_REQUIRE(a.Sq <= 64 && a.Sk <= 64 * ATTN_RES_MAX, "grouped attention needs Sq <= 64 and Sk <= %d (got %d, %d)", 64 * ATTN_RES_MAX, a.Sq, a.Sk);
+  XFM_REQUIRE(a.Sq <= 64, "grouped attention needs Sq <= 64 (got %d)", a.Sq);   // (Sk > 256: the streamed-key kernels)
   XFM_REQUIRE(a.bias == nullptr && a.dbias == nullptr && a.causal == 0 && a.kv_index == nullptr,
               "grouped attention: no bias / causal mask / kv_index (the group index IS the key/value source)");
   return XFM_OK;
@@ -1568,6 +1812,10 @@ int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
     rc = attn_check_grouped(a);
     if (rc != XFM_OK) return rc;
     attn_grouped_lds();
+    if (a.Sk > 64 * ATTN_RES_MAX) {
+      hipLaunchKernelGGL(xattn_fwd_stream_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)2 * ATTN_SLOT, st, a);
+      return xfm_check_launch("xattn_fwd_stream");
+    }
     hipLaunchKernelGGL(xattn_fwd_kernel<false>, dim3(1, a.H, a.n_groups), dim3(512), (size_t)cdiv(a.Sk, 64) * ATTN_SLOT, st, a);
     return xfm_check_launch("xattn_fwd");
   }
@@ -1603,7 +1851,8 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
     if (rc != XFM_OK) return rc;
     attn_grouped_lds();
     if (a.bwd_phase != 2) {
-      hipLaunchKernelGGL(xattn_dq_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)cdiv(a.Sk, 64) * ATTN_SLOT, st, a);
+      if (a.Sk > 64 * ATTN_RES_MAX) hipLaunchKernelGGL(xattn_dq_stream_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)2 * ATTN_SLOT, st, a);
+      else hipLaunchKernelGGL(xattn_dq_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)cdiv(a.Sk, 64) * ATTN_SLOT, st, a);
       rc = xfm_check_launch("xattn_dq");
       if (rc != XFM_OK || a.bwd_phase == 1) return rc;
     }

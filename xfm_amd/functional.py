@@ -257,8 +257,9 @@ def kv_groups(kv_index, U):
 
 
 def attn_grouped_ok(Sq, Sk):
-    """Shapes the grouped (one workgroup per key/value source) kernels cover."""
-    return Sq <= 64 and Sk <= 256
+    """Shapes the grouped (one workgroup per key/value source) kernels cover: up to 64 queries per row; any number of keys (more than
+    256 -- the 577 / 901 image tokens of the 384 / 480 px fine-tuning configurations -- stream through LDS chunk by chunk)."""
+    return Sq <= 64
 
 
 def _attn_args(q, k, v, o, lse, B, H, Sq, Sk, scale, bias, key_keep, causal, drop, bias_t=None, kv_index=None, groups=None,

@@ -34,6 +34,9 @@ _PACK_SYNC = os.environ.get("XFM_PACK_SYNC", "1") != "0"
 # the same (9.84 vs 9.67 ms for the fusion encoder's fwd+bwd: the generic kernels size their grid for the fullest image), so off
 _LAST_ROWS = os.environ.get("XFM_LAST_LAYER_ROWS", "0") != "0"   # fusion tower: last layer only on the rows ITM / MLM read (measured neutral: off)
 _XATTN_RANGES = os.environ.get("XFM_XATTN_RANGES", "0") != "0"
+# ITM outside the pre-training step (retrieval fine-tuning, get_matching_loss): project every image's K / V once instead of once per
+# row of the 3B (positive | negative image | negative text) stack; XFM_DEDUP_IMAGES=0 replays the reference's stacked copies
+_DEDUP_IMAGES = os.environ.get("XFM_DEDUP_IMAGES", "1") != "0"
 
 
 class AllGather(torch.autograd.Function):
@@ -371,15 +374,21 @@ class XFMBase(nn.Module):
             out.append(row_normalize(linear_slot(text_embeds[:, 0, :], self._s_tproj, out_fp32=True)))
         return out[0] if len(out) == 1 else tuple(out)
 
-    def get_cross_embeds(self, image_embeds, image_atts, text_ids=None, text_embeds=None, text_atts=None, is_pretrain=True):
+    def get_cross_embeds(self, image_embeds, image_atts, text_ids=None, text_embeds=None, text_atts=None, is_pretrain=True,
+                         image_index=None):
+        """`image_index` (extension, default None = the reference's call): int tensor [rows] -- text row r attends image
+        image_embeds[image_index[r]].  The image states are then NOT copied once per row (xfm.py:781-793 stacks 3B of them): every
+        layer projects its K / V once per image and the grouped cross-attention kernels serve all the rows of an image from one
+        staging; the image gradient comes back summed over those rows.  Same values on every row."""
         self._ready()
         enc = self.fusion_encoder.bert
+        kw = {} if image_index is None else {"encoder_batch_index": image_index}
         if text_embeds is None:
             return enc(text_ids, attention_mask=text_atts, encoder_hidden_states=image_embeds,
-                       encoder_attention_mask=image_atts, return_dict=True).last_hidden_state
+                       encoder_attention_mask=image_atts, return_dict=True, **kw).last_hidden_state
         encoder_embeds = text_embeds.detach() if is_pretrain else text_embeds
         return enc(encoder_embeds=encoder_embeds, attention_mask=text_atts, encoder_hidden_states=image_embeds,
-                   encoder_attention_mask=image_atts, return_dict=True).last_hidden_state
+                   encoder_attention_mask=image_atts, return_dict=True, **kw).last_hidden_state
 
     # ---- grounding head ----------------------------------------------------------------------------
     def predict_bbox(self, image_embeds, text_ids, text_atts, text_embeds, is_pretrain=True):
@@ -461,12 +470,19 @@ class XFMBase(nn.Module):
             text_neg_idx = torch.as_tensor(neg_idx[1], dtype=torch.long, device=image_embeds.device)
         bs = image_feat.size(0)
         # rows [0,B): positives ; [B,2B): (negative image, text) ; [2B,3B): (image, negative text)   xfm.py:781-793
-        image_all = torch.cat([image_embeds, image_embeds.index_select(0, image_neg_idx), image_embeds], dim=0)
-        image_atts_all = torch.cat([image_atts, image_atts.index_select(0, image_neg_idx), image_atts], dim=0)
         text_all = torch.cat([text_embeds, text_embeds, text_embeds.index_select(0, text_neg_idx)], dim=0)
         text_atts_all = torch.cat([text_atts, text_atts, text_atts.index_select(0, text_neg_idx)], dim=0)
-        cross = self.get_cross_embeds(image_all, image_atts_all, text_embeds=text_all, text_atts=text_atts_all,
-                                      is_pretrain=is_pretrain)[:, 0, :]
+        from .functional import attn_grouped_ok
+        if _DEDUP_IMAGES and image_embeds.is_cuda and attn_grouped_ok(text_all.shape[1], image_embeds.shape[1]):
+            # the 3B rows attend B distinct images: hand the fusion tower the images once and a row -> image index
+            ar = torch.arange(bs, device=image_embeds.device)
+            cross = self.get_cross_embeds(image_embeds, image_atts, text_embeds=text_all, text_atts=text_atts_all, is_pretrain=is_pretrain,
+                                          image_index=torch.cat([ar, image_neg_idx, ar]))[:, 0, :]
+        else:
+            image_all = torch.cat([image_embeds, image_embeds.index_select(0, image_neg_idx), image_embeds], dim=0)
+            image_atts_all = torch.cat([image_atts, image_atts.index_select(0, image_neg_idx), image_atts], dim=0)
+            cross = self.get_cross_embeds(image_all, image_atts_all, text_embeds=text_all, text_atts=text_atts_all,
+                                          is_pretrain=is_pretrain)[:, 0, :]
         output = self.itm_head(cross)
         dev = image_embeds.device  # built on the device: a host tensor + .to(device) is a blocking pageable copy
         itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)

@@ -297,8 +297,7 @@ class _EncoderFn(torch.autograd.Function):
                     c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, groups=groups,
                                            q_pack=qp, zero_fill=zf)
                 elif pack is not None:
-                    raise NotImplementedError("packed rows with cross-attention need the grouped kernels (T <= 64, N <= 256) and "
-                                              "an encoder_batch_index")
+                    raise NotImplementedError("packed rows with cross-attention need the grouped kernels (T <= 64) and an encoder_batch_index")
                 else:
                     c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, kv_index=enc_index)
                 h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
