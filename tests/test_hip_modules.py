@@ -325,7 +325,10 @@ def test_retrieval_model_vs_golden(fixture):
     itc, itm = m(b["image"], b["text_ids"], b["text_atts"], idx=idx, neg_idx=(meta["image_neg_idx"], meta["text_neg_idx"]))
     ri, rm = float(z["loss_itc"]), float(z["loss_itm"])
     assert abs(float(itc) - ri) <= 3e-3 * max(abs(ri), 1.0) and abs(float(itm) - rm) <= 3e-2 * max(abs(rm), 1.0), (float(itc), ri, float(itm), rm)
-    assert abs(float(itc + itm) - (ri + rm)) <= 2e-3 * (ri + rm)
+    # the sum: 3e-3.  The ITM term is a 2-way CE over 3B = 12 rows fed by bf16 towers; two forward-attention kernels that are equally
+    # close to fp64 attention (rel-L2 2.0e-3 both, tools/attn_err_probe.py) move it by 1.4e-3 (0.81007 / 0.81116 against 0.80753), i.e.
+    # the sum by 1.9e-3 / 2.35e-3 -- the previous 2e-3 bound sat inside that rounding noise
+    assert abs(float(itc + itm) - (ri + rm)) <= 3e-3 * (ri + rm)
     (itc + itm).backward()
     # d loss / d temp = -(1 / temp^2) * sum_ij (p_ij - y_ij) sim_ij: with temp = 0.07 a residual of ~1e-3 between cancelling terms is
     # amplified 204 x, so the bf16 features' 1e-3 similarity error moves this ONE scalar by ~0.02 of 0.21 -- held to 0.05 absolute
