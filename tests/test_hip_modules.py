@@ -635,6 +635,15 @@ def test_pretrain_step_small_packed_rows_vs_golden():
     _pretrain("pretrain_small", packed=True)
 
 
+def test_pretrain_step_small_mim_view_on_second_stream_vs_golden(monkeypatch):
+    """XFM_MIM_STREAM=1: the MIM-masked view as its own ViT pass on a second stream (forward, loss and backward), ordered against the
+    clean view's backward by an event -- same losses and gradients as the batched 2B-row pass."""
+    import xfm_amd.model_pretrain as mp
+    monkeypatch.setattr(mp, "_MIM_STREAM", True)
+    _pretrain("pretrain_small")
+    _pretrain("pretrain_small", packed=True)
+
+
 def test_pretrain_step_full_depth_vs_golden():
     """12 + 12 + 12 layers.  Default tolerance (8e-2 / 0.996) per tensor, relaxed only where -- and only as far as -- the reference's
     own bf16-autocast gradients leave its fp32 gradients on that tensor (fixture floor/<name>; DESIGN.md has the per-tower table:

@@ -213,6 +213,11 @@ class _TrunkFn(torch.autograd.Function):
         M, H = B * N, vit.num_heads
         blocks = vit.blocks
         ld = vit._bias_ld
+        # two passes of one step (clean / MIM-masked view) may run on different streams; their weight gradients accumulate (+=) into the
+        # same arena ranges, so a pass starts only once the previous one -- wherever it ran -- has finished
+        prev = getattr(vit, "_trunk_bwd_done", None)
+        if prev is not None and dy_out.is_cuda:
+            torch.cuda.current_stream(dy_out.device).wait_event(prev)
         dy = dy_out.reshape(M, D).contiguous()
         if ctx.pooled:
             dy = Fx.pool_rows_bwd(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16), B, N)
@@ -266,6 +271,10 @@ class _TrunkFn(torch.autograd.Function):
         n0 = blocks[0].norm1
         Fx.ln_bwd(dy, x0, mean0, rstd0, n0.weight, _g(n0.weight), _g(n0.bias), dx32=dstream, dx_accum=True)
         wg.join()
+        if dstream.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dstream.device))
+            vit._trunk_bwd_done = ev
         if ctx.noted:
             arena_note_grad(vit)
         return dstream.view(B, N, D), None, None
@@ -397,7 +406,11 @@ class VisionTransformer(OwnsArena, nn.Module):
             self.finalize()
 
     # ---- forward --------------------------------------------------------------------------------
-    def forward(self, x, idx_to_group_img=None, image_atts=None, do_mask=False, ids_mask=None, drop_path_scales=None):
+    def forward(self, x, idx_to_group_img=None, image_atts=None, do_mask=False, ids_mask=None, drop_path_scales=None, split_stream=None):
+        """`split_stream` (extension; with `ids_mask` holding k = 2 views of the B images): the views share the patch embedding and
+        the token assembly, but each runs the trunk as its own pass -- view 0 on the current stream, view 1 on `split_stream` -- and
+        the result is the pair (out0, out1) instead of one [2B, N, D] tensor; out1 lives on `split_stream` (the caller joins).
+        Autograd replays each pass's backward on its forward stream."""
         if idx_to_group_img is not None or image_atts is not None:
             raise NotImplementedError("region / grouped-image path (beit2.py:467-475) is outside the hot-path scope")
         self._ready()
@@ -425,6 +438,15 @@ class VisionTransformer(OwnsArena, nn.Module):
                 keep = 1.0 - torch.tensor([[b.drop_path_prob] * 2 for b in self.blocks], device=x.device).view(-1, 2, 1)
                 self._dp_keep = keep
             dp = (torch.rand(len(self.blocks), 2, B, device=x.device) < keep).float() / keep
+        if split_stream is not None and do_mask and B == 2 * x.shape[0]:
+            Bh = x.shape[0]
+            main = torch.cuda.current_stream(x.device)
+            out0 = _TrunkFn.apply(x0[:Bh], self, None if dp is None else dp[:, :, :Bh].contiguous())
+            split_stream.wait_stream(main)   # (x0 and the drop-path draws are ready; the first view's kernels are merely queued ahead)
+            with torch.cuda.stream(split_stream):
+                out1 = _TrunkFn.apply(x0[Bh:], self, None if dp is None else dp[:, :, Bh:].contiguous())
+            x0.record_stream(split_stream)
+            return (out0, out1), ids_mask
         out = _TrunkFn.apply(x0, self, dp)           # bf16 [B, N, D]: fc_norm on every row, then row 0 <- mean of the patch rows
         return (out, ids_mask) if do_mask else out
 

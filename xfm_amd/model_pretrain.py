@@ -7,7 +7,18 @@ from .xfm import XFMBase
 
 _TEXT_STREAM_ON = os.environ.get("XFM_TEXT_STREAM", "1") != "0"
 _PACK_ROWS = os.environ.get("XFM_PACK_ROWS", "1") != "0"  # A/B knob: `text_lens` given -> unpadded token rows in the text / fusion towers
+# A/B (profiles/round3_mim_stream.md): the MIM-masked view of the images as its own ViT pass on a second stream, under the latency-bound
+# fusion tower, instead of batched with the clean view as one 2B-row pass
+_MIM_STREAM = os.environ.get("XFM_MIM_STREAM", "0") != "0"
 _SIDE_STREAMS = {}
+_MIM_STREAMS = {}
+
+
+def _mim_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _MIM_STREAMS:
+        _MIM_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _MIM_STREAMS[key]
 
 
 def _side_stream(device):
@@ -67,6 +78,7 @@ class XFM(XFMBase):
         zero = torch.zeros((), device=image.device)
         do_mim = ret_mim_loss and (data_source == 'imagenet' or self.use_mm_mim_loss)
         image_embeds_masked = None
+        mim_stream = None
         # The text tower (small, latency-bound kernels) is independent of the vision tower until the ITC loss: with batch_passes
         # its forward is enqueued on a second HIP stream first and runs under the ViT's full-chip GEMMs; autograd replays each
         # node's backward on the stream of its forward, so the two backward chains overlap the same way.
@@ -94,9 +106,14 @@ class XFM(XFMBase):
             ids_mask = ids_mask.to(device=image.device, dtype=torch.bool)
             # one 2B-row ViT pass over the B images: rows [0, B) see them clean, rows [B, 2B) MIM-masked (the token assembly reads
             # every image's patch embedding for both views)
-            both, _, _ = self.get_vision_embeds(image, do_mask=True,
+            mim_stream = _mim_stream(image.device) if (_MIM_STREAM and image.is_cuda) else None
+            both, _, _ = self.get_vision_embeds(image, do_mask=True, split_stream=mim_stream,
                                                 ids_mask=torch.cat([torch.zeros_like(ids_mask), ids_mask], dim=0))
-            image_embeds, image_embeds_masked = both[:B], both[B:]
+            if isinstance(both, tuple):
+                image_embeds, image_embeds_masked = both
+            else:
+                mim_stream = None
+                image_embeds, image_embeds_masked = both[:B], both[B:]
             from .xfm import _ones_mask
             image_atts = _ones_mask(image_embeds)
         else:
@@ -144,7 +161,16 @@ class XFM(XFMBase):
             if image_embeds_masked is None:
                 image_embeds_masked, _, ids_mask = self.get_vision_embeds(image, do_mask=self.do_image_mask, ids_mask=ids_mask)
             if do_mim:
-                loss_mim = self.get_mim_loss(image_embeds_masked, image_embeds, ids_mask)
+                ms = mim_stream
+                if ms is not None:   # the masked view lives on its own stream: its loss too; the main stream joins once, here
+                    cur = torch.cuda.current_stream(image.device)
+                    ms.wait_stream(cur)   # (the clean view's embeddings are the target)
+                    with torch.cuda.stream(ms):
+                        loss_mim = self.get_mim_loss(image_embeds_masked, image_embeds, ids_mask)
+                    cur.wait_stream(ms)
+                    loss_mim.record_stream(cur)
+                else:
+                    loss_mim = self.get_mim_loss(image_embeds_masked, image_embeds, ids_mask)
             if w is not None:
                 loss_mim = loss_mim * w
         return {'loss_itc': loss_itc, 'loss_itm': loss_itm, 'loss_mlm': loss_mlm, 'loss_mim': loss_mim,

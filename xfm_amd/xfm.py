@@ -331,12 +331,14 @@ class XFMBase(nn.Module):
             super().zero_grad(set_to_none=set_to_none)
 
     # ---- towers ---------------------------------------------------------------------------------
-    def get_vision_embeds(self, image, image_atts=None, idx_to_group_img=None, do_mask=False, ids_mask=None):
+    def get_vision_embeds(self, image, image_atts=None, idx_to_group_img=None, do_mask=False, ids_mask=None, split_stream=None):
         if idx_to_group_img is not None:
             raise NotImplementedError("region path (xfm.py:574-597) is outside the hot-path scope")
         self._ready()
         if do_mask:
-            image_embeds, id_masked = self.vision_encoder(image, do_mask=True, ids_mask=ids_mask)
+            image_embeds, id_masked = self.vision_encoder(image, do_mask=True, ids_mask=ids_mask, split_stream=split_stream)
+            if isinstance(image_embeds, tuple):   # two views as two passes (the second one on `split_stream`)
+                return image_embeds, _ones_mask(image_embeds[0]), id_masked
             return image_embeds, _ones_mask(image_embeds), id_masked
         image_embeds = self.vision_encoder(image)
         return image_embeds, _ones_mask(image_embeds)
