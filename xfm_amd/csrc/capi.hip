@@ -23,6 +23,13 @@ int xfm_check_launch(const char* what) {
   return XFM_OK;
 }
 
+// compute units of the current device (persistent kernels launch one workgroup per CU)
+int xfm_cu_count() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return n;
+}
+
 #include "gemm.hip"
 #include "layernorm.hip"
 #include "attention.hip"

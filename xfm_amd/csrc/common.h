@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 // host side: thread-local error message (C-ABI: xfm_last_error)
 void xfm_set_error(const char* fmt, ...);
 int xfm_check_launch(const char* what);
+int xfm_cu_count();
 
 #define XFM_REQUIRE(cond, ...)            \
   do {                                    \

@@ -405,53 +405,78 @@ __device__ __forceinline__ void wait_younger(int y) {  // leave the y youngest u
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g) {
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait_younger with NS more memory operations (the previous tile's output stores, issued between the staging units of the
+// prologue and those of the K loop) allowed to stay in flight
+template <int NS>
+__device__ __forceinline__ void wait_younger_plus(int y) {
+  if (y >= 3) wait_vm<6 + NS>();
+  else if (y == 2) wait_vm<4 + NS>();
+  else if (y == 1) wait_vm<2 + NS>();
+  else wait_vm<NS>();
+}
+
+// PERSIST: one workgroup per CU walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the same tile -> XCD assignment as one
+// workgroup per tile, gridDim.x being a multiple of 8).  The staging units 0..4 of the NEXT tile are issued before the epilogue of
+// this one -- LDS is free once the K loop is over -- so the next tile's first-K-tile latency and this tile's output stores (whose
+// acknowledgement a terminating wave would have to wait for) overlap instead of adding up with a workgroup launch in between.
+// CDNA counts stores in vmcnt, in issue order with the loads: an interior tile issues exactly NS output stores per lane between
+// unit 4 and unit 5 of the next tile, and the three waits that retire units 1..3 allow for them (wait_younger_plus); the wait that
+// retires unit 5 (P3 of K-tile 0, four phases later) is the first that needs the stores acknowledged.
+template <int EPI, bool PERSIST>
+__global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g, int tiles) {
   constexpr int BM = 256, BN = 256, MT = 8, NT = 4;
   constexpr int XBYTES = 256 * 128, BUF = 2 * XBYTES;
+  // output stores per lane of an interior tile (16-B stores; fp32 output: two per 8 columns; GELU also stores gelu')
+  constexpr int NS = !PERSIST ? 0 : EPI == EPI_GELU || EPI == EPI_F32 ? 32 : EPI == EPI_F32_ACC ? 0 : 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 2, wc = w & 3;
   const int lr = lane & 15, lg = lane >> 4;
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  int tm, tn;
-  grouped_tile(wg, tiles_m, tiles_n, g.group_m, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
   const int nk = g.K / 64;
   const int total = 4 * nk;  // staging units
 
-  // per-lane global element offsets of the 8 (unit, instruction) loads; the K offset is added per K-tile
+  // per-lane global element offsets of the 8 (unit, instruction) loads of a tile; the K offset is added per K-tile
   unsigned soff[4][2];
   int doff[4][2];
+  auto tile_origin = [&](int v, int& m0, int& n0) {
+    int tm, tn;
+    grouped_tile(xcd_remap(v, tiles), tiles_m, tiles_n, g.group_m, tm, tn);
+    m0 = tm * BM;
+    n0 = tn * BN;
+  };
+  auto tile_offsets = [&](int m0, int n0) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int u = (i * 8 + w) * 8 + (lane >> 3);
-    {
-      const int r = unit_row<0>(u);
-      int gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;
-      soff[0][i] = (unsigned)gr * (unsigned)g.lda + (((lane & 7) ^ swz_x(r)) << 3);
-      doff[0][i] = (r >> 3) * 1024;
+    for (int i = 0; i < 2; ++i) {
+      const int u = (i * 8 + w) * 8 + (lane >> 3);
+      {
+        const int r = unit_row<0>(u);
+        int gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;
+        soff[0][i] = (unsigned)gr * (unsigned)g.lda + (((lane & 7) ^ swz_x(r)) << 3);
+        doff[0][i] = (r >> 3) * 1024;
+      }
+      {
+        const int r = unit_row<3>(u);
+        int gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;
+        soff[3][i] = (unsigned)gr * (unsigned)g.lda + (((lane & 7) ^ swz_x(r)) << 3);
+        doff[3][i] = (r >> 3) * 1024;
+      }
+      {
+        const int r = unit_row<1>(u);
+        int gr = n0 + r; gr = gr < g.N ? gr : g.N - 1;
+        soff[1][i] = (unsigned)gr * (unsigned)g.ldb + (((lane & 7) ^ swz_w(r)) << 3);
+        doff[1][i] = XBYTES + (r >> 3) * 1024;
+      }
+      {
+        const int r = unit_row<2>(u);
+        int gr = n0 + r; gr = gr < g.N ? gr : g.N - 1;
+        soff[2][i] = (unsigned)gr * (unsigned)g.ldb + (((lane & 7) ^ swz_w(r)) << 3);
+        doff[2][i] = XBYTES + (r >> 3) * 1024;
+      }
     }
-    {
-      const int r = unit_row<3>(u);
-      int gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;
-      soff[3][i] = (unsigned)gr * (unsigned)g.lda + (((lane & 7) ^ swz_x(r)) << 3);
-      doff[3][i] = (r >> 3) * 1024;
-    }
-    {
-      const int r = unit_row<1>(u);
-      int gr = n0 + r; gr = gr < g.N ? gr : g.N - 1;
-      soff[1][i] = (unsigned)gr * (unsigned)g.ldb + (((lane & 7) ^ swz_w(r)) << 3);
-      doff[1][i] = XBYTES + (r >> 3) * 1024;
-    }
-    {
-      const int r = unit_row<2>(u);
-      int gr = n0 + r; gr = gr < g.N ? gr : g.N - 1;
-      soff[2][i] = (unsigned)gr * (unsigned)g.ldb + (((lane & 7) ^ swz_w(r)) << 3);
-      doff[2][i] = XBYTES + (r >> 3) * 1024;
-    }
-  }
+  };
   auto issue = [&](int s) {  // unit s = (K-tile s >> 2, part s & 3); warp-uniform branch
     if (s >= total) return;
     const int kt = s >> 2, j = s & 3;
@@ -466,10 +491,6 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g) {
   };
 
   f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // per-lane LDS byte offsets of the fragment reads (the 16-B chunk index c = ks*4 + lg is XOR-ed with the row swizzle)
   const int xr0 = wr * 128 + lr;                                  // + mt*16
@@ -505,51 +526,83 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g) {
     __builtin_amdgcn_s_setprio(0);                                                                               \
   } while (0)
 
-  // prologue: units 0..4 in flight, units 0 and 1 (a0, b0 of K-tile 0) retired and visible
+  int v = blockIdx.x, m0, n0;
+  tile_origin(v, m0, n0);
+  tile_offsets(m0, n0);
+  // prologue: units 0..4 in flight
 #pragma unroll
   for (int s = 0; s < 5; ++s) issue(s);
-  wait_younger((total - 1 < 4 ? total - 1 : 4) - 1);
-  XFM_BAR();
-  if (wr == 1) XFM_BAR();  // stagger the second M-wave group by one barrier
+  bool stores_behind = false;  // NS output stores of the previous tile were issued after the units 0..4 of this one
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* buf = smem + (kt & 1) * BUF;
-    const int ph = 4 * kt;
-    int last;
-    // ---- P0: (a0, b0)
-    issue(ph + 5);
-    read_x(buf, 0);
-    read_w(buf, 0, wb0);
-    last = ph + 5 < total ? ph + 5 : total - 1;
-    wait_younger(last - (ph + 2));
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // units 0 and 1 (a0, b0 of K-tile 0) retired and visible
+    {
+      const int y = (total - 1 < 4 ? total - 1 : 4) - 1;
+      if (NS > 0 && stores_behind) wait_younger_plus<NS>(y);
+      else wait_younger(y);
+    }
     XFM_BAR();
-    XFM_QUAD(0, 0, wb0);
-    XFM_BAR();
-    // ---- P1: (a0, b1)
-    issue(ph + 6);
-    read_w(buf, 1, wb1);
-    last = ph + 6 < total ? ph + 6 : total - 1;
-    wait_younger(last - (ph + 3));
-    XFM_BAR();
-    XFM_QUAD(0, 1, wb1);
-    XFM_BAR();
-    // ---- P2: (a1, b1)
-    issue(ph + 7);
-    read_x(buf, 1);
-    XFM_BAR();
-    XFM_QUAD(1, 1, wb1);
-    XFM_BAR();
-    // ---- P3: (a1, b0); retire a0, b0 of the next K-tile
-    issue(ph + 8);
-    last = ph + 8 < total ? ph + 8 : total - 1;
-    wait_younger(last - (ph + 5) < 0 ? 0 : last - (ph + 5));
-    XFM_BAR();
-    XFM_QUAD(1, 0, wb0);
-    XFM_BAR();
+    if (wr == 1) XFM_BAR();  // stagger the second M-wave group by one barrier
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* buf = smem + (kt & 1) * BUF;
+      const int ph = 4 * kt;
+      const bool plus = NS > 0 && stores_behind && kt == 0;
+      int last;
+      // ---- P0: (a0, b0)
+      issue(ph + 5);
+      read_x(buf, 0);
+      read_w(buf, 0, wb0);
+      last = ph + 5 < total ? ph + 5 : total - 1;
+      if (plus) wait_younger_plus<NS>(last - (ph + 2));
+      else wait_younger(last - (ph + 2));
+      XFM_BAR();
+      XFM_QUAD(0, 0, wb0);
+      XFM_BAR();
+      // ---- P1: (a0, b1)
+      issue(ph + 6);
+      read_w(buf, 1, wb1);
+      last = ph + 6 < total ? ph + 6 : total - 1;
+      if (plus) wait_younger_plus<NS>(last - (ph + 3));
+      else wait_younger(last - (ph + 3));
+      XFM_BAR();
+      XFM_QUAD(0, 1, wb1);
+      XFM_BAR();
+      // ---- P2: (a1, b1)
+      issue(ph + 7);
+      read_x(buf, 1);
+      XFM_BAR();
+      XFM_QUAD(1, 1, wb1);
+      XFM_BAR();
+      // ---- P3: (a1, b0); retire a0, b0 of the next K-tile
+      issue(ph + 8);
+      last = ph + 8 < total ? ph + 8 : total - 1;
+      wait_younger(last - (ph + 5) < 0 ? 0 : last - (ph + 5));
+      XFM_BAR();
+      XFM_QUAD(1, 0, wb0);
+      XFM_BAR();
+    }
+    if (wr == 0) XFM_BAR();  // both groups are past their last LDS read
+    const int cm0 = m0, cn0 = n0;
+    v += gridDim.x;
+    const bool more = PERSIST && v < tiles;
+    if (more) {
+      tile_origin(v, m0, n0);
+      tile_offsets(m0, n0);
+#pragma unroll
+      for (int s = 0; s < 5; ++s) issue(s);
+    }
+    gemm_epilogue<MT, NT, EPI>(g, acc, cm0 + wr * 128, cn0 + wc * 64, lr, lg);
+    if (!more) break;
+    XFM_FENCE();
+    // exactly NS stores per lane only when every lane stored every (mt, np) with one 16-B (2 x 16-B for fp32) instruction
+    stores_behind = cm0 + BM <= g.M && cn0 + BN <= g.N && (g.ldc % 8) == 0 && (EPI != EPI_GELU || (g.ldaux % 8) == 0);
   }
-  if (wr == 0) XFM_BAR();
 #undef XFM_QUAD
-  gemm_epilogue<MT, NT, EPI>(g, acc, m0 + wr * 128, n0 + wc * 64, lr, lg);
 }
 
 static int launch_nt_256(const GemmNT& g, int epi, hipStream_t st) {
@@ -559,15 +612,23 @@ static int launch_nt_256(const GemmNT& g, int epi, hipStream_t st) {
     xfm_set_error("gemm_nt: operand too large for the 256x256 kernel's 32-bit element offsets");
     return XFM_E_ARG;
   }
+  // more tiles than CUs: one persistent workgroup per CU (XFM_GEMM_PERSIST=0: one workgroup per tile)
+  static const int persist_env = getenv("XFM_GEMM_PERSIST") ? atoi(getenv("XFM_GEMM_PERSIST")) : 1;
+  static const int cus = xfm_cu_count();
+  const bool persist = persist_env && cus >= 8 && tiles > cus;
+  const int grid = persist ? cus & ~7 : tiles;
 #define XFM_256_CASE(E)                                                                                        \
   case E: {                                                                                                    \
     static bool attr_set = false;                                                                              \
     if (!attr_set) {                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<E>),                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<E, false>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<E, true>),                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
       attr_set = true;                                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL((gemm_nt_256_kernel<E>), dim3(tiles), dim3(512), smem, st, g);                          \
+    if (persist) hipLaunchKernelGGL((gemm_nt_256_kernel<E, true>), dim3(grid), dim3(512), smem, st, g, tiles); \
+    else hipLaunchKernelGGL((gemm_nt_256_kernel<E, false>), dim3(grid), dim3(512), smem, st, g, tiles);        \
     break;                                                                                                     \
   }
   switch (epi) {
