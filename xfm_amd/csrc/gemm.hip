@@ -43,8 +43,12 @@ __device__ __forceinline__ int swz_w(int r) { return ((r >> 1) & 1) | (((r >> 3)
 
 // Epilogue of one wave's (MT*16) x (NT*16) sub-tile: lane (lg, lr) owns row m_base + mt*16 + lr and the 8 consecutive
 // columns n_base + np*32 + 8*lg .. +7 of every (mt, np): bias / GELU in registers, one 16-B store per (mt, np).
+// lds_bias (optional): the wave's NT*16 bias values already in LDS (fp32, index = column - n_base), zeros when there is no bias -- for
+// the persistent 256 x 256 kernel, whose epilogue runs with the next tile's staging loads in flight: a load issued here has to wait
+// for all of them (loads return in order).
 template <int MT, int NT, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmNT& g, f32x4 (&acc)[MT][NT], int m_base, int n_base, int lr, int lg) {
+__device__ __forceinline__ void gemm_epilogue(const GemmNT& g, f32x4 (&acc)[MT][NT], int m_base, int n_base, int lr, int lg,
+                                              const float* lds_bias = nullptr) {
   const bool vec_c = (g.ldc % 8) == 0;
   // DGELU: all gelu'(x) loads of the sub-tile go out first, so their latency is paid once, not once per (mt, np)
   bf16x8 pre_all[EPI == EPI_DGELU ? NT / 2 : 1][EPI == EPI_DGELU ? MT : 1];
@@ -58,13 +62,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNT& g, f32x4 (&acc)[MT][
         const int mc = m < g.M ? m : g.M - 1, nc = nb + 8 <= g.N ? nb : 0;  // clamped: out-of-range lanes are never stored
         pre_all[np][mt] = *reinterpret_cast<const bf16x8*>(g.aux + (long)mc * g.ldaux + nc);
       }
+    // every chunk counts as read here: a chunk left pending on the paths that skip its rows would make the compiler drain all
+    // memory operations before the persistent kernel's next tile may reuse the register
+#pragma unroll
+    for (int np = 0; np < NT / 2; ++np)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(pre_all[np][mt]));
   }
 #pragma unroll
   for (int np = 0; np < NT / 2; ++np) {
     const int nb = n_base + np * 32 + 8 * lg;
     float bv[8];
+    if (lds_bias != nullptr) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(lds_bias + np * 32 + 8 * lg), b1 = *reinterpret_cast<const f32x4*>(lds_bias + np * 32 + 8 * lg + 4);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bv[i] = (g.bias != nullptr && nb + i < g.N) ? g.bias[nb + i] : 0.f;
+      for (int i = 0; i < 4; ++i) { bv[i] = b0[i]; bv[4 + i] = b1[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bv[i] = (g.bias != nullptr && nb + i < g.N) ? g.bias[nb + i] : 0.f;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = m_base + mt * 16 + lr;
@@ -407,40 +423,49 @@ __device__ __forceinline__ void wait_younger(int y) {  // leave the y youngest u
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// wait_younger with NS more memory operations (the previous tile's output stores, issued between the staging units of the
-// prologue and those of the K loop) allowed to stay in flight
-template <int NS>
-__device__ __forceinline__ void wait_younger_plus(int y) {
-  if (y >= 3) wait_vm<6 + NS>();
+// leave the y youngest staging units (2 loads each) in flight, plus NS more memory operations (the previous tile's output stores,
+// issued between the staging units of the prologue and those of the K loop)
+template <int NS, int YMAX>
+__device__ __forceinline__ void wait_units(int y) {
+  if (YMAX >= 7 && y >= 7) wait_vm<14 + NS>();
+  else if (YMAX >= 6 && y == 6) wait_vm<12 + NS>();
+  else if (YMAX >= 5 && y == 5) wait_vm<10 + NS>();
+  else if (YMAX >= 4 && y == 4) wait_vm<8 + NS>();
+  else if (y >= 3) wait_vm<6 + NS>();
   else if (y == 2) wait_vm<4 + NS>();
   else if (y == 1) wait_vm<2 + NS>();
   else wait_vm<NS>();
 }
-
+// Ring form of the pipeline above: the staging units live in R = D + 3 slots of 16 KiB (unit s in slot s mod R, its 128 rows
+// contiguous), phase ph issues unit ph + D, and D - 2 units (2 (D - 2) loads per wave) stay in flight across every barrier.  D = 5 is
+// the schedule described above in 128 KiB; D = 7 uses all 160 KiB of LDS and keeps 80 KiB per CU in flight: the K loop runs at the
+// pace (operand latency) / (look-ahead) -- the first fetch of every operand line comes from HBM or the Infinity Cache, and the
+// workgroups that share it ask for it at the same time -- so two more units in flight shorten every phase.
+//
 // PERSIST: one workgroup per CU walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the same tile -> XCD assignment as one
-// workgroup per tile, gridDim.x being a multiple of 8).  The staging units 0..4 of the NEXT tile are issued before the epilogue of
-// this one -- LDS is free once the K loop is over -- so the next tile's first-K-tile latency and this tile's output stores (whose
+// workgroup per tile, gridDim.x being a multiple of 8).  The first D units of the NEXT tile are issued before the epilogue of this
+// one -- LDS is free once the K loop is over -- so the next tile's first-K-tile latency and this tile's output stores (whose
 // acknowledgement a terminating wave would have to wait for) overlap instead of adding up with a workgroup launch in between.
 // CDNA counts stores in vmcnt, in issue order with the loads: an interior tile issues exactly NS output stores per lane between
-// unit 4 and unit 5 of the next tile, and the three waits that retire units 1..3 allow for them (wait_younger_plus); the wait that
-// retires unit 5 (P3 of K-tile 0, four phases later) is the first that needs the stores acknowledged.
-template <int EPI, bool PERSIST>
+// unit D - 1 and unit D of the next tile, and the waits that retire units 1..3 allow for them; the wait that retires unit 5 (P3 of
+// K-tile 0) is the first that needs the stores acknowledged.
+template <int EPI, bool PERSIST, int D>
 __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g, int tiles) {
   constexpr int BM = 256, BN = 256, MT = 8, NT = 4;
-  constexpr int XBYTES = 256 * 128, BUF = 2 * XBYTES;
+  constexpr int R = D + 3, UNIT = 128 * 128;
   // output stores per lane of an interior tile (16-B stores; fp32 output: two per 8 columns; GELU also stores gelu')
   constexpr int NS = !PERSIST ? 0 : EPI == EPI_GELU || EPI == EPI_F32 ? 32 : EPI == EPI_F32_ACC ? 0 : 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 2, wc = w & 3;
   const int lr = lane & 15, lg = lane >> 4;
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   const int nk = g.K / 64;
   const int total = 4 * nk;  // staging units
 
-  // per-lane global element offsets of the 8 (unit, instruction) loads of a tile; the K offset is added per K-tile
+  // per-lane global element offsets of the 8 (unit, instruction) loads of a tile; the K offset is added per K-tile.  Instruction i
+  // of wave w fills the 1-KiB block (i*8 + w) of the unit's slot: unit rows (i*8 + w)*8 + (lane >> 3), 16-B chunk lane & 7.
   unsigned soff[4][2];
-  int doff[4][2];
   auto tile_origin = [&](int v, int& m0, int& n0) {
     int tm, tn;
     grouped_tile(xcd_remap(v, tiles), tiles_m, tiles_n, g.group_m, tm, tn);
@@ -455,64 +480,66 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g, int tiles) {
         const int r = unit_row<0>(u);
         int gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;
         soff[0][i] = (unsigned)gr * (unsigned)g.lda + (((lane & 7) ^ swz_x(r)) << 3);
-        doff[0][i] = (r >> 3) * 1024;
       }
       {
         const int r = unit_row<3>(u);
         int gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;
         soff[3][i] = (unsigned)gr * (unsigned)g.lda + (((lane & 7) ^ swz_x(r)) << 3);
-        doff[3][i] = (r >> 3) * 1024;
       }
       {
         const int r = unit_row<1>(u);
         int gr = n0 + r; gr = gr < g.N ? gr : g.N - 1;
         soff[1][i] = (unsigned)gr * (unsigned)g.ldb + (((lane & 7) ^ swz_w(r)) << 3);
-        doff[1][i] = XBYTES + (r >> 3) * 1024;
       }
       {
         const int r = unit_row<2>(u);
         int gr = n0 + r; gr = gr < g.N ? gr : g.N - 1;
         soff[2][i] = (unsigned)gr * (unsigned)g.ldb + (((lane & 7) ^ swz_w(r)) << 3);
-        doff[2][i] = XBYTES + (r >> 3) * 1024;
       }
     }
   };
-  auto issue = [&](int s) {  // unit s = (K-tile s >> 2, part s & 3); warp-uniform branch
+  int iss = 0;  // ring slot of the next unit to issue
+  auto issue = [&](int s) {  // unit s = (K-tile s >> 2, part s & 3) into slot iss; wave-uniform branch
+    char* base = smem + iss * UNIT + w * 1024;
+    iss = iss + 1 == R ? 0 : iss + 1;
     if (s >= total) return;
     const int kt = s >> 2, j = s & 3;
-    char* base = smem + (kt & 1) * BUF;
     const bf16* src = ((j == 0 || j == 3) ? g.A : g.B) + kt * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const unsigned so = j == 0 ? soff[0][i] : j == 1 ? soff[1][i] : j == 2 ? soff[2][i] : soff[3][i];
-      const int dofs = j == 0 ? doff[0][i] : j == 1 ? doff[1][i] : j == 2 ? doff[2][i] : doff[3][i];
-      __builtin_amdgcn_global_load_lds(GLB_PTR(void, src + (size_t)so), LDS_PTR(void, base + __builtin_amdgcn_readfirstlane(dofs)), 16, 0, 0);
+      // inline asm on purpose: a direct-to-LDS load the compiler can see is drained (s_waitcnt vmcnt(0)) in front of the ds_reads
+      // it cannot prove disjoint from it -- every read of a ring slot
+      const unsigned lds_addr = (unsigned)(uintptr_t)LDS_PTR(void, base) + (unsigned)(i * 8192);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + (size_t)so), "s"(lds_addr) : "memory", "m0");
     }
   };
 
   f32x4 acc[MT][NT];
 
-  // per-lane LDS byte offsets of the fragment reads (the 16-B chunk index c = ks*4 + lg is XOR-ed with the row swizzle)
-  const int xr0 = wr * 128 + lr;                                  // + mt*16
-  const int xs = swz_x(xr0);
-  const int wr0 = wc * 64 + 8 * (lr >> 2) + (lr & 3);             // + (nt>>1)*32 + 4*(nt&1)
-  const int ws = swz_w(wr0);
-  const int xbase0 = xr0 * 128 + (((0 + lg) ^ xs) << 4), xbase1 = xr0 * 128 + (((4 + lg) ^ xs) << 4);
-  const int wbase0 = XBYTES + wr0 * 128 + (((0 + lg) ^ ws) << 4), wbase1 = XBYTES + wr0 * 128 + (((4 + lg) ^ ws) << 4);
+  // per-lane byte offsets of the fragment reads inside a unit's slot (the 16-B chunk index ks*4 + lg is XOR-ed with the row swizzle,
+  // which only depends on the low row bits the unit row shares with the tile row):
+  //   X units (a0 / a1): tile rows wr*128 + half*64 + m*16 + lr -> unit rows wr*64 + m*16 + lr
+  //   W units (b0 / b1): tile rows wc*64 + half*32 + 4*n + 8*(lr>>2) + (lr&3) -> unit rows wc*32 + 4*n + 8*(lr>>2) + (lr&3)
+  const int xs = swz_x(lr);
+  const int wu = 8 * (lr >> 2) + (lr & 3);
+  const int ws = swz_w(wu);
+  const int xbase0 = (wr * 64 + lr) * 128 + (((0 + lg) ^ xs) << 4), xbase1 = (wr * 64 + lr) * 128 + (((4 + lg) ^ xs) << 4);
+  const int wbase0 = (wc * 32 + wu) * 128 + (((0 + lg) ^ ws) << 4), wbase1 = (wc * 32 + wu) * 128 + (((4 + lg) ^ ws) << 4);
 
   bf16x8 xa[4][2], wb0[2][2], wb1[2][2];
-  auto read_x = [&](const char* buf, int half) {
+  auto read_x = [&](const char* slot) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      xa[m][0] = *reinterpret_cast<const bf16x8*>(buf + xbase0 + (half * 4 + m) * 2048);
-      xa[m][1] = *reinterpret_cast<const bf16x8*>(buf + xbase1 + (half * 4 + m) * 2048);
+      xa[m][0] = *reinterpret_cast<const bf16x8*>(slot + xbase0 + m * 2048);
+      xa[m][1] = *reinterpret_cast<const bf16x8*>(slot + xbase1 + m * 2048);
     }
   };
-  auto read_w = [&](const char* buf, int half, bf16x8 (&wb)[2][2]) {
+  auto read_w = [&](const char* slot, bf16x8 (&wb)[2][2]) {
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-      wb[n][0] = *reinterpret_cast<const bf16x8*>(buf + wbase0 + half * 4096 + n * 512);
-      wb[n][1] = *reinterpret_cast<const bf16x8*>(buf + wbase1 + half * 4096 + n * 512);
+      wb[n][0] = *reinterpret_cast<const bf16x8*>(slot + wbase0 + n * 512);
+      wb[n][1] = *reinterpret_cast<const bf16x8*>(slot + wbase1 + n * 512);
     }
   };
 #define XFM_QUAD(MH, NH, WB)                                                                                     \
@@ -529,10 +556,10 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g, int tiles) {
   int v = blockIdx.x, m0, n0;
   tile_origin(v, m0, n0);
   tile_offsets(m0, n0);
-  // prologue: units 0..4 in flight
+  // prologue: units 0..D-1 in flight
 #pragma unroll
-  for (int s = 0; s < 5; ++s) issue(s);
-  bool stores_behind = false;  // NS output stores of the previous tile were issued after the units 0..4 of this one
+  for (int s = 0; s < D; ++s) issue(s);
+  bool stores_behind = false;  // NS output stores of the previous tile were issued after the units 0..D-1 of this one
 
   while (true) {
 #pragma unroll
@@ -541,62 +568,85 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g, int tiles) {
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // units 0 and 1 (a0, b0 of K-tile 0) retired and visible
     {
-      const int y = (total - 1 < 4 ? total - 1 : 4) - 1;
-      if (NS > 0 && stores_behind) wait_younger_plus<NS>(y);
-      else wait_younger(y);
+      const int y = (total - 1 < D - 1 ? total - 1 : D - 1) - 1;
+      if (NS > 0 && stores_behind) wait_units<NS, D - 2>(y);
+      else wait_units<0, D - 2>(y);
     }
     XFM_BAR();
     if (wr == 1) XFM_BAR();  // stagger the second M-wave group by one barrier
 
+    int rs = 0;  // ring slot of unit 4*kt
     for (int kt = 0; kt < nk; ++kt) {
-      const char* buf = smem + (kt & 1) * BUF;
       const int ph = 4 * kt;
       const bool plus = NS > 0 && stores_behind && kt == 0;
+      const char* s_a0 = smem + rs * UNIT;
+      const char* s_b0 = smem + (rs + 1 >= R ? rs + 1 - R : rs + 1) * UNIT;
+      const char* s_b1 = smem + (rs + 2 >= R ? rs + 2 - R : rs + 2) * UNIT;
+      const char* s_a1 = smem + (rs + 3 >= R ? rs + 3 - R : rs + 3) * UNIT;
+      rs = rs + 4 >= R ? rs + 4 - R : rs + 4;
       int last;
       // ---- P0: (a0, b0)
-      issue(ph + 5);
-      read_x(buf, 0);
-      read_w(buf, 0, wb0);
-      last = ph + 5 < total ? ph + 5 : total - 1;
-      if (plus) wait_younger_plus<NS>(last - (ph + 2));
-      else wait_younger(last - (ph + 2));
+      issue(ph + D);
+      read_x(s_a0);
+      read_w(s_b0, wb0);
+      last = ph + D < total ? ph + D : total - 1;
+      if (plus) wait_units<NS, D - 2>(last - (ph + 2));
+      else wait_units<0, D - 2>(last - (ph + 2));
       XFM_BAR();
       XFM_QUAD(0, 0, wb0);
       XFM_BAR();
       // ---- P1: (a0, b1)
-      issue(ph + 6);
-      read_w(buf, 1, wb1);
-      last = ph + 6 < total ? ph + 6 : total - 1;
-      if (plus) wait_younger_plus<NS>(last - (ph + 3));
-      else wait_younger(last - (ph + 3));
+      issue(ph + D + 1);
+      read_w(s_b1, wb1);
+      last = ph + D + 1 < total ? ph + D + 1 : total - 1;
+      if (plus) wait_units<NS, D - 2>(last - (ph + 3));
+      else wait_units<0, D - 2>(last - (ph + 3));
       XFM_BAR();
       XFM_QUAD(0, 1, wb1);
       XFM_BAR();
       // ---- P2: (a1, b1)
-      issue(ph + 7);
-      read_x(buf, 1);
+      issue(ph + D + 2);
+      read_x(s_a1);
       XFM_BAR();
       XFM_QUAD(1, 1, wb1);
       XFM_BAR();
       // ---- P3: (a1, b0); retire a0, b0 of the next K-tile
-      issue(ph + 8);
-      last = ph + 8 < total ? ph + 8 : total - 1;
-      wait_younger(last - (ph + 5) < 0 ? 0 : last - (ph + 5));
+      issue(ph + D + 3);
+      last = ph + D + 3 < total ? ph + D + 3 : total - 1;
+      if (D > 5 && plus) wait_units<NS, D - 2>(last - (ph + 5) < 0 ? 0 : last - (ph + 5));  // D > 5: units 6.. of the prologue are older than the stores too
+      else wait_units<0, D - 2>(last - (ph + 5) < 0 ? 0 : last - (ph + 5));
       XFM_BAR();
       XFM_QUAD(1, 0, wb0);
       XFM_BAR();
     }
     if (wr == 0) XFM_BAR();  // both groups are past their last LDS read
     const int cm0 = m0, cn0 = n0;
+    // The bias goes out BEFORE the next tile's staging loads and is waited for with a count that leaves exactly those in flight
+    // (loads return in order): this wave's 64 values, into the last ring slot (free until P2 of the next tile's first K-tile).
+    // (DGELU's gelu'(x) chunks are still loaded inside the epilogue, behind the staging loads: 64 more live registers do not fit.)
+    float* lds_bias = reinterpret_cast<float*>(smem + (R - 1) * UNIT + w * 256);
+    if (g.bias != nullptr) {
+      int col = cn0 + wc * 64 + lane;
+      col = col < g.N ? col : g.N - 1;
+      const unsigned lds_addr = (unsigned)(uintptr_t)LDS_PTR(void, lds_bias);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g.bias + col), "s"(lds_addr) : "memory", "m0");
+    } else {
+      lds_bias[lane] = 0.f;
+    }
     v += gridDim.x;
     const bool more = PERSIST && v < tiles;
+    int ahead = 0;  // staging units of the next tile in flight
     if (more) {
       tile_origin(v, m0, n0);
       tile_offsets(m0, n0);
+      iss = 0;
 #pragma unroll
-      for (int s = 0; s < 5; ++s) issue(s);
+      for (int s = 0; s < D; ++s) issue(s);
+      ahead = total < D ? total : D;
     }
-    gemm_epilogue<MT, NT, EPI>(g, acc, cm0 + wr * 128, cn0 + wc * 64, lr, lg);
+    wait_units<0, D>(ahead);
+    if (g.bias == nullptr) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    gemm_epilogue<MT, NT, EPI>(g, acc, cm0 + wr * 128, cn0 + wc * 64, lr, lg, lds_bias);
     if (!more) break;
     XFM_FENCE();
     // exactly NS stores per lane only when every lane stored every (mt, np) with one 16-B (2 x 16-B for fp32) instruction
@@ -605,32 +655,40 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g, int tiles) {
 #undef XFM_QUAD
 }
 
+template <int E, bool P, int D>
+static void launch_nt_256_as(const GemmNT& g, int grid, int tiles, hipStream_t st) {
+  constexpr int smem = (D + 3) * 128 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<E, P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_256_kernel<E, P, D>), dim3(grid), dim3(512), smem, st, g, tiles);
+}
+
 static int launch_nt_256(const GemmNT& g, int epi, hipStream_t st) {
   const int tiles = cdiv(g.M, 256) * cdiv(g.N, 256);
-  const size_t smem = 4 * 256 * 128;
   if ((unsigned long)g.M * (unsigned long)g.lda >= (1ul << 32) || (unsigned long)g.N * (unsigned long)g.ldb >= (1ul << 32)) {
     xfm_set_error("gemm_nt: operand too large for the 256x256 kernel's 32-bit element offsets");
     return XFM_E_ARG;
   }
-  // more tiles than CUs: one persistent workgroup per CU (XFM_GEMM_PERSIST=0: one workgroup per tile)
+  // more tiles than CUs: one persistent workgroup per CU (XFM_GEMM_PERSIST=0: one workgroup per tile); XFM_GEMM_NT_D = look-ahead
+  // in staging units (5: 128 KiB of LDS, 7: 160 KiB)
   static const int persist_env = getenv("XFM_GEMM_PERSIST") ? atoi(getenv("XFM_GEMM_PERSIST")) : 1;
+  static const int d_env = getenv("XFM_GEMM_NT_D") ? atoi(getenv("XFM_GEMM_NT_D")) : 7;
   static const int cus = xfm_cu_count();
   const bool persist = persist_env && cus >= 8 && tiles > cus;
   const int grid = persist ? cus & ~7 : tiles;
-#define XFM_256_CASE(E)                                                                                        \
-  case E: {                                                                                                    \
-    static bool attr_set = false;                                                                              \
-    if (!attr_set) {                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<E, false>),                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<E, true>),                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
-      attr_set = true;                                                                                         \
-    }                                                                                                          \
-    if (persist) hipLaunchKernelGGL((gemm_nt_256_kernel<E, true>), dim3(grid), dim3(512), smem, st, g, tiles); \
-    else hipLaunchKernelGGL((gemm_nt_256_kernel<E, false>), dim3(grid), dim3(512), smem, st, g, tiles);        \
-    break;                                                                                                     \
-  }
+#define XFM_256_CASE(E)                                                                 \
+  case E:                                                                               \
+    if (d_env == 5) {                                                                   \
+      if (persist) launch_nt_256_as<E, true, 5>(g, grid, tiles, st);                    \
+      else launch_nt_256_as<E, false, 5>(g, grid, tiles, st);                           \
+    } else {                                                                            \
+      if (persist) launch_nt_256_as<E, true, 7>(g, grid, tiles, st);                    \
+      else launch_nt_256_as<E, false, 7>(g, grid, tiles, st);                           \
+    }                                                                                   \
+    break;
   switch (epi) {
     XFM_256_CASE(EPI_BF16)
     XFM_256_CASE(EPI_F32)
