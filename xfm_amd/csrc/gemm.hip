@@ -34,6 +34,7 @@ struct GemmNT {
   int M, N, K;
   int group_m;  // row-panels per tile group (L2 locality of the block order)
   int k_splits; // small-tile kernels, EPI_F32_ACC only: gridDim.y K-slices, fp32 atomics into C (1 = off)
+  int k_rot;    // 256 x 256 kernel: column phases of the K rotation (0 / 1 = every tile starts at K-tile 0)
 };
 
 // LDS swizzles (16-B chunk index XOR) for 128-B tile rows read with ds_read_b128.
@@ -466,11 +467,18 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g, int tiles) {
   // per-lane global element offsets of the 8 (unit, instruction) loads of a tile; the K offset is added per K-tile.  Instruction i
   // of wave w fills the 1-KiB block (i*8 + w) of the unit's slot: unit rows (i*8 + w)*8 + (lane >> 3), 16-B chunk lane & 7.
   unsigned soff[4][2];
+  // K rotation: the tiles of one row panel that run at the same time on an XCD (GM row panels x 32 / GM columns) would ask for the
+  // same A lines at the same moment, and every one of them would wait out the full miss (requests merged on an in-flight fill are
+  // "hits" that cost a miss).  Column tn therefore starts its K loop at K-tile (tn mod P) * nk / P: each of the P tiles is the
+  // first to touch 1/P of the panel, and reads the rest from L2 several K-steps after a neighbour brought it in.
+  int kt0 = 0;
+  const int rot_p = g.k_rot < tiles_n ? g.k_rot : tiles_n;
   auto tile_origin = [&](int v, int& m0, int& n0) {
     int tm, tn;
     grouped_tile(xcd_remap(v, tiles), tiles_m, tiles_n, g.group_m, tm, tn);
     m0 = tm * BM;
     n0 = tn * BN;
+    kt0 = rot_p > 1 ? (tn % rot_p) * (nk / rot_p) : 0;
   };
   auto tile_offsets = [&](int m0, int n0) {
 #pragma unroll
@@ -503,7 +511,9 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g, int tiles) {
     char* base = smem + iss * UNIT + w * 1024;
     iss = iss + 1 == R ? 0 : iss + 1;
     if (s >= total) return;
-    const int kt = s >> 2, j = s & 3;
+    const int j = s & 3;
+    int kt = (s >> 2) + kt0;
+    kt = kt >= nk ? kt - nk : kt;
     const bf16* src = ((j == 0 || j == 3) ? g.A : g.B) + kt * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -675,7 +685,7 @@ static int launch_nt_256(const GemmNT& g, int epi, hipStream_t st) {
   // more tiles than CUs: one persistent workgroup per CU (XFM_GEMM_PERSIST=0: one workgroup per tile); XFM_GEMM_NT_D = look-ahead
   // in staging units (5: 128 KiB of LDS, 7: 160 KiB)
   static const int persist_env = getenv("XFM_GEMM_PERSIST") ? atoi(getenv("XFM_GEMM_PERSIST")) : 1;
-  static const int d_env = getenv("XFM_GEMM_NT_D") ? atoi(getenv("XFM_GEMM_NT_D")) : 7;
+  static const int d_env = getenv("XFM_GEMM_NT_D") ? atoi(getenv("XFM_GEMM_NT_D")) : 5;
   static const int cus = xfm_cu_count();
   const bool persist = persist_env && cus >= 8 && tiles > cus;
   const int grid = persist ? cus & ~7 : tiles;
@@ -794,7 +804,8 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
               "gemm_nt: operands must be 16-byte aligned");
   XFM_REQUIRE((epi != EPI_GELU && epi != EPI_DGELU) || aux != nullptr, "gemm_nt: epilogue %d needs aux", epi);
   static const int gm_env = getenv("XFM_GEMM_GROUP_M") ? atoi(getenv("XFM_GEMM_GROUP_M")) : 0;  // tuning knob
-  GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K, gm_env > 0 ? gm_env : 8, 1};
+  static const int rot_env = getenv("XFM_GEMM_KROT") ? atoi(getenv("XFM_GEMM_KROT")) : 0;  // tuning knob (measured neutral)
+  GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K, gm_env > 0 ? gm_env : 8, 1, rot_env};
   int rows_a = 0, k_splits = 1;
   const int cfg = nt_plan(M, N, K, epi, tile_hint, &rows_a, &k_splits);
   if (rows_a > 0) {  // tail split: whole rounds of 256x256 tiles first, the remaining rows on the small-tile kernels
