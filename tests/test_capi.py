@@ -79,3 +79,25 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("tools/oracle", ""), f"{f} references the oracle"
+
+
+def test_register_bound_kernels_keep_their_budgets():
+    """The 256 x 256 GEMM kernels run two waves per SIMD (<= 256 VGPRs) inside counted-vmcnt pipelines, the short-sequence attention
+    backward kernels three (<= 168): a compiler or source change that spills them to scratch (VMEM traffic the wait counts do not
+    know about) or drops their occupancy must fail here, not show up as a slow bench.  The shipped ViT forward kernel sits at its
+    256-register limit with two spilled registers outside its loops; more than that is a regression."""
+    from xfm_amd import build
+    use = build.resource_usage()
+    seen = 0
+    for name, u in use.items():
+        if "gemm_nt_256_kernel" in name or "gemm_tn_256_kernel" in name:
+            seen += 1
+            assert u["vgprs"] + u.get("agprs", 0) <= 256, (name, u)
+            assert u["spill"] == 0 and u["scratch"] == 0, (name, u)
+        if "attn_bwd_dq_short_kernel" in name or "attn_bwd_dkv_short_kernel" in name:
+            seen += 1
+            assert u["vgprs"] <= 168 and u["spill"] == 0 and u["scratch"] == 0, (name, u)
+        if "attn_fwd_vit_kernelILb1ELi13ELb1E" in name:   # <bias, 13 tiles, tiled bias>: the pre-training step's instantiation
+            seen += 1
+            assert u["scratch"] <= 16, (name, u)
+    assert seen >= 26, sorted(use)[:20]

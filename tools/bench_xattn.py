@@ -28,9 +28,11 @@ def timeit(fn, iters=20):
 
 for name, kk, p in (("mask+dropout", keep, 0.1), ("dropout only", None, 0.1), ("mask only", keep, 0.0), ("plain", None, 0.0)):
     drop = Fx.drop_params(p, 1234)
-    o, lse = Fx.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, Sq, Sk, 0.125, key_keep=kk, groups=groups, drop=drop)
+    fast = os.environ.get("FAST", "0") == "1"   # FAST=1: delta from the forward's output halves (one sweep in the dQ kernel)
+    o, lse, *rest = Fx.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, Sq, Sk, 0.125, key_keep=kk, groups=groups, drop=drop, lo=fast)
+    o_lo = rest[0] if fast else None
     dq, dkv = torch.empty_like(q), torch.empty((U * Sk, 2 * D), dtype=torch.bfloat16, device="cuda")
-    tf = timeit(lambda: Fx.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, Sq, Sk, 0.125, key_keep=kk, groups=groups, drop=drop))
+    tf = timeit(lambda: Fx.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, Sq, Sk, 0.125, key_keep=kk, groups=groups, drop=drop, lo=fast))
     tb = timeit(lambda: Fx.attn_bwd(dout, q, kv[:, :D], kv[:, D:], o, lse, dq, dkv[:, :D], dkv[:, D:], B, H, Sq, Sk, 0.125,
-                                    key_keep=kk, groups=groups, drop=drop))
+                                    key_keep=kk, groups=groups, drop=drop, o_lo=o_lo))
     print(f"{name:14s} fwd {tf:6.1f} us   bwd (dq + dkv) {tb:6.1f} us", flush=True)

@@ -5,3 +5,7 @@ from .rccl_ddp_accelerator import RCCLDDPAccelerator
 
 ACCELERATOR_MAP = {"RCCLDDP": RCCLDDPAccelerator, "DDP": RCCLDDPAccelerator, "ApexDDP": RCCLDDPAccelerator,
                    "TorchAMPDDP": RCCLDDPAccelerator}
+
+# ApexDDP / TorchAMPDDP / DDP of the reference (accelerators/__init__.py:12-15) all map to the one bf16 data-parallel back end:
+# FP16_OPT_LEVEL, FP16_LOSS_SCALE, AUTO_CAST and SYNCBN have no effect here (bf16 compute with fp32 master weights needs no loss
+# scaling; the path has no BatchNorm); RCCLDDPAccelerator.__init__ logs the ones a config sets.

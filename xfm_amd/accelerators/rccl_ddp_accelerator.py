@@ -81,6 +81,11 @@ class RCCLDDPAccelerator(Accelerator):
         # -- in a process group of ONE rank, so that they execute through ProcessGroupNCCL (RCCL) on a single-GPU box; the result
         # must equal the no-collective run (mean over one rank)
         self.force = bool(g("FORCE_COLLECTIVES", os.environ.get("XFM_DDP_FORCE", "0") == "1"))
+        # the reference's fp16 / apex knobs (apex_ddp_accelerator.py:26-33, ddp_accelerator.py:20-27) have no effect on the bf16 path
+        ignored = [k for k in ("FP16_OPT_LEVEL", "FP16_LOSS_SCALE", "AUTO_CAST", "SYNCBN") if g(k, None) not in (None, False)]
+        if ignored:
+            msg = "RCCLDDPAccelerator: bf16 compute with fp32 master weights; ignoring " + ", ".join(ignored)
+            (logger.info if logger is not None and hasattr(logger, "info") else print)(msg)
         self.world_size, self.rank = 1, 0
         self._dist = False         # collectives on: world_size > 1, or forced in an initialised group
         self.stats = {"exchange_bytes": 0, "exchange_calls": 0, "overlapped_bytes": 0}   # of the last synchronising backward

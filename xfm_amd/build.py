@@ -24,17 +24,43 @@ def is_stale():
     return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
 
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-inline-asm"]
+
+
 def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Wno-inline-asm",
-           os.path.join(CSRC, "capi.hip"), "-o", LIB]
+    cmd = [_hipcc()] + FLAGS + ["-shared", os.path.join(CSRC, "capi.hip"), "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
     return LIB
+
+
+def resource_usage():
+    """{kernel symbol: {"vgprs": n, "agprs": n, "spill": n, "scratch": bytes per lane, "lds": bytes}} from a device-only compile with
+    -Rpass-analysis=kernel-resource-usage (no GPU needed): the register-bound kernels (256 x 256 GEMM tiles: two waves per SIMD,
+    <= 256 VGPRs, no scratch) are held to their budgets by tests/test_capi.py."""
+    import re
+    cmd = [_hipcc()] + FLAGS + ["-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, "capi.hip"),
+                                "-o", os.devnull]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    out, cur = {}, None
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "VGPRs Spill": "spill", "ScratchSize [bytes/lane]": "scratch", "LDS Size [bytes/block]": "lds",
+            "SGPRs Spill": "sgpr_spill"}
+    for line in r.stderr.splitlines():
+        m = re.search(r"remark: +Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark: +([A-Za-z \[\]/]+): (\d+)", line)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return out
 
 
 if __name__ == "__main__":
