@@ -676,7 +676,10 @@ def main():
         if os.path.exists(tpath):  # PMC passes are separate rocprofv3 runs of this same command (profiles/README.md)
             with open(tpath) as f:
                 tj = json.load(f)
-            dk = tj["families"].get("kernel:gemm_nt_256_kernel<0>")
+            # every instantiation of the plain-bf16 256 x 256 kernel (round 3: <0, persistent?, look-ahead>; before: <0>)
+            dks = [v for k, v in tj["families"].items() if k.startswith("kernel:gemm_nt_256_kernel<0")]
+            dk = {"hbm_bytes_per_step_corrected": sum(v["hbm_bytes_per_step_corrected"] for v in dks),
+                  "launches_per_step": sum(v["launches_per_step"] for v in dks)} if dks else None
             if dk and dk["launches_per_step"] > 0:  # the dominant kernel's own launches (its average launch, like `achieved`)
                 traffic = dk["hbm_bytes_per_step_corrected"] / dk["launches_per_step"]
                 traffic_note = f"bytes beyond L2 per launch of gemm_nt_256_kernel<0>, averaged over its {dk['launches_per_step']:.0f} launches per step " \

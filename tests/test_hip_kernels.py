@@ -94,6 +94,39 @@ def test_gemm_nt_gelu_and_dgelu(M, N, K, hint):
     _close(got, ref, 1e-2, "dgelu")
 
 
+@pytest.mark.parametrize("M,N,K", [(25000, 3000, 768), (17000, 1000, 128), (16400, 1001, 64), (66000, 520, 320)])
+def test_gemm_nt_persistent_tiles_every_epilogue(M, N, K):
+    """More 256 x 256 tiles than CUs: one workgroup per CU walks several tiles, the next tile's staging loads are in flight while
+    this tile's epilogue stores go out (counted in the same vmcnt), and the bias comes through LDS.  Ragged M and N (edge tiles take
+    the scalar store path and the uncounted wait), K of one to twelve K-tiles, an output stride that is not a multiple of 8 (N = 1001),
+    every epilogue, against fp32 math; the one-workgroup-per-tile 128 x 128 kernel must agree bit for bit where the K order is the
+    same (bf16 / GELU outputs)."""
+    Fx = _fx()
+    a, b = _rand((M, K), seed=31), _rand((N, K), 0.05, seed=32)
+    bias = _rand((N,), 0.5, F32, seed=33)
+    pre = a.float() @ b.float().t() + bias
+    out = Fx.gemm_nt(a, b, bias, tile_hint=5)
+    _close(out, pre, 1e-2, "bf16 out")
+    assert torch.equal(out, Fx.gemm_nt(a, b, bias, tile_hint=1))
+    assert torch.equal(Fx.gemm_nt(a, b, None, tile_hint=5), Fx.gemm_nt(a, b, None, tile_hint=1))   # no bias: zeros through LDS
+    h, u = Fx.gemm_nt(a, b, bias, epi=Fx.EPI_GELU, tile_hint=5)
+    x = pre.to(BF16).float()
+    _close(h, torch.nn.functional.gelu(x), 1e-2, "gelu(pre)")
+    _close(u, gelu_grad(x), 1e-2, "gelu'(pre)")
+    h1, u1 = Fx.gemm_nt(a, b, bias, epi=Fx.EPI_GELU, tile_hint=1)
+    assert torch.equal(h, h1) and torch.equal(u, u1)
+    aux = gelu_grad(_rand((M, N), 1.0, seed=34).float()).to(BF16)
+    got = Fx.gemm_nt(a, b, epi=Fx.EPI_DGELU, aux=aux, tile_hint=5)
+    _close(got, (a.float() @ b.float().t()) * aux.float(), 1e-2, "dgelu")
+    ld = (N + 63) // 64 * 64
+    buf = torch.full((M, ld), 7.0, dtype=F32, device="cuda")
+    Fx.gemm_nt(a, b, bias, epi=Fx.EPI_F32, out=buf, n=N, tile_hint=5)
+    _close(buf[:, :N], pre, 2e-5, "fp32 out")
+    assert ld == N or float((buf[:, N:] - 7.0).abs().max()) == 0.0
+    Fx.gemm_nt(a, b, None, epi=Fx.EPI_F32_ACC, out=buf, n=N, tile_hint=5)
+    _close(buf[:, :N], 2 * pre - bias, 2e-5, "fp32 accumulate")
+
+
 @pytest.mark.parametrize("M,N,K,splits", [(788, 200, 136, 0), (1920, 768, 768, 0), (1920, 768, 3072, 3), (64, 136, 64, 1),
                                            (960, 1000, 768, 0),
                                            (4100, 768, 768, 2), (12608, 2304, 768, 5), (5003, 520, 136, 0), (12608, 768, 768, 0), (960, 1000, 136, 1),
