@@ -61,10 +61,10 @@ for step in range(4):
     err = float("nan")
     if step < 2:  # step 0: plain sweep after backward (live ranges unknown yet); step 1: the overlapped, chunked exchange
         # (a) what the exchange must produce: every rank's LOCAL gradient (accelerator told it is alone), averaged by hand
-        acc.world_size = 1
+        acc.world_size, acc._dist = 1, False
         fwd_bwd(True)
         expect = model._arena.grad.clone()
-        acc.world_size = world
+        acc.world_size, acc._dist = world, True
         dist.all_reduce(expect)
         expect /= world
         model._arena.zero_grad()

@@ -302,7 +302,10 @@ class _TokensFn(torch.autograd.Function):
 # noise (41.6 vs 41.5 ms, tools/ab.sh) -- off by default, the exact two-pass form costs nothing
 _FAST_DELTA = __import__("os").environ.get("XFM_ATTN_FAST_DELTA", "0") != "0"
 _VIT_FUSED_BWD = __import__("os").environ.get("XFM_ATTN_VIT_BWD", "0") != "0"   # opt-in single-pass attention backward (measured slower than the split pair: csrc/attention_vit.hip)
-_GRAD_CHUNK_BLOCKS = 4  # the trunk's gradients leave for the all-reduce in chunks of this many blocks (12 blocks: 3 chunks)
+# the trunk's gradients leave for the all-reduce in chunks of this many blocks, from inside its backward; what is still there when the
+# backward ends (blocks 0 .. chunk, the embeddings) is the exposed tail of the exchange: 2 -> 3 blocks = 85 MB of fp32 gradients behind
+# five overlapped 57-MB collectives (round 2: 4 -> 5 blocks = 142 MB behind two of 114 MB)
+_GRAD_CHUNK_BLOCKS = max(1, int(__import__("os").environ.get("XFM_VIT_GRAD_CHUNK", "2")))
 
 
 def _g(p):

@@ -816,11 +816,15 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
                             aux ? (void*)((bf16*)aux + (long)rows_a * ldaux) : nullptr, ldaux, M - rows_a, N, K, epi, -1, st);
   }
   g.k_splits = k_splits;
+  static const int exp_cfg = getenv("XFM_GEMM_EXP_CFG") ? atoi(getenv("XFM_GEMM_EXP_CFG")) : 0;  // experiment: replaces config 7 at M >= 4096
+  if (exp_cfg > 0 && tile_hint == 0 && cfg == 7 && M >= 4096 && k_splits == 1) return exp_cfg == 9 ? launch_nt<128, 128, 3>(g, epi, st) : exp_cfg == 10 ? launch_nt<128, 128, 4>(g, epi, st) : launch_nt<128, 128, 2>(g, epi, st);
   switch (cfg) {
     case 1: return launch_nt<128, 128, 2>(g, epi, st);
     case 2: return launch_nt<64, 128, 2>(g, epi, st);
     case 7: return launch_nt<64, 128, 3>(g, epi, st);
     case 8: return launch_nt<64, 64, 4>(g, epi, st);
+    case 9: return launch_nt<128, 128, 3>(g, epi, st);
+    case 10: return launch_nt<128, 128, 4>(g, epi, st);
     case 4: return launch_nt_ring(g, epi, st);
     case 5: return launch_nt_256(g, epi, st);
     default: return launch_nt<64, 64, 2>(g, epi, st);
