@@ -755,9 +755,11 @@ def test_attention_grouped_by_kv_source(B, U, Sq, Sk, p):
     ref = torch.zeros(U, Sk * 2 * D, device="cuda").index_add_(0, idx.long(), dkv_rows.float().view(B, -1)).view(U * Sk, 2 * D)
     dq, dkv = torch.empty_like(q), torch.full((U * Sk, 2 * D), 7.0, dtype=BF16, device="cuda")
     Fx.attn_bwd(dout, q, kv[:, :D], kv[:, D:], o, lse, dq, dkv[:, :D], dkv[:, D:], B, H, Sq, Sk, 0.125, key_keep=keep, groups=groups, drop=drop)
-    # (resident keys: the same arithmetic in the same order; streamed keys sum the chunks' dQ in fp32 like the general kernel but round the
-    # bf16 result from a differently associated sum -- one bf16 ulp of the largest entry)
-    _close(dq, dq_ref, 1e-6 if Sk <= 256 else 4e-3, "grouped dQ")
+    # (the grouped kernels take the probabilities in the exponent of 2 -- exp2(s c log2e - lse log2e) against exp(s c - lse) -- and the
+    # streamed ones sum the chunks' dQ in a different association: the fp32 values agree to rounding, the bf16 results to one ulp of the
+    # largest entry)
+    _close(dq, dq_ref, 4e-3, "grouped dQ")
+    assert float((dq.float() - dq_ref.float()).abs().mean()) <= 2e-4 * float(dq_ref.float().abs().max()), "grouped dQ: mean deviation"
     _close(dkv, ref, 1e-2, "grouped dK/dV (summed per source)")
     if U > 1:
         assert float(dkv.view(U, -1)[U - 1].float().abs().max()) == 0.0, "unused source must get zero gradients"

@@ -1265,6 +1265,11 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
   }
 }
 
+// MASK / DROP: key-keep flags / dropout present (compiled out otherwise: the packed fusion tower has dropout and no mask).  The
+// probabilities are taken in the exponent of 2 (one FMA with scale*log2(e) and -lse*log2(e), then v_exp), the past-the-last-key test
+// only runs on the chunk that holds key Sk, and the dropout decisions of the first sweep (delta) are kept as 16 bits per chunk and
+// lane for the second (dS): the counter hash -- two quarter-rate integer multiplies per score -- was half of this kernel's VALU time.
+template <bool MASK, bool DROP>
 __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
@@ -1276,12 +1281,18 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
   const bf16* kb = a.k + (long)kvb * a.Sk * a.k_rs + h * 64;
   const bf16* vb = a.v + (long)kvb * a.Sk * a.v_rs + h * 64;
   const int nchunks = (a.Sk + 63) / 64;
+  constexpr float LOG2E = 1.4426950408889634f;
   for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, a.Sk, w, nw, lane);
+  // MASK: what a key adds to every score of its column, in the exponent of 2 (-10000 when masked, "minus infinity" past the last key),
+  // once per workgroup in LDS behind the K / V slots -- 16 mask registers per lane did not fit beside the two accumulator sets
+  float* madd = reinterpret_cast<float*>(lds + nchunks * ATTN_SLOT);
+  if (MASK && tid < nchunks * 64)
+    madd[tid] = tid < a.Sk ? (a.key_keep[(long)kvb * a.Sk + tid] == 0 ? MASK_NEG * LOG2E : 0.f) : -3.0e38f;
   stage_wait();
   const int tq = (a.Sq + 15) / 16, rpp = nw / tq;
   const int jr = w / tq, tile = w - jr * tq;
-  const bool has_mask = a.key_keep != nullptr;
   if (jr >= rpp) return;
+  const float c2 = a.scale * LOG2E;
   for (int j = jr; j < nrows; j += rpp) {
     const int b = a.grp_rows[rstart + j];
     long qbase;
@@ -1291,7 +1302,7 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
     const int qi = tile * 16 + lr;
     const bool qvalid = qi < sq;
     const int qc = qvalid ? qi : sq - 1;
-    const uint32_t dkey = drop_key(a, b, h, qi);
+    const uint32_t dkey = DROP ? drop_key(a, b, h, qi) : 0u;
     const bf16* qp = a.q + (qbase + qc) * a.q_rs + h * 64;
     const bf16* dop = a.dout + (qbase + qc) * a.do_rs + h * 64;
     const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp + 8 * lg);
@@ -1299,12 +1310,12 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
     const bf16x8 df0 = *reinterpret_cast<const bf16x8*>(dop + 8 * lg);
     const bf16x8 df1 = *reinterpret_cast<const bf16x8*>(dop + 32 + 8 * lg);
     const long stat_idx = ((long)b * a.H + h) * a.stat_ld + qc;
-    const float lse_q = qvalid ? a.lse[stat_idx] : 3.0e38f;
-    auto probs = [&](int kc, f32x4 (&st)[4], f32x4 (&dp)[4]) {
+    const float nlse2 = qvalid ? -a.lse[stat_idx] * LOG2E : -3.0e38f;   // rows past the sequence: every probability 0
+    uint32_t keep_lo = 0u, keep_hi = 0u;  // dropout decisions of chunks 0,1 / 2,3: bit (t*4 + r) of the 16-bit field (kc & 1)
+    // FIRST: the sweep that draws the dropout decisions (and stores them); later sweeps read them back
+    auto probs = [&](int kc, f32x4 (&st)[4], f32x4 (&dp)[4], bool first) {
       const char* sK = lds + kc * ATTN_SLOT;
       const char* sV = sK + ATTN_TILE;
-      int kk[4][4];
-      if (has_mask) load_keep(a, kvb, kc, lg, kk);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1314,17 +1325,37 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
         dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 0, lr, lg), df0, dp[t], 0, 0, 0);
         dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 1, lr, lg), df1, dp[t], 0, 0, 0);
       }
+      const bool tail = !MASK && (kc + 1) * 64 > a.Sk;  // uniform: only this chunk holds keys past the last one
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        f32x4 ma = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (MASK) ma = *reinterpret_cast<const f32x4*>(madd + kc * 64 + t * 16 + 4 * lg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          st[t][r] = __expf(score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, false, qi, kc * 64 + t * 16 + 4 * lg + r, a.Sk) - lse_q);
-      if (a.drop_thresh != 0u) {
+        for (int r = 0; r < 4; ++r) {
+          float e = fmaf(st[t][r], c2, nlse2);
+          if constexpr (MASK) e += ma[r];
+          if (tail) e = kc * 64 + t * 16 + 4 * lg + r >= a.Sk ? -3.0e38f : e;
+          st[t][r] = __builtin_amdgcn_exp2f(e);
+        }
+      }
+      if (DROP) {
+        const int sh = (kc & 1) * 16;
+        uint32_t bits;
+        if (first) {
+          bits = 0u;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bits |= drop_keep(a, dkey, kc * 64 + t * 16 + 4 * lg + r) ? (1u << (t * 4 + r)) : 0u;
+          if (kc < 2) keep_lo |= bits << sh;
+          else keep_hi |= bits << sh;
+        } else {
+          bits = (kc < 2 ? keep_lo : keep_hi) >> sh;
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            dp[t][r] = drop_keep(a, dkey, kc * 64 + t * 16 + 4 * lg + r) ? dp[t][r] * a.drop_scale : 0.f;
+          for (int r = 0; r < 4; ++r) dp[t][r] = (bits & (1u << (t * 4 + r))) ? dp[t][r] * a.drop_scale : 0.f;
       }
     };
     float delta = 0.f;
@@ -1334,7 +1365,7 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
       delta = delta_from_out(a, qbase + qc, h, lg, df0, df1);
     } else {
       for (int kc = 0; kc < nchunks; ++kc) {
-        probs(kc, st, dp);
+        probs(kc, st, dp, true);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -1347,7 +1378,7 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kc = 0; kc < nchunks; ++kc) {
-      if (nchunks > 1 || fast_delta) probs(kc, st, dp);
+      if (nchunks > 1 || fast_delta) probs(kc, st, dp, fast_delta);
       const char* sK = lds + kc * ATTN_SLOT;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -1376,6 +1407,10 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
 
 // dK/dV of one (source, head): wave w owns 16 keys; the group's rows go through LDS four at a time (one 64-slot query chunk
 // per row, Sq <= 64), gradients accumulate in registers across ALL rows and are written once, at the source's rows.
+// DROP: the dropout stream is keyed per query row (two hash rounds) and a lane walks query rows here, so the row keys of the staged
+// sequences are computed once per workgroup into LDS (behind the query slots) instead of once per score; probabilities in the
+// exponent of 2 as in the dQ kernel.
+template <bool DROP>
 __global__ __launch_bounds__(512, 4) void xattn_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
@@ -1394,7 +1429,14 @@ __global__ __launch_bounds__(512, 4) void xattn_dkv_kernel(AttnArgs a) {
   const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + 32 + 8 * lg);
   const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vp + 8 * lg);
   const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vp + 32 + 8 * lg);
-  const float key_add = (a.key_keep != nullptr && a.key_keep[(long)kvb * a.Sk + kcl] == 0) ? MASK_NEG : 0.f;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float c2 = a.scale * LOG2E;
+  // what this lane's key adds to its scores in the exponent of 2: -10000 when masked, "minus infinity" for a lane past the last key
+  const float key_add2 = !kvalid ? -3.0e38f : (a.key_keep != nullptr && a.key_keep[(long)kvb * a.Sk + kcl] == 0) ? MASK_NEG * LOG2E : 0.f;
+  // per staged sequence and query row, behind the query slots: dropout row key | -lse * log2(e) | delta  ([ATTN_RES_MAX][64] each)
+  uint32_t* rowkeys = reinterpret_cast<uint32_t*>(lds + ATTN_RES_MAX * ATTN_SLOT);
+  float* nlse2s = reinterpret_cast<float*>(rowkeys + ATTN_RES_MAX * 64);
+  float* deltas = nlse2s + ATTN_RES_MAX * 64;
   f32x4 dkacc[4], dvacc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -1409,55 +1451,54 @@ __global__ __launch_bounds__(512, 4) void xattn_dkv_kernel(AttnArgs a) {
       q_seq(a, b, qbase, sq);
       stage_slot(lds + jj * ATTN_SLOT, a.q + qbase * a.q_rs + h * 64, a.q_rs, a.dout + qbase * a.do_rs + h * 64, a.do_rs, 0, sq, w, nw, lane);
     }
+    if (tid < nb * 64) {
+      const int jj = tid >> 6, qi = tid & 63;
+      const int b = a.grp_rows[rstart + j0 + jj];
+      if (DROP) rowkeys[tid] = drop_key(a, b, h, qi);
+      const long si = ((long)b * a.H + h) * a.stat_ld + qi;
+      nlse2s[tid] = qi < a.Sq ? a.lse[si] * -LOG2E : 0.f;
+      deltas[tid] = qi < a.Sq ? a.delta[si] : 0.f;
+    }
     stage_wait();
     if (!wave_active) continue;
     for (int jj = 0; jj < nb; ++jj) {
       const int b = a.grp_rows[rstart + j0 + jj];
       const char* sQ = lds + jj * ATTN_SLOT;
       const char* sD = sQ + ATTN_TILE;
-      const float* lse_b = a.lse + ((long)b * a.H + h) * a.stat_ld;
-      const float* del_b = a.delta + ((long)b * a.H + h) * a.stat_ld;
       const int sq = a.q_len != nullptr ? a.q_len[b] : a.Sq;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         if (s2 * 32 >= a.Sq) continue;  // uniform: no query in this half (Sq = 30 lives in the first)
-        f32x4 st[2], dp[2], pd[2], lsev[2], delv[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int qi0 = (2 * s2 + u) * 16 + 4 * lg;
-          lsev[u] = delv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (qi0 < a.Sq) {
-            lsev[u] = *reinterpret_cast<const f32x4*>(lse_b + qi0);
-            delv[u] = *reinterpret_cast<const f32x4*>(del_b + qi0);
-          }
-        }
+        f32x4 st[2], pd[2];
         if (s2 * 32 >= sq) continue;  // uniform per row: the whole 32-query step lies past the sequence's end
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int t = 2 * s2 + u;
+          const int qi0 = t * 16 + 4 * lg;
           st[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          dp[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 dpu = f32x4{0.f, 0.f, 0.f, 0.f};
           if (t * 16 < sq) {  // (an empty second tile contributes zero probabilities below: skip its four products)
             st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 0, lr, lg), kf0, st[u], 0, 0, 0);
             st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sQ, t * 16, 1, lr, lg), kf1, st[u], 0, 0, 0);
-            dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 0, lr, lg), vf0, dp[u], 0, 0, 0);
-            dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 1, lr, lg), vf1, dp[u], 0, 0, 0);
+            dpu = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 0, lr, lg), vf0, dpu, 0, 0, 0);
+            dpu = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sD, t * 16, 1, lr, lg), vf1, dpu, 0, 0, 0);
           }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
+          u32x4 rk = u32x4{0u, 0u, 0u, 0u};
+          if (DROP) rk = *reinterpret_cast<const u32x4*>(rowkeys + jj * 64 + qi0);
+          const f32x4 nl = *reinterpret_cast<const f32x4*>(nlse2s + jj * 64 + qi0);
+          const f32x4 dlv = *reinterpret_cast<const f32x4*>(deltas + jj * 64 + qi0);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int qi = (2 * s2 + u) * 16 + 4 * lg + r;
-            const bool ok = qi < sq && kvalid;
-            float pv = __expf(fmaf(st[u][r], a.scale, key_add) - lsev[u][r]);
+            const bool ok = qi0 + r < sq;
+            float pv = __builtin_amdgcn_exp2f(fmaf(st[u][r], c2, nl[r] + key_add2));
             pv = ok ? pv : 0.f;
-            const float dl = ok ? delv[u][r] : 0.f;
+            const float dl = ok ? dlv[r] : 0.f;
             float keepf = 1.f;
-            if (a.drop_thresh != 0u) keepf = drop_keep(a, drop_key(a, b, h, qi), kj) ? a.drop_scale : 0.f;
+            if (DROP) keepf = rng_keep(rng_u32(rk[r], (uint32_t)kj), a.drop_thresh) ? a.drop_scale : 0.f;
             pd[u][r] = pv * keepf;
-            st[u][r] = pv * (dp[u][r] * keepf - dl);
+            st[u][r] = pv * (dpu[r] * keepf - dl);
           }
+        }
         const bf16x8 pf = pack_pair(pd[0], pd[1]);
         const bf16x8 sf = pack_pair(st[0], st[1]);
 #pragma unroll
@@ -1796,11 +1837,15 @@ static int attn_check_grouped(const AttnArgs& a) {
 static void attn_grouped_lds() {
   static bool attr_set = false;
   if (!attr_set) {
-    const int mx = ATTN_RES_MAX * ATTN_SLOT;
+    const int mx = ATTN_RES_MAX * ATTN_SLOT + 3 * ATTN_RES_MAX * 64 * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dq_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dq_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dq_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dq_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
     attr_set = true;
   }
 }
@@ -1852,13 +1897,23 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
     attn_grouped_lds();
     if (a.bwd_phase != 2) {
       if (a.Sk > 64 * ATTN_RES_MAX) hipLaunchKernelGGL(xattn_dq_stream_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)2 * ATTN_SLOT, st, a);
-      else hipLaunchKernelGGL(xattn_dq_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)cdiv(a.Sk, 64) * ATTN_SLOT, st, a);
+      else {
+        const dim3 grid(1, a.H, a.n_groups);
+        const bool mask = a.key_keep != nullptr, drop = a.drop_thresh != 0u;
+        const size_t lds = (size_t)cdiv(a.Sk, 64) * ATTN_SLOT + (mask ? 1024 : 0);
+        if (mask && drop) hipLaunchKernelGGL((xattn_dq_kernel<true, true>), grid, dim3(512), lds, st, a);
+        else if (mask) hipLaunchKernelGGL((xattn_dq_kernel<true, false>), grid, dim3(512), lds, st, a);
+        else if (drop) hipLaunchKernelGGL((xattn_dq_kernel<false, true>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((xattn_dq_kernel<false, false>), grid, dim3(512), lds, st, a);
+      }
       rc = xfm_check_launch("xattn_dq");
       if (rc != XFM_OK || a.bwd_phase == 1) return rc;
     }
     int knw, kblocks;
     attn_geom(a.Sk, knw, kblocks);
-    hipLaunchKernelGGL(xattn_dkv_kernel, dim3(kblocks, a.H, a.n_groups), dim3(knw * 64), (size_t)ATTN_RES_MAX * ATTN_SLOT, st, a);
+    const size_t dkv_lds = (size_t)ATTN_RES_MAX * ATTN_SLOT + 3 * ATTN_RES_MAX * 64 * 4;
+    if (a.drop_thresh != 0u) hipLaunchKernelGGL(xattn_dkv_kernel<true>, dim3(kblocks, a.H, a.n_groups), dim3(knw * 64), dkv_lds, st, a);
+    else hipLaunchKernelGGL(xattn_dkv_kernel<false>, dim3(kblocks, a.H, a.n_groups), dim3(knw * 64), dkv_lds, st, a);
     return xfm_check_launch("xattn_dkv");
   }
   if (attn_vit3_shape(a)) return launch_attn_bwd_vit3(a, st);
