@@ -1145,7 +1145,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------
 // PACK: the same wave layout serves small self-attention (Sq, Sk <= 64, e.g. the 30-token text rows): a workgroup takes nw/tq
 // CONSECUTIVE batch rows, each with its own key/value source in its own LDS slot -- 8 waves per workgroup instead of 2.
-template <bool PACK>
+// MASK / DROP (grouped mode only; the packed mode keeps its run-time switches): key-keep flags / dropout present.  Grouped mode works in
+// the exponent of 2 like its backward kernels: scores scaled by scale*log2(e), the key's additive term (mask, past-the-end) from an LDS
+// vector.
+template <bool PACK, bool MASK, bool DROP>
 __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
@@ -1182,9 +1185,14 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
     const bf16* vb = a.v + (long)g * a.Sk * a.v_rs + h * 64;
     for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, a.Sk, w, nw, lane);
   }
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  float* madd = reinterpret_cast<float*>(lds + nchunks * ATTN_SLOT);  // grouped + MASK: see xattn_dq_kernel
+  if (!PACK && tid < nchunks * 64)
+    madd[tid] = tid < a.Sk ? (MASK && a.key_keep[(long)g * a.Sk + tid] == 0 ? MASK_NEG * LOG2E : 0.f) : -3.0e38f;
   stage_wait();
   const int jr = w / tq, tile = w - jr * tq;
   const bool has_mask = a.key_keep != nullptr;
+  const float c2 = a.scale * LOG2E;
   const bool causal = PACK && a.causal != 0;
   if (jr >= rpp) return;  // no barriers below
   for (int j = jr; j < nrows; j += rpp) {
@@ -1210,7 +1218,7 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
       const char* sV = sK + ATTN_TILE;
       f32x4 st[4];
       int kk[4][4];
-      if (has_mask) load_keep(a, kvb, kc, lg, kk);
+      if (PACK && has_mask) load_keep(a, kvb, kc, lg, kk);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1218,25 +1226,37 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
         st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sK, t * 16, 1, lr, lg), qf1, st[t], 0, 0, 0);
       }
       float mx = EXCL_NEG;
+      if constexpr (!PACK) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 ma = *reinterpret_cast<const f32x4*>(madd + kc * 64 + t * 16 + 4 * lg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          st[t][r] = score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, causal, qi, kc * 64 + t * 16 + 4 * lg + r, sk);
-          mx = fmaxf(mx, st[t][r]);
+          for (int r = 0; r < 4; ++r) {
+            st[t][r] = fmaf(st[t][r], c2, ma[r]);
+            mx = fmaxf(mx, st[t][r]);
+          }
         }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            st[t][r] = score_masked(a, st[t][r], 0.f, has_mask, has_mask ? kk[t][r] : 1, causal, qi, kc * 64 + t * 16 + 4 * lg + r, sk);
+            mx = fmaxf(mx, st[t][r]);
+          }
+      }
       mx = group4_max(mx);
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = __expf(m_run - m_new);
+      const float alpha = PACK ? __expf(m_run - m_new) : __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          st[t][r] = __expf(st[t][r] - m_new);
+          st[t][r] = PACK ? __expf(st[t][r] - m_new) : __builtin_amdgcn_exp2f(st[t][r] - m_new);
           psum += st[t][r];
         }
-      if (a.drop_thresh != 0u) {
+      if (PACK ? a.drop_thresh != 0u : DROP) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -1260,14 +1280,14 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
     }
     if (qi < sq) {
       store_out(a, qbase + qi, h, lg, oacc, 1.0f / l_run);
-      if (lg == 0) a.lse[((long)b * a.H + h) * a.stat_ld + qi] = m_run + __logf(l_run);
+      if (lg == 0) a.lse[((long)b * a.H + h) * a.stat_ld + qi] = PACK ? m_run + __logf(l_run) : m_run * LN2 + __logf(l_run);
     }
   }
 }
 
 // MASK / DROP: key-keep flags / dropout present (compiled out otherwise: the packed fusion tower has dropout and no mask).  The
-// probabilities are taken in the exponent of 2 (one FMA with scale*log2(e) and -lse*log2(e), then v_exp), the past-the-last-key test
-// only runs on the chunk that holds key Sk, and the dropout decisions of the first sweep (delta) are kept as 16 bits per chunk and
+// probabilities are taken in the exponent of 2 (one FMA with scale*log2(e) and -lse*log2(e) + the key's additive term, then v_exp), and
+// the dropout decisions of the first sweep (delta) are kept as 16 bits per chunk and
 // lane for the second (dS): the counter hash -- two quarter-rate integer multiplies per score -- was half of this kernel's VALU time.
 template <bool MASK, bool DROP>
 __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
@@ -1283,11 +1303,11 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
   const int nchunks = (a.Sk + 63) / 64;
   constexpr float LOG2E = 1.4426950408889634f;
   for (int kc = 0; kc < nchunks; ++kc) stage_slot(lds + kc * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, kc * 64, a.Sk, w, nw, lane);
-  // MASK: what a key adds to every score of its column, in the exponent of 2 (-10000 when masked, "minus infinity" past the last key),
-  // once per workgroup in LDS behind the K / V slots -- 16 mask registers per lane did not fit beside the two accumulator sets
+  // what a key adds to every score of its column, in the exponent of 2 (-10000 when masked, "minus infinity" past the last key), once
+  // per workgroup in LDS behind the K / V slots: one ds_read_b128 + 4 adds per 16-key tile instead of 16 mask registers and selects
   float* madd = reinterpret_cast<float*>(lds + nchunks * ATTN_SLOT);
-  if (MASK && tid < nchunks * 64)
-    madd[tid] = tid < a.Sk ? (a.key_keep[(long)kvb * a.Sk + tid] == 0 ? MASK_NEG * LOG2E : 0.f) : -3.0e38f;
+  if (tid < nchunks * 64)
+    madd[tid] = tid < a.Sk ? (MASK && a.key_keep[(long)kvb * a.Sk + tid] == 0 ? MASK_NEG * LOG2E : 0.f) : -3.0e38f;
   stage_wait();
   const int tq = (a.Sq + 15) / 16, rpp = nw / tq;
   const int jr = w / tq, tile = w - jr * tq;
@@ -1325,18 +1345,11 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
         dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 0, lr, lg), df0, dp[t], 0, 0, 0);
         dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(sV, t * 16, 1, lr, lg), df1, dp[t], 0, 0, 0);
       }
-      const bool tail = !MASK && (kc + 1) * 64 > a.Sk;  // uniform: only this chunk holds keys past the last one
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        f32x4 ma = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (MASK) ma = *reinterpret_cast<const f32x4*>(madd + kc * 64 + t * 16 + 4 * lg);
+        const f32x4 ma = *reinterpret_cast<const f32x4*>(madd + kc * 64 + t * 16 + 4 * lg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float e = fmaf(st[t][r], c2, nlse2);
-          if constexpr (MASK) e += ma[r];
-          if (tail) e = kc * 64 + t * 16 + 4 * lg + r >= a.Sk ? -3.0e38f : e;
-          st[t][r] = __builtin_amdgcn_exp2f(e);
-        }
+        for (int r = 0; r < 4; ++r) st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, nlse2 + ma[r]));
       }
       if (DROP) {
         const int sh = (kc & 1) * 16;
@@ -1411,7 +1424,7 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
 // sequences are computed once per workgroup into LDS (behind the query slots) instead of once per score; probabilities in the
 // exponent of 2 as in the dQ kernel.
 template <bool DROP>
-__global__ __launch_bounds__(512, 4) void xattn_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(1024) void xattn_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
@@ -1838,8 +1851,11 @@ static void attn_grouped_lds() {
   static bool attr_set = false;
   if (!attr_set) {
     const int mx = ATTN_RES_MAX * ATTN_SLOT + 3 * ATTN_RES_MAX * 64 * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_fwd_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dq_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dq_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_dq_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
@@ -1861,7 +1877,15 @@ int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
       hipLaunchKernelGGL(xattn_fwd_stream_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)2 * ATTN_SLOT, st, a);
       return xfm_check_launch("xattn_fwd_stream");
     }
-    hipLaunchKernelGGL(xattn_fwd_kernel<false>, dim3(1, a.H, a.n_groups), dim3(512), (size_t)cdiv(a.Sk, 64) * ATTN_SLOT, st, a);
+    {
+      const dim3 grid(1, a.H, a.n_groups);
+      const bool mask = a.key_keep != nullptr, drop = a.drop_thresh != 0u;
+      const size_t lds = (size_t)cdiv(a.Sk, 64) * ATTN_SLOT + 1024;
+      if (mask && drop) hipLaunchKernelGGL((xattn_fwd_kernel<false, true, true>), grid, dim3(512), lds, st, a);
+      else if (mask) hipLaunchKernelGGL((xattn_fwd_kernel<false, true, false>), grid, dim3(512), lds, st, a);
+      else if (drop) hipLaunchKernelGGL((xattn_fwd_kernel<false, false, true>), grid, dim3(512), lds, st, a);
+      else hipLaunchKernelGGL((xattn_fwd_kernel<false, false, false>), grid, dim3(512), lds, st, a);
+    }
     return xfm_check_launch("xattn_fwd");
   }
   if (attn_packable(a)) {
@@ -1869,7 +1893,7 @@ int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
     int rpb = 8 / tq < ATTN_RES_MAX ? 8 / tq : ATTN_RES_MAX;
     if (rpb > a.B) rpb = a.B;
     attn_grouped_lds();
-    hipLaunchKernelGGL(xattn_fwd_kernel<true>, dim3(1, a.H, cdiv(a.B, rpb)), dim3(rpb * tq * 64), (size_t)rpb * ATTN_SLOT, st, a);
+    hipLaunchKernelGGL((xattn_fwd_kernel<true, false, false>), dim3(1, a.H, cdiv(a.B, rpb)), dim3(rpb * tq * 64), (size_t)rpb * ATTN_SLOT, st, a);
     return xfm_check_launch("xattn_fwd<pack>");
   }
   if (attn_vit_shape(a)) return launch_attn_fwd_vit(a, st);
@@ -1900,7 +1924,7 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
       else {
         const dim3 grid(1, a.H, a.n_groups);
         const bool mask = a.key_keep != nullptr, drop = a.drop_thresh != 0u;
-        const size_t lds = (size_t)cdiv(a.Sk, 64) * ATTN_SLOT + (mask ? 1024 : 0);
+        const size_t lds = (size_t)cdiv(a.Sk, 64) * ATTN_SLOT + 1024;
         if (mask && drop) hipLaunchKernelGGL((xattn_dq_kernel<true, true>), grid, dim3(512), lds, st, a);
         else if (mask) hipLaunchKernelGGL((xattn_dq_kernel<true, false>), grid, dim3(512), lds, st, a);
         else if (drop) hipLaunchKernelGGL((xattn_dq_kernel<false, true>), grid, dim3(512), lds, st, a);
@@ -1910,7 +1934,8 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
       if (rc != XFM_OK || a.bwd_phase == 1) return rc;
     }
     int knw, kblocks;
-    attn_geom(a.Sk, knw, kblocks);
+    static const int dkv_nw = getenv("XFM_XATTN_DKV_NW") ? atoi(getenv("XFM_XATTN_DKV_NW")) : 16;  // tuning knob: waves (16-key tiles) per workgroup
+    attn_geom(a.Sk, knw, kblocks, dkv_nw);
     const size_t dkv_lds = (size_t)ATTN_RES_MAX * ATTN_SLOT + 3 * ATTN_RES_MAX * 64 * 4;
     if (a.drop_thresh != 0u) hipLaunchKernelGGL(xattn_dkv_kernel<true>, dim3(kblocks, a.H, a.n_groups), dim3(knw * 64), dkv_lds, st, a);
     else hipLaunchKernelGGL(xattn_dkv_kernel<false>, dim3(kblocks, a.H, a.n_groups), dim3(knw * 64), dkv_lds, st, a);
