@@ -729,7 +729,8 @@ def test_attention_shared_kv_sources_and_row_fold():
                                          (11, 4, 40, 577, 0.1),    # 384-px retrieval: streamed keys (10 chunks through a two-slot ring)
                                          (7, 3, 40, 901, 0.0),     # 480-px VQA: 15 chunks, the last one 5 keys
                                          (30, 2, 40, 300, 0.1)])   # ~15 rows x 3 tiles per image: three passes of 16 tile slots
-def test_attention_grouped_by_kv_source(B, U, Sq, Sk, p):
+@pytest.mark.parametrize("masked", [True, False])
+def test_attention_grouped_by_kv_source(B, U, Sq, Sk, p, masked):
     """Grouped mode (one workgroup per key/value source and head, dK/dV summed over the group's rows in registers; more than 256 keys
     stream through LDS) against the kv_index path + row fold: same masks, same dropout stream (keyed by the query batch row), empty
     groups give zero dK/dV."""
@@ -740,8 +741,10 @@ def test_attention_grouped_by_kv_source(B, U, Sq, Sk, p):
     idx = torch.randint(0, max(U - 1, 1), (B,), generator=gen).to(torch.int32).cuda()  # the last source stays unused when U > 1
     q = _rand((B * Sq, D), seed=210)
     kv = _rand((U * Sk, 2 * D), seed=211)
-    keep = torch.ones(U, Sk, dtype=torch.int32, device="cuda")
-    keep[0, Sk - 20:] = 0
+    keep = None   # masked = False: the instantiations without key-keep flags (the packed fusion tower's case)
+    if masked:
+        keep = torch.ones(U, Sk, dtype=torch.int32, device="cuda")
+        keep[0, Sk - 20:] = 0
     dout = _rand((B * Sq, D), seed=212)
     drop = Fx.drop_params(p, 1234567)
     o_ref, lse_ref = Fx.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, Sq, Sk, 0.125, key_keep=keep, kv_index=idx, drop=drop)
