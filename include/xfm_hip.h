@@ -28,7 +28,7 @@ extern "C" {
 #define XFM_E_LAUNCH (-2)
 #define XFM_E_UNSUPPORTED (-3)
 
-#define XFM_ABI_VERSION 4
+#define XFM_ABI_VERSION 5
 
 const char* xfm_last_error(void);
 int xfm_abi_version(void);
@@ -179,6 +179,11 @@ typedef struct {
      backward.  One bias tile is then one contiguous 1-KB wave load instead of 16 strided row segments.  NULL = read `bias` /
      `bias_t`. */
   const float* bias_tiled; const float* bias_t_tiled;
+  /* xfm_attn_bwd with dbias on a problem too long for the in-register bias-gradient kernels (Sk > 256: the 577 / 901 tokens of the
+     384 / 480 px ViT, beit2.py:126-166): optional fp32 workspace [B,H,Sq,bias_ld].  The dQ kernel then STORES every batch entry's dS
+     there (coalesced 16-byte stores) and a second kernel adds the sum over the batch to dbias -- instead of one float atomic per
+     score and batch entry (234 M atomics per layer at B = 24, 901 tokens: 3.1 ms; with the workspace 0.6 ms).  NULL = atomics. */
+  float* dbias_ws;
 } xfm_attn_args;
 
 int xfm_attn_fwd(const xfm_attn_args* a, void* stream);

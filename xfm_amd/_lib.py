@@ -13,7 +13,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # XFM_HIP_LIB: A/B a differently built library (kernel experiments); the default is the in-tree build.
 LIB_PATH = os.environ.get("XFM_HIP_LIB") or os.path.join(_HERE, "libxfm_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_void_p, c_int, c_long, c_float, c_u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint32
 
@@ -52,7 +52,8 @@ class AttnArgs(ctypes.Structure):
                 ("stat_ld", c_long), ("bias_t", c_void_p), ("bias_t_ld", c_long), ("kv_index", c_void_p),
                 ("grp_start", c_void_p), ("grp_rows", c_void_p), ("n_groups", c_int),
                 ("q_start", c_void_p), ("q_len", c_void_p), ("k_start", c_void_p), ("k_len", c_void_p),
-                ("bwd_phase", c_int), ("o_lo", c_void_p), ("bias_tiled", c_void_p), ("bias_t_tiled", c_void_p)]
+                ("bwd_phase", c_int), ("o_lo", c_void_p), ("bias_tiled", c_void_p), ("bias_t_tiled", c_void_p),
+                ("dbias_ws", c_void_p)]
 
 
 class EmbedArgs(ctypes.Structure):

@@ -457,6 +457,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
       }
       if (!wave_active) continue;
       const char* sK = lds + (resident ? kc : (kc & 1)) * ATTN_SLOT;
+      // bias gradient without the in-register sums (NKC = 0): this entry's dS goes to the workspace [B,H,Sq,bias_ld] when there is
+      // one (dbias_reduce_kernel adds the batch sum to dbias afterwards), else one float atomic per score
+      float* wsrow = (!DBIAS && a.dbias != nullptr && a.dbias_ws != nullptr) ? a.dbias_ws + (((long)b * a.H + h) * a.Sq + qi) * a.bias_ld : nullptr;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int kj0 = kc * 64 + t * 16 + 4 * lg;
@@ -465,7 +468,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
           const int kj = kj0 + r;
           const float ds = st[t][r] * (dp[t][r] - delta);
           st[t][r] = ds;
-          if (!DBIAS && a.dbias != nullptr && kj < sk && qvalid) atomicAdd(a.dbias + ((long)h * a.Sq + qi) * a.bias_ld + kj, ds);
+          if (!DBIAS && a.dbias != nullptr && wsrow == nullptr && kj < sk && qvalid) atomicAdd(a.dbias + ((long)h * a.Sq + qi) * a.bias_ld + kj, ds);
+        }
+        if (!DBIAS && wsrow != nullptr && qvalid) {
+          if (kj0 + 4 <= a.bias_ld) *reinterpret_cast<f32x4*>(wsrow + kj0) = st[t];  // (columns in [Sk, bias_ld) get exact zeros: P = 0 there)
+          else
+            for (int r = 0; r < 4; ++r)
+              if (kj0 + r < a.bias_ld) wsrow[kj0 + r] = st[t][r];
         }
       }
       if (DBIAS) {  // static register indices only: a wave-uniform compare selects the chunk's accumulator
@@ -1912,7 +1921,19 @@ int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
   return xfm_check_launch("attn_fwd");
 }
 
-int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
+// dbias[h, q, :] += sum_b ws[b, h, q, :]   (fp32, rows of ld floats; one thread per 4 columns, fixed summation order)
+__global__ __launch_bounds__(256) void dbias_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dbias, int B, long per_entry) {
+  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= per_entry) return;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(dbias + e);
+  for (int b = 0; b < B; ++b) acc += *reinterpret_cast<const f32x4*>(ws + (long)b * per_entry + e);
+  *reinterpret_cast<f32x4*>(dbias + e) = acc;
+}
+
+int xfm_attn_bwd_impl(const AttnArgs& a_in, hipStream_t st) {
+  AttnArgs a = a_in;
+  // the workspace path stores / sums 16-byte pieces of whole bias rows: every column of a row must lie in a key chunk the kernel visits
+  if (a.dbias == nullptr || a.bias_ld % 4 != 0 || (long)cdiv(a.Sk, 64) * 64 < a.bias_ld || a.q_start != nullptr) a.dbias_ws = nullptr;
   int rc = attn_check(a, true);
   if (rc != XFM_OK) return rc;
   if (a.grp_start != nullptr) {
@@ -1950,6 +1971,9 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
   const bool short_dq = short_env && plain && a.Sk <= 64 * ATTN_RES_MAX && a.q_start == nullptr && a.k_start == nullptr &&
                         a.kv_index == nullptr && (a.bias == nullptr || a.bias_ld >= (long)cdiv(a.Sk, 16) * 16) &&
                         (a.dbias == nullptr || a.bias_ld >= a.Sk);
+  // the dQ kernel without in-register bias-gradient sums (NKC = 0) runs, and has a workspace to put each entry's dS into
+  const bool dbias_via_ws = a.bwd_phase != 2 && !short_dq && !(a.dbias != nullptr && res && plain) && a.dbias != nullptr && a.dbias_ws != nullptr;
+  if (!dbias_via_ws) a.dbias_ws = nullptr;
   if (a.bwd_phase == 2) {
     // dK/dV alone: `delta` was written by an earlier phase-1 call
   } else if (short_dq) {
@@ -1990,7 +2014,14 @@ int xfm_attn_bwd_impl(const AttnArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<0, false, false>), dim3(blocks, a.H, a.B), dim3(nw * 64), attn_lds_bytes(a.Sk, nw, 0), st, a, 1);
   }
   rc = xfm_check_launch("attn_bwd_dq");
-  if (rc != XFM_OK || a.bwd_phase == 1) return rc;
+  if (rc != XFM_OK) return rc;
+  if (dbias_via_ws) {
+    const long per_entry = (long)a.H * a.Sq * a.bias_ld;
+    hipLaunchKernelGGL(dbias_reduce_kernel, dim3(cdiv(per_entry / 4, 256)), dim3(256), 0, st, a.dbias_ws, a.dbias, a.B, per_entry);
+    rc = xfm_check_launch("dbias_reduce");
+    if (rc != XFM_OK) return rc;
+  }
+  if (a.bwd_phase == 1) return rc;
   if (short_dq && a.Sq <= 224) {  // (same preconditions as the short dQ kernel; Sq bounded by the LDS images)
     static bool attr_set = false;
     if (!attr_set) {

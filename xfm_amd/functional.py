@@ -353,6 +353,11 @@ def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, 
     a.dk, a.dk_rs = dk.data_ptr(), dk.stride(0)
     a.dv, a.dv_rs = dv.data_ptr(), dv.stride(0)
     a.delta, a.dbias = delta.data_ptr(), _ptr(dbias)
+    if dbias is not None and Sk > 256 and phase != 2 and dbias.stride(1) % 4 == 0:
+        # long sequences (the 577 / 901 tokens of the 384 / 480 px ViT): every entry's dS goes to a workspace and is summed over the
+        # batch by a second kernel instead of one float atomic per score and entry (xfm_attn_args.dbias_ws)
+        ws = workspace(B * H * Sq * dbias.stride(1) * 4, q.device)
+        a.dbias_ws = ws.data_ptr()
     check(_lib.load().xfm_attn_bwd(ctypes.byref(a), _stream()), "attn_bwd")
     return delta
 
