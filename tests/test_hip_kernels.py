@@ -131,7 +131,8 @@ def test_gemm_nt_persistent_tiles_every_epilogue(M, N, K):
                                            (960, 1000, 768, 0),
                                            (4100, 768, 768, 2), (12608, 2304, 768, 5), (5003, 520, 136, 0), (12608, 768, 768, 0), (960, 1000, 136, 1),
                                            (1920, 768, 768, -3), (64, 256, 256, -3), (12608, 2304, 768, -3), (25216, 768, 3072, 0),
-                                           (7680, 3072, 768, 0), (12608, 768, 768, -4)])
+                                           (7680, 3072, 768, 0), (12608, 768, 768, -4),
+                                           (8250, 768, 3072, 0), (21624, 2304, 768, 0)])   # ragged M: 256 x 256 kernel on M - M % 64 rows + a tail call
 def test_gemm_tn_wgrad_accumulates(M, N, K, splits):
     Fx = _fx()
     dy, x = _rand((M, N), seed=10), _rand((M, K), seed=11)

@@ -1417,7 +1417,8 @@ static int tn128_plan(int M, int N, int K, int splits_hint, int& splits, int& mp
   splits = splits_hint < 0 ? 0 : splits_hint;
   if (splits <= 0) {
     splits = (432 + tiles / 2) / tiles;        // measured optimum: ~432 workgroups in total (tools/tune_gemm.py)
-    const int max_splits = M / 480;            // ... while every split still walks >= ~8 K-steps
+    int max_splits = M / 480;                  // ... while every split still walks >= ~8 K-steps
+    if (max_splits < 2 && M >= 640) max_splits = 2;  // (M = 928, the VQA / retrieval text rows: two splits 15-24 us, one 25-33 us)
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
   }
@@ -1428,9 +1429,20 @@ static int tn128_plan(int M, int N, int K, int splits_hint, int& splits, int& mp
 
 // Workspace (bytes) xfm_gemm_tn wants for this shape with splits_hint = 0: the split partials of whichever kernel the
 // heuristic picks (0 when a single split writes dW directly).
+// Ragged M on an otherwise 256-tileable problem (the 577 / 901-token ViT of the 384 / 480 px configurations: M = B * tokens is no
+// multiple of 64): the leading rows run on the 256 x 256 kernel and the last M % 64 rows as a second, single-split call that adds
+// into dW -- the 128 x 128 ring kernel on all of M costs 30-40 % more (591 vs 900+ TFLOP/s at M = 21624).
+static int tn256_body_rows(int M, int N, int K) {
+  const int M0 = M - M % 64;
+  if (M % 64 == 0 || M0 < 4096 || N % 256 != 0 || K % 256 != 0) return 0;
+  int splits, mps;
+  return tn256_plan(M0, N, K, splits, mps) >= 18 ? M0 : 0;
+}
+
 long xfm_gemm_tn_workspace_impl(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   int splits, mps;
+  if (const int M0 = tn256_body_rows(M, N, K)) return xfm_gemm_tn_workspace_impl(M0, N, K);
   if (tn256_eligible(N, K, M, N, K)) {
     const int t256 = tn256_plan(M, N, K, splits, mps);
     if (t256 >= 18 && M >= 4096) return (long)splits * N * K * 4;
@@ -1448,6 +1460,16 @@ int xfm_gemm_tn_impl(const void* dY, long ldy, const void* X, long ldx, float* d
   // Split partials go to the caller's workspace with plain coalesced stores and are summed by a reduce kernel: fp32 atomics
   // into dW run at ~0.8 TB/s on this part (28 MB of them cost more than the MFMA loop of a mid-size wgrad).  A single
   // split updates dW with plain read-modify-writes.  Atomics remain only when splits > 1 and no workspace was passed.
+  if (splits_hint == 0) {
+    if (const int M0 = tn256_body_rows(M, N, K)) {
+      if (tn256_eligible(ldy, ldx, M0, N, K) && workspace != nullptr && workspace_bytes >= xfm_gemm_tn_workspace_impl(M0, N, K)) {
+        int rc = xfm_gemm_tn_impl(dY, ldy, X, ldx, dW, ldw, dbias, M0, N, K, 0, workspace, workspace_bytes, st);
+        if (rc != XFM_OK) return rc;
+        return xfm_gemm_tn_impl((const bf16*)dY + (long)M0 * ldy, ldy, (const bf16*)X + (long)M0 * ldx, ldx, dW, ldw, dbias, M - M0, N, K, 1,
+                                workspace, workspace_bytes, st);
+      }
+    }
+  }
   // 256 x 256 phase-pipelined kernel: shapes without edges and with enough output tiles (splits_hint -3 forces, -4 forbids).
   if (tn256_eligible(ldy, ldx, M, N, K) && splits_hint != -4) {
     int splits, mps;
