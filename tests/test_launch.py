@@ -66,6 +66,7 @@ def test_bench_bare_multi_gpu_invocation_starts_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True, timeout=300)
-    assert "### launch:" in r.stdout and "--nproc-per-node=2" in r.stdout
+    assert "### launch:" in r.stderr and "--nproc-per-node=2" in r.stderr   # (on stderr: stdout is rank 0's one JSON line)
+    assert "### launch:" not in r.stdout
     assert r.returncode != 0
     assert "bench.py needs a GPU" in (r.stdout + r.stderr)

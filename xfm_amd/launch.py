@@ -71,5 +71,5 @@ def launch(script, script_args, nproc, master_port=None, env=None, visible_devic
         e["CUDA_VISIBLE_DEVICES"] = visible_devices
     if env:
         e.update(env)
-    print("### launch:", " ".join(cmd), flush=True)
+    print("### launch:", " ".join(cmd), file=sys.stderr, flush=True)   # stderr: a caller's stdout may be a one-line JSON contract (bench.py)
     return subprocess.call(cmd, env=e)
