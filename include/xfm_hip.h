@@ -28,7 +28,7 @@ extern "C" {
 #define XFM_E_LAUNCH (-2)
 #define XFM_E_UNSUPPORTED (-3)
 
-#define XFM_ABI_VERSION 5
+#define XFM_ABI_VERSION 6
 
 const char* xfm_last_error(void);
 int xfm_abi_version(void);
@@ -49,6 +49,16 @@ int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* 
  * configuration (the tile_hint numbering), *rows_a > 0 = tail split: the leading rows_a rows run as whole rounds of 256x256 tiles
  * (configuration 5), the remaining rows are planned again with tile_hint -1. */
 int xfm_gemm_nt_plan(int M, int N, int K, int epilogue, int tile_hint, int* cfg, int* rows_a);
+
+/* out[M,N] = A[M,K] . B[N,K]^T (+ bias) for a very long K against few output tiles -- the activation gradient of the vocabulary
+ * projection (RobertaLMHead.decoder, xroberta.py:1325-1333; BertLMPredictionHead.decoder, xbert.py:680-697: K = the padded vocabulary).
+ * K is sliced over the grid; the slices' fp32 partial planes go to `workspace` (xfm_gemm_nt_ksplit_workspace bytes; 0 = the shape
+ * runs unsliced and needs none) and are summed in slice order by a second kernel that rounds once to the output type
+ * (out_bf16 != 0: bf16, else fp32): bit-reproducible, unlike the fp32-atomic merge of XFM_EPI_F32_ACC.  Sliced shapes need
+ * N % 8 == 0 and ldo % 8 == 0. */
+long xfm_gemm_nt_ksplit_workspace(int M, int N, int K);
+int xfm_gemm_nt_ksplit(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* out, long ldo, int out_bf16, const float* bias,
+                       int M, int N, int K, float* workspace, long workspace_bytes, void* stream);
 
 /* dW[N,K] (fp32) += dY[M,N]^T . X[M,K]   (weight gradient, split over M).
  * dbias (optional, fp32 [N]) += column sums of dY: the bias gradient rides along in the same pass over dY.

@@ -101,3 +101,28 @@ def test_register_bound_kernels_keep_their_budgets():
             seen += 1
             assert u["scratch"] <= 16, (name, u)
     assert seen >= 26, sorted(use)[:20]
+
+
+def test_persistent_gemm_epilogue_issues_the_stores_its_wait_counts_assume():
+    """gemm_nt_256_kernel<EPI, PERSIST, D> retires the next tile's first staging units with `s_waitcnt vmcnt(6 + NS)`: the 2 D
+    staging loads are OLDER than the NS output stores of an interior tile, so the wait is only sufficient if the compiler really
+    issues >= NS store instructions per lane on that path (fewer -- merged or dropped stores -- and a wave would read a ring slot
+    whose direct-to-LDS load has not landed; more are harmless, the wait only gets stricter).  Pinned here from the gfx950 ISA:
+    the full-width path of every instantiation holds exactly NS `global_store_dwordx4` (16: bf16 / GELU-dgrad; 32: fp32 and
+    GELU + gelu'), the ragged-edge path stores element-wise with narrower instructions."""
+    import re
+    from xfm_amd import build
+    isa = build.kernel_isa()
+    want = {0: 16, 1: 32, 2: 32, 3: 16}   # EPI_BF16, EPI_F32, EPI_GELU, EPI_DGELU (EPI_F32_ACC waits without the allowance)
+    seen = 0
+    for name, body in isa.items():
+        m = re.match(r"_Z18gemm_nt_256_kernelILi(\d)ELb([01])ELi(\d)EE", name)
+        if not m or int(m.group(1)) not in want:
+            continue
+        seen += 1
+        x4 = sum(1 for l in body if l.startswith("global_store_dwordx4"))
+        assert x4 == want[int(m.group(1))], (name, x4)
+        if m.group(2) == "1":   # the allowance itself: vmcnt(6 + NS) is in the persistent instantiation's code
+            assert any(re.search(r"s_waitcnt vmcnt\(%d\)" % (6 + want[int(m.group(1))]), l) for l in body), name
+    assert seen == 16, seen
+

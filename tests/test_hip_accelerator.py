@@ -266,14 +266,15 @@ def test_collectives_through_rccl_in_a_group_of_one():
     assert "AVG" in out["op"]
     assert out["identity_fp32"]["ranges"] >= 15 and out["identity_fp32"]["bad"] == 0, out["identity_fp32"]
     assert out["identity_bf16"]["ranges"] >= 15 and out["identity_bf16"]["bad"] == 0, out["identity_bf16"]
-    # two runs of the same step differ by the float atomics of the small weight-gradient path: 1e-9 as a rule, 1.1e-3 seen once in
-    # ~20 runs (the run WITHOUT collectives was the odd one); a collective that mixed up ranges or scaling would show as O(1).  The
-    # bit-exact statement is the snapshot identity above.
-    assert out["first_step_grad_rel_l2_vs_no_collectives"] < 5e-3, out
+    # two runs of the same step differ by the float atomics of the small weight-gradient path only: 1e-8 of the gradient norm.  (Round
+    # 3 saw 1.1e-3 once in ~20 runs: the LM-head activation gradient was summed over its K-slices with fp32 atomics and then rounded
+    # to bf16 -- a rounding flip of one element that the backward below it amplified.  That sum is in a fixed order now,
+    # xfm_gemm_nt_ksplit; tools/cold_probe.py localised it.)  The worker prints the per-parameter table when this is exceeded.
+    assert out["first_step_grad_rel_l2_vs_no_collectives"] < 1e-6, (out, r.stdout[-6000:])
     # from the step after the live set is agreed, ranges leave for the all-reduce from INSIDE backward (tower hooks + ViT chunks)
     s3 = out["stats_fp32"][2]
     assert s3["overlapped_ranges"] >= 3 and s3["overlapped_bytes"] > 0.5 * s3["exchange_bytes"], s3
     assert s3["exchange_bytes"] == 4 * out["live_elems"], (s3, out["live_elems"])   # every live element exactly once, fp32
     assert out["stats_bf16"][2]["exchange_bytes"] == 2 * out["live_elems"]
     # bf16 wire format: one rounding of each exchanged gradient
-    assert out["first_step_grad_rel_l2_bf16_wire"] < 8e-3 and out["param_rel_l2_after_3_steps"] < 1e-2, out
+    assert out["first_step_grad_rel_l2_bf16_wire"] < 4e-3 and out["param_rel_l2_after_3_steps"] < 1e-2, out

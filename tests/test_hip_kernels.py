@@ -782,6 +782,31 @@ def test_gemm_nt_split_k_accumulate():
     _close(c, ref, 1e-4, "split-K fp32 accumulate")
 
 
+@pytest.mark.parametrize("M,N,K", [(960, 768, 50304), (60, 768, 50304), (225, 768, 30528), (960, 768, 4096)])
+def test_gemm_nt_ksplit_is_exact_and_reproducible(M, N, K):
+    """The LM-head activation gradient (xroberta.py:1325-1333): K sliced over the grid, partial planes summed in slice order.  Values
+    vs fp32 math (bf16 and fp32 outputs, with and without a bias), and -- the point of it -- the same bits on every launch: the
+    atomics merge it replaced changed the last bits of the sum from run to run, which the bf16 rounding that follows turns into
+    whole-ulp differences of an activation gradient (tools/cold_probe.py).  (960, 768, 4096) takes the unsliced plan."""
+    Fx = _fx()
+    a, b = _rand((M, K), 0.05, seed=41), _rand((N, K), 0.05, seed=42)
+    bias = _rand((N,), 0.5, F32, seed=43)
+    ref = a.float() @ b.float().t()
+    o32 = Fx.gemm_nt_ksplit(a, b, out_dtype=F32)
+    _close(o32, ref, 1e-4, "k-sliced fp32")
+    _close(Fx.gemm_nt_ksplit(a, b, bias=bias, out_dtype=F32), ref + bias, 1e-4, "k-sliced fp32 + bias")
+    o16 = Fx.gemm_nt_ksplit(a, b)
+    assert o16.dtype == BF16
+    if Fx._lib.load().xfm_gemm_nt_ksplit_workspace(M, N, K) > 0:   # sliced: ONE rounding of the fp32 sum
+        assert torch.equal(o16, o32.to(BF16))
+    else:
+        _close(o16, ref, 1e-2, "unsliced bf16")
+    for _ in range(5):
+        junk = torch.empty(64 << 20, dtype=torch.uint8, device="cuda").random_(0, 255)   # other traffic between the launches
+        del junk
+        assert torch.equal(Fx.gemm_nt_ksplit(a, b), o16) and torch.equal(Fx.gemm_nt_ksplit(a, b, out_dtype=F32), o32)
+
+
 # ---- contrastive / matching glue (xfm.py:614-621, 683-746) ---------------------------------------------------------------------
 @pytest.mark.parametrize("R,E", [(64, 256), (7, 768), (300, 64)])
 def test_rownorm_matches_normalize(R, E):

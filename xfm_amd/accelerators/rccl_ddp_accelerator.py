@@ -126,9 +126,10 @@ class RCCLDDPAccelerator(Accelerator):
         if world_size > 1 and not dist.is_initialized():
             dist.init_process_group(backend="nccl" if use_cuda else "gloo", world_size=world_size, rank=rank)
         self._dist = world_size > 1 or (self.force and dist.is_available() and dist.is_initialized())
-        if self.force and self._dist:
-            from .. import xfm as _xfm
-            _xfm.FORCE_COLLECTIVES = True
+        # (module-level switch of xfm.allgather, set to THIS accelerator's choice at every set_up: a forced run must not leave
+        # later models of the process gathering in a group of one)
+        from .. import xfm as _xfm
+        _xfm.FORCE_COLLECTIVES = bool(self.force and self._dist)
         # RCCL averages in the collective itself (no extra pass over the 1.4 GB of live gradients)
         self._op = dist.ReduceOp.AVG if (self._dist and dist.get_backend() == "nccl") else dist.ReduceOp.SUM
         if hasattr(model, "finalize"):

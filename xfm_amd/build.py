@@ -39,20 +39,37 @@ def build(force=False, verbose=False):
     return LIB
 
 
+_DEVICE_COMPILE = {}
+
+
+def _device_compile():
+    """One device-only compile to assembly with -Rpass-analysis=kernel-resource-usage (no GPU needed) -> (remarks, assembly text);
+    cached for the process (40 s)."""
+    if "asm" not in _DEVICE_COMPILE:
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, "xfm.s")
+            cmd = [_hipcc()] + FLAGS + ["-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, "capi.hip"),
+                                        "-o", out]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+            _DEVICE_COMPILE["remarks"] = r.stderr
+            with open(out) as f:
+                _DEVICE_COMPILE["asm"] = f.read()
+    return _DEVICE_COMPILE["remarks"], _DEVICE_COMPILE["asm"]
+
+
 def resource_usage():
     """{kernel symbol: {"vgprs": n, "agprs": n, "spill": n, "scratch": bytes per lane, "lds": bytes}} from a device-only compile with
     -Rpass-analysis=kernel-resource-usage (no GPU needed): the register-bound kernels (256 x 256 GEMM tiles: two waves per SIMD,
     <= 256 VGPRs, no scratch) are held to their budgets by tests/test_capi.py."""
     import re
-    cmd = [_hipcc()] + FLAGS + ["-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, "capi.hip"),
-                                "-o", os.devnull]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    remarks, _ = _device_compile()
     out, cur = {}, None
     keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "VGPRs Spill": "spill", "ScratchSize [bytes/lane]": "scratch", "LDS Size [bytes/block]": "lds",
             "SGPRs Spill": "sgpr_spill"}
-    for line in r.stderr.splitlines():
+    for line in remarks.splitlines():
         m = re.search(r"remark: +Function Name: (\S+)", line)
         if m:
             cur = out.setdefault(m.group(1), {})
@@ -60,6 +77,26 @@ def resource_usage():
         m = re.search(r"remark: +([A-Za-z \[\]/]+): (\d+)", line)
         if m and cur is not None and m.group(1).strip() in keys:
             cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return out
+
+
+def kernel_isa():
+    """{kernel symbol: [instruction lines]} of the gfx950 code (same compile as resource_usage): what tests/test_capi.py reads to pin
+    the instruction counts that the counted `s_waitcnt vmcnt` schedules depend on."""
+    import re
+    _, asm = _device_compile()
+    out, cur = {}, None
+    for line in asm.splitlines():
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = out.setdefault(m.group(1), [])
+            continue
+        if line.startswith(".Lfunc_end"):
+            cur = None
+        elif cur is not None:
+            s = line.strip()
+            if s and not s.startswith((";", ".")) :
+                cur.append(s)
     return out
 
 

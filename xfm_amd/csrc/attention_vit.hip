@@ -271,13 +271,18 @@ static bool attn_vit_shape(const AttnArgs& a) {
   static const bool on = getenv("XFM_ATTN_VIT") ? atoi(getenv("XFM_ATTN_VIT")) != 0 : true;  // A/B knob: 0 = the general kernels
   return on && a.Sq == a.Sk && a.Sq > 64 && a.Sq <= 16 * VF_MAXT && a.key_keep == nullptr && a.causal == 0 && a.drop_thresh == 0u &&
          a.q_start == nullptr && a.k_start == nullptr && a.kv_index == nullptr && a.grp_start == nullptr &&
-         (a.bias == nullptr || a.bias_ld >= (long)cdiv(a.Sk, 16) * 16) && ((uintptr_t)a.bias % 16) == 0;
+         (a.bias == nullptr || (a.bias_ld >= (long)cdiv(a.Sk, 16) * 16 && a.bias_ld % 4 == 0)) &&  // (untiled bias rows are read 16 B at a time)
+         ((uintptr_t)a.bias % 16) == 0;
 }
 
-// (template instantiation + the one-time dynamic-LDS attribute of a kernel)
-template <typename K>
+// (template instantiation + the one-time dynamic-LDS attribute of a kernel: TAG makes one guard per kernel instantiation)
+template <int TAG, typename K>
 static void vit_launch(K kernel, int lds, dim3 grid, dim3 blk, hipStream_t st, const AttnArgs& a, const VitMap& vm) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(kernel, grid, blk, lds, st, a, vm);
 }
 
@@ -286,14 +291,14 @@ static int launch_attn_fwd_vit(const AttnArgs& a, hipStream_t st) {
   const dim3 grid(vm.grid), blk(VF_NW * 64);
   const bool k13 = cdiv(a.Sq, 16) == 13;
   if (a.bias == nullptr) {
-    if (k13) vit_launch(attn_fwd_vit_kernel<false, 13, false>, VF_LDS, grid, blk, st, a, vm);
-    else vit_launch(attn_fwd_vit_kernel<false, 0, false>, VF_LDS, grid, blk, st, a, vm);
+    if (k13) vit_launch<1>(attn_fwd_vit_kernel<false, 13, false>, VF_LDS, grid, blk, st, a, vm);
+    else vit_launch<2>(attn_fwd_vit_kernel<false, 0, false>, VF_LDS, grid, blk, st, a, vm);
   } else if (a.bias_tiled != nullptr) {
-    if (k13) vit_launch(attn_fwd_vit_kernel<true, 13, true>, VF_LDS, grid, blk, st, a, vm);
-    else vit_launch(attn_fwd_vit_kernel<true, 0, true>, VF_LDS, grid, blk, st, a, vm);
+    if (k13) vit_launch<3>(attn_fwd_vit_kernel<true, 13, true>, VF_LDS, grid, blk, st, a, vm);
+    else vit_launch<4>(attn_fwd_vit_kernel<true, 0, true>, VF_LDS, grid, blk, st, a, vm);
   } else {
-    if (k13) vit_launch(attn_fwd_vit_kernel<true, 13, false>, VF_LDS, grid, blk, st, a, vm);
-    else vit_launch(attn_fwd_vit_kernel<true, 0, false>, VF_LDS, grid, blk, st, a, vm);
+    if (k13) vit_launch<5>(attn_fwd_vit_kernel<true, 13, false>, VF_LDS, grid, blk, st, a, vm);
+    else vit_launch<6>(attn_fwd_vit_kernel<true, 0, false>, VF_LDS, grid, blk, st, a, vm);
   }
   return xfm_check_launch("attn_fwd_vit");
 }
@@ -665,7 +670,7 @@ static bool attn_vit3_shape(const AttnArgs& a) {
 
 static int launch_attn_bwd_vit3(const AttnArgs& a, hipStream_t st) {
   const VitMap vm = vit_map(a.B, a.H);
-  if (a.bias != nullptr) vit_launch(attn_bwd_vit3_kernel<true>, V3_LDS, dim3(vm.grid), dim3(512), st, a, vm);
-  else vit_launch(attn_bwd_vit3_kernel<false>, V3_LDS, dim3(vm.grid), dim3(512), st, a, vm);
+  if (a.bias != nullptr) vit_launch<7>(attn_bwd_vit3_kernel<true>, V3_LDS, dim3(vm.grid), dim3(512), st, a, vm);
+  else vit_launch<8>(attn_bwd_vit3_kernel<false>, V3_LDS, dim3(vm.grid), dim3(512), st, a, vm);
   return xfm_check_launch("attn_bwd_vit3");
 }

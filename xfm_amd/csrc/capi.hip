@@ -54,6 +54,12 @@ int xfm_gemm_nt(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* 
 int xfm_gemm_nt_plan(int M, int N, int K, int epilogue, int tile_hint, int* cfg, int* rows_a) {
   return xfm_gemm_nt_plan_impl(M, N, K, epilogue, tile_hint, cfg, rows_a);
 }
+long xfm_gemm_nt_ksplit_workspace(int M, int N, int K) { return xfm_gemm_nt_ksplit_workspace_impl(M, N, K); }
+int xfm_gemm_nt_ksplit(const xfm_bf16* A, long lda, const xfm_bf16* B, long ldb, void* out, long ldo, int out_bf16, const float* bias, int M,
+                       int N, int K, float* workspace, long workspace_bytes, void* stream) {
+  XFM_REQUIRE(A && B && out, "gemm_nt_ksplit: null operand");
+  return xfm_gemm_nt_ksplit_impl(A, lda, B, ldb, out, ldo, out_bf16, bias, M, N, K, workspace, workspace_bytes, ST(stream));
+}
 long xfm_gemm_tn_workspace(int M, int N, int K) { return xfm_gemm_tn_workspace_impl(M, N, K); }
 
 int xfm_gemm_tn(const xfm_bf16* dY, long ldy, const xfm_bf16* X, long ldx, float* dW, long ldw, float* dbias, int M, int N,

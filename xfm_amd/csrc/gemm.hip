@@ -35,6 +35,7 @@ struct GemmNT {
   int group_m;  // row-panels per tile group (L2 locality of the block order)
   int k_splits; // small-tile kernels, EPI_F32_ACC only: gridDim.y K-slices, fp32 atomics into C (1 = off)
   int k_rot;    // 256 x 256 kernel: column phases of the K rotation (0 / 1 = every tile starts at K-tile 0)
+  long split_stride;  // EPI_F32 with k_splits > 1: K-slice y stores its partial tile to C + y * split_stride (elements), plain stores
 };
 
 // LDS swizzles (16-B chunk index XOR) for 128-B tile rows read with ds_read_b128.
@@ -82,6 +83,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNT& g, f32x4 (&acc)[MT][
 #pragma unroll
       for (int i = 0; i < 8; ++i) bv[i] = (g.bias != nullptr && nb + i < g.N) ? g.bias[nb + i] : 0.f;
     }
+    if (EPI == EPI_F32 && g.k_splits > 1 && blockIdx.y != 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bv[i] = 0.f;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = m_base + mt * 16 + lr;
@@ -95,6 +100,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNT& g, f32x4 (&acc)[MT][
       const bool full = (nb + 8 <= g.N) && vec_c;
       if (EPI == EPI_F32 || EPI == EPI_F32_ACC) {
         float* cp = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + nb;
+        if (EPI == EPI_F32 && g.k_splits > 1) {  // K-slices leave as separate planes, summed in a fixed order by ksplit_reduce_kernel
+          cp += (long)blockIdx.y * g.split_stride;  // (slice 0 carries the bias: bv is zero on the others)
+        }
         if (EPI == EPI_F32_ACC && g.k_splits > 1) {  // K-slices meet in C through fp32 atomics; slice 0 carried the bias
           for (int i = 0; i < 8; ++i)
             if (nb + i < g.N) atomicAdd(cp + i, v[i] - (blockIdx.y == 0 ? 0.f : bv[i]));
@@ -805,7 +813,7 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
   XFM_REQUIRE((epi != EPI_GELU && epi != EPI_DGELU) || aux != nullptr, "gemm_nt: epilogue %d needs aux", epi);
   static const int gm_env = getenv("XFM_GEMM_GROUP_M") ? atoi(getenv("XFM_GEMM_GROUP_M")) : 0;  // tuning knob
   static const int rot_env = getenv("XFM_GEMM_KROT") ? atoi(getenv("XFM_GEMM_KROT")) : 0;  // tuning knob (measured neutral)
-  GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K, gm_env > 0 ? gm_env : 8, 1, rot_env};
+  GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, ldaux, M, N, K, gm_env > 0 ? gm_env : 8, 1, rot_env, 0};
   int rows_a = 0, k_splits = 1;
   const int cfg = nt_plan(M, N, K, epi, tile_hint, &rows_a, &k_splits);
   if (rows_a > 0) {  // tail split: whole rounds of 256x256 tiles first, the remaining rows on the small-tile kernels
@@ -829,6 +837,80 @@ int xfm_gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, 
     case 5: return launch_nt_256(g, epi, st);
     default: return launch_nt<64, 64, 2>(g, epi, st);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deterministic K-sliced C = A . B^T for a very long K against few output tiles (the LM-head dgrad of xroberta.py:1325-1333 /
+// xbert.py:680-697: K = the padded vocabulary, 50304, against a [rows, 768] output).  The slices of gridDim.y write fp32 partial
+// planes to a workspace with plain stores and ksplit_reduce_kernel sums them IN SLICE ORDER, rounding once to the output type.
+// Why not the fp32-atomic merge of EPI_F32_ACC (round 1-3): the order of the atomic adds changes the last bits of the sum from run
+// to run, the sum is an ACTIVATION gradient that is rounded to bf16 next, and an element that sits on a rounding boundary then comes
+// out one bf16 ulp apart -- a 2e-5 perturbation that the remaining backward (bf16 roundings at every layer) amplifies to 1e-3 of the
+// gradient norm (tools/cold_probe.py: 2 of 28 cold runs, both landing on the same second value).  Atomics stay where their sum is a
+// final fp32 parameter gradient.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float* __restrict__ ws, int slices, long plane, int M, int N, void* __restrict__ out,
+                                                            long ldo, int out_bf16) {
+  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 8;  // 8 consecutive columns of one row (N % 8 == 0)
+  if (e >= (long)M * N) return;
+  const int m = (int)(e / N), n = (int)(e - (long)m * N);
+  f32x4 a0 = *reinterpret_cast<const f32x4*>(ws + e), a1 = *reinterpret_cast<const f32x4*>(ws + e + 4);
+  for (int s = 1; s < slices; ++s) {
+    a0 += *reinterpret_cast<const f32x4*>(ws + (long)s * plane + e);
+    a1 += *reinterpret_cast<const f32x4*>(ws + (long)s * plane + e + 4);
+  }
+  if (out_bf16) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = f2bf(a0[i]); o[4 + i] = f2bf(a1[i]); }
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(out) + (long)m * ldo + n) = o;
+  } else {
+    float* op = reinterpret_cast<float*>(out) + (long)m * ldo + n;
+    *reinterpret_cast<f32x4*>(op) = a0;
+    *reinterpret_cast<f32x4*>(op + 4) = a1;
+  }
+}
+
+// K-slices for a shape (1 = the plain kernels are the better plan) and the K-tiles per slice
+static int ksplit_plan(int M, int N, int K, int* nk_per_out) {
+  const long t = (long)cdiv(M, 64) * cdiv(N, 128);
+  int sp = 1;
+  if (K >= 8192 && t < 192) {
+    sp = (int)(512 / t);
+    if (sp > K / 1024) sp = K / 1024;
+    if (sp < 1) sp = 1;
+  }
+  const int nk_all = K / 64, nk_per = cdiv(nk_all, sp);
+  *nk_per_out = nk_per;
+  return cdiv(nk_all, nk_per);  // slices that own at least one K-tile
+}
+
+long xfm_gemm_nt_ksplit_workspace_impl(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int nk_per;
+  const int slices = ksplit_plan(M, N, K, &nk_per);
+  return slices > 1 ? (long)slices * M * N * 4 : 0;
+}
+
+int xfm_gemm_nt_ksplit_impl(const void* A, long lda, const void* B, long ldb, void* out, long ldo, int out_bf16, const float* bias, int M, int N,
+                            int K, float* ws, long ws_bytes, hipStream_t st) {
+  XFM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_nt_ksplit: bad shape M=%d N=%d K=%d", M, N, K);
+  int nk_per;
+  const int slices = ksplit_plan(M, N, K, &nk_per);
+  if (slices <= 1) return xfm_gemm_nt_impl(A, lda, B, ldb, out, ldo, bias, nullptr, 0, M, N, K, out_bf16 ? EPI_BF16 : EPI_F32, 0, st);
+  XFM_REQUIRE(N % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)out % 16) == 0, "gemm_nt_ksplit: N=%d, ldo=%ld must be multiples of 8 and out 16-byte aligned", N, ldo);
+  XFM_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_nt_ksplit: operands must be 16-byte aligned rows");
+  XFM_REQUIRE(ws != nullptr && ((uintptr_t)ws % 16) == 0 && ws_bytes >= (long)slices * M * N * 4,
+              "gemm_nt_ksplit: workspace of %ld bytes needed (xfm_gemm_nt_ksplit_workspace)", (long)slices * M * N * 4);
+  static const int gm_env = getenv("XFM_GEMM_GROUP_M") ? atoi(getenv("XFM_GEMM_GROUP_M")) : 0;
+  GemmNT g{(const bf16*)A, lda, (const bf16*)B, ldb, ws, (long)N, bias, nullptr, 0, M, N, K, gm_env > 0 ? gm_env : 8, slices, 0, (long)M * N};
+  // k_splits = the slices that own K-tiles; the kernel re-derives nk_per = ceil(nk_all / k_splits) <= the planned one, under which
+  // exactly those slices stay non-empty, so every plane of the workspace is written in full
+  XFM_REQUIRE(cdiv(K / 64, cdiv(K / 64, slices)) == slices, "gemm_nt_ksplit: slice plan mismatch");
+  int rc = launch_nt<64, 128, 3>(g, EPI_F32, st);
+  if (rc != XFM_OK) return rc;
+  hipLaunchKernelGGL(ksplit_reduce_kernel, dim3(cdiv((long)M * N / 8, 256)), dim3(256), 0, st, ws, slices, (long)M * N, M, N, out, ldo, out_bf16);
+  return xfm_check_launch("ksplit_reduce");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -72,6 +72,23 @@ def gemm_nt(a, b, bias=None, epi=EPI_BF16, aux=None, out=None, n=None, tile_hint
     return (out, aux) if epi == EPI_GELU else out
 
 
+def gemm_nt_ksplit(a, b, n=None, bias=None, out_dtype=BF16):
+    """out[M,N] = a[M,K] @ b[N(,pad),K]^T (+ bias) with K sliced over the grid and the slices summed in a FIXED order (bit-reproducible;
+    the LM-head activation gradient: K = the padded vocabulary).  Returns a new bf16 / fp32 tensor."""
+    _dev(a)
+    assert a.dtype == BF16 and b.dtype == BF16 and a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0] if n is None else n
+    assert b.shape[1] == K, (a.shape, b.shape)
+    lib = _lib.load()
+    out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    need = lib.xfm_gemm_nt_ksplit_workspace(M, N, K)
+    ws = workspace(need, a.device) if need > 0 else None
+    check(lib.xfm_gemm_nt_ksplit(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), int(out_dtype == BF16),
+                                 _ptr(bias), M, N, K, _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream()), "gemm_nt_ksplit")
+    return out
+
+
 def gemm_tn(dy, x, dw, n=None, splits=0, dbias=None):
     """dw[N,K] (fp32) += dy[M,N]^T @ x[M,K]; optionally dbias[N] (fp32) += dy.sum(0) in the same pass."""
     _dev(dy)

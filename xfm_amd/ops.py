@@ -214,11 +214,10 @@ class _LMHeadCEFn(torch.autograd.Function):
             scale = (g / nvalid if ctx.reduction == "mean" else g).reshape(1).to(F32).contiguous()
         dlogits = Fx.ce_bwd(logits, V, labels, lse, scale, logits.shape[1])
         Fx.gemm_tn(dlogits, y, sv.dw, n=V, dbias=sv.db)
-        # dgrad of the vocabulary projection: K = 50304 against a 960 x 768 output -- the fp32-accumulate epilogue lets the
-        # launcher slice K over the grid (atomics into a zeroed fp32 buffer) instead of 90 workgroups walking 786 K-tiles each
-        dy32 = torch.zeros((dlogits.shape[0], sv.K), dtype=F32, device=dlogits.device)
-        Fx.gemm_nt(dlogits, sv.wt, epi=Fx.EPI_F32_ACC, out=dy32, n=sv.K)
-        dy = dy32.to(BF16)
+        # dgrad of the vocabulary projection: K = 50304 against a 960 x 768 output -- K is sliced over the grid instead of 90 workgroups
+        # walking 786 K-tiles each, and the slices are summed in a fixed order (xfm_gemm_nt_ksplit): this activation gradient is rounded
+        # to bf16 right here, so an order-dependent sum (fp32 atomics, rounds 1-3) made the whole backward below it bimodal
+        dy = Fx.gemm_nt_ksplit(dlogits, sv.wt, n=sv.K)
         dhact = torch.empty_like(hact)
         ln = head.layer_norm
         Fx.ln_bwd(dy, hact, mean, rstd, ln.weight, grad_view(ln.weight), grad_view(ln.bias), dx16=dhact)

@@ -449,13 +449,9 @@ class XFMBase(nn.Module):
             sim_i2t = image_feat @ text_feat.t() / self.temp
             weights_i2t = F.softmax(sim_i2t, dim=1) + 1e-5
             weights_t2i = F.softmax(sim_i2t.t(), dim=1) + 1e-5
-            if idx is None:
-                weights_i2t.fill_diagonal_(0)
-                weights_t2i.fill_diagonal_(0)
-            else:
-                mask = torch.eq(idx.view(-1, 1), idx.view(1, -1))
-                weights_i2t.masked_fill_(mask, 0)
-                weights_t2i.masked_fill_(mask, 0)
+            mask = torch.eq(idx.view(-1, 1), idx.view(1, -1))
+            weights_i2t.masked_fill_(mask, 0)
+            weights_t2i.masked_fill_(mask, 0)
             image_neg_idx = torch.multinomial(weights_t2i, 1).view(-1)
             text_neg_idx = torch.multinomial(weights_i2t, 1).view(-1)
         return image_neg_idx, text_neg_idx
