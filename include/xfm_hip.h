@@ -198,6 +198,12 @@ typedef struct {
 
 int xfm_attn_fwd(const xfm_attn_args* a, void* stream);
 int xfm_attn_bwd(const xfm_attn_args* a, void* stream);
+/* bytes of `dbias_ws` an xfm_attn_bwd call with these arguments wants (0: none).  Long dense unmasked problems with a bias gradient
+ * (Sk > 256: the 577 / 901 tokens of the 384 / 480 px ViT) sum dS over the batch inside a kernel that walks the batch entries of a
+ * slice with a 128 x 128 block of the gradient in registers; with more than one slice the per-slice sums are [slices, H, Sq, bias_ld]
+ * planes in this workspace (a few MB) that a second kernel folds into dbias in slice order.  The general kernels (masked / dropped
+ * problems) still take the [B, H, Sq, bias_ld] form described at xfm_attn_args.dbias_ws. */
+long xfm_attn_bwd_workspace(const xfm_attn_args* a);
 /* dense additive bias [H,S,ld] (fp32) -> two tiled copies, each [H][T][T][64 lanes][4] floats with T = ceil(S / 16), pre-divided by
  * `scale` (the kernels start the score accumulators from bias / scale):
  *   tiled  [h][a][b][lane][r] = bias[h][16a + (lane & 15)][16b + 4 (lane >> 4) + r] / scale        (query on the lane: forward)

@@ -441,6 +441,11 @@ def _attn_ref(q, k, v, B, H, Sq, Sk, scale, bias=None, keep=None, causal=False, 
     (2, 3, 224, 224, True, False, False),    # ... the longest query side the short dK/dV kernel takes (14 query tiles)
     (2, 2, 300, 256, True, False, False),    # ... short dQ kernel (16 key tiles) + general dK/dV kernel (Sq > 224)
     (70, 1, 33, 197, False, False, False),   # ... more batch entries than one round of workgroups: long per-workgroup loops
+    (5, 2, 577, 577, True, False, False),    # long-sequence kernels (attention_long.hip): the bias-gradient kernel walks a batch slice
+    (3, 2, 300, 700, True, False, False),    # ... Sq != Sk: 2 query blocks x 3 key blocks of 256, ragged tiles on both sides
+    (2, 3, 700, 300, True, False, False),    # ... and the other way round
+    (2, 2, 577, 577, False, False, False),   # ... without a bias
+    (9, 1, 260, 258, True, False, False),    # ... just past the short kernels' reach; nine entries in several slices
 ])
 def test_attention_fwd_bwd(B, H, Sq, Sk, use_bias, use_keep, causal):
     Fx = _fx()

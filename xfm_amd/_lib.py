@@ -128,6 +128,7 @@ SIGNATURES = {
                                   c_void_p, c_long, c_void_p]),
     "xfm_attn_fwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
     "xfm_attn_bwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
+    "xfm_attn_bwd_workspace": (c_long, [c_void_p]),
     "xfm_bias_tile": (c_int, [c_void_p, c_int, c_int, c_long, c_float, c_void_p, c_void_p, c_void_p]),
     "xfm_rows_index_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),
     "xfm_relpos_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),

@@ -181,8 +181,12 @@ class _TrunkFn(torch.autograd.Function):
                 dense, dense_t = Fx.relpos_gather(blk.attn.relative_position_bias_table, vit._index32, H, N, ld, transposed=True)
                 if 64 < N <= 224:   # the batch-walking ViT-shape kernels (csrc/attention_vit.hip) read accumulator-layout copies
                     tiles = Fx.bias_tiles(dense, N, blk.attn.scale, fwd=True, bwd=_VIT_FUSED_BWD and ctx.needs_input_grad[0])
+                elif N > 256 and ctx.needs_input_grad[0]:   # 384 / 480 px: the long-sequence backward kernels (csrc/attention_long.hip)
+                    tiles = Fx.bias_tiles(dense, N, blk.attn.scale, fwd=True, bwd=True)   # read both copies (dQ: query on the lane, dK/dV: key)
             qkv = Fx.gemm_nt(y, s["qkv"].wb, s["qkv"].b)
-            if ctx.needs_input_grad[0] and _FAST_DELTA:
+            # long sequences keep the low half of O: the backward then takes delta from dO . (O + O_lo) instead of a first pass over
+            # the keys (two of the dQ kernel's five matrix products: 355 -> 224 us per layer at 901 tokens for 24 us of forward)
+            if ctx.needs_input_grad[0] and (_FAST_DELTA or N > 256):
                 ctxv, lse, ctxv_lo = Fx.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, lo=True,
                                                  bias_tiles=tiles)
             else:
@@ -254,7 +258,7 @@ class _TrunkFn(torch.autograd.Function):
                 ddense = ddense_all[i]
             Fx.attn_bwd(dctx, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ctxv, lse, dqkv[:, :D], dqkv[:, D:2 * D],
                         dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense, bias_t=dense_t, o_lo=ctxv_lo,
-                        bias_tiles=tiles if _VIT_FUSED_BWD else None)
+                        bias_tiles=tiles if (_VIT_FUSED_BWD or N > 256) else None)
             if dense is not None:
                 Fx.relpos_scatter_sorted(ddense, vit._relpos_order, vit._relpos_start, H, N, ld, g(blk.attn.relative_position_bias_table))
             wg.gemm_tn(dqkv, y, s["qkv"].dw, dbias=s["qkv"].db)

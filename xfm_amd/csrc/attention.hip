@@ -1930,6 +1930,8 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(dbias + e) = acc;
 }
 
+#include "attention_long.hip"
+
 int xfm_attn_bwd_impl(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
   // the workspace path stores / sums 16-byte pieces of whole bias rows: every column of a row must lie in a key chunk the kernel visits
@@ -1963,6 +1965,19 @@ int xfm_attn_bwd_impl(const AttnArgs& a_in, hipStream_t st) {
     return xfm_check_launch("xattn_dkv");
   }
   if (attn_vit3_shape(a)) return launch_attn_bwd_vit3(a, st);
+  // long dense unmasked problems (577 / 901 image tokens): attention_long.hip.  The dK/dV kernel reads the transposed bias copy;
+  // without one that half stays on the general kernel.
+  const bool long_ok = attn_long_shape(a);
+  const bool long_dkv = long_ok && (a.bias == nullptr || a.bias_t != nullptr || long_tiled(a, a.bias_t_tiled));
+  if (long_ok) {
+    if (a.bwd_phase != 2) {
+      rc = launch_attn_bwd_long_dq(a, st);
+      if (rc != XFM_OK || a.bwd_phase == 1) return rc;
+    }
+    if (long_dkv) return launch_attn_bwd_long_dkv(a, st);
+    a.bwd_phase = 2;  // (fall through to the general dK/dV kernel)
+    a.dbias_ws = nullptr;
+  }
   int nw, blocks;
   attn_geom(a.Sq, nw, blocks);
   const bool res = attn_resident(a.Sk, nw);

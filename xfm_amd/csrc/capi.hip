@@ -127,6 +127,7 @@ int xfm_attn_bwd(const xfm_attn_args* a, void* stream) {
   XFM_REQUIRE(a->q && a->k && a->v && a->o && a->lse, "attn_bwd: null operand");
   return xfm_attn_bwd_impl(*a, ST(stream));
 }
+long xfm_attn_bwd_workspace(const xfm_attn_args* a) { return a == nullptr ? 0 : xfm_attn_bwd_workspace_impl(*a); }
 int xfm_rows_index_sum(const xfm_bf16* src, const int* index, int R, int U, long len, xfm_bf16* dst, void* stream) {
   XFM_REQUIRE(src && index && dst, "rows_index_sum: null operand");
   return xfm_rows_index_sum_impl(src, index, R, U, len, dst, ST(stream));

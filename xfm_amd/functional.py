@@ -370,11 +370,13 @@ def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, 
     a.dk, a.dk_rs = dk.data_ptr(), dk.stride(0)
     a.dv, a.dv_rs = dv.data_ptr(), dv.stride(0)
     a.delta, a.dbias = delta.data_ptr(), _ptr(dbias)
-    if dbias is not None and Sk > 256 and phase != 2 and dbias.stride(1) % 4 == 0:
-        # long sequences (the 577 / 901 tokens of the 384 / 480 px ViT): every entry's dS goes to a workspace and is summed over the
-        # batch by a second kernel instead of one float atomic per score and entry (xfm_attn_args.dbias_ws)
-        ws = workspace(B * H * Sq * dbias.stride(1) * 4, q.device)
-        a.dbias_ws = ws.data_ptr()
+    if dbias is not None and Sk > 256 and phase != 2:
+        # long sequences (the 577 / 901 tokens of the 384 / 480 px ViT): the library says how much scratch the bias gradient wants --
+        # a few MB of per-slice planes for the batch-walking kernel of dense unmasked problems, the [B, H, Sq, ld] per-entry dS of the
+        # general kernels otherwise (xfm_attn_bwd_workspace)
+        need = _lib.load().xfm_attn_bwd_workspace(ctypes.byref(a))
+        if need > 0:
+            a.dbias_ws = workspace(need, q.device).data_ptr()
     check(_lib.load().xfm_attn_bwd(ctypes.byref(a), _stream()), "attn_bwd")
     return delta
 
