@@ -350,15 +350,19 @@ int xfm_rlayer_bwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, const xf
  *   itc          logits = I . T^T / temp over N gathered rows; loss = (CE(logits, arange) + CE(logits^T, arange)) / 2 (xfm.py:699-703);
  *                fwd: lse [2N] (rows of logits, then rows of logits^T), loss_sum[0] += the loss; bwd: dI, dT (fully written) and
  *                dtemp[0] += for the upstream gradient g[0]
+ *                idx != NULL (int64 [N], the gathered image ids of the retrieval fine-tuning step, xfm.py:705-713): soft labels -- the
+ *                positives of row r are the rows with the same id, weight 1 / cnt_r each; fwd writes cnt [N], bwd reads it
  *   hard_neg     per row of the LOCAL batch: softmax(sim / temp) + 1e-5, own entry zeroed, ONE categorical draw (xfm.py:727-744:
- *                torch.multinomial(...).item() per row on the host there); text_neg[i] for image i, image_neg[j] for text j  -------- */
+ *                torch.multinomial(...).item() per row on the host there); text_neg[i] for image i, image_neg[j] for text j;
+ *                idx != NULL (int64 [B]): every entry with the row's image id is zeroed (xfm.py:731-734)  -------- */
 int xfm_rownorm_fwd(const float* x, int R, int E, float* y, float* inv, void* stream);
 int xfm_rownorm_bwd(const float* dy, const float* y, const float* inv, int R, int E, float* dx, void* stream);
-int xfm_itc_fwd(const float* I, const float* T, const float* temp, int N, int E, float* lse, float* loss_sum, void* stream);
+int xfm_itc_fwd(const float* I, const float* T, const float* temp, int N, int E, float* lse, float* loss_sum, const int64_t* idx,
+                float* cnt, void* stream);
 int xfm_itc_bwd(const float* I, const float* T, const float* temp, const float* lse, const float* g, int N, int E, float* dI, float* dT,
-                float* dtemp, void* stream);
+                float* dtemp, const int64_t* idx, const float* cnt, void* stream);
 int xfm_hard_negatives(const float* I, const float* T, const float* temp, int B, int E, uint64_t seed, int64_t* image_neg,
-                       int64_t* text_neg, void* stream);
+                       int64_t* text_neg, const int64_t* idx, void* stream);
 
 /* ---- Vocabulary cross-entropy, ignore_index -100 (xroberta.py:1296-1297, 1107-1114) ------------------------------ */
 int xfm_ce_fwd(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, void* stream);

@@ -851,6 +851,61 @@ def test_itc_loss_matches_two_cross_entropies(N, E, temp):
     assert abs(float(t.grad) - float(tr.grad)) <= 1e-4 * max(abs(float(tr.grad)), 1e-3)
 
 
+@pytest.mark.parametrize("N,E", [(32, 256), (7, 256), (300, 128)])
+def test_itc_loss_with_image_ids_matches_the_soft_label_form(N, E):
+    """Retrieval fine-tuning (xfm.py:705-713): captions that share an image id are each other's positives, labels = pos / pos.sum(1);
+    loss, both feature gradients and the temperature gradient against fp64 torch."""
+    from xfm_amd.ops import itc_loss
+    F = torch.nn.functional
+    I = F.normalize(_rand((N, E), 1.0, F32, seed=11), dim=-1).requires_grad_(True)
+    T = F.normalize(_rand((N, E), 1.0, F32, seed=12) + 0.5 * I.detach(), dim=-1).requires_grad_(True)
+    t = torch.tensor(0.07, device="cuda", requires_grad=True)
+    idx = torch.tensor([(i * 7) % max(N // 3, 2) for i in range(N)], device="cuda")   # ids shared by ~3 rows each
+    Ir, Tr, tr = (v.detach().double().requires_grad_(True) for v in (I, T, t))
+    loss = itc_loss(I, T, t, idx=idx)
+    logits = Ir @ Tr.t() / tr
+    pos = torch.eq(idx.view(-1, 1), idx.view(1, -1)).double()
+    labels = pos / pos.sum(1, keepdim=True)
+    ref = (-torch.sum(F.log_softmax(logits, dim=1) * labels, dim=1).mean() - torch.sum(F.log_softmax(logits.t(), dim=1) * labels, dim=1).mean()) / 2
+    (loss * 1.3).backward()
+    (ref * 1.3).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(abs(float(ref)), 1.0)
+    _close(I.grad, Ir.grad, 1e-4, "d image_feat (idx)")
+    _close(T.grad, Tr.grad, 1e-4, "d text_feat (idx)")
+    assert abs(float(t.grad) - float(tr.grad)) <= 1e-4 * max(abs(float(tr.grad)), 1e-3)
+
+
+def test_hard_negative_draws_with_image_ids_never_pick_the_same_image():
+    """xfm.py:731-734: entries of the row's own image id carry weight 0; the others follow softmax + 1e-5 (chi-square as below)."""
+    Fx = _fx()
+    F = torch.nn.functional
+    B, E, draws = 8, 256, 3000
+    I = F.normalize(_rand((B, E), 1.0, F32, seed=5), dim=-1)
+    T = F.normalize(_rand((B, E), 1.0, F32, seed=6) + 0.3 * I, dim=-1)
+    temp = torch.tensor([0.25], device="cuda")
+    idx = torch.tensor([5, 9, 5, 2, 7, 1, 9, 3], device="cuda")
+    same = torch.eq(idx.view(-1, 1), idx.view(1, -1))
+    sim = I @ T.t() / temp
+    w_i2t = (F.softmax(sim, dim=1) + 1e-5).masked_fill(same, 0)
+    w_t2i = (F.softmax(sim.t(), dim=1) + 1e-5).masked_fill(same, 0)
+    cnt_t, cnt_i = torch.zeros(B, B, device="cuda"), torch.zeros(B, B, device="cuda")
+    ar = torch.arange(B, device="cuda")
+    for s in range(draws):
+        im, tx = Fx.hard_negatives(I, T, temp, (77 << 32) | s, idx=idx)
+        cnt_i[ar, im] += 1
+        cnt_t[ar, tx] += 1
+    for cnt, w in ((cnt_t, w_i2t), (cnt_i, w_t2i)):
+        assert float(cnt[same].sum()) == 0, "a row drew an entry of its own image id"
+        p = (w / w.sum(1, keepdim=True)).double().cpu()
+        c = cnt.double().cpu()
+        for r in range(B):
+            keep = p[r] * draws >= 5
+            exp = torch.cat([p[r][keep] * draws, (p[r][~keep].sum() * draws).reshape(1)])
+            obs = torch.cat([c[r][keep], c[r][~keep].sum().reshape(1)])
+            m = exp > 0
+            assert float((((obs - exp) ** 2)[m] / exp[m]).sum()) < 40.0
+
+
 def test_hard_negative_draws_follow_the_reference_weights():
     """Frequencies of 4000 draws per row against softmax(sim / temp) + 1e-5 with the own entry zeroed (xfm.py:727-744); never the
     own index; chi-square per row at p = 1e-4 (df = B - 2) with the 1e-5 floor entries pooled."""

@@ -410,6 +410,132 @@ def gen_retrieval(B=4, res=224, T=30, name="retrieval_small"):
                                   "text_neg_idx": [int(i) for i in captured["text_neg_idx"]], "unused": unused})
 
 
+class ChunkedVision:
+    """Config-shape fixtures (B = 32 at 384 px, B = 24 at 480 px, 12-block tower): the reference's vision tower alone would hold
+    2-4 GB of fp32 activations per block for the whole batch.  Same arithmetic, bounded memory: the tower's forward is re-bound (instance
+    attribute, no reference source touched) to run `chunk` images at a time without a graph and hand the model a LEAF tensor; after the
+    model's backward, finish() re-runs each chunk with a graph and back-propagates that chunk's slice of the leaf's gradient into the
+    tower's parameters.  Gradients of a sum over images, summed in chunks."""
+
+    def __init__(self, tower, chunk=8):
+        self.tower, self.chunk, self.orig, self.calls = tower, chunk, tower.forward, []
+        tower.forward = self.forward
+
+    def forward(self, image, *a, **kw):
+        assert not a and not kw, "config-shape fixtures call the tower on the image alone"
+        with torch.no_grad():
+            outs = [self.orig(image[i:i + self.chunk]) for i in range(0, image.shape[0], self.chunk)]
+        leaf = torch.cat(outs, 0).float().requires_grad_(True)
+        self.calls.append((image, leaf))
+        return leaf
+
+    def finish(self):
+        for image, leaf in self.calls:
+            for i in range(0, image.shape[0], self.chunk):
+                out = self.orig(image[i:i + self.chunk])
+                out.backward(leaf.grad[i:i + self.chunk].to(out.dtype))
+        self.calls = []
+
+    def restore(self):
+        self.tower.forward = self.orig
+
+
+def floor_of(module, fp32, out, prefix="floor"):
+    for n, p in module.named_parameters():
+        if p.grad is None or n not in fp32:
+            continue
+        g, r = p.grad.detach().double().reshape(-1), fp32[n].reshape(-1)
+        rn = float(r.norm())
+        out[f"{prefix}/{n}"] = np.asarray([float((g - r).norm()) / max(rn, 1e-30), float((g @ r) / max(float(g.norm()) * rn, 1e-30))],
+                                          dtype=np.float32)
+
+
+def gen_retrieval_cfg(B=32, res=384, T=40, name="retrieval_cfg"):
+    """BASELINE configs[2] at its REAL shape (configs/xfm-ft/Retrieval_coco.yaml: batch 32, 384 px, 40 tokens, 12-block tower, 12 + 12
+    layers): losses, every parameter gradient (probes + moments) and the reference's own bf16-autocast floor per tensor, on the inputs
+    of tests/test_hip_configs.py::test_retrieval_step_at_config_shape_vs_oracle (same batch seed, idx pattern and given negatives)."""
+    from models.model_retrieval import XFMForRetrieval
+    ref_shim.init_single_process_group()
+    torch.manual_seed(0)
+    cfg = ref_shim.pretrain_config(text_layers=12, fusion_layers=12, overrides={"image_res": res, "max_tokens": T, "max_words": T})
+    m = XFMForRetrieval(cfg)
+    load_formula(m)
+    m.eval()
+    b = syn.pretrain_batch(B, seed=384, image_res=res, max_tokens=T)
+    idx = torch.tensor([i if i % 8 else max(i - 1, 0) for i in range(B)])
+    neg_i = [(i + 5) % B if idx[(i + 5) % B] != idx[i] else (i + 7) % B for i in range(B)]
+    neg_t = [(i + 11) % B if idx[(i + 11) % B] != idx[i] else (i + 13) % B for i in range(B)]
+    m.get_hard_negatives = lambda *a, **kw: (torch.tensor(neg_i), torch.tensor(neg_t))
+    cv = ChunkedVision(m.vision_encoder)
+
+    def run():
+        loss_itc, loss_itm = m(b["image"], b["text_ids"], b["text_atts"], idx=idx)
+        (loss_itc + loss_itm).float().backward()
+        cv.finish()
+        return float(loss_itc), float(loss_itm)
+
+    li, lm = run()
+    print("retrieval_cfg fp32", li, lm, flush=True)
+    out = {"loss_itc": np.asarray(li), "loss_itm": np.asarray(lm)}
+    grads_of(m, out)
+    unused = [n for n, p in m.named_parameters() if p.grad is None]
+    fp32 = {n: p.grad.detach().double().clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ai, am = run()
+    print("retrieval_cfg bf16 autocast", ai, am, flush=True)
+    out["amp_loss_itc"], out["amp_loss_itm"] = np.asarray(ai), np.asarray(am)
+    floor_of(m, fp32, out)
+    cv.restore()
+    save(name, out, {"spec": spec_of(m), "B": B, "text_layers": 12, "fusion_layers": 12, "vit_depth": 12, "idx": idx.tolist(),
+                     "image_res": res, "max_tokens": T, "image_neg_idx": neg_i, "text_neg_idx": neg_t, "unused": unused})
+
+
+def gen_vqa_cfg(B=24, res=480, name="vqa_cfg"):
+    """BASELINE configs[3] at its REAL shape (configs/xfm-ft/VQA.yaml: batch 24, 480 px, 12 + 12 layers + 12-layer answer decoder):
+    the weighted answer loss, every parameter gradient and the reference's bf16-autocast floor, on the inputs of
+    tests/test_hip_configs.py::test_vqa_step_at_config_shape_vs_oracle (syn.vqa_batch(24, seed=480))."""
+    from types import SimpleNamespace as NS
+
+    def build_tokenizer(*a, **kw):
+        raise RuntimeError("dataset.build_tokenizer is stubbed: the reference's dataset package needs torchvision / PIL")
+
+    ref_shim._stub("dataset", build_tokenizer=build_tokenizer)
+    from models.model_generation import XFMForVQA
+    ref_shim.init_single_process_group()
+    torch.manual_seed(0)
+    cfg = ref_shim.pretrain_config(text_layers=12, fusion_layers=12,
+                                   overrides={"pad_token_id": 1, "decoder_fusion_start_at": 0, "num_dec_layers": 12, "image_res": res})
+    m = XFMForVQA(cfg)
+    load_formula(m)
+    m.eval()
+    x = syn.vqa_batch(B, seed=480, image_res=res)
+    q, a = NS(input_ids=x.q_ids, attention_mask=x.q_atts), NS(input_ids=x.a_ids, attention_mask=x.a_atts)
+    cv = ChunkedVision(m.vision_encoder, chunk=6)
+
+    def run():
+        loss = m(x.image, q, a, k=x.k, weights=x.weights, train=True)
+        loss.float().backward()
+        cv.finish()
+        return float(loss)
+
+    l32 = run()
+    print("vqa_cfg fp32", l32, flush=True)
+    out = {"loss_vqa": np.asarray(l32)}
+    grads_of(m, out)
+    unused = [n for n, p in m.named_parameters() if p.grad is None]
+    fp32 = {n: p.grad.detach().double().clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        l16 = run()
+    print("vqa_cfg bf16 autocast", l16, flush=True)
+    out["amp_loss_vqa"] = np.asarray(l16)
+    floor_of(m, fp32, out)
+    cv.restore()
+    save(name, out, {"spec": spec_of(m), "B": B, "image_res": res, "text_layers": 12, "fusion_layers": 12, "vit_depth": 12, "dec_layers": 12,
+                     "dec_fusion_start": 0, "pad_token_id": 1, "answers": int(sum(x.k)), "unused": unused})
+
+
 def gen_checkpoint():
     """Checkpoint key surgery (xfm.py:408-468) at equal resolution: a pre-training checkpoint ({'model': state_dict}, text tower with
     LM heads) loaded into the fine-tuning XFMForRetrieval (bare text encoder) by the reference's own load_pretrained."""
@@ -699,12 +825,15 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--full", action="store_true", help="also emit the 12/12/12 end-to-end step (slow)")
     a = ap.parse_args()
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("GEN_THREADS", "8")))
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
             "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval, "harness": gen_harness, "checkpoint_vqa": gen_checkpoint_vqa, "grounding": gen_grounding,
             "retrieval_384": lambda: gen_retrieval(B=8, res=384, T=40, name="retrieval_384"),
             "vqa_480": lambda: gen_vqa(res=480, name="vqa_480")}
+    cfg_jobs = {"retrieval_cfg": gen_retrieval_cfg, "vqa_cfg": gen_vqa_cfg}   # config-shape fixtures: minutes of CPU each, only on request
+    if a.only in cfg_jobs:
+        jobs[a.only] = cfg_jobs[a.only]
     if a.full:
         jobs["pretrain_full"] = lambda: gen_pretrain("pretrain_full", 12, 12, with_floor=True)
     for k, fn in jobs.items():

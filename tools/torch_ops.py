@@ -16,12 +16,14 @@ optimizer = bench.make_optimizer(model)
 acc = RCCLDDPAccelerator({"RNG_SEED": 42, "CLIP_GRAD_NORM": 1.0, "GRAD_ACCUMULATE_STEPS": 1})
 wrapped, optimizer, _ = acc.set_up(model, optimizer, None, 0, 1, 0)
 model.train(True)
-batch = {k: v.to(device) for k, v in syn.pretrain_batch(64, seed=1234).items()}
+host = syn.pretrain_batch(64, seed=1234)
+batch = {k: v.to(device) for k, v in host.items()}
+lens = host["text_atts"].sum(1)   # packed token rows, as bench.py runs the step
 
 
 def step():
     losses = wrapped(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
-                     masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], ret_mim_loss=True, data_source="image")
+                     masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], ret_mim_loss=True, data_source="image", text_lens=lens)
     total = losses["loss_itc"] + losses["loss_itm"] + losses["loss_mlm"] + losses["loss_mim"]
     acc.backward_step(total, optimizer)
     acc.optimizer_step(optimizer, model)
@@ -45,7 +47,7 @@ for e in rows[:40]:
 rows = [e for e in prof.key_averages(group_by_stack_n=6) if e.key.startswith("aten::") and dev_us(e) > 0]
 rows.sort(key=lambda e: -dev_us(e))
 print("== the same by call site")
-for e in rows[:40]:
+for e in rows[:70]:
     stack = [f for f in e.stack if "xfm_amd" in f or "bench.py" in f][:2]
     print(f"{e.key:22s} calls={e.count:4d} gpu={dev_us(e):9.1f}us  {' <- '.join(x.strip()[-70:] for x in stack)}")
 print("== device activities named like copies / fills")

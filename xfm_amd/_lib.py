@@ -158,9 +158,10 @@ SIGNATURES = {
                                   c_void_p]),
     "xfm_rownorm_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "xfm_rownorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "xfm_itc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "xfm_itc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "xfm_hard_negatives": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
+    "xfm_itc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xfm_itc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p]),
+    "xfm_hard_negatives": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xfm_rows_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "xfm_rows_scatter_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }

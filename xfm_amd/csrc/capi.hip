@@ -229,19 +229,20 @@ int xfm_rownorm_bwd(const float* dy, const float* y, const float* inv, int R, in
   XFM_REQUIRE(dy && y && inv && dx, "rownorm_bwd: null operand");
   return xfm_rownorm_bwd_impl(dy, y, inv, R, E, dx, ST(stream));
 }
-int xfm_itc_fwd(const float* I, const float* T, const float* temp, int N, int E, float* lse, float* loss_sum, void* stream) {
+int xfm_itc_fwd(const float* I, const float* T, const float* temp, int N, int E, float* lse, float* loss_sum, const int64_t* idx, float* cnt,
+                void* stream) {
   XFM_REQUIRE(I && T && temp && lse && loss_sum, "itc_fwd: null operand");
-  return xfm_itc_fwd_impl(I, T, temp, N, E, lse, loss_sum, ST(stream));
+  return xfm_itc_fwd_impl(I, T, temp, N, E, lse, loss_sum, idx, cnt, ST(stream));
 }
 int xfm_itc_bwd(const float* I, const float* T, const float* temp, const float* lse, const float* g, int N, int E, float* dI, float* dT,
-                float* dtemp, void* stream) {
+                float* dtemp, const int64_t* idx, const float* cnt, void* stream) {
   XFM_REQUIRE(I && T && temp && lse && g && dI && dT && dtemp, "itc_bwd: null operand");
-  return xfm_itc_bwd_impl(I, T, temp, lse, g, N, E, dI, dT, dtemp, ST(stream));
+  return xfm_itc_bwd_impl(I, T, temp, lse, g, N, E, dI, dT, dtemp, idx, cnt, ST(stream));
 }
 int xfm_hard_negatives(const float* I, const float* T, const float* temp, int B, int E, uint64_t seed, int64_t* image_neg,
-                       int64_t* text_neg, void* stream) {
+                       int64_t* text_neg, const int64_t* idx, void* stream) {
   XFM_REQUIRE(I && T && temp && image_neg && text_neg, "hard_negatives: null operand");
-  return xfm_hard_negatives_impl(I, T, temp, B, E, seed, image_neg, text_neg, ST(stream));
+  return xfm_hard_negatives_impl(I, T, temp, B, E, seed, image_neg, text_neg, idx, ST(stream));
 }
 
 int xfm_ce_fwd(const float* logits, long ld, int R, int V, const int64_t* labels, float* lse, float* loss, void* stream) {

@@ -44,9 +44,12 @@ __device__ __forceinline__ float block_add256(float v, float* red) {
 #define XFM_LOSS_MAXN 16000
 
 // blocks [0, N): rows of logits (image i against every text); blocks [N, 2N): rows of logits^T.  loss_sum += (lse - logit[r, r]) / (2N)
+// idx != NULL (retrieval fine-tuning, xfm.py:705-713): soft labels -- every row j with idx[j] == idx[r] is a positive of row r with
+// weight 1 / cnt_r (cnt_r = the number of such rows, written to cnt[r]): loss_sum += (lse - mean of the positives' logits) / (2N)
 template <int EPL>
 __global__ __launch_bounds__(256) void itc_fwd_kernel(const float* __restrict__ I, const float* __restrict__ T, const float* __restrict__ temp,
-                                                       int N, int E, float* __restrict__ lse, float* __restrict__ loss_sum) {
+                                                       int N, int E, float* __restrict__ lse, float* __restrict__ loss_sum,
+                                                       const int64_t* __restrict__ idx, float* __restrict__ cnt) {
   extern __shared__ float lg[];
   float* red = lg + N;
   const int r = blockIdx.x < N ? blockIdx.x : blockIdx.x - N;
@@ -59,10 +62,23 @@ __global__ __launch_bounds__(256) void itc_fwd_kernel(const float* __restrict__ 
   float s = 0.f;
   for (int j = threadIdx.x; j < N; j += 256) s += __expf(lg[j] - mx);
   s = block_add256(s, red);
+  float pos = 0.f, npos = 0.f;
+  if (idx != nullptr) {
+    const int64_t mine = idx[r];
+    for (int j = threadIdx.x; j < N; j += 256)
+      if (idx[j] == mine) { pos += lg[j]; npos += 1.f; }
+    pos = block_add256(pos, red);
+    npos = block_add256(npos, red);
+  }
   if (threadIdx.x == 0) {
     const float l = mx + __logf(s);
     lse[blockIdx.x] = l;
-    atomicAdd(loss_sum, (l - lg[r]) / (2.0f * N));
+    if (idx != nullptr) {
+      if (rows) cnt[r] = npos;
+      atomicAdd(loss_sum, (l - pos / npos) / (2.0f * N));
+    } else {
+      atomicAdd(loss_sum, (l - lg[r]) / (2.0f * N));
+    }
   }
 }
 
@@ -71,7 +87,8 @@ __global__ __launch_bounds__(256) void itc_fwd_kernel(const float* __restrict__ 
 template <int EPL>
 __global__ __launch_bounds__(256) void itc_bwd_kernel(const float* __restrict__ I, const float* __restrict__ T, const float* __restrict__ temp,
                                                        const float* __restrict__ lse, const float* __restrict__ g, int N, int E,
-                                                       float* __restrict__ dI, float* __restrict__ dT, float* __restrict__ dtemp) {
+                                                       float* __restrict__ dI, float* __restrict__ dT, float* __restrict__ dtemp,
+                                                       const int64_t* __restrict__ idx, const float* __restrict__ cnt) {
   extern __shared__ float lg[];
   float* red = lg + N;
   const int r = blockIdx.x < N ? blockIdx.x : blockIdx.x - N;
@@ -83,9 +100,15 @@ __global__ __launch_bounds__(256) void itc_bwd_kernel(const float* __restrict__ 
   const float* lse_oth = lse + (rows ? N : 0);     // ... and of the other direction, indexed by the column
   float tpart = 0.f;
   const float own = lse_own[r];
+  // soft labels (idx): the positives of (r, j) weigh 1 / cnt_r in the row direction and 1 / cnt_j in the column direction
+  const int64_t mine = idx != nullptr ? idx[r] : 0;
+  const float inv_cnt_r = idx != nullptr ? 1.0f / cnt[r] : 0.f;
   for (int j = threadIdx.x; j < N; j += 256) {
     const float L = lg[j];
-    const float G = __expf(L - own) + __expf(L - lse_oth[j]) - (j == r ? 2.0f : 0.0f);
+    float lab;
+    if (idx != nullptr) lab = idx[j] == mine ? inv_cnt_r + 1.0f / cnt[j] : 0.f;
+    else lab = j == r ? 2.0f : 0.0f;
+    const float G = __expf(L - own) + __expf(L - lse_oth[j]) - lab;
     tpart += G * L;
     lg[j] = G * gs;  // dL of (r, j) in place
   }
@@ -106,7 +129,7 @@ __global__ __launch_bounds__(256) void itc_bwd_kernel(const float* __restrict__ 
 template <int EPL>
 __global__ __launch_bounds__(256) void hard_neg_kernel(const float* __restrict__ I, const float* __restrict__ T, const float* __restrict__ temp,
                                                         int B, int E, uint32_t seed_lo, uint32_t seed_hi, int64_t* __restrict__ image_neg,
-                                                        int64_t* __restrict__ text_neg) {
+                                                        int64_t* __restrict__ text_neg, const int64_t* __restrict__ idx) {
   extern __shared__ float lg[];
   float* red = lg + B;
   const int r = blockIdx.x < B ? blockIdx.x : blockIdx.x - B;
@@ -121,7 +144,9 @@ __global__ __launch_bounds__(256) void hard_neg_kernel(const float* __restrict__
   const float inv = 1.0f / s;
   float wsum = 0.f;
   for (int j = threadIdx.x; j < B; j += 256) {
-    const float wj = j == r ? 0.f : __expf(lg[j] - mx) * inv + 1e-5f;   // softmax + 1e-5, own entry zeroed
+    // softmax + 1e-5, own entry zeroed -- with idx (xfm.py:731-734) every entry of the same image id
+    const bool same = idx != nullptr ? idx[j] == idx[r] : j == r;
+    const float wj = same ? 0.f : __expf(lg[j] - mx) * inv + 1e-5f;
     lg[j] = wj;
     wsum += wj;
   }
@@ -194,25 +219,28 @@ int xfm_rownorm_bwd_impl(const float* dy, const float* y, const float* inv, int 
   XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((rownorm_bwd_kernel<EPL>), dim3(cdiv(R, 4)), dim3(256), 0, st, dy, y, inv, R, E, dx));
   return xfm_check_launch("rownorm_bwd");
 }
-int xfm_itc_fwd_impl(const float* I, const float* T, const float* temp, int N, int E, float* lse, float* loss_sum, hipStream_t st) {
+int xfm_itc_fwd_impl(const float* I, const float* T, const float* temp, int N, int E, float* lse, float* loss_sum, const int64_t* idx,
+                     float* cnt, hipStream_t st) {
   int rc = loss_check(N, E);
   if (rc != XFM_OK) return rc;
-  XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((itc_fwd_kernel<EPL>), dim3(2 * N), dim3(256), (N + 4) * sizeof(float), st, I, T, temp, N, E, lse, loss_sum));
+  XFM_REQUIRE(idx == nullptr || cnt != nullptr, "itc_fwd: idx needs the cnt output");
+  XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((itc_fwd_kernel<EPL>), dim3(2 * N), dim3(256), (N + 4) * sizeof(float), st, I, T, temp, N, E, lse, loss_sum, idx, cnt));
   return xfm_check_launch("itc_fwd");
 }
 int xfm_itc_bwd_impl(const float* I, const float* T, const float* temp, const float* lse, const float* g, int N, int E, float* dI,
-                     float* dT, float* dtemp, hipStream_t st) {
+                     float* dT, float* dtemp, const int64_t* idx, const float* cnt, hipStream_t st) {
   int rc = loss_check(N, E);
   if (rc != XFM_OK) return rc;
-  XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((itc_bwd_kernel<EPL>), dim3(2 * N), dim3(256), (N + 4) * sizeof(float), st, I, T, temp, lse, g, N, E, dI, dT, dtemp));
+  XFM_REQUIRE(idx == nullptr || cnt != nullptr, "itc_bwd: idx needs the cnt the forward wrote");
+  XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((itc_bwd_kernel<EPL>), dim3(2 * N), dim3(256), (N + 4) * sizeof(float), st, I, T, temp, lse, g, N, E, dI, dT, dtemp, idx, cnt));
   return xfm_check_launch("itc_bwd");
 }
 int xfm_hard_negatives_impl(const float* I, const float* T, const float* temp, int B, int E, uint64_t seed, int64_t* image_neg,
-                            int64_t* text_neg, hipStream_t st) {
+                            int64_t* text_neg, const int64_t* idx, hipStream_t st) {
   int rc = loss_check(B, E);
   if (rc != XFM_OK) return rc;
   XFM_REQUIRE(B >= 2, "hard_negatives: a batch of one has no negative");
   XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((hard_neg_kernel<EPL>), dim3(2 * B), dim3(256), (B + 4) * sizeof(float), st, I, T, temp, B, E, (uint32_t)(seed & 0xFFFFFFFFu),
-                                         (uint32_t)(seed >> 32), image_neg, text_neg));
+                                         (uint32_t)(seed >> 32), image_neg, text_neg, idx));
   return xfm_check_launch("hard_negatives");
 }

@@ -564,38 +564,51 @@ def rownorm_bwd(dy, y, inv):
     return dx
 
 
-def itc_fwd(image_feat, text_feat, temp):
-    """In-batch contrastive loss over N gathered rows (xfm.py:683-703, idx=None) -> (loss [1], lse [2N])."""
+def _idx64(idx, n):
+    if idx is None:
+        return None
+    idx = idx.reshape(-1).to(torch.int64).contiguous()
+    assert idx.numel() == n and idx.is_cuda
+    return idx
+
+
+def itc_fwd(image_feat, text_feat, temp, idx=None):
+    """Contrastive loss over N gathered rows (xfm.py:683-715) -> (loss [1], lse [2N], cnt [N] | None).  idx (int64 [N], the gathered
+    image ids): soft labels over the rows that share an id (xfm.py:705-713); None: in-batch labels."""
     _dev(image_feat)
     N, E = image_feat.shape
     assert image_feat.dtype == F32 and text_feat.dtype == F32 and image_feat.is_contiguous() and text_feat.is_contiguous()
     assert text_feat.shape == (N, E) and temp.dtype == F32 and temp.numel() == 1
+    idx = _idx64(idx, N)
     lse = torch.empty(2 * N, dtype=F32, device=image_feat.device)
+    cnt = torch.empty(N, dtype=F32, device=image_feat.device) if idx is not None else None
     loss = torch.zeros(1, dtype=F32, device=image_feat.device)
     check(_lib.load().xfm_itc_fwd(image_feat.data_ptr(), text_feat.data_ptr(), temp.data_ptr(), N, E, lse.data_ptr(), loss.data_ptr(),
-                                  _stream()), "itc_fwd")
-    return loss, lse
+                                  _ptr(idx), _ptr(cnt), _stream()), "itc_fwd")
+    return loss, lse, cnt
 
 
-def itc_bwd(image_feat, text_feat, temp, lse, g):
+def itc_bwd(image_feat, text_feat, temp, lse, g, idx=None, cnt=None):
     """-> (d image_feat, d text_feat, d temp [1]) for the upstream gradient g (fp32 [1])."""
     N, E = image_feat.shape
+    idx = _idx64(idx, N)
     dI, dT = torch.empty_like(image_feat), torch.empty_like(text_feat)
     dtemp = torch.zeros(1, dtype=F32, device=image_feat.device)
     check(_lib.load().xfm_itc_bwd(image_feat.data_ptr(), text_feat.data_ptr(), temp.data_ptr(), lse.data_ptr(), g.data_ptr(), N, E,
-                                  dI.data_ptr(), dT.data_ptr(), dtemp.data_ptr(), _stream()), "itc_bwd")
+                                  dI.data_ptr(), dT.data_ptr(), dtemp.data_ptr(), _ptr(idx), _ptr(cnt), _stream()), "itc_bwd")
     return dI, dT, dtemp
 
 
-def hard_negatives(image_feat, text_feat, temp, seed):
-    """One categorical draw per row from softmax(sim / temp) + 1e-5 with the own entry zeroed (xfm.py:717-746, idx=None)
-    -> (image_neg_idx, text_neg_idx) int64 [B]."""
+def hard_negatives(image_feat, text_feat, temp, seed, idx=None):
+    """One categorical draw per row from softmax(sim / temp) + 1e-5 with the own entry -- with idx (int64 [B]): every entry of the
+    same image id -- zeroed (xfm.py:717-746) -> (image_neg_idx, text_neg_idx) int64 [B]."""
     _dev(image_feat)
     B, E = image_feat.shape
     assert image_feat.dtype == F32 and text_feat.dtype == F32 and image_feat.is_contiguous() and text_feat.is_contiguous()
+    idx = _idx64(idx, B)
     out = torch.empty((2, B), dtype=torch.int64, device=image_feat.device)
     check(_lib.load().xfm_hard_negatives(image_feat.data_ptr(), text_feat.data_ptr(), temp.data_ptr(), B, E, int(seed),
-                                         out[0].data_ptr(), out[1].data_ptr(), _stream()), "hard_negatives")
+                                         out[0].data_ptr(), out[1].data_ptr(), _ptr(idx), _stream()), "hard_negatives")
     return out[0], out[1]
 
 

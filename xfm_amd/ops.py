@@ -107,28 +107,30 @@ def row_normalize(x):
 
 
 class _ItcFn(torch.autograd.Function):
-    """(CE(I T^T / temp, arange) + CE(T I^T / temp, arange)) / 2 (xfm.py:683-703) as one kernel each way."""
+    """(CE(I T^T / temp, labels) + CE(T I^T / temp, labels)) / 2 (xfm.py:683-715) as one kernel each way; labels = arange, or with
+    `idx` the soft labels over the rows that share an image id (xfm.py:705-713)."""
 
     @staticmethod
-    def forward(ctx, image_feat, text_feat, temp):
+    def forward(ctx, image_feat, text_feat, temp, idx):
         I, T = image_feat.float().contiguous(), text_feat.float().contiguous()
         tv = temp.detach().float().reshape(1)
-        loss, lse = Fx.itc_fwd(I, T, tv)
+        loss, lse, cnt = Fx.itc_fwd(I, T, tv, idx)
         ctx.save_for_backward(I, T, tv, lse)
+        ctx.idx, ctx.cnt = idx, cnt
         ctx.temp_shape = temp.shape
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         I, T, tv, lse = ctx.saved_tensors
-        dI, dT, dtemp = Fx.itc_bwd(I, T, tv, lse, g.float().reshape(1).contiguous())
-        return dI, dT, (dtemp.reshape(ctx.temp_shape) if ctx.needs_input_grad[2] else None)
+        dI, dT, dtemp = Fx.itc_bwd(I, T, tv, lse, g.float().reshape(1).contiguous(), ctx.idx, ctx.cnt)
+        return dI, dT, (dtemp.reshape(ctx.temp_shape) if ctx.needs_input_grad[2] else None), None
 
 
-def itc_loss(image_feat, text_feat, temp):
+def itc_loss(image_feat, text_feat, temp, idx=None):
     if not torch.is_tensor(temp):
         temp = torch.full((1,), float(temp), dtype=F32, device=image_feat.device)
-    return _ItcFn.apply(image_feat, text_feat, temp)
+    return _ItcFn.apply(image_feat, text_feat, temp, idx)
 
 
 class _SmallCEFn(torch.autograd.Function):

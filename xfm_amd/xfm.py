@@ -428,33 +428,27 @@ class XFMBase(nn.Module):
         image_feat_all, text_feat_all = allgather(image_feat), allgather(text_feat)
         if idx is None:   # in-batch labels: similarity, both cross-entropies and their backward as one kernel each way
             return itc_loss(image_feat_all, text_feat_all, self.temp)
-        logits = image_feat_all @ text_feat_all.t() / self.temp
+        # retrieval fine-tuning (xfm.py:705-713): soft labels over the gathered rows that share an image id, in the same kernels
         idx = idx.view(-1, 1)
         assert idx.size(0) == image_feat.size(0)
         idx_all = allgather(idx)
-        pos_idx = torch.eq(idx_all, idx_all.t()).float()
-        labels = pos_idx / pos_idx.sum(1, keepdim=True)
-        loss_i2t = -torch.sum(F.log_softmax(logits, dim=1) * labels, dim=1).mean()
-        loss_t2i = -torch.sum(F.log_softmax(logits.t(), dim=1) * labels, dim=1).mean()
-        return (loss_i2t + loss_t2i) / 2
+        if not image_feat_all.is_cuda:   # (CPU: the gloo tests of the data-parallel glue)
+            logits = image_feat_all @ text_feat_all.t() / self.temp
+            pos_idx = torch.eq(idx_all, idx_all.t()).float()
+            labels = pos_idx / pos_idx.sum(1, keepdim=True)
+            loss_i2t = -torch.sum(F.log_softmax(logits, dim=1) * labels, dim=1).mean()
+            loss_t2i = -torch.sum(F.log_softmax(logits.t(), dim=1) * labels, dim=1).mean()
+            return (loss_i2t + loss_t2i) / 2
+        return itc_loss(image_feat_all, text_feat_all, self.temp, idx=idx_all.reshape(-1))
 
     def get_hard_negatives(self, image_feat, text_feat, idx=None):
-        """Returns device index tensors (image_neg_idx, text_neg_idx), each [B] int64."""
-        if idx is None:   # one kernel: similarity row, softmax + 1e-5, own entry zeroed, one inverse-CDF draw per row
-            from .xroberta import _next_seed
-            temp = self.temp.detach().float().reshape(1) if torch.is_tensor(self.temp) else \
-                torch.full((1,), float(self.temp), dtype=torch.float32, device=image_feat.device)
-            return Fx.hard_negatives(image_feat.detach().float().contiguous(), text_feat.detach().float().contiguous(), temp, _next_seed())
-        with torch.no_grad():
-            sim_i2t = image_feat @ text_feat.t() / self.temp
-            weights_i2t = F.softmax(sim_i2t, dim=1) + 1e-5
-            weights_t2i = F.softmax(sim_i2t.t(), dim=1) + 1e-5
-            mask = torch.eq(idx.view(-1, 1), idx.view(1, -1))
-            weights_i2t.masked_fill_(mask, 0)
-            weights_t2i.masked_fill_(mask, 0)
-            image_neg_idx = torch.multinomial(weights_t2i, 1).view(-1)
-            text_neg_idx = torch.multinomial(weights_i2t, 1).view(-1)
-        return image_neg_idx, text_neg_idx
+        """Returns device index tensors (image_neg_idx, text_neg_idx), each [B] int64: one kernel -- similarity row, softmax + 1e-5, own
+        entry (with `idx`: every entry of the same image id, xfm.py:731-734) zeroed, one inverse-CDF draw per row."""
+        from .xroberta import _next_seed
+        temp = self.temp.detach().float().reshape(1) if torch.is_tensor(self.temp) else \
+            torch.full((1,), float(self.temp), dtype=torch.float32, device=image_feat.device)
+        return Fx.hard_negatives(image_feat.detach().float().contiguous(), text_feat.detach().float().contiguous(), temp, _next_seed(),
+                                 idx=None if idx is None else idx.reshape(-1))
 
     def get_matching_loss(self, image_embeds, image_atts, image_feat, text_ids, text_atts, text_feat, idx=None,
                           return_cross_embeds=False, text_embeds=None, is_pretrain=True, neg_idx=None):
