@@ -244,6 +244,8 @@ int xfm_pool_rows_bwd(const xfm_bf16* dy, int B, int N, int D, xfm_bf16* out, vo
  * bytes.  fwd: sums[3] += {sum (x-t)^2 over masked patch rows, the same over the cls rows, number of masked patches} (caller zeroes);
  * loss = sums[0] / max(sums[2] * D, 1) + sums[1] / (B * D).  bwd: dx (bf16 [B, N, D], fully written) = gout[0] * d loss / d x;
  * cls_term = 0 drops the cls part (the reference's `mim_cls_only` flag returns the patch term alone). */
+#define XFM_MIM_PARTIALS 512
+#define XFM_MIM_SUMS_FLOATS (3 + 3 * XFM_MIM_PARTIALS)
 int xfm_mim_loss_fwd(const xfm_bf16* x, const xfm_bf16* t, const uint8_t* mask, int B, int N, int D, float* sums, void* stream);
 int xfm_mim_loss_bwd(const xfm_bf16* x, const xfm_bf16* t, const uint8_t* mask, const float* sums, const float* gout, int cls_term,
                      int B, int N, int D, xfm_bf16* dx, void* stream);
@@ -372,12 +374,13 @@ int xfm_ce_bwd(const float* logits, long ld, int R, int V, const int64_t* labels
 
 /* ---- Flat-arena optimiser step (optim.py:4-50 + clip, apex_ddp_accelerator.py:100-110) --------------------------- */
 typedef struct {
-  float* p; const float* g; float* m; float* v;
+  float* p; float* g; float* m; float* v;
   const uint8_t* group;       /* group id per 256-element block */
   float lr[4]; float wd[4];
   float beta1, beta2, eps, bc1, bc2;
   const float* clip_coef;     /* device scalar or NULL */
   long n;
+  int zero_grad;              /* != 0: g is zeroed in the same sweep (the step's optimizer.zero_grad(): one pass over the arena less) */
 } xfm_adamw_args;
 int xfm_adamw(const xfm_adamw_args* a, void* stream);
 /* out[0] += sum x[i]^2 (n % 4 == 0), bit-reproducible: fixed-grid block partials through `workspace`

@@ -167,12 +167,24 @@ def test_retrieval_step_at_config_shape_vs_oracle():
     (itc + itm).backward()
     torch.cuda.synchronize()
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
-    with torch.no_grad():
-        ri, rm = O.retrieval_forward(_oracle_params(sd), O.default_cfg(12, 12, 12), b, idx, neg_i, neg_t)
-    ri, rm = float(ri), float(rm)
-    print(f"retrieval B={B} {R}px T={T}: itc {float(itc):.5f} vs {ri:.5f}, itm {float(itm):.5f} vs {rm:.5f}, peak {peak:.1f} GiB")
-    assert abs(float(itc) - ri) <= 3e-3 * max(abs(ri), 1.0) and abs(float(itm) - rm) <= 3e-2 * max(abs(rm), 1.0)
-    assert abs(float(itc + itm) - (ri + rm)) <= 2e-3 * (ri + rm)
+    # The REFERENCE at this very shape (tools/oracle/gen_golden.py --only retrieval_cfg: models.model_retrieval.XFMForRetrieval, fp32,
+    # same batch / idx / negatives): its two losses, every parameter gradient, and its own bf16-autocast floor per tensor.
+    from golden_util import load
+    from test_hip_modules import _check_grads
+    z, meta = load("retrieval_cfg")
+    assert meta["B"] == B and meta["image_res"] == R and meta["idx"] == idx.tolist() and meta["image_neg_idx"] == neg_i and meta["text_neg_idx"] == neg_t
+    ri, rm = float(z["loss_itc"]), float(z["loss_itm"])
+    ai, am = float(z["amp_loss_itc"]), float(z["amp_loss_itm"])
+    with torch.no_grad():   # (and the oracle, live, against that fixture: the restatement is pinned at this shape too)
+        oi, om = O.retrieval_forward(_oracle_params(sd), O.default_cfg(12, 12, 12), b, idx, neg_i, neg_t)
+    assert abs(float(oi) - ri) <= 2e-4 * ri and abs(float(om) - rm) <= 2e-4 * rm, (float(oi), ri, float(om), rm)
+    print(f"retrieval B={B} {R}px T={T}: itc {float(itc):.5f} vs {ri:.5f} (reference bf16 autocast {ai:.5f}), itm {float(itm):.5f} vs {rm:.5f} "
+          f"({am:.5f}), peak {peak:.1f} GiB")
+    assert abs(float(itc) - ri) <= 1e-3 * ri, (float(itc), ri)
+    # the 96-row two-way ITM loss moves by 3e-3 between the reference's own fp32 and bf16-autocast runs: held to 4x that, the total to 1e-3
+    assert abs(float(itm) - rm) <= max(1e-2 * rm, 4.0 * abs(am - rm)), (float(itm), rm, am)
+    assert abs(float(itc + itm) - (ri + rm)) <= 1e-3 * (ri + rm), (float(itc + itm), ri + rm)
+    _check_grads(z, "grad", m, min_rms=1e-6, abs_ok={"temp": 0.05, "itm_head.3.bias": 2e-3}, floor="floor")
     dead = _finite_and_complete(m, expect_zero=("vision_encoder.mask_token", "self.key.bias", "crossattention.self.key.bias"))
     # what takes no part (model_retrieval.py:25-36): the text tower's unused cross-attention blocks, the fusion tower's own embeddings
     # and LM heads (it is fed the text tower's states).  Every tower layer, both projections, the ITM head and the temperature train.

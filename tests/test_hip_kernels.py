@@ -689,6 +689,12 @@ def test_adamw_and_sumsq_flat_arena():
     clip = torch.tensor([0.5], device="cuda")
     for step in (1, 2):
         Fx.adamw(p, g, m, v, group, lrs, wds, 0.9, 0.98, 1e-8, step, clip)
+    # zero_grad in the same sweep: same update, gradient left at exactly zero
+    p2, m2, v2, g2 = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), g.clone()
+    Fx.adamw(p2, g2, m2, v2, group, lrs, wds, 0.9, 0.98, 1e-8, 1, clip, zero_grad=True)
+    p3, m3, v3 = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    Fx.adamw(p3, g, m3, v3, group, lrs, wds, 0.9, 0.98, 1e-8, 1, clip)
+    assert torch.equal(p2, p3) and torch.equal(m2, m3) and torch.equal(v2, v3) and float(g2.abs().max()) == 0.0 and float(g.abs().max()) > 0
     ref = p0.clone().requires_grad_(True)
     mask = (group.repeat_interleave(256) == 0)
     ref_a, ref_b = ref[mask].detach().clone().requires_grad_(True), ref[~mask].detach().clone().requires_grad_(True)

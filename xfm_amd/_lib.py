@@ -102,7 +102,10 @@ class AdamWArgs(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("group", c_void_p),
                 ("lr", c_float * 4), ("wd", c_float * 4),
                 ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("bc1", c_float), ("bc2", c_float),
-                ("clip_coef", c_void_p), ("n", c_long)]
+                ("clip_coef", c_void_p), ("n", c_long), ("zero_grad", c_int)]
+
+
+MIM_SUMS_FLOATS = 3 + 3 * 512   # XFM_MIM_SUMS_FLOATS
 
 
 # name -> (restype, argtypes); mirrors include/xfm_hip.h one to one

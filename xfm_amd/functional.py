@@ -453,7 +453,7 @@ def mim_loss_fwd(x, t, mask):
     B, N, D = x.shape
     assert x.dtype == BF16 and t.dtype == BF16 and x.is_contiguous() and t.is_contiguous() and t.shape == x.shape
     assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape == (B, N - 1)
-    sums = torch.zeros(3, dtype=F32, device=x.device)
+    sums = torch.zeros(_lib.MIM_SUMS_FLOATS, dtype=F32, device=x.device)   # [0:3] the sums, the rest scratch of the two-stage reduction
     check(_lib.load().xfm_mim_loss_fwd(x.data_ptr(), t.data_ptr(), mask.data_ptr(), B, N, D, sums.data_ptr(), _stream()), "mim_loss_fwd")
     return sums
 
@@ -638,10 +638,11 @@ def sumsq(x, out):
     check(_lib.load().xfm_sumsq(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), _stream()), "sumsq")
 
 
-def adamw(p, g, m, v, group, lrs, wds, beta1, beta2, eps, step, clip_coef=None):
+def adamw(p, g, m, v, group, lrs, wds, beta1, beta2, eps, step, clip_coef=None, zero_grad=False):
+    """zero_grad: g is zeroed in the same sweep (saves the separate fill pass over the live gradient ranges)."""
     a = AdamWArgs(p=p.data_ptr(), g=g.data_ptr(), m=m.data_ptr(), v=v.data_ptr(), group=group.data_ptr(),
                   beta1=beta1, beta2=beta2, eps=eps, bc1=1.0 - beta1 ** step, bc2=1.0 - beta2 ** step,
-                  clip_coef=_ptr(clip_coef), n=p.numel())
+                  clip_coef=_ptr(clip_coef), n=p.numel(), zero_grad=int(zero_grad))
     for i in range(4):
         a.lr[i] = lrs[i] if i < len(lrs) else 0.0
         a.wd[i] = wds[i] if i < len(wds) else 0.0
