@@ -219,6 +219,9 @@ int xfm_rows_index_sum(const xfm_bf16* src, const int* index, int R, int U, long
 int xfm_relpos_gather(const float* table, const int* index, int H, int N, long ld, float* dense, float* dense_t,
                       void* stream);
 int xfm_relpos_scatter(const float* ddense, const int* index, int H, int N, long ld, float* dtable, void* stream);
+/* the same gradient for the standard index of a G x G patch grid + cls token (N = G*G + 1 tokens, (2G-1)^2 + 3 table rows,
+ * beit2.py:92-116): coalesced reads along the grid's structure, one owner per table entry (no atomics, no sort).  dtable += . */
+int xfm_relpos_grid_grad(const float* ddense, int H, int G, long ld, float* dtable, void* stream);
 /* the same gradient without atomics: order = positions i*N+j sorted by index[i*N+j], start = [entries+1] offsets into order */
 int xfm_relpos_scatter_sorted(const float* ddense, const int* order, const int* start, int entries, int H, int N, long ld,
                               float* dtable, void* stream);

@@ -5,12 +5,14 @@ run live on the same formula weights and synthetic batch:
               xbert text encoder AND on the xroberta one (configs/xfm-ft/glue_mrpc.yaml names roberta-base; BASELINE names the xbert path)
               -- loss within 1e-3 rel, every gradient by the module tests' rule (rel-L2 <= 8e-2, cosine >= 0.996);
   configs[2]  retrieval fine-tune (Retrieval.py:35-74 -> model_retrieval.py:25-36): B = 32, 384 px (577 image tokens), T = 40,
-              12-block ViT + 12 text + 12 fusion layers -- ITC / ITM against the oracle's forward; finite, complete gradients;
+              12-block ViT + 12 text + 12 fusion layers -- against `retrieval_cfg.npz`, the REFERENCE run at this very shape: ITC within
+              1e-3, total within 1e-3, every parameter gradient by the module rule with the reference's own autocast floor;
   configs[3]  VQA fine-tune (VQA.py:35-72 -> model_generation.py:96-133): B = 24, 480 px (901 image tokens), k ~ U[1, 10] answers per
-              question through the 12-layer causal decoder -- weighted loss against the oracle's forward; finite, complete gradients.
+              question through the 12-layer causal decoder -- against `vqa_cfg.npz` (the reference at this shape): loss within 1e-3,
+              every parameter gradient as above.
 (configs[1], ImageNet at B = 128, is test_hip_modules.test_classification_imagenet_at_batch_128_vs_oracle.)
-The full-depth GRADIENTS of the towers are pinned by the reference fixtures (pretrain_full, classification_*, vqa_*, retrieval_*);
-here the oracle's backward is only run where it takes seconds (the text-only model)."""
+The config-shape fixtures come from tools/oracle/gen_golden.py --only retrieval_cfg | vqa_cfg (the reference's vision tower run in
+chunks of images so that its fp32 activations fit the build container; same arithmetic); the oracle is held to them live."""
 import json
 import os
 
@@ -184,7 +186,12 @@ def test_retrieval_step_at_config_shape_vs_oracle():
     # the 96-row two-way ITM loss moves by 3e-3 between the reference's own fp32 and bf16-autocast runs: held to 4x that, the total to 1e-3
     assert abs(float(itm) - rm) <= max(1e-2 * rm, 4.0 * abs(am - rm)), (float(itm), rm, am)
     assert abs(float(itc + itm) - (ri + rm)) <= 1e-3 * (ri + rm), (float(itc + itm), ri + rm)
-    _check_grads(z, "grad", m, min_rms=1e-6, abs_ok={"temp": 0.05, "itm_head.3.bias": 2e-3}, floor="floor")
+    # every parameter gradient, by the module tests' rule (rel-L2 <= 8e-2, cosine >= 0.996), a tensor above it held to the reference's
+    # own autocast floor on that tensor x 1.5 (1 - cosine: x 2.3 = 1.5^2).  Measured: 621 tensors, worst rel-L2 0.105; 6 of them (fusion layers
+    # 0-5, where the text gradient of this fine-tuning step has crossed 12 + 12 bf16 layers) sit at 1.35-1.45 x their floor -- the
+    # text / fusion towers keep their LayerNorm outputs and residual stream in bf16, the reference's autocast keeps those in fp32;
+    # the 256-entry probe of a tensor against the floor's whole-tensor figure adds ~10 %.
+    _check_grads(z, "grad", m, min_rms=1e-6, abs_ok={"temp": 0.05, "itm_head.3.bias": 2e-3}, floor="floor", floor_err=1.5, floor_cos=2.3)
     dead = _finite_and_complete(m, expect_zero=("vision_encoder.mask_token", "self.key.bias", "crossattention.self.key.bias"))
     # what takes no part (model_retrieval.py:25-36): the text tower's unused cross-attention blocks, the fusion tower's own embeddings
     # and LM heads (it is fed the text tower's states).  Every tower layer, both projections, the ITM head and the temperature train.
@@ -210,11 +217,20 @@ def test_vqa_step_at_config_shape_vs_oracle():
     loss.backward()
     torch.cuda.synchronize()
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    # The REFERENCE at this very shape (tools/oracle/gen_golden.py --only vqa_cfg: models.model_generation.XFMForVQA, fp32, the same
+    # syn.vqa_batch(24, seed=480)): the weighted answer loss, every parameter gradient, its own bf16-autocast floor per tensor.
+    from golden_util import load
+    from test_hip_modules import _check_grads
+    z, meta = load("vqa_cfg")
+    assert meta["B"] == B and meta["image_res"] == R and meta["answers"] == int(sum(x.k))
+    ref, amp = float(z["loss_vqa"]), float(z["amp_loss_vqa"])
     cfg = dict(O.default_cfg(12, 12, 12), dec_layers=12, dec_fusion_start=0)
-    with torch.no_grad():
-        ref = float(O.vqa_train_loss(_oracle_params(sd), cfg, x.image, x.q_ids, x.q_atts, x.a_ids, x.a_atts, x.k, x.weights, 1))
-    print(f"VQA B={B} {R}px answers={sum(x.k)}: loss {float(loss):.5f} vs oracle {ref:.5f}, peak {peak:.1f} GiB")
-    assert abs(float(loss) - ref) <= 5e-3 * abs(ref), (float(loss), ref)
+    with torch.no_grad():   # (the oracle, live, against the fixture)
+        orc = float(O.vqa_train_loss(_oracle_params(sd), cfg, x.image, x.q_ids, x.q_atts, x.a_ids, x.a_atts, x.k, x.weights, 1))
+    assert abs(orc - ref) <= 2e-4 * abs(ref), (orc, ref)
+    print(f"VQA B={B} {R}px answers={sum(x.k)}: loss {float(loss):.5f} vs reference {ref:.5f} (its bf16 autocast: {amp:.5f}), peak {peak:.1f} GiB")
+    assert abs(float(loss) - ref) <= max(1e-3 * abs(ref), 2.0 * abs(amp - ref)), (float(loss), ref, amp)
+    _check_grads(z, "grad", m, min_rms=1e-6, floor="floor", floor_err=1.5, floor_cos=2.3)
     dead = _finite_and_complete(m, expect_zero=("vision_encoder.mask_token", "key.bias"))
     assert all(_unused_by_design(k) for k in dead), [k for k in dead if not _unused_by_design(k)][:8]
     assert len(dead) < 0.35 * sum(1 for _ in m.parameters())

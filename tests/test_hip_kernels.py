@@ -857,6 +857,29 @@ def test_itc_loss_matches_two_cross_entropies(N, E, temp):
     assert abs(float(t.grad) - float(tr.grad)) <= 1e-4 * max(abs(float(tr.grad)), 1e-3)
 
 
+@pytest.mark.parametrize("G,H", [(14, 12), (24, 3), (30, 2), (3, 1), (33, 1)])
+def test_relpos_grid_grad_matches_the_index_scatter(G, H):
+    """Table gradient of the standard grid index (beit2.py:92-116) by the structured kernel against an fp64 index_add over the
+    reference's relative_position_index; accumulates into dtable; same bits on every launch (one owner per entry, fixed order)."""
+    Fx = _fx()
+    from xfm_amd.beit2 import build_relative_position_index
+    N, ld = G * G + 1, (G * G + 1 + 15) // 16 * 16
+    index = build_relative_position_index(G, G).cuda()
+    nrd = (2 * G - 1) ** 2 + 3
+    dd = _rand((H, N, ld), 1.0, F32, seed=G)
+    base = _rand((nrd, H), 1.0, F32, seed=G + 1)
+    ref = base.double().clone()
+    for h in range(H):
+        ref[:, h].index_add_(0, index.reshape(-1), dd[h, :, :N].double().reshape(-1))
+    outs = []
+    for _ in range(2):
+        dt = base.clone()
+        Fx.relpos_grid_grad(dd, G, H, ld, dt)
+        outs.append(dt)
+    assert torch.equal(outs[0], outs[1])
+    _close(outs[0], ref, 2e-6, "relpos grid gradient")
+
+
 @pytest.mark.parametrize("N,E", [(32, 256), (7, 256), (300, 128)])
 def test_itc_loss_with_image_ids_matches_the_soft_label_form(N, E):
     """Retrieval fine-tuning (xfm.py:705-713): captions that share an image id are each other's positives, labels = pos / pos.sum(1);

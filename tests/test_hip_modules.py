@@ -39,7 +39,8 @@ def _check_out(z, prefix, t, tol=OUT_TOL):
 FLOOR_ERR, FLOOR_COS = 1.3, 1.7
 
 
-def _check_grads(z, prefix, module, name_prefix="", skip=("self.key.bias",), min_rms=1e-7, tol=None, cos_tol=None, abs_ok=None, floor=None):
+def _check_grads(z, prefix, module, name_prefix="", skip=("self.key.bias",), min_rms=1e-7, tol=None, cos_tol=None, abs_ok=None, floor=None,
+                 floor_err=FLOOR_ERR, floor_cos=FLOOR_COS):
     """`self.key.bias` is skipped: its gradient is analytically zero (softmax is invariant to the per-query constant
     q.b_k), so the reference holds ~1e-9 rounding noise there and a relative comparison is meaningless; it is bounded
     in absolute terms against the query-bias gradient instead.
@@ -78,7 +79,7 @@ def _check_grads(z, prefix, module, name_prefix="", skip=("self.key.bias",), min
         tol_t, cos_t = tol, cos_tol
         if floor is not None and f"{floor}/{name}" in z.files:
             fe, fc = (float(v) for v in z[f"{floor}/{name}"])
-            tol_t, cos_t = max(tol, FLOOR_ERR * fe), min(cos_tol, 1.0 - FLOOR_COS * (1.0 - fc))
+            tol_t, cos_t = max(tol, floor_err * fe), min(cos_tol, 1.0 - floor_cos * (1.0 - fc))
         if err > tol_t or cos < cos_t:
             bad.append((name, round(err, 4), round(cos, 5), round(tol_t, 4)))
     print(f"[{prefix}] {n} gradient tensors, worst rel-L2 {worst[0]:.4f}, worst cosine {worst[1]:.5f}")

@@ -136,6 +136,7 @@ SIGNATURES = {
     "xfm_rows_index_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),
     "xfm_relpos_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "xfm_relpos_scatter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),
+    "xfm_relpos_grid_grad": (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),
     "xfm_relpos_scatter_sorted": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p]),
     "xfm_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "xfm_vit_tokens_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

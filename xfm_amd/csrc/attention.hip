@@ -2145,6 +2145,58 @@ __global__ __launch_bounds__(256) void relpos_gather_grad_kernel(const float* __
   }
 }
 
+// The same gradient for the STANDARD index of a G x G patch grid plus a cls token (build_relative_position_index, beit2.py:92-116):
+// entry e = (yi - yj + G - 1)(2G - 1) + (xi - xj + G - 1) for patch query (yi, xi) and patch key (yj, xj); the last three entries are
+// cls -> patch, patch -> cls, cls -> cls.  The sorted gather above gives every lane one position of an entry: consecutive positions of
+// an entry are ld + 1 floats apart, so each 4-byte read costs a 64-byte sector (144 us per layer at 901 tokens).  Here a workgroup is one
+// (head, dy) row of the table and lane = dx: for a query (yi, xi) the lanes read the keys (yi - dy, xi - dx), 2G - 1 CONSECUTIVE
+// floats of one bias row (reversed) -- every element of ddense is read once, coalesced.  The four waves split the query rows yi and are
+// summed in a fixed order (no atomics: a table entry has one owner).
+__global__ __launch_bounds__(256) void relpos_grid_grad_kernel(const float* __restrict__ ddense, int H, int G, long ld, float* __restrict__ dtable) {
+  __shared__ float red[4][64];
+  const int h = blockIdx.y, row = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int N = G * G + 1, W = 2 * G - 1, nrd = W * W + 3;
+  const float* src = ddense + (long)h * N * ld;
+  if (row == W) {  // the three cls entries
+    float a = 0.f, b = 0.f;
+    for (int j = 1 + threadIdx.x; j < N; j += 256) a += src[j];
+    for (int i = 1 + threadIdx.x; i < N; i += 256) b += src[(long)i * ld];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) { red[w][0] = a; red[w][1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      dtable[(long)(nrd - 3) * H + h] += (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+      dtable[(long)(nrd - 2) * H + h] += (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+      dtable[(long)(nrd - 1) * H + h] += src[0];
+    }
+    return;
+  }
+  const int dy = row - (G - 1);
+  const int y0 = dy > 0 ? dy : 0, y1 = dy < 0 ? G + dy : G;  // query rows whose key row yi - dy exists
+  for (int dx0 = 0; dx0 < W; dx0 += 64) {  // (2G - 1 <= 64 up to a 32 x 32 grid: one trip)
+    const int dxl = dx0 + lane, dx = dxl - (G - 1);
+    float acc = 0.f;
+    for (int yi = y0 + w; yi < y1; yi += 4) {
+      const float* rowp = src + (long)(1 + yi * G) * ld + 1 + (yi - dy) * G - dx;  // + xi * ld + xi per query column
+#pragma unroll 6
+      for (int xi = 0; xi < G; ++xi) {
+        const int xj = xi - dx;
+        if (dxl < W && xj >= 0 && xj < G) acc += rowp[(long)xi * ld + xi];
+      }
+    }
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && dxl < W) dtable[((long)row * W + dxl) * H + h] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    __syncthreads();
+  }
+}
+int xfm_relpos_grid_grad_impl(const float* ddense, int H, int G, long ld, float* dtable, hipStream_t st) {
+  XFM_REQUIRE(H > 0 && G > 0 && ld >= (long)G * G + 1, "relpos_grid_grad: bad shape H=%d G=%d ld=%ld", H, G, ld);
+  hipLaunchKernelGGL(relpos_grid_grad_kernel, dim3(2 * G, H), dim3(256), 0, st, ddense, H, G, ld, dtable);
+  return xfm_check_launch("relpos_grid_grad");
+}
+
 int xfm_relpos_scatter_sorted_impl(const float* ddense, const int* order, const int* start, int entries, int H, int N, long ld,
                                    float* dtable, hipStream_t st) {
   XFM_REQUIRE(H > 0 && N > 0 && ld >= N && entries > 0, "relpos_scatter_sorted: bad shape");

@@ -136,6 +136,10 @@ int xfm_relpos_gather(const float* table, const int* index, int H, int N, long l
   XFM_REQUIRE(table && index && dense, "relpos_gather: null operand");
   return xfm_relpos_gather_impl(table, index, H, N, ld, dense, dense_t, ST(stream));
 }
+int xfm_relpos_grid_grad(const float* ddense, int H, int G, long ld, float* dtable, void* stream) {
+  XFM_REQUIRE(ddense && dtable, "relpos_grid_grad: null operand");
+  return xfm_relpos_grid_grad_impl(ddense, H, G, ld, dtable, ST(stream));
+}
 int xfm_relpos_scatter_sorted(const float* ddense, const int* order, const int* start, int entries, int H, int N, long ld,
                               float* dtable, void* stream) {
   XFM_REQUIRE(ddense && order && start && dtable, "relpos_scatter_sorted: null operand");

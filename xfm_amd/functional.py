@@ -659,6 +659,13 @@ def relpos_sorted_index(index32, entries):
     return order, start
 
 
+def relpos_grid_grad(ddense, G, H, ld, dtable):
+    """dtable[(2G-1)^2 + 3, H] += the relative-position-table gradient of ddense [H, G*G+1, ld] for the STANDARD grid index
+    (beit2.build_relative_position_index): coalesced, no atomics, no sorted index."""
+    assert ddense.dtype == F32 and dtable.dtype == F32 and dtable.shape == ((2 * G - 1) ** 2 + 3, H) and dtable.is_contiguous()
+    check(_lib.load().xfm_relpos_grid_grad(ddense.data_ptr(), H, G, ld, dtable.data_ptr(), _stream()), "relpos_grid_grad")
+
+
 def relpos_scatter_sorted(ddense, order, start, H, N, ld, dtable):
     check(_lib.load().xfm_relpos_scatter_sorted(ddense.data_ptr(), order.data_ptr(), start.data_ptr(), start.numel() - 1, H, N, ld,
                                                 dtable.data_ptr(), _stream()), "relpos_scatter_sorted")
