@@ -12,12 +12,14 @@ optimizer = bench.make_optimizer(model)
 acc = RCCLDDPAccelerator({"RNG_SEED": 42, "CLIP_GRAD_NORM": 1.0, "GRAD_ACCUMULATE_STEPS": 1})
 wrapped, optimizer, _ = acc.set_up(model, optimizer, None, 0, 1, 0)
 model.train(True)
-batch = {k: v.to(device) for k, v in syn.pretrain_batch(64, seed=1234).items()}
+hostb = syn.pretrain_batch(64, seed=1234)
+batch = {k: v.to(device) for k, v in hostb.items()}
+lens = hostb["text_atts"].sum(1)   # packed token rows, as bench.py runs the step (XFM_PACK_SYNC=0: no host sync inside the step)
 
 
 def step():
     losses = wrapped(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
-                     masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], ret_mim_loss=True, data_source="image")
+                     masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], ret_mim_loss=True, data_source="image", text_lens=lens)
     total = losses["loss_itc"] + losses["loss_itm"] + losses["loss_mlm"] + losses["loss_mim"]
     acc.backward_step(total, optimizer)
     acc.optimizer_step(optimizer, model)

@@ -13,7 +13,17 @@ ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.g
 ks.sort()
 t0, t1 = ks[0][0], max(k[1] for k in ks)
 cut = t1 - (t1 - t0) * frac
-ks = [k for k in ks if k[0] >= cut]
+import os
+step_kernel = os.environ.get("STEP_KERNEL")   # e.g. STEP_KERNEL=adamw_kernel:3:4 -> the window is ONE step: from the end of the
+# 3rd-launch-per-step kernel of step 3 to its end in step 4 (the optimizer's last launch closes a step)
+if step_kernel:
+    name, per, idx = step_kernel.split(":")
+    ends = [k[1] for k in ks if name in k[2]]
+    marks = ends[int(per) - 1::int(per)]
+    lo, hi = marks[int(idx) - 1], marks[int(idx)]
+    ks = [k for k in ks if k[0] >= lo and k[1] <= hi]
+else:
+    ks = [k for k in ks if k[0] >= cut]
 span = max(k[1] for k in ks) - ks[0][0]
 per_q = defaultdict(int)
 for s, e, n, q in ks:
@@ -39,3 +49,22 @@ for s, e, n, q in ks:
 print("| kernel | calls | total ms | avg us | % of window |")
 for name, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"| {name} | {c} | {t / 1e6:.3f} | {t / c / 1e3:.1f} | {100.0 * t / span:.1f} |")
+
+# gaps on the busiest queue: where the main chain waits (for another queue's event, or for the host)
+main_q = max(per_q.items(), key=lambda kv: kv[1])[0]
+mk = [k for k in ks if k[3] == main_q]
+gaps = []
+for a, b in zip(mk[:-1], mk[1:]):
+    g = b[0] - a[1]
+    if g > 0:
+        gaps.append((g, a[2].replace("void ", "").split("(")[0][:48], b[2].replace("void ", "").split("(")[0][:48]))
+tot = sum(g[0] for g in gaps)
+print(f"\nqueue {main_q}: {len(mk)} kernels, {tot / 1e6:.3f} ms of gaps between consecutive kernels ({sum(1 for g in gaps if g[0] > 5000)} gaps > 5 us = "
+      f"{sum(g[0] for g in gaps if g[0] > 5000) / 1e6:.3f} ms)")
+pair = defaultdict(lambda: [0, 0])
+for g, a, b in gaps:
+    pair[(a, b)][0] += 1
+    pair[(a, b)][1] += g
+print("| after | before | count | total us | avg us |")
+for (a, b), (c, t) in sorted(pair.items(), key=lambda kv: -kv[1][1])[:28]:
+    print(f"| {a} | {b} | {c} | {t / 1e3:.1f} | {t / c / 1e3:.2f} |")

@@ -1516,7 +1516,10 @@ static int tn128_plan(int M, int N, int K, int splits_hint, int& splits, int& mp
 // into dW -- the 128 x 128 ring kernel on all of M costs 30-40 % more (591 vs 900+ TFLOP/s at M = 21624).
 static int tn256_body_rows(int M, int N, int K) {
   const int M0 = M - M % 64;
-  if (M % 64 == 0 || M0 < 4096 || N % 256 != 0 || K % 256 != 0) return 0;
+  // (from 8192 rows: at the fusion tower's packed M ~ 5200 the 7 x 36 workgroups of the 256 x 256 plan walk 12 K-steps each and lose to
+  // the ring kernel -- 73 vs 56 us at 5252 x 3072 x 768; round 3 had put those calls here too)
+  static const int min_rows = getenv("XFM_TN256_RAGGED_MIN") ? atoi(getenv("XFM_TN256_RAGGED_MIN")) : 8192;  // A/B knob
+  if (M % 64 == 0 || M0 < min_rows || N % 256 != 0 || K % 256 != 0) return 0;
   int splits, mps;
   return tn256_plan(M0, N, K, splits, mps) >= 18 ? M0 : 0;
 }
