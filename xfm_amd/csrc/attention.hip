@@ -1553,6 +1553,31 @@ __global__ __launch_bounds__(1024) void xattn_dkv_kernel(AttnArgs a) {
 // each other's staging.  dK / dV come from xattn_dkv_kernel above, which already walks any number of keys.
 // ---------------------------------------------------------------------------------------------
 #define XS_SLOTS 2
+#define XS_RING 3   // K | V chunks of 64 keys in a 3-slot ring filled by inline-asm direct-to-LDS loads (round 4; two slots + the
+// compiler-visible builtin before: hipcc drains a visible LDS-DMA in front of every LDS read, so each chunk paid its whole fetch latency)
+__device__ __forceinline__ void xs_wait_vm(int n) {  // wave-uniform
+  if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// this wave's two 1-KiB pieces (rows 8 w .. 8 w + 7 of the K tile and of the V tile) of chunk kc -> ring slot kc mod 3 (8 waves)
+__device__ __forceinline__ void xs_stage(char* lds, const bf16* kb, long k_rs, const bf16* vb, long v_rs, int kc, int sk, int w, int lane) {
+  char* slot = lds + (kc % XS_RING) * ATTN_SLOT;
+  const int r = w * 8 + (lane >> 3);
+  const int c = (lane & 7) ^ swz_a(r);
+  int gr = kc * 64 + r;
+  gr = gr < sk ? gr : sk - 1;
+  const bf16* s0 = kb + (long)gr * k_rs + c * 8;
+  const bf16* s1 = vb + (long)gr * v_rs + c * 8;
+  const unsigned d0 = (unsigned)(uintptr_t)LDS_PTR(void, slot) + (unsigned)__builtin_amdgcn_readfirstlane(w * 1024);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(s0), "s"(d0) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(s1), "s"(d0 + (unsigned)ATTN_TILE) : "memory", "m0");
+}
+__device__ __forceinline__ void xs_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 __global__ __launch_bounds__(512, 2) void xattn_fwd_stream_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
@@ -1591,11 +1616,17 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_stream_kernel(AttnArgs a) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) oacc[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    stage_slot(lds, kb, a.k_rs, vb, a.v_rs, 0, a.Sk, w, nw, lane);
+    // (the compiler's wait for the fragments above lands here, not inside the chunk loop where it would drain the ring)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < XS_SLOTS; ++i) asm volatile("" : "+v"(qf[i][0]), "+v"(qf[i][1]));
+    xs_stage(lds, kb, a.k_rs, vb, a.v_rs, 0, a.Sk, w, lane);
+    if (nchunks > 1) xs_stage(lds, kb, a.k_rs, vb, a.v_rs, 1, a.Sk, w, lane);
     for (int kc = 0; kc < nchunks; ++kc) {
-      stage_wait();  // chunk kc has landed, everyone is done with chunk kc - 1 -> refill its slot
-      if (kc + 1 < nchunks) stage_slot(lds + ((kc + 1) & 1) * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, (kc + 1) * 64, a.Sk, w, nw, lane);
-      const char* sK = lds + (kc & 1) * ATTN_SLOT;
+      xs_wait_vm(kc + 1 < nchunks ? 2 : 0);  // this wave's pieces of chunk kc are in (chunk kc + 1 may still fly)
+      xs_barrier();                          // ... everyone's; everyone is done with chunk kc - 1, whose slot chunk kc + 2 takes
+      if (kc + 2 < nchunks) xs_stage(lds, kb, a.k_rs, vb, a.v_rs, kc + 2, a.Sk, w, lane);
+      const char* sK = lds + (kc % XS_RING) * ATTN_SLOT;
       const char* sV = sK + ATTN_TILE;
       int kk[4][4];
       if (has_mask) load_keep(a, g, kc, lg, kk);
@@ -1658,7 +1689,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_stream_kernel(AttnArgs a) {
         if (lg == 0) a.lse[((long)b_[i] * a.H + h) * a.stat_ld + qi_[i]] = m_run[i] + __logf(l_run[i]);
       }
     }
-    __syncthreads();  // the next pass refills slot 0
+    __syncthreads();  // the next pass refills the ring
   }
 }
 
@@ -1709,12 +1740,18 @@ __global__ __launch_bounds__(512, 2) void xattn_dq_stream_kernel(AttnArgs a) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dqacc[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see the forward kernel)
+#pragma unroll
+    for (int i = 0; i < XS_SLOTS; ++i)
+      asm volatile("" : "+v"(qf[i][0]), "+v"(qf[i][1]), "+v"(df[i][0]), "+v"(df[i][1]), "+v"(lse_q[i]), "+v"(delta[i]));
     for (int sweep = fast_delta ? 1 : 0; sweep < 2; ++sweep) {
-      stage_slot(lds, kb, a.k_rs, vb, a.v_rs, 0, a.Sk, w, nw, lane);
+      xs_stage(lds, kb, a.k_rs, vb, a.v_rs, 0, a.Sk, w, lane);
+      if (nchunks > 1) xs_stage(lds, kb, a.k_rs, vb, a.v_rs, 1, a.Sk, w, lane);
       for (int kc = 0; kc < nchunks; ++kc) {
-        stage_wait();
-        if (kc + 1 < nchunks) stage_slot(lds + ((kc + 1) & 1) * ATTN_SLOT, kb, a.k_rs, vb, a.v_rs, (kc + 1) * 64, a.Sk, w, nw, lane);
-        const char* sK = lds + (kc & 1) * ATTN_SLOT;
+        xs_wait_vm(kc + 1 < nchunks ? 2 : 0);
+        xs_barrier();
+        if (kc + 2 < nchunks) xs_stage(lds, kb, a.k_rs, vb, a.v_rs, kc + 2, a.Sk, w, lane);
+        const char* sK = lds + (kc % XS_RING) * ATTN_SLOT;
         const char* sV = sK + ATTN_TILE;
         int kk[4][4];
         if (has_mask) load_keep(a, g, kc, lg, kk);
@@ -1883,7 +1920,7 @@ int xfm_attn_fwd_impl(const AttnArgs& a, hipStream_t st) {
     if (rc != XFM_OK) return rc;
     attn_grouped_lds();
     if (a.Sk > 64 * ATTN_RES_MAX) {
-      hipLaunchKernelGGL(xattn_fwd_stream_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)2 * ATTN_SLOT, st, a);
+      hipLaunchKernelGGL(xattn_fwd_stream_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)XS_RING * ATTN_SLOT, st, a);
       return xfm_check_launch("xattn_fwd_stream");
     }
     {
@@ -1943,7 +1980,7 @@ int xfm_attn_bwd_impl(const AttnArgs& a_in, hipStream_t st) {
     if (rc != XFM_OK) return rc;
     attn_grouped_lds();
     if (a.bwd_phase != 2) {
-      if (a.Sk > 64 * ATTN_RES_MAX) hipLaunchKernelGGL(xattn_dq_stream_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)2 * ATTN_SLOT, st, a);
+      if (a.Sk > 64 * ATTN_RES_MAX) hipLaunchKernelGGL(xattn_dq_stream_kernel, dim3(1, a.H, a.n_groups), dim3(512), (size_t)XS_RING * ATTN_SLOT, st, a);
       else {
         const dim3 grid(1, a.H, a.n_groups);
         const bool mask = a.key_keep != nullptr, drop = a.drop_thresh != 0u;
