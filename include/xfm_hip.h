@@ -342,6 +342,7 @@ typedef struct {        /* byte offsets inside slab / bslab (256-byte aligned) *
   long qkv, c1, lse1, h, z1, m1, r1, y1, q2, c2, lse2, z2, m2, r2, y2, hact, u, z3, m3, r3, y3, fwd_bytes;
   long dh3, dres3, du, d1a, dh2, dres2, dc2, dq2, delta2, d2a, dh1, dres1, dc1, dqkv, delta1, dprev, bwd_bytes;
   long ws_main_bytes, ws_side_bytes;             /* workspace the backward wants on each stream */
+  long c2lo;                                     /* forward slab: low half of the cross-attention output (O = c2 + c2lo to fp32-ish precision) */
 } xfm_rlayer_layout_t;
 
 int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int xq_max, int dropout,

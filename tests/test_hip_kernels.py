@@ -779,6 +779,21 @@ def test_attention_grouped_by_kv_source(B, U, Sq, Sk, p, masked):
     _close(dkv, ref, 1e-2, "grouped dK/dV (summed per source)")
     if U > 1:
         assert float(dkv.view(U, -1)[U - 1].float().abs().max()) == 0.0, "unused source must get zero gradients"
+    # one-sweep form (what the layer executor runs): the forward also leaves the low half of O, delta = dO . (O + Olo)
+    o2, lse2, o_lo = Fx.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, Sq, Sk, 0.125, key_keep=keep, groups=groups, drop=drop, lo=True)
+    assert torch.equal(o2, o) and torch.equal(lse2[groups[1].long()][..., :Sq], lse[groups[1].long()][..., :Sq])
+    dq1, dkv1 = torch.empty_like(q), torch.full((U * Sk, 2 * D), 7.0, dtype=BF16, device="cuda")
+    d1 = Fx.attn_bwd(dout, q, kv[:, :D], kv[:, D:], o, lse, dq1, dkv1[:, :D], dkv1[:, D:], B, H, Sq, Sk, 0.125, key_keep=keep, groups=groups,
+                     drop=drop, o_lo=o_lo)
+    d0 = Fx.attn_bwd(dout, q, kv[:, :D], kv[:, D:], o, lse, dq, dkv[:, :D], dkv[:, D:], B, H, Sq, Sk, 0.125, key_keep=keep, groups=groups, drop=drop)
+    rows = groups[1].long()   # (rows of empty trailing sources never appear; every listed row has its statistics written)
+    # (dO . O carries the bf16 rounding of the probabilities that went into the P V product; the two-sweep sum uses them in fp32)
+    _close(d1[rows][..., :Sq], d0[rows][..., :Sq], 4e-3, "delta from the output halves vs the two-sweep sum")
+    for name, x, y in (("dq", dq1, dq), ("dkv", dkv1, dkv)):   # the bound of test_attention_backward_single_pass_delta_vs_two_pass
+        rel = float((x.float() - y.float()).norm() / (y.float().norm() + 1e-30))
+        assert rel <= 6e-3, (name, rel)
+    _close(dq1, dq_ref, 1e-2, "grouped dQ, one sweep")
+    _close(dkv1, ref, 1e-2, "grouped dK/dV, one sweep")
 
 
 def test_gemm_nt_split_k_accumulate():

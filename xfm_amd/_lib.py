@@ -95,7 +95,7 @@ class RLayerLayout(ctypes.Structure):
     _fields_ = [(n, _L) for n in ("qkv", "c1", "lse1", "h", "z1", "m1", "r1", "y1", "q2", "c2", "lse2", "z2", "m2", "r2", "y2", "hact", "u",
                                   "z3", "m3", "r3", "y3", "fwd_bytes",
                                   "dh3", "dres3", "du", "d1a", "dh2", "dres2", "dc2", "dq2", "delta2", "d2a", "dh1", "dres1", "dc1", "dqkv",
-                                  "delta1", "dprev", "bwd_bytes", "ws_main_bytes", "ws_side_bytes")]
+                                  "delta1", "dprev", "bwd_bytes", "ws_main_bytes", "ws_side_bytes", "c2lo")]
 
 
 class AdamWArgs(ctypes.Structure):

@@ -33,9 +33,10 @@ int xfm_rlayer_layout_impl(int R, int B, int T, int D, int H, int FF, int has_cr
   o->z1 = take(rd); o->m1 = take(rvec); o->r1 = take(rvec); o->y1 = take(rd);
   if (has_cross) {
     o->q2 = take(rd); o->c2 = take(rd); o->lse2 = take(xstat);
+    o->c2lo = take(rd);   // what the bf16 rounding of c2 lost: the backward gets delta = dO . (O + Olo) without a sweep over the keys
     o->z2 = take(rd); o->m2 = take(rvec); o->r2 = take(rvec); o->y2 = take(rd);
   } else {
-    o->q2 = o->c2 = o->lse2 = o->z2 = o->m2 = o->r2 = o->y2 = -1;
+    o->q2 = o->c2 = o->c2lo = o->lse2 = o->z2 = o->m2 = o->r2 = o->y2 = -1;
   }
   o->hact = take((long)R * FF * 2); o->u = take((long)R * FF * 2);
   o->z3 = take(rd); o->m3 = take(rvec); o->r3 = take(rvec); o->y3 = take(rd);
@@ -101,6 +102,7 @@ static AttnArgs rl_cross_attn(const RLP& p, const RLIO& io, const RLL& L, char* 
   a.q = reinterpret_cast<bf16*>(s + L.q2); a.q_rs = D;
   a.k = io.kv; a.v = io.kv + D; a.k_rs = a.v_rs = io.kv_ld;
   a.o = reinterpret_cast<bf16*>(s + L.c2); a.o_rs = D;
+  a.o_lo = reinterpret_cast<bf16*>(s + L.c2lo);
   a.lse = reinterpret_cast<float*>(s + L.lse2);
   a.key_keep = io.enc_keep;
   a.B = io.B; a.H = p.H; a.Sq = io.T; a.Sk = io.Nenc;

@@ -291,19 +291,21 @@ class _EncoderFn(torch.autograd.Function):
                 q2 = Fx.gemm_nt(y1, s["q2"].wb, s["q2"].b)
                 kv = pre.take(kv_ready.pop(li))
                 if xq is not None:  # RANGE mode: sequences laid out image by image -> one ragged problem per image, full query tiles
-                    c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], enc.shape[0] // Nenc, H, xq[2], Nenc, scale, key_keep=enc_keep,
-                                           drop=d_att2, q_pack=(xq[0], xq[1]), zero_fill=zf)
+                    c2, lse2, c2lo = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], enc.shape[0] // Nenc, H, xq[2], Nenc, scale, key_keep=enc_keep,
+                                                 drop=d_att2, q_pack=(xq[0], xq[1]), zero_fill=zf, lo=True)
                 elif groups is not None:  # one workgroup per (image, head): K/V staged once for every row that reads it
-                    c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, groups=groups,
-                                           q_pack=qp, zero_fill=zf)
+                    # (lo: the low half of the output -- the backward's delta = dO . (O + Olo) then needs no sweep over the keys)
+                    c2, lse2, c2lo = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, groups=groups,
+                                                 q_pack=qp, zero_fill=zf, lo=True)
                 elif pack is not None:
                     raise NotImplementedError("packed rows with cross-attention need the grouped kernels (T <= 64) and an encoder_batch_index")
                 else:
                     c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, T, Nenc, scale, key_keep=enc_keep, drop=d_att2, kv_index=enc_index)
+                    c2lo = None
                 h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
                 ln2 = co.output.LayerNorm
                 y2, z2, m2, r2 = Fx.ln_post_fwd(h2, y1, ln2.weight, ln2.bias, ln2.eps, d_h2)
-                rec.update(q2=q2, kv=kv, c2=c2, lse2=lse2, z2=z2, m2=m2, r2=r2, y2=y2, d_att2=d_att2, d_h2=d_h2)
+                rec.update(q2=q2, kv=kv, c2=c2, c2lo=c2lo, lse2=lse2, z2=z2, m2=m2, r2=r2, y2=y2, d_att2=d_att2, d_h2=d_h2)
             d_h3 = Fx.drop_params(p_hid, _next_seed())
             hact, u = Fx.gemm_nt(y2, s["i"].wb, s["i"].b, epi=Fx.EPI_GELU)
             h3 = Fx.gemm_nt(hact, s["out"].wb, s["out"].b)
@@ -391,10 +393,10 @@ class _EncoderFn(torch.autograd.Function):
                     if xq is not None:
                         args = (dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], enc.shape[0] // Nenc, H,
                                 xq[2], Nenc, scale)
-                        kw = dict(key_keep=enc_keep, drop=r["d_att2"], q_pack=(xq[0], xq[1]))
+                        kw = dict(key_keep=enc_keep, drop=r["d_att2"], q_pack=(xq[0], xq[1]), o_lo=r["c2lo"])
                     else:
                         args = (dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, T, Nenc, scale)
-                        kw = dict(key_keep=enc_keep, drop=r["d_att2"], groups=groups, q_pack=qp)
+                        kw = dict(key_keep=enc_keep, drop=r["d_att2"], groups=groups, q_pack=qp, o_lo=r["c2lo"])
                     delta = Fx.attn_bwd(*args, phase=1, **kw)
                     wg.run(lambda: Fx.attn_bwd(*args, phase=2, delta=delta, **kw), keep=args[:9] + (delta,))
                 else:
@@ -483,11 +485,12 @@ class _LastLayerRowsFn(torch.autograd.Function):
             d_att2, d_h2 = Fx.drop_params(p_att, _next_seed()), Fx.drop_params(p_hid, _next_seed())
             q2 = Fx.gemm_nt(y1, s["q2"].wb, s["q2"].b)
             kv = pre.take(kv_pair)
-            c2, lse2 = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, Tq, Nenc, scale, drop=d_att2, groups=groups, q_pack=sel, zero_fill=False)
+            c2, lse2, c2lo = Fx.attn_fwd(q2, kv[:, :D], kv[:, D:], B, H, Tq, Nenc, scale, drop=d_att2, groups=groups, q_pack=sel, zero_fill=False,
+                                         lo=True)
             h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
             ln2 = layer.crossattention.output.LayerNorm
             y2, z2, m2, r2 = Fx.ln_post_fwd(h2, y1, ln2.weight, ln2.bias, ln2.eps, d_h2)
-            rec.update(q2=q2, kv=kv, c2=c2, lse2=lse2, z2=z2, m2=m2, r2=r2, y2=y2, d_att2=d_att2, d_h2=d_h2)
+            rec.update(q2=q2, kv=kv, c2=c2, c2lo=c2lo, lse2=lse2, z2=z2, m2=m2, r2=r2, y2=y2, d_att2=d_att2, d_h2=d_h2)
         d_h3 = Fx.drop_params(p_hid, _next_seed())
         hact, u = Fx.gemm_nt(y2, s["i"].wb, s["i"].b, epi=Fx.EPI_GELU)
         h3 = Fx.gemm_nt(hact, s["out"].wb, s["out"].b)
@@ -530,7 +533,7 @@ class _LastLayerRowsFn(torch.autograd.Function):
             dq2 = torch.empty_like(r["q2"])
             dkv = torch.empty((enc.shape[0], 2 * D), dtype=BF16, device=dq2.device)
             args = (dc2, r["q2"], kv[:, :D], kv[:, D:], r["c2"], r["lse2"], dq2, dkv[:, :D], dkv[:, D:], B, H, Tq, Nenc, scale)
-            kw = dict(drop=r["d_att2"], groups=groups, q_pack=sel)
+            kw = dict(drop=r["d_att2"], groups=groups, q_pack=sel, o_lo=r["c2lo"])
             delta = Fx.attn_bwd(*args, phase=1, **kw)
             wg.run(lambda: Fx.attn_bwd(*args, phase=2, delta=delta, **kw), keep=args[:9] + (delta,))
             wg.gemm_tn(dq2, r["y1"], s["q2"].dw, dbias=s["q2"].db)
