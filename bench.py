@@ -590,6 +590,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, world_size=world, rank=rank)
 
+    from xfm_amd import marks
     from xfm_amd.accelerators import RCCLDDPAccelerator
 
     wl = dict(WORKLOADS[args.workload], name=args.workload)
@@ -608,15 +609,19 @@ def main():
     def step(timed_comm=False):
         j = counter[0] % args.pool
         counter[0] += 1
+        marks.mark("step begin")
         total, parts = forward(wrapped, j)
+        marks.mark("forward end")
         if timed_comm and world > 1:  # end of backward -> gradient all-reduce complete, on the launch stream
             acc.timing = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             comm_events.append(acc.timing)
         acc.backward_step(total, optimizer)
+        marks.mark("backward end")
         if args.no_optimizer:
             model.zero_grad()
         else:
             acc.optimizer_step(optimizer, model)
+        marks.mark("step end")
         return parts
 
     def barrier():
@@ -637,10 +642,17 @@ def main():
             losses = step()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            if i == max(0, args.steps - 10):
+                marks.reset()   # XFM_MARKS=1: the table of the last (up to) ten steps
             losses = step(timed_comm=True)
         barrier()
         elapsed = time.perf_counter() - t0
+        if marks.ON and rank == 0:
+            rows, n_avg = marks.mean_table()
+            print(f"step marks (mean of the last {n_avg} steps)  | stream | queued by the host at ms | reached by the GPU at ms |", file=sys.stderr)
+            for lab, st, h, g in rows:
+                print(f"  {lab:24s} | {st} | {h:8.3f} | {g:8.3f} |", file=sys.stderr)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

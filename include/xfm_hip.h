@@ -76,6 +76,21 @@ long xfm_gemm_tn_batch_workspace(int nb, int M, int N, int K);
 int xfm_gemm_tn_batch(int nb, const void* const* dY, long ldy, const void* const* X, long ldx, float* const* dW, long ldw,
                       float* const* dbias, int M, int N, int K, float* workspace, long workspace_bytes, void* stream);
 
+/* Any number of weight gradients over the SAME M rows in persistent grouped launches (the deferred weight gradients of a whole tower:
+ * every wgrad of one ViT block has 9-36 output tiles of 256 x 256 and needs 7 M-splits, partial planes and a reduce to fill the chip; the
+ * tiles of all blocks together are walked whole, one owner per dW element, and only the last total % CUs tiles are cut stream-K
+ * style and fixed up in workgroup order -- deterministic).  `items` is HOST memory.  Problems with N or K not a multiple of 256 (or
+ * M < 1024) and the last M % 64 rows of every problem run through xfm_gemm_tn. */
+typedef struct {
+  const xfm_bf16* dY; long ldy;   /* [M, N] */
+  const xfm_bf16* X; long ldx;    /* [M, K] */
+  float* dW; long ldw;            /* [N, K] += */
+  float* dbias;                   /* optional [N] += column sums of dY */
+  int N, K;
+} xfm_tn_item;
+long xfm_gemm_tn_group_workspace(int n, const xfm_tn_item* items, int M);
+int xfm_gemm_tn_group(int n, const xfm_tn_item* items, int M, float* workspace, long workspace_bytes, void* stream);
+
 /* fp32 master weight [N,K] -> bf16 copy wb[N,ldb] and/or transposed bf16 copy wt[K,ldt] (zero padded). */
 int xfm_cast_transpose(const float* w, int N, int K, xfm_bf16* wb, long ldb, xfm_bf16* wt, long ldt, void* stream);
 

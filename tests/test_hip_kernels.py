@@ -1046,6 +1046,45 @@ def test_gemm_tn_batch_equals_separate_calls(M, N, K, nb):
             _close(db_a[i], dys[i].float().sum(0), 2e-3, f"batched dbias[{i}]")
 
 
+@pytest.mark.parametrize("M,shapes", [
+    (2048, [(768, 768), (1024, 256), (512, 512)]),                         # 17 tiles: every tile cut over the workgroups (stream-K only)
+    (1536, [(1536, 768)] * 12 + [(3072, 768)] * 3),                        # 324 tiles: 256 whole ones, 68 cut over 102 workgroups
+    (1024, [(768, 3072)] * 22),                                            # 792 tiles: three whole waves + 24 tiles, pieces = whole tiles
+    (2048 + 40, [(768, 768), (320, 256), (256, 768), (768, 200)]),         # ragged M (tail rows) and shapes the 256 x 256 pipeline refuses
+    (1152, [(256, 256)] * 50),                                             # more problems than one launch's table holds
+])
+def test_gemm_tn_group_whole_tiles_and_stream_k_tail(M, shapes):
+    """Grouped weight gradients (the deferred wgrads of a tower in persistent launches): values against fp32 math with dW += and the
+    bias gradients of every other problem; exact on small-integer operands (a misplaced tile or piece cannot hide); and the same bits
+    on every run -- whole tiles have one owner, the cut tiles' pieces are added in workgroup order."""
+    Fx = _fx()
+    n = len(shapes)
+    dys = [_rand((M, N), 1.0, seed=100 + i) for i, (N, K) in enumerate(shapes)]
+    xs = [_rand((M, K), 1.0, seed=200 + i) for i, (N, K) in enumerate(shapes)]
+
+    def run(dys, xs, init):
+        dws = [torch.full((N, K), init, dtype=F32, device="cuda") for N, K in shapes]
+        dbs = [torch.full((N,), init, dtype=F32, device="cuda") if i % 2 == 0 else None for i, (N, K) in enumerate(shapes)]
+        Fx.gemm_tn_group([(dys[i], xs[i], dws[i], dbs[i]) for i in range(n)])
+        return dws, dbs
+
+    dws, dbs = run(dys, xs, 0.5)
+    for i in range(n):
+        _close(dws[i], 0.5 + dys[i].float().t() @ xs[i].float(), 2e-4, f"grouped dW[{i}]")
+        if dbs[i] is not None:
+            _close(dbs[i], 0.5 + dys[i].float().sum(0), 2e-4, f"grouped dbias[{i}]")
+    dws2, _ = run(dys, xs, 0.5)
+    for i, (N, K) in enumerate(shapes):   # (the shapes that fall back to xfm_gemm_tn may take its atomics path)
+        assert N % 256 or K % 256 or torch.equal(dws[i], dws2[i]), f"dW[{i}] differs between two runs"
+    dyi = [((torch.arange(M * N, device="cuda").reshape(M, N) * (7 + i)) % 13 - 6).to(BF16) for i, (N, K) in enumerate(shapes)]
+    xi = [((torch.arange(M * K, device="cuda").reshape(M, K) * (5 + i)) % 11 - 5).to(BF16) for i, (N, K) in enumerate(shapes)]
+    dwi, dbi = run(dyi, xi, 0.0)
+    for i in range(n):
+        assert torch.equal(dwi[i], dyi[i].float().t() @ xi[i].float()), f"integer dW[{i}]"
+        if dbi[i] is not None:
+            assert torch.equal(dbi[i], dyi[i].float().sum(0)), f"integer dbias[{i}]"
+
+
 @pytest.mark.parametrize("C", [2, 3, 5, 10, 101, 1000])
 def test_small_ce_any_class_count_and_ignored_labels(C):
     """ops.small_ce = F.cross_entropy for every class count (the kernels read 4-column granules: widths that are not a multiple of 4 go

@@ -68,3 +68,48 @@ for g, a, b in gaps:
 print("| after | before | count | total us | avg us |")
 for (a, b), (c, t) in sorted(pair.items(), key=lambda kv: -kv[1][1])[:28]:
     print(f"| {a} | {b} | {c} | {t / 1e3:.1f} | {t / c / 1e3:.2f} |")
+
+# GANTT=<ms>: the window in buckets of that many ms -- per queue the busy share of the bucket and the kernel that took most of it
+if os.environ.get("GANTT"):
+    step = float(os.environ["GANTT"]) * 1e6
+    lo = ks[0][0]
+    nb = int(span / step) + 1
+    qs = sorted(per_q, key=lambda q: -per_q[q])
+    table = {q: [defaultdict(int) for _ in range(nb)] for q in qs}
+    for s, e, n, q in ks:
+        name = n.replace("void ", "").split("(")[0].split("<")[0][:22]
+        b0, b1 = int((s - lo) / step), int((e - lo) / step)
+        for b in range(b0, min(b1, nb - 1) + 1):
+            a, z = max(s, lo + b * step), min(e, lo + (b + 1) * step)
+            if z > a:
+                table[q][b][name] += z - a
+    print("\n| ms | " + " | ".join(f"queue {q}" for q in qs) + " |")
+    for b in range(nb):
+        cells = []
+        for q in qs:
+            d = table[q][b]
+            if not d:
+                cells.append("")
+                continue
+            tot_b = sum(d.values())
+            name = max(d.items(), key=lambda kv: kv[1])[0]
+            cells.append(f"{100.0 * tot_b / step:3.0f}% {name}")
+        print(f"| {b * step / 1e6:5.1f} | " + " | ".join(cells) + " |")
+
+# WAKE=<ms>: every kernel that starts a queue's work after that queue sat idle for at least <ms>, with the kernels that ended last on
+# the other queues before it -- what the queue was waiting for
+if os.environ.get("WAKE"):
+    thr = float(os.environ["WAKE"]) * 1e6
+    lo = ks[0][0]
+    last_end = {}
+    hist = []
+    print("\n| queue | wakes at ms | idle ms | first kernel | ended just before (queue: kernel @ ms) |")
+    for s, e, n, q in ks:
+        if q in last_end and s - last_end[q] >= thr:
+            before = sorted([(ee, qq, nn) for ss, ee, nn, qq in hist if qq != q and ee <= s + 2000], reverse=True)[:3]
+            desc = "; ".join(f"{qq}: {nn.replace('void ', '').split('(')[0][:28]} @ {(ee - lo) / 1e6:.3f}" for ee, qq, nn in before)
+            print(f"| {q} | {(s - lo) / 1e6:.3f} | {(s - last_end[q]) / 1e6:.2f} | {n.replace('void ', '').split('(')[0][:36]} | {desc} |")
+        last_end[q] = max(last_end.get(q, 0), e)
+        hist.append((s, e, n, q))
+        if len(hist) > 400:
+            hist = hist[-200:]

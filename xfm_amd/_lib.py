@@ -91,6 +91,10 @@ class RLayerBwd(ctypes.Structure):
                 ("need_dprev", _I), ("side_stream", _P), ("ws_main", _P), ("ws_main_bytes", _L), ("ws_side", _P), ("ws_side_bytes", _L)]
 
 
+class TnItem(ctypes.Structure):   # xfm_tn_item
+    _fields_ = [("dY", _P), ("ldy", _L), ("X", _P), ("ldx", _L), ("dW", _P), ("ldw", _L), ("dbias", _P), ("N", _I), ("K", _I)]
+
+
 class RLayerLayout(ctypes.Structure):
     _fields_ = [(n, _L) for n in ("qkv", "c1", "lse1", "h", "z1", "m1", "r1", "y1", "q2", "c2", "lse2", "z2", "m2", "r2", "y2", "hact", "u",
                                   "z3", "m3", "r3", "y3", "fwd_bytes",
@@ -157,6 +161,8 @@ SIGNATURES = {
     "xfm_rlayer_layout": (c_int, [c_int] * 11 + [ctypes.POINTER(RLayerLayout)]),
     "xfm_rlayer_fwd": (c_int, [ctypes.POINTER(RLayerParams), ctypes.POINTER(RLayerIO), c_void_p]),
     "xfm_rlayer_bwd": (c_int, [ctypes.POINTER(RLayerParams), ctypes.POINTER(RLayerIO), ctypes.POINTER(RLayerBwd), c_void_p]),
+    "xfm_gemm_tn_group_workspace": (c_long, [c_int, c_void_p, c_int]),
+    "xfm_gemm_tn_group": (c_int, [c_int, c_void_p, c_int, c_void_p, c_long, c_void_p]),
     "xfm_gemm_tn_batch_workspace": (c_long, [c_int, c_int, c_int, c_int]),
     "xfm_gemm_tn_batch": (c_int, [c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_void_p, c_long,
                                   c_void_p]),

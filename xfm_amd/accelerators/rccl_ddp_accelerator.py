@@ -213,15 +213,17 @@ class RCCLDDPAccelerator(Accelerator):
         if delta < 0 and rec[0] == 0 and rec[2] is not None and self._overlap_ok:
             self._launch(rec[2])
 
-    def _on_blocks_done(self, vit, lo, hi, wgrad_stream):
-        """Blocks [lo, hi) of the vision trunk have their final gradients (called from the trunk's backward).  Only when this
-        backward is the tower's last pending use of the step (two ViT passes accumulate into the same range).  Returns whether the
-        range was handed to the all-reduce."""
+    def _on_blocks_done(self, vit, lo, hi, wgrad):
+        """Blocks [lo, hi) of the vision trunk have passed their backward (called from the trunk's backward; `wgrad` is its
+        _WgradStream).  Only when this backward is the tower's last pending use of the step (two ViT passes accumulate into the same
+        range).  The blocks' queued weight gradients are launched first (one grouped call for the chunk); the exchange waits for the
+        stream they run on.  Returns whether the range was handed to the all-reduce."""
         rec = self._use[id(vit)]
         if not (rec[0] == 1 and self._overlap_ok):
             return False
+        wgrad.flush()
         ps = [p for b in vit.blocks[lo:hi] for p in b.parameters()]
-        self._launch(self.arena.range_of(ps), extra_stream=wgrad_stream)
+        self._launch(self.arena.range_of(ps), extra_stream=wgrad.side if wgrad.on else None)
         return True
 
     def _exchange(self, a, b, async_ok=True):

@@ -231,9 +231,12 @@ class _TrunkFn(torch.autograd.Function):
             dy = Fx.pool_rows_bwd(dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16), B, N)
         dstream = torch.zeros((M, D), dtype=torch.float32, device=dy.device)
         from .xroberta import _WgradStream
-        wg = _WgradStream(dy.device)
+        wg = _WgradStream(dy.device, "vit bwd")
         done = len(blocks)
         ddense_all = None
+        # the blocks' weight gradients are QUEUED and run as one grouped launch at the end of the trunk (or before each hand-over of a
+        # gradient range to the data-parallel accelerator below): 48 projections x 9-36 output tiles walk whole tiles over all of M
+        tn = wg.defer_tn if (_DEFER_WGRAD and dy.is_cuda) else wg.gemm_tn
         for i in reversed(range(len(blocks))):
             blk, s = blocks[i], vit._slots[i]
             (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t, ctxv_lo, tiles) = ctx.saved[i]
@@ -246,13 +249,13 @@ class _TrunkFn(torch.autograd.Function):
             dg2 = g(blk.gamma_2) if blk.gamma_2 is not None else None
             dh2 = Fx.ln_ls_bwd(dy, dstream, x2, meann, rstdn, nxt.weight, h2, g2, dp2, N, g(nxt.weight), g(nxt.bias),
                                s["fc2"].db, dg2)
-            wg.gemm_tn(dh2, hact, s["fc2"].dw)
+            tn(dh2, hact, s["fc2"].dw)
             du = Fx.gemm_nt(dh2, s["fc2"].wt, epi=Fx.EPI_DGELU, aux=u, n=s["fc2"].K)
-            wg.gemm_tn(du, y2, s["fc1"].dw, dbias=s["fc1"].db)
+            tn(du, y2, s["fc1"].dw, dbias=s["fc1"].db)
             dy2 = Fx.gemm_nt(du, s["fc1"].wt, n=s["fc1"].K)
             dh1 = Fx.ln_ls_bwd(dy2, dstream, x1, mean2, rstd2, blk.norm2.weight, h1, g1, dp1, N, g(blk.norm2.weight),
                                g(blk.norm2.bias), s["proj"].db, dg1)
-            wg.gemm_tn(dh1, ctxv, s["proj"].dw)
+            tn(dh1, ctxv, s["proj"].dw)
             dctx = Fx.gemm_nt(dh1, s["proj"].wt, n=s["proj"].K)
             dqkv = torch.empty_like(qkv)
             ddense = None
@@ -269,15 +272,18 @@ class _TrunkFn(torch.autograd.Function):
                     Fx.relpos_grid_grad(ddense, G, H, ld, g(blk.attn.relative_position_bias_table))   # 144 -> ~20 us at 901 tokens
                 else:
                     Fx.relpos_scatter_sorted(ddense, vit._relpos_order, vit._relpos_start, H, N, ld, g(blk.attn.relative_position_bias_table))
-            wg.gemm_tn(dqkv, y, s["qkv"].dw, dbias=s["qkv"].db)
+            tn(dqkv, y, s["qkv"].dw, dbias=s["qkv"].db)
             dy = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K)
             ctx.saved[i] = None
+            if _WGRAD_GROUP_BLOCKS > 0 and i % _WGRAD_GROUP_BLOCKS == 0:
+                wg.flush()
             # data parallel: the gradients of blocks [i + 1, done) are final now (block i's own norm1 gradient is only written while
             # block i - 1 is processed) once this pass is the tower's last pending use -- hand that arena range to the accelerator,
             # so its all-reduce runs under the remaining blocks' backward
             if ctx.noted and i > 0 and i % _GRAD_CHUNK_BLOCKS == 0 and i + 1 < done:
                 hook = getattr(vit, "_block_grad_hook", None)
-                if hook is not None and hook(vit, i + 1, done, wg.side if wg.on else None):
+                # (the hook flushes the queued weight gradients itself once it knows the range really leaves now)
+                if hook is not None and hook(vit, i + 1, done, wg):
                     done = i + 1
         x0, mean0, rstd0 = ctx.first
         n0 = blocks[0].norm1
@@ -317,6 +323,9 @@ _VIT_FUSED_BWD = __import__("os").environ.get("XFM_ATTN_VIT_BWD", "0") != "0"   
 # the trunk's gradients leave for the all-reduce in chunks of this many blocks, from inside its backward; what is still there when the
 # backward ends (blocks 0 .. chunk, the embeddings) is the exposed tail of the exchange: 2 -> 3 blocks = 85 MB of fp32 gradients behind
 # five overlapped 57-MB collectives (round 2: 4 -> 5 blocks = 142 MB behind two of 114 MB)
+# XFM_VIT_DEFER_WGRAD=0: one xfm_gemm_tn per projection as the backward reaches it (rounds 1-3) instead of the grouped launch
+_DEFER_WGRAD = __import__("os").environ.get("XFM_VIT_DEFER_WGRAD", "1") != "0"
+_WGRAD_GROUP_BLOCKS = int(__import__("os").environ.get("XFM_VIT_WGRAD_GROUP", "0"))   # blocks per grouped launch (0: the whole trunk at its end)
 _GRAD_CHUNK_BLOCKS = max(1, int(__import__("os").environ.get("XFM_VIT_GRAD_CHUNK", "2")))
 
 

@@ -75,6 +75,11 @@ int xfm_gemm_tn_batch(int nb, const void* const* dY, long ldy, const void* const
   return xfm_gemm_tn_batch_impl(nb, dY, ldy, X, ldx, dW, ldw, dbias, M, N, K, workspace, workspace_bytes, ST(stream));
 }
 
+long xfm_gemm_tn_group_workspace(int n, const xfm_tn_item* items, int M) { return xfm_gemm_tn_group_workspace_impl(n, items, M); }
+int xfm_gemm_tn_group(int n, const xfm_tn_item* items, int M, float* workspace, long workspace_bytes, void* stream) {
+  return xfm_gemm_tn_group_impl(n, items, M, workspace, workspace_bytes, ST(stream));
+}
+
 int xfm_cast_transpose_batch(const xfm_cast_item* items, int n_items, long total_tiles, void* stream) {
   return xfm_cast_transpose_batch_impl(items, n_items, total_tiles, ST(stream));
 }

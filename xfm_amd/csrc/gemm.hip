@@ -1257,23 +1257,22 @@ __global__ __launch_bounds__(256) void tn_reduce128_kernel(const float* __restri
 // on the matrix cores: in the k-tile-0 workgroups wave wc multiplies its wc-th dY fragment of each half with a ones
 // fragment (4 extra MFMA per K-tile per wave).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmTN g) {
+// One (tile, M-range) of the pipeline: rows [mbeg, mbeg + 64 nk) of dY columns [n0, n0 + 256) against X columns [k0, k0 + 256).
+struct Tn256Seg {
+  const bf16* dY; const bf16* X;
+  unsigned ldy, ldx;
+  int n0, k0, mbeg, nk;
+  bool do_bias;
+};
+
+__device__ __forceinline__ void tn256_mainloop(const Tn256Seg& sg, char* smem, f32x4 (&acc)[8][4], f32x4 (&bacc)[2]) {
   constexpr int UNIT = 64 * 256, BUF = 4 * UNIT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 2, wc = w & 3;
   const int lr = lane & 15, lg = lane >> 4;
-  const int tiles_k = g.K / 256, tiles_n = g.N / 256;
-  const int per_split = tiles_k * tiles_n;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = wg / per_split, t = wg % per_split;
-  const int n0 = (t / tiles_k) * 256, k0 = (t % tiles_k) * 256;
-  const int mbeg = split * g.m_per_split;
-  int mend = mbeg + g.m_per_split;
-  mend = mend < g.M ? mend : g.M;
-  const int nk = (mend - mbeg) / 64;
+  const int n0 = sg.n0, k0 = sg.k0, mbeg = sg.mbeg, nk = sg.nk;
   const int total = 4 * nk;
-  const bool do_bias = g.dbias != nullptr && k0 == 0;
+  const bool do_bias = sg.do_bias;
 
   // per-lane source element offsets (K-tile 0) and wave-uniform LDS destinations of the 8 (unit, instruction) loads
   unsigned soff[4][2];
@@ -1283,7 +1282,7 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmTN g) {
     const int b = i * 8 + w;                 // 1-KiB block of the unit: rows 4b .. 4b+3
     const int r = 4 * b + (lane >> 4);
     const int c = ((lane & 15) ^ swz_t(r)) * 8;  // logical column (0..127) stored at this lane's 16-B slot
-    const unsigned rowy = (unsigned)(mbeg + r) * (unsigned)g.ldy, rowx = (unsigned)(mbeg + r) * (unsigned)g.ldx;
+    const unsigned rowy = (unsigned)(mbeg + r) * (unsigned)sg.ldy, rowx = (unsigned)(mbeg + r) * (unsigned)sg.ldx;
     soff[0][i] = rowy + n0 + (c >> 6) * 128 + (c & 63);
     soff[3][i] = rowy + n0 + (c >> 6) * 128 + 64 + (c & 63);
     soff[1][i] = rowx + k0 + (c >> 5) * 64 + (c & 31);
@@ -1298,7 +1297,7 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmTN g) {
     const int kt = s >> 2, j = s & 3;
     char* base = smem + (kt & 1) * BUF;
     const bool isy = (j == 0 || j == 3);
-    const bf16* src = (isy ? g.dY : g.X) + (size_t)kt * 64 * (size_t)(isy ? g.ldy : g.ldx);
+    const bf16* src = (isy ? sg.dY : sg.X) + (size_t)kt * 64 * (size_t)(isy ? sg.ldy : sg.ldx);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const unsigned so = j == 0 ? soff[0][i] : j == 1 ? soff[1][i] : j == 2 ? soff[2][i] : soff[3][i];
@@ -1310,12 +1309,11 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmTN g) {
     }
   };
 
-  f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 bacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  bacc[0] = bacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 ones;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = f2bf(1.0f);
@@ -1425,20 +1423,34 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmTN g) {
 #undef XFM_TQUAD
 #undef XFM_TBIAS
 
-  if (do_bias && lr == 0) {  // D[i = n][j]: every column j holds the same sum; lane (lg, lr = 0) owns rows 4*lg .. 4*lg+3
+}
+
+// the bias gradient of the tile's 256 dY columns: D[i = n][j], every column j holds the same sum; lane (lg, lr = 0) owns rows 4 lg .. 4 lg + 3
+template <bool ATOMIC>
+__device__ __forceinline__ void tn256_bias_out(float* dbias, int n0, const f32x4 (&bacc)[2]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 2, wc = w & 3, lr = lane & 15, lg = lane >> 4;
+  if (lr != 0) return;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) atomicAdd(g.dbias + n0 + wr * 128 + h * 64 + wc * 16 + 4 * lg + i, bacc[h][i]);
-  }
-  if (g.ws != nullptr) {  // partial tile, one coalesced 16-B store per accumulator register quad; tn_reduce_kernel sums the splits
-    f32x4* wsp = reinterpret_cast<f32x4*>(g.ws) + ((((long)split * per_split + t) * 8 + w) * 32) * 64 + lane;
+    for (int i = 0; i < 4; ++i) {
+      float* d = dbias + n0 + wr * 128 + h * 64 + wc * 16 + 4 * lg + i;
+      if (ATOMIC) atomicAdd(d, bacc[h][i]);
+      else *d += bacc[h][i];
+    }
+}
+// partial tile -> workspace slot, one coalesced 16-B store per accumulator register quad (the reduce kernels read the same order)
+__device__ __forceinline__ void tn256_store_partial(float* ws, long slot, const f32x4 (&acc)[8][4]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  f32x4* wsp = reinterpret_cast<f32x4*>(ws) + ((slot * 8 + w) * 32) * 64 + lane;
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
+  for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) wsp[(nt * 4 + kt) * 64] = acc[nt][kt];
-    return;
-  }
+    for (int kt = 0; kt < 4; ++kt) wsp[(nt * 4 + kt) * 64] = acc[nt][kt];
+}
+template <bool ATOMIC>
+__device__ __forceinline__ void tn256_add_out(float* dW, long ldw, int n0, int k0, const f32x4 (&acc)[8][4]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 2, wc = w & 3, lr = lane & 15, lg = lane >> 4;
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
@@ -1447,9 +1459,149 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmTN g) {
 #pragma unroll
       for (int rgi = 0; rgi < 4; ++rgi) {
         const int n = n0 + wr * 128 + nt * 16 + 4 * lg + rgi;
-        atomicAdd(g.dW + (long)n * g.ldw + k, acc[nt][kt][rgi]);
+        if (ATOMIC) atomicAdd(dW + (long)n * ldw + k, acc[nt][kt][rgi]);
+        else dW[(long)n * ldw + k] += acc[nt][kt][rgi];
       }
     }
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmTN g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_k = g.K / 256, tiles_n = g.N / 256;
+  const int per_split = tiles_k * tiles_n;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = wg / per_split, t = wg % per_split;
+  const int n0 = (t / tiles_k) * 256, k0 = (t % tiles_k) * 256;
+  const int mbeg = split * g.m_per_split;
+  int mend = mbeg + g.m_per_split;
+  mend = mend < g.M ? mend : g.M;
+  const Tn256Seg sg{g.dY, g.X, (unsigned)g.ldy, (unsigned)g.ldx, n0, k0, mbeg, (mend - mbeg) / 64, g.dbias != nullptr && k0 == 0};
+  f32x4 acc[8][4], bacc[2];
+  tn256_mainloop(sg, smem, acc, bacc);
+  if (sg.do_bias) tn256_bias_out<true>(g.dbias, n0, bacc);
+  if (g.ws != nullptr) {  // tn_reduce_kernel sums the splits
+    tn256_store_partial(g.ws, (long)split * per_split + t, acc);
+    return;
+  }
+  tn256_add_out<true>(g.dW, g.ldw, n0, k0, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GROUPED weight gradients (round 4): many problems of one M (every projection of several layers) in ONE persistent launch.
+// A single wgrad has 9-36 output tiles of 256 x 256 and needs 7+ M-splits to fill 256 CUs: each split writes a 256-KB fp32 partial
+// per tile (64 MB per GEMM whatever its shape -- one accumulator tile per CU) that a reduce kernel reads back, ~20 % on top of the MFMA
+// loop.  With the tiles of ALL queued problems in one list, workgroup i walks WHOLE tiles i, i + G, ... over the full M (one owner per
+// dW element: plain += into the fp32 gradient, bias gradient included) and only the last total % G tiles are cut stream-K style:
+// their R = r * nk K-steps are dealt out evenly over the G workgroups (boundaries snapped so that no piece is shorter than 4 steps),
+// at most two partial pieces per workgroup go to workspace slots 2 i / 2 i + 1, and a fix-up kernel adds each cut tile's pieces in
+// workgroup order -- the same bits on every run.
+// ---------------------------------------------------------------------------------------------
+#define TN_GROUP_MAX 48
+struct TnGroupProb {
+  const bf16* dY; const bf16* X;
+  float* dW; float* dbias;
+  unsigned ldy, ldx;
+  long ldw;
+  int tiles_k;
+  int tile_end;   // prefix: this problem owns tiles [previous tile_end, tile_end)
+};
+struct TnGroup {
+  int nprob, nk;             // problems; K-steps (64 rows of M) per tile
+  int total_tiles, full_tiles;
+  int sk_wgs;                // workgroups that share the cut tiles (0: none)
+  long sk_iters;             // (total_tiles - full_tiles) * nk
+  float* ws;
+  TnGroupProb p[TN_GROUP_MAX];
+};
+__host__ __device__ __forceinline__ long tn_sk_bound(long R, int nk, int sk_wgs, int i) {
+  long raw = (long)i * R / sk_wgs;
+  const int rem = (int)(raw % nk);
+  if (rem < 4) raw -= rem;
+  else if (nk - rem < 4) raw += nk - rem;
+  return raw;
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wg = xcd_remap(blockIdx.x, gridDim.x), nwg = gridDim.x;
+  int dp_t = wg;
+  long sk_pos = 0, sk_end = 0;
+  if (wg < G.sk_wgs) {
+    sk_pos = tn_sk_bound(G.sk_iters, G.nk, G.sk_wgs, wg);
+    sk_end = tn_sk_bound(G.sk_iters, G.nk, G.sk_wgs, wg + 1);
+  }
+  const long sk_a = sk_pos;
+  bool first = true;
+  for (;;) {   // (everything that steers this loop is a function of blockIdx: uniform over the workgroup)
+    int tile, it0, it1;
+    long slot = -1;   // >= 0: partial piece
+    if (dp_t < G.full_tiles) {
+      tile = dp_t;
+      dp_t += nwg;
+      it0 = 0;
+      it1 = G.nk;
+    } else if (sk_pos < sk_end) {
+      const int rt = (int)(sk_pos / G.nk);
+      const long t_end = (long)(rt + 1) * G.nk;
+      it0 = (int)(sk_pos - (long)rt * G.nk);
+      it1 = (int)((sk_end < t_end ? sk_end : t_end) - (long)rt * G.nk);
+      tile = G.full_tiles + rt;
+      if (it0 != 0 || it1 != G.nk) slot = 2l * wg + (sk_pos == sk_a ? 0 : 1);
+      sk_pos = (long)rt * G.nk + it1;
+    } else {
+      break;
+    }
+    if (!first) __syncthreads();   // the previous piece's LDS reads are over before this one's staging lands
+    first = false;
+    int pi = 0;
+    while (pi + 1 < G.nprob && tile >= G.p[pi].tile_end) ++pi;
+    const TnGroupProb& P = G.p[pi];
+    const int tl = tile - (pi > 0 ? G.p[pi - 1].tile_end : 0);
+    const int n0 = (tl / P.tiles_k) * 256, k0 = (tl % P.tiles_k) * 256;
+    const Tn256Seg sg{P.dY, P.X, P.ldy, P.ldx, n0, k0, it0 * 64, it1 - it0, P.dbias != nullptr && k0 == 0};
+    f32x4 acc[8][4], bacc[2];
+    tn256_mainloop(sg, smem, acc, bacc);
+    if (slot >= 0) {
+      if (sg.do_bias) tn256_bias_out<true>(P.dbias, n0, bacc);
+      tn256_store_partial(G.ws, slot, acc);
+    } else {
+      if (sg.do_bias) tn256_bias_out<false>(P.dbias, n0, bacc);
+      tn256_add_out<false>(P.dW, P.ldw, n0, k0, acc);
+    }
+  }
+}
+
+// the cut tiles: dW += the pieces in workgroup order.  grid (64, cut tiles): one thread per accumulator quad, as tn_reduce_kernel.
+__global__ __launch_bounds__(256) void tn_group_fixup_kernel(TnGroup G) {
+  const int rt = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // < 8 * 32 * 64
+  const long R = G.sk_iters;
+  const long a = (long)rt * G.nk, b = a + G.nk;
+  int i0 = (int)(a * G.sk_wgs / R);
+  i0 = i0 < G.sk_wgs - 1 ? i0 : G.sk_wgs - 1;
+  while (i0 > 0 && tn_sk_bound(R, G.nk, G.sk_wgs, i0) > a) --i0;
+  while (i0 + 1 < G.sk_wgs && tn_sk_bound(R, G.nk, G.sk_wgs, i0 + 1) <= a) ++i0;
+  int i1 = i0;
+  while (i1 + 1 < G.sk_wgs && tn_sk_bound(R, G.nk, G.sk_wgs, i1 + 1) < b) ++i1;
+  if (i0 == i1) return;   // one workgroup walked the whole tile and added it to dW itself
+  const f32x4* ws = reinterpret_cast<const f32x4*>(G.ws);
+  f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = i0; i <= i1; ++i) {
+    const long slot = 2l * i + (tn_sk_bound(R, G.nk, G.sk_wgs, i) >= a ? 0 : 1);
+    sum += ws[slot * (8 * 32 * 64) + idx];
+  }
+  const int tile = G.full_tiles + rt;
+  int pi = 0;
+  while (pi + 1 < G.nprob && tile >= G.p[pi].tile_end) ++pi;
+  const TnGroupProb& P = G.p[pi];
+  const int tl = tile - (pi > 0 ? G.p[pi - 1].tile_end : 0);
+  const int n0 = (tl / P.tiles_k) * 256, k0 = (tl % P.tiles_k) * 256;
+  const int lane = idx & 63, q = (idx >> 6) & 31, w = idx >> 11;
+  const int wr = w >> 2, wc = w & 3, lr = lane & 15, lg = lane >> 4, nt = q >> 2, kt = q & 3;
+  const int k = k0 + wc * 64 + kt * 16 + lr;
+  const int n = n0 + wr * 128 + nt * 16 + 4 * lg;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) P.dW[(long)(n + i) * P.ldw + k] += sum[i];
 }
 
 // dW += sum over splits of the partial tiles written by gemm_tn_256_kernel (deterministic: fixed summation order).
@@ -1665,6 +1817,114 @@ int xfm_gemm_tn_batch_impl(int nb, const void* const* dY, long ldy, const void* 
   hipLaunchKernelGGL(tn_reduce128_kernel, dim3((unsigned)cdiv(quads, 256), nb), dim3(256), 0, st, workspace, bt.dW[0], ldw, N, K, cdiv(K, 128),
                      tiles, splits, bt);
   return xfm_check_launch("gemm_tn_batch_reduce");
+}
+
+// Any number of weight gradients over the SAME M rows (all the projections of the layers whose dY are still alive) -> persistent
+// grouped launches of gemm_tn_group_kernel, TN_GROUP_MAX problems each.  Problems the 256 x 256 pipeline does not take (N or K not a
+// multiple of 256, fewer than 1024 rows) and the last M % 64 rows of every problem go through xfm_gemm_tn one by one.
+static int tn_group_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    n = n / 8 * 8 > 0 ? n / 8 * 8 : 8;
+  }
+  return n;
+}
+static bool tn_group_item_ok(const xfm_tn_item& it, int M0) {
+  return M0 >= 1024 && tn256_eligible(it.ldy, it.ldx, M0, it.N, it.K) && ((uintptr_t)it.dY % 16) == 0 && ((uintptr_t)it.X % 16) == 0;
+}
+static void tn_group_plan(int tiles, int nk, int G, int& full, int& sk_wgs, long& R) {
+  full = tiles / G * G;
+  R = (long)(tiles - full) * nk;
+  sk_wgs = 0;
+  if (R > 0) {
+    const long m = R / 16;   // >= 16 K-steps per workgroup: pieces stay >= 4 steps after the boundaries snap to tile edges
+    sk_wgs = (int)(m < G ? m : G);
+    if (sk_wgs < 1) sk_wgs = 1;
+  }
+}
+long xfm_gemm_tn_group_workspace_impl(int n, const xfm_tn_item* items, int M) {
+  if (n <= 0 || items == nullptr || M <= 0) return 0;
+  const int M0 = M - M % 64, G = tn_group_cus();
+  long need = 0;
+  int tiles = 0, np = 0;
+  auto close = [&]() {
+    if (np == 0) return;
+    int full, sk;
+    long R;
+    tn_group_plan(tiles, M0 / 64, G, full, sk, R);
+    const long b = sk > 1 ? 2l * sk * 256 * 256 * 4 : 0;
+    need = b > need ? b : need;
+    tiles = np = 0;
+  };
+  for (int i = 0; i < n; ++i) {
+    const xfm_tn_item& it = items[i];
+    if (tn_group_item_ok(it, M0)) {
+      tiles += (it.N / 256) * (it.K / 256);
+      if (++np == TN_GROUP_MAX) close();
+    } else {
+      const long b = xfm_gemm_tn_workspace_impl(M, it.N, it.K);
+      need = b > need ? b : need;
+    }
+  }
+  close();
+  return need;
+}
+int xfm_gemm_tn_group_impl(int n, const xfm_tn_item* items, int M, float* workspace, long workspace_bytes, hipStream_t st) {
+  XFM_REQUIRE(n >= 0 && (n == 0 || items != nullptr) && M > 0, "gemm_tn_group: bad arguments");
+  XFM_REQUIRE(workspace_bytes >= xfm_gemm_tn_group_workspace_impl(n, items, M) && (workspace != nullptr || workspace_bytes == 0),
+              "gemm_tn_group: workspace smaller than xfm_gemm_tn_group_workspace()");
+  const int M0 = M - M % 64, G = tn_group_cus();
+  static bool attr_set = false;
+  const size_t smem = 2 * 4 * 64 * 256;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  TnGroup g{};
+  g.nk = M0 / 64;
+  g.ws = workspace;
+  auto flush = [&]() -> int {
+    if (g.nprob == 0) return XFM_OK;
+    tn_group_plan(g.total_tiles, g.nk, G, g.full_tiles, g.sk_wgs, g.sk_iters);
+    const int grid = g.full_tiles > 0 ? G : g.sk_wgs;
+    hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(grid), dim3(512), smem, st, g);
+    int rc = xfm_check_launch("gemm_tn_group");
+    if (rc == XFM_OK && g.sk_wgs > 1) {
+      hipLaunchKernelGGL(tn_group_fixup_kernel, dim3(64, g.total_tiles - g.full_tiles), dim3(256), 0, st, g);
+      rc = xfm_check_launch("gemm_tn_group_fixup");
+    }
+    g.nprob = g.total_tiles = 0;
+    return rc;
+  };
+  for (int i = 0; i < n; ++i) {
+    const xfm_tn_item& it = items[i];
+    XFM_REQUIRE(it.dY && it.X && it.dW && it.N > 0 && it.K > 0, "gemm_tn_group: bad problem %d", i);
+    if (!tn_group_item_ok(it, M0)) continue;
+    TnGroupProb& P = g.p[g.nprob++];
+    P.dY = (const bf16*)it.dY; P.X = (const bf16*)it.X; P.dW = it.dW; P.dbias = it.dbias;
+    P.ldy = (unsigned)it.ldy; P.ldx = (unsigned)it.ldx; P.ldw = it.ldw;
+    P.tiles_k = it.K / 256;
+    g.total_tiles += (it.N / 256) * (it.K / 256);
+    P.tile_end = g.total_tiles;
+    if (g.nprob == TN_GROUP_MAX) {
+      const int rc = flush();
+      if (rc != XFM_OK) return rc;
+    }
+  }
+  int rc = flush();
+  if (rc != XFM_OK) return rc;
+  for (int i = 0; i < n; ++i) {   // what the grouped kernel did not take
+    const xfm_tn_item& it = items[i];
+    if (!tn_group_item_ok(it, M0))
+      rc = xfm_gemm_tn_impl(it.dY, it.ldy, it.X, it.ldx, it.dW, it.ldw, it.dbias, M, it.N, it.K, 0, workspace, workspace_bytes, st);
+    else if (M0 < M)
+      rc = xfm_gemm_tn_impl((const bf16*)it.dY + (long)M0 * it.ldy, it.ldy, (const bf16*)it.X + (long)M0 * it.ldx, it.ldx, it.dW, it.ldw, it.dbias,
+                            M - M0, it.N, it.K, 1, workspace, workspace_bytes, st);
+    if (rc != XFM_OK) return rc;
+  }
+  return XFM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

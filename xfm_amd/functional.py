@@ -124,6 +124,26 @@ def gemm_tn_batch(dys, xs, dws, dbiases=None):
                                 0 if ws is None else ws.numel() * 4, _stream()), "gemm_tn_batch")
 
 
+def gemm_tn_group(items):
+    """items: (dy [M, N] bf16, x [M, K] bf16, dw [N, K] fp32, dbias [N] fp32 | None), all over the SAME M rows: dw += dy^T @ x (dbias +=
+    column sums of dy) for all of them in persistent grouped launches -- whole 256 x 256 tiles with one owner each, no M-split planes
+    (xfm_gemm_tn_group).  The caller keeps every tensor alive until the stream has run the call."""
+    if not items:
+        return
+    M = items[0][0].shape[0]
+    arr = (_lib.TnItem * len(items))()
+    for a, (dy, x, dw, db) in zip(arr, items):
+        assert dy.dtype == BF16 and x.dtype == BF16 and dw.dtype == F32 and dy.shape[0] == M and x.shape[0] == M
+        assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(-1) == 1 and dw.shape[0] >= dy.shape[1] and dw.shape[1] == x.shape[1]
+        assert db is None or (db.dtype == F32 and db.is_contiguous() and db.numel() >= dy.shape[1])
+        a.dY, a.ldy, a.X, a.ldx, a.dW, a.ldw, a.dbias = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0), _ptr(db)
+        a.N, a.K = dy.shape[1], x.shape[1]
+    lib = _lib.load()
+    need = lib.xfm_gemm_tn_group_workspace(len(items), ctypes.addressof(arr), M)
+    ws = workspace(need, items[0][0].device) if need > 0 else None
+    check(lib.xfm_gemm_tn_group(len(items), ctypes.addressof(arr), M, _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream()), "gemm_tn_group")
+
+
 def cast_table(entries, device):
     """Device-resident xfm_cast_item table for cast_transpose_batch.  entries: (w fp32 [N,K], wb bf16 [N,ldb] | None,
     wt bf16 [K,ldt] | None).  Returns (table uint8 tensor, n_items, total_tiles)."""

@@ -29,6 +29,9 @@ def _side_stream(device):
 
 
 
+from . import marks as _marks  # noqa: E402
+
+
 class _JoinAfterBackward(torch.autograd.Function):
     """Identity on the forward; in the backward it queues an end-of-backward callback that makes `main` wait for `side`.  The text
     tower's backward runs on the side stream (autograd replays nodes on their forward stream) and writes its weight gradients
@@ -95,10 +98,13 @@ class XFM(XFMBase):
             text_stream = _side_stream(image.device)
             text_stream.wait_stream(main)
             with torch.cuda.stream(text_stream):
+                _marks.mark("text fwd begin")
                 if both_passes:
                     text_embeds, mlm_embeds = self.get_text_embeds_with_masked(text_ids, text_atts, text_ids_masked, pack=pack)
                 else:
                     text_embeds = self.get_text_embeds(text_ids, text_atts)
+                _marks.mark("text fwd end")
+        _marks.mark("vit fwd begin")
         if self.batch_passes and do_mim and self.do_image_mask:
             B = image.shape[0]
             if ids_mask is None:
@@ -118,6 +124,7 @@ class XFM(XFMBase):
             image_atts = _ones_mask(image_embeds)
         else:
             image_embeds, image_atts = self.get_vision_embeds(image)
+        _marks.mark("vit fwd end")
         if data_source != 'imagenet':
             if text_stream is not None:  # re-join: the text features are consumed on the main stream from here on
                 main.wait_stream(text_stream)

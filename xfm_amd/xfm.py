@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as Fx
+from . import marks as _marks
 from .arena import LinearSlot, ParamArena
 from .beit2 import _Affine, beit_base_patch16
 from .ops import itc_loss, layer_norm, linear_slot, row_normalize, small_ce
@@ -511,7 +512,9 @@ class XFMBase(nn.Module):
             if neg_idx is not None:   # given by the caller: host data already
                 im, tn = [int(j) for j in neg_idx[0]], [int(j) for j in neg_idx[1]]
             else:
+                _marks.mark("negatives: read-back queued")
                 im, tn = torch.stack([image_neg_idx, text_neg_idx]).cpu().tolist()
+                _marks.mark("negatives: host has them")
             seq_len = lh + lh + [lh[j] for j in tn] + lh                       # the reference's order: pos | neg img | neg txt | mlm
             seq_img = list(range(bs)) + im + list(range(bs)) + list(range(bs))
             seq_txt = list(range(bs)) + list(range(bs)) + tn + [bs + j for j in range(bs)]   # sequence of the text tower's pack
@@ -529,10 +532,12 @@ class XFMBase(nn.Module):
             if prune:
                 sel_rows = torch.cat([start_of[:3 * bs], (start_of[3 * bs:, None] + masked_pos.to(torch.int32)).reshape(-1)])
                 out_rows = (sel_rows, meta[3].contiguous(), meta[4].contiguous(), M)
+            _marks.mark("fusion fwd begin")
             seq = self.fusion_encoder.bert(encoder_embeds=text_all, attention_mask=None, encoder_hidden_states=image_embeds,
                                            encoder_attention_mask=image_atts, return_dict=True, encoder_batch_index=enc_index,
                                            pack=fpack, encoder_row_ranges=ranges if _XATTN_RANGES else None,
                                            output_rows=out_rows).last_hidden_state
+            _marks.mark("fusion fwd end")
             if prune:   # the result IS the gathered rows: 3B [CLS] rows, then B x M masked positions
                 output = self.itm_head(seq[:3 * bs])
                 itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
