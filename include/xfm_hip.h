@@ -79,8 +79,8 @@ int xfm_gemm_tn_batch(int nb, const void* const* dY, long ldy, const void* const
 /* Any number of weight gradients over the SAME M rows in persistent grouped launches (the deferred weight gradients of a whole tower:
  * every wgrad of one ViT block has 9-36 output tiles of 256 x 256 and needs 7 M-splits, partial planes and a reduce to fill the chip; the
  * tiles of all blocks together are walked whole, one owner per dW element, and only the last total % CUs tiles are cut stream-K
- * style and fixed up in workgroup order -- deterministic).  `items` is HOST memory.  Problems with N or K not a multiple of 256 (or
- * M < 1024) and the last M % 64 rows of every problem run through xfm_gemm_tn. */
+ * style and fixed up in workgroup order -- deterministic).  `items` is HOST memory.  Any M from 1024 rows (a short last K-step is
+ * staged as zeros); problems with N or K not a multiple of 256 (or fewer rows) run through xfm_gemm_tn. */
 typedef struct {
   const xfm_bf16* dY; long ldy;   /* [M, N] */
   const xfm_bf16* X; long ldx;    /* [M, K] */
@@ -351,6 +351,10 @@ typedef struct {        /* backward-only */
   int need_dprev;                                /* produce the gradient w.r.t. the layer input (dprev_a + dprev_b in bslab) */
   void* side_stream;
   float* ws_main; long ws_main_bytes; float* ws_side; long ws_side_bytes;
+  int defer_wgrad;                               /* 1: launch NO weight-gradient GEMM -- the caller queues them (the dY / X operands sit at the
+                                                    layout's offsets in bslab / slab, which it keeps alive) and runs the queue of the whole
+                                                    tower as grouped launches (xfm_gemm_tn_group).  Bias gradients that ride on a weight
+                                                    gradient (dbi, dbq2, dbkv2, dbqkv) are deferred with it */
 } xfm_rlayer_bwd_args;
 
 typedef struct {        /* byte offsets inside slab / bslab (256-byte aligned) */

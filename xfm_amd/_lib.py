@@ -88,7 +88,8 @@ class RLayerIO(ctypes.Structure):
 
 class RLayerBwd(ctypes.Structure):
     _fields_ = [("bslab", _P), ("dy_a", _P), ("dy_b", _P), ("enc", _P), ("dkv", _P), ("dkv_ld", _L), ("denc32", _P),
-                ("need_dprev", _I), ("side_stream", _P), ("ws_main", _P), ("ws_main_bytes", _L), ("ws_side", _P), ("ws_side_bytes", _L)]
+                ("need_dprev", _I), ("side_stream", _P), ("ws_main", _P), ("ws_main_bytes", _L), ("ws_side", _P), ("ws_side_bytes", _L),
+                ("defer_wgrad", _I)]
 
 
 class TnItem(ctypes.Structure):   # xfm_tn_item

@@ -231,7 +231,9 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
     (void)hipEventRecord(e, st);
     (void)hipStreamWaitEvent(side, e, 0);
   };
+  static const bool skip_wgrad = getenv("XFM_RL_SKIP_WGRAD") != nullptr;   // timing experiment only: WRONG gradients
   auto wgrad = [&](const bf16* dY, long ldy, const bf16* X, long ldx, float* dW, long ldw, float* db, int M, int N, int K) {
+    if (skip_wgrad || b.defer_wgrad) return (int)XFM_OK;
     fork();
     return xfm_gemm_tn_impl(dY, ldy, X, ldx, dW, ldw, db, M, N, K, 0, b.ws_side, b.ws_side_bytes, side);
   };
@@ -239,7 +241,7 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
   // out as ONE batched launch once the last of their dY exists.  Measured on the step: 1 ms SLOWER than one launch each as their dY
   // appear (the three then trail the activation-gradient chain in one 432-workgroup lump instead of filling its gaps) -- off.
   static const bool tn_batch = getenv("XFM_TN_BATCH") ? atoi(getenv("XFM_TN_BATCH")) != 0 : false;
-  const bool batch3 = cross && tn_batch;
+  const bool batch3 = cross && tn_batch && !b.defer_wgrad;
   const uint32_t c_att = io.seed_ctr + 1, c_h1 = io.seed_ctr + 2, c_att2 = io.seed_ctr + 3, c_h2 = io.seed_ctr + 4;
   const uint32_t c_h3 = cross ? io.seed_ctr + 5 : io.seed_ctr + 3;
   const bf16* y_in = cross ? S16(L.y2) : S16(L.y1);  // input of the feed-forward block
@@ -273,7 +275,8 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
     a.bwd_phase = 2;
     RL_TRY(xfm_attn_bwd_impl(a, side));
     if (!batch3) RL_TRY(wgrad(G16(L.dq2), D, S16(L.y1), D, p.dwq2, D, p.dbq2, R, D, D));
-    RL_TRY(xfm_gemm_tn_impl(b.dkv, b.dkv_ld, b.enc, D, p.dwkv2, D, p.dbkv2, io.U * io.Nenc, 2 * D, D, 0, b.ws_side, b.ws_side_bytes, side));
+    if (!skip_wgrad && !b.defer_wgrad)
+      RL_TRY(xfm_gemm_tn_impl(b.dkv, b.dkv_ld, b.enc, D, p.dwkv2, D, p.dbkv2, io.U * io.Nenc, 2 * D, D, 0, b.ws_side, b.ws_side_bytes, side));
     if (b.denc32 != nullptr)
       RL_TRY(xfm_gemm_nt_impl(b.dkv, b.dkv_ld, p.wkv2_t, p.ld_wkv2_t, b.denc32, D, nullptr, nullptr, 0, io.U * io.Nenc, D, 2 * D, EPI_F32_ACC, 0, side));
     RL_TRY(xfm_gemm_nt_impl(G16(L.dq2), D, p.wq2_t, p.ld_wq2_t, G16(L.d2a), D, nullptr, nullptr, 0, R, D, D, EPI_BF16, 0, st));

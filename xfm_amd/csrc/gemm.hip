@@ -1263,8 +1263,12 @@ struct Tn256Seg {
   unsigned ldy, ldx;
   int n0, k0, mbeg, nk;
   bool do_bias;
+  int rows;   // RAGGED: rows of this piece that exist (the last K-step of a problem whose M is no multiple of 64 is short)
 };
+__device__ __attribute__((aligned(16))) const unsigned tn_zero16[4] = {0u, 0u, 0u, 0u};
 
+// RAGGED: rows at or past sg.rows are staged as zeros (their lanes point the direct-to-LDS load at a 16-byte zero constant).
+template <bool RAGGED>
 __device__ __forceinline__ void tn256_mainloop(const Tn256Seg& sg, char* smem, f32x4 (&acc)[8][4], f32x4 (&bacc)[2]) {
   constexpr int UNIT = 64 * 256, BUF = 4 * UNIT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1305,7 +1309,9 @@ __device__ __forceinline__ void tn256_mainloop(const Tn256Seg& sg, char* smem, f
       // Issued as inline asm on purpose: when the compiler sees a direct-to-LDS load it drains it (s_waitcnt vmcnt(0)) in
       // front of every ds_read_b64_tr_b16, whose intrinsic carries no alias information -- that serialises the pipeline.
       const unsigned lds_addr = (unsigned)(uintptr_t)LDS_PTR(void, base) + (unsigned)__builtin_amdgcn_readfirstlane(dofs);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + (size_t)so), "s"(lds_addr) : "memory", "m0");
+      const bf16* ptr = src + (size_t)so;
+      if (RAGGED && kt * 64 + 4 * (i * 8 + w) + (lane >> 4) >= sg.rows) ptr = reinterpret_cast<const bf16*>(tn_zero16);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(ptr), "s"(lds_addr) : "memory", "m0");
     }
   };
 
@@ -1475,9 +1481,9 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmTN g) {
   const int mbeg = split * g.m_per_split;
   int mend = mbeg + g.m_per_split;
   mend = mend < g.M ? mend : g.M;
-  const Tn256Seg sg{g.dY, g.X, (unsigned)g.ldy, (unsigned)g.ldx, n0, k0, mbeg, (mend - mbeg) / 64, g.dbias != nullptr && k0 == 0};
+  const Tn256Seg sg{g.dY, g.X, (unsigned)g.ldy, (unsigned)g.ldx, n0, k0, mbeg, (mend - mbeg) / 64, g.dbias != nullptr && k0 == 0, 0};
   f32x4 acc[8][4], bacc[2];
-  tn256_mainloop(sg, smem, acc, bacc);
+  tn256_mainloop<false>(sg, smem, acc, bacc);
   if (sg.do_bias) tn256_bias_out<true>(g.dbias, n0, bacc);
   if (g.ws != nullptr) {  // tn_reduce_kernel sums the splits
     tn256_store_partial(g.ws, (long)split * per_split + t, acc);
@@ -1506,7 +1512,8 @@ struct TnGroupProb {
   int tile_end;   // prefix: this problem owns tiles [previous tile_end, tile_end)
 };
 struct TnGroup {
-  int nprob, nk;             // problems; K-steps (64 rows of M) per tile
+  int nprob, nk;             // problems; K-steps (64 rows of M, the last one possibly short) per tile
+  int M;                     // rows
   int total_tiles, full_tiles;
   int sk_wgs;                // workgroups that share the cut tiles (0: none)
   long sk_iters;             // (total_tiles - full_tiles) * nk
@@ -1558,9 +1565,9 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup G) {
     const TnGroupProb& P = G.p[pi];
     const int tl = tile - (pi > 0 ? G.p[pi - 1].tile_end : 0);
     const int n0 = (tl / P.tiles_k) * 256, k0 = (tl % P.tiles_k) * 256;
-    const Tn256Seg sg{P.dY, P.X, P.ldy, P.ldx, n0, k0, it0 * 64, it1 - it0, P.dbias != nullptr && k0 == 0};
+    const Tn256Seg sg{P.dY, P.X, P.ldy, P.ldx, n0, k0, it0 * 64, it1 - it0, P.dbias != nullptr && k0 == 0, G.M - it0 * 64};
     f32x4 acc[8][4], bacc[2];
-    tn256_mainloop(sg, smem, acc, bacc);
+    tn256_mainloop<true>(sg, smem, acc, bacc);
     if (slot >= 0) {
       if (sg.do_bias) tn256_bias_out<true>(P.dbias, n0, bacc);
       tn256_store_partial(G.ws, slot, acc);
@@ -1821,7 +1828,7 @@ int xfm_gemm_tn_batch_impl(int nb, const void* const* dY, long ldy, const void* 
 
 // Any number of weight gradients over the SAME M rows (all the projections of the layers whose dY are still alive) -> persistent
 // grouped launches of gemm_tn_group_kernel, TN_GROUP_MAX problems each.  Problems the 256 x 256 pipeline does not take (N or K not a
-// multiple of 256, fewer than 1024 rows) and the last M % 64 rows of every problem go through xfm_gemm_tn one by one.
+// multiple of 256, fewer than 1024 rows) go through xfm_gemm_tn one by one.
 static int tn_group_cus() {
   static int n = 0;
   if (n == 0) {
@@ -1831,8 +1838,10 @@ static int tn_group_cus() {
   }
   return n;
 }
-static bool tn_group_item_ok(const xfm_tn_item& it, int M0) {
-  return M0 >= 1024 && tn256_eligible(it.ldy, it.ldx, M0, it.N, it.K) && ((uintptr_t)it.dY % 16) == 0 && ((uintptr_t)it.X % 16) == 0;
+static bool tn_group_item_ok(const xfm_tn_item& it, int M) {   // (any M from 1024 rows: the kernel zero-fills a short last K-step)
+  return M >= 1024 && it.N % 256 == 0 && it.K % 256 == 0 && it.N >= 256 && it.K >= 256 && it.ldy % 8 == 0 && it.ldx % 8 == 0 &&
+         (unsigned long)(M + 64) * (unsigned long)(it.ldy > it.ldx ? it.ldy : it.ldx) < (1ul << 32) && ((uintptr_t)it.dY % 16) == 0 &&
+         ((uintptr_t)it.X % 16) == 0;
 }
 static void tn_group_plan(int tiles, int nk, int G, int& full, int& sk_wgs, long& R) {
   full = tiles / G * G;
@@ -1846,21 +1855,21 @@ static void tn_group_plan(int tiles, int nk, int G, int& full, int& sk_wgs, long
 }
 long xfm_gemm_tn_group_workspace_impl(int n, const xfm_tn_item* items, int M) {
   if (n <= 0 || items == nullptr || M <= 0) return 0;
-  const int M0 = M - M % 64, G = tn_group_cus();
+  const int G = tn_group_cus();
   long need = 0;
   int tiles = 0, np = 0;
   auto close = [&]() {
     if (np == 0) return;
     int full, sk;
     long R;
-    tn_group_plan(tiles, M0 / 64, G, full, sk, R);
+    tn_group_plan(tiles, cdiv(M, 64), G, full, sk, R);
     const long b = sk > 1 ? 2l * sk * 256 * 256 * 4 : 0;
     need = b > need ? b : need;
     tiles = np = 0;
   };
   for (int i = 0; i < n; ++i) {
     const xfm_tn_item& it = items[i];
-    if (tn_group_item_ok(it, M0)) {
+    if (tn_group_item_ok(it, M)) {
       tiles += (it.N / 256) * (it.K / 256);
       if (++np == TN_GROUP_MAX) close();
     } else {
@@ -1875,7 +1884,7 @@ int xfm_gemm_tn_group_impl(int n, const xfm_tn_item* items, int M, float* worksp
   XFM_REQUIRE(n >= 0 && (n == 0 || items != nullptr) && M > 0, "gemm_tn_group: bad arguments");
   XFM_REQUIRE(workspace_bytes >= xfm_gemm_tn_group_workspace_impl(n, items, M) && (workspace != nullptr || workspace_bytes == 0),
               "gemm_tn_group: workspace smaller than xfm_gemm_tn_group_workspace()");
-  const int M0 = M - M % 64, G = tn_group_cus();
+  const int G = tn_group_cus();
   static bool attr_set = false;
   const size_t smem = 2 * 4 * 64 * 256;
   if (!attr_set) {
@@ -1883,7 +1892,8 @@ int xfm_gemm_tn_group_impl(int n, const xfm_tn_item* items, int M, float* worksp
     attr_set = true;
   }
   TnGroup g{};
-  g.nk = M0 / 64;
+  g.nk = cdiv(M, 64);
+  g.M = M;
   g.ws = workspace;
   auto flush = [&]() -> int {
     if (g.nprob == 0) return XFM_OK;
@@ -1901,7 +1911,7 @@ int xfm_gemm_tn_group_impl(int n, const xfm_tn_item* items, int M, float* worksp
   for (int i = 0; i < n; ++i) {
     const xfm_tn_item& it = items[i];
     XFM_REQUIRE(it.dY && it.X && it.dW && it.N > 0 && it.K > 0, "gemm_tn_group: bad problem %d", i);
-    if (!tn_group_item_ok(it, M0)) continue;
+    if (!tn_group_item_ok(it, M)) continue;
     TnGroupProb& P = g.p[g.nprob++];
     P.dY = (const bf16*)it.dY; P.X = (const bf16*)it.X; P.dW = it.dW; P.dbias = it.dbias;
     P.ldy = (unsigned)it.ldy; P.ldx = (unsigned)it.ldx; P.ldw = it.ldw;
@@ -1917,11 +1927,8 @@ int xfm_gemm_tn_group_impl(int n, const xfm_tn_item* items, int M, float* worksp
   if (rc != XFM_OK) return rc;
   for (int i = 0; i < n; ++i) {   // what the grouped kernel did not take
     const xfm_tn_item& it = items[i];
-    if (!tn_group_item_ok(it, M0))
+    if (!tn_group_item_ok(it, M))
       rc = xfm_gemm_tn_impl(it.dY, it.ldy, it.X, it.ldx, it.dW, it.ldw, it.dbias, M, it.N, it.K, 0, workspace, workspace_bytes, st);
-    else if (M0 < M)
-      rc = xfm_gemm_tn_impl((const bf16*)it.dY + (long)M0 * it.ldy, it.ldy, (const bf16*)it.X + (long)M0 * it.ldx, it.ldx, it.dW, it.ldw, it.dbias,
-                            M - M0, it.N, it.K, 1, workspace, workspace_bytes, st);
     if (rc != XFM_OK) return rc;
   }
   return XFM_OK;

@@ -215,14 +215,20 @@ class _WgradStream:
         if not self.queue:
             return
         items, self.queue = self.queue, []
+        by_m = {}
+        for it in items:   # one grouped launch per distinct row count (a tower's projections share M; the K/V projections of the image states
+            by_m.setdefault(it[0].shape[0], []).append(it)   # and the pruned last layer have their own)
         if not self.on:
-            return Fx.gemm_tn_group(items)
+            for group in by_m.values():
+                Fx.gemm_tn_group(group)
+            return
         ev = torch.cuda.Event()
         ev.record(self.main)
         self.side.wait_event(ev)
         self.keep.append(items)
         with torch.cuda.stream(self.side):
-            Fx.gemm_tn_group(items)
+            for group in by_m.values():
+                Fx.gemm_tn_group(group)
 
     def gemm_tn(self, dy, x, dw, **kw):
         if not self.on:
@@ -261,6 +267,11 @@ class _WgradStream:
         self.keep.append(tuple(keep))
         with torch.cuda.stream(self.side):
             return fn()
+
+    def sync_side(self):
+        """The launch stream waits for what the second stream has been given so far (queued weight gradients are not launched)."""
+        if self.on:
+            self.main.wait_stream(self.side)
 
     def join(self):
         if self.label is not None:
@@ -663,6 +674,9 @@ def _view(slab, off, rows, cols, dtype=BF16):
     return slab[off:off + n].view(dtype).view(rows, cols)
 
 
+_RL_DEFER_WGRAD = os.environ.get("XFM_RL_DEFER_WGRAD", "1") != "0"
+
+
 class _EncoderFnNative(torch.autograd.Function):
     """Layers [lo, hi) of a RobertaEncoder with ONE C-ABI call per layer and direction (csrc/encoder.hip sequences the kernels of
     the layer on the native side).  Same kernels, same order, same dropout streams as _EncoderFn -- results are bit-identical --
@@ -802,6 +816,10 @@ class _EncoderFnNative(torch.autograd.Function):
         bw.denc32 = Fx._ptr(denc32)
         st = Fx._stream()
         keep = [ws_main, ws_side]
+        # XFM_RL_DEFER_WGRAD (default on): the executor launches no weight gradient; the tower's queue runs as grouped launches at its
+        # end (whole 256 x 256 tiles over all of M instead of 10 M-splits + a reduce per projection: the fusion + text towers' weight
+        # gradients cost 2.8 ms of the step one by one under the activation-gradient chain, ~1.6 ms grouped)
+        defer = _RL_DEFER_WGRAD and R >= 1024
         for k in reversed(range(len(layers))):
             layer = layers[k]
             slab, x_in, kv, ctr, cross = ctx.saved[k]
@@ -822,8 +840,22 @@ class _EncoderFnNative(torch.autograd.Function):
                 io.kv = 0
             bw.bslab, bw.dy_a, bw.dy_b = bslab.data_ptr(), dy_a.data_ptr(), Fx._ptr(dy_b)
             bw.need_dprev = int(k > 0 or need_dx)
+            bw.defer_wgrad = int(defer)
             _rl_touch(layer, arena, cross)
             check(lib.xfm_rlayer_bwd(ctypes.byref(_rlayer_params(layer, cfg)), ctypes.byref(io), ctypes.byref(bw), st), "rlayer_bwd")
+            if defer:   # the layer's weight gradients join the tower's queue: operands at the layout's offsets of the two slabs (kept alive)
+                sl, FF = layer._s, cfg.intermediate_size
+                Sv = lambda off, cols, slab=slab: _view(slab, off, R, cols)       # noqa: E731
+                Gv = lambda off, cols, bslab=bslab: _view(bslab, off, R, cols)    # noqa: E731
+                wg.defer_tn(Gv(L.dh3, D), Sv(L.hact, FF), sl["out"]._dw)
+                wg.defer_tn(Gv(L.du, FF), Sv(L.y2 if cross else L.y1, D), sl["i"]._dw, sl["i"]._db)
+                if cross:
+                    wg.defer_tn(Gv(L.dh2, D), Sv(L.c2, D), sl["o2"]._dw)
+                    wg.defer_tn(Gv(L.dq2, D), Sv(L.y1, D), sl["q2"]._dw, sl["q2"]._db)
+                    dkv_v = dkv_all[:, j * 2 * D:(j + 1) * 2 * D] if concat_k else dkv
+                    wg.defer_tn(dkv_v, enc, sl["kv2"]._dw, sl["kv2"]._db)   # (dK|dV comes from the side stream: the flush runs there too)
+                wg.defer_tn(Gv(L.dh1, D), Sv(L.c1, D), sl["o"]._dw)
+                wg.defer_tn(Gv(L.dqkv, 3 * D), x_in[:R], sl["qkv"]._dw, sl["qkv"]._db)
             dy_a, dy_b = _view(bslab, L.dprev, R, D), _view(bslab, L.dres1, R, D)
             ctx.saved[k] = None
         dx = (dy_a.float() + dy_b.float()).to(BF16) if need_dx else None
@@ -832,10 +864,10 @@ class _EncoderFnNative(torch.autograd.Function):
         denc = None
         if concat_k:
             wt_cat = torch.cat([layer._s["kv2"].wt[:, :2 * D] for layer in cross_layers], dim=1)
-            wg.join()
+            wg.sync_side()   # dK|dV of every layer (second stream) -- the queued weight gradients are launched by the join below
             denc = Fx.gemm_nt(dkv_all, wt_cat)
         elif need_denc:
-            wg.join()
+            wg.sync_side()
             denc = denc32.to(BF16)
         wg.join()
         del keep
