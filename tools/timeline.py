@@ -113,3 +113,13 @@ if os.environ.get("WAKE"):
         hist.append((s, e, n, q))
         if len(hist) > 400:
             hist = hist[-200:]
+
+# LIST=<from_ms>:<to_ms>: every kernel that starts in that part of the window (queue, start, duration)
+if os.environ.get("LIST"):
+    a_ms, b_ms = (float(v) for v in os.environ["LIST"].split(":"))
+    lo = ks[0][0]
+    print(f"\n| queue | start ms | us | kernel |   ({a_ms} .. {b_ms} ms of the window)")
+    for s, e, n, q in ks:
+        t = (s - lo) / 1e6
+        if a_ms <= t < b_ms:
+            print(f"| {q} | {t:7.3f} | {(e - s) / 1e3:7.1f} | {n.replace('void ', '')[:90]} |")

@@ -215,7 +215,11 @@ class _LMHeadCEFn(torch.autograd.Function):
         else:
             scale = (g / nvalid if ctx.reduction == "mean" else g).reshape(1).to(F32).contiguous()
         dlogits = Fx.ce_bwd(logits, V, labels, lse, scale, logits.shape[1])
-        Fx.gemm_tn(dlogits, y, sv.dw, n=V, dbias=sv.db)
+        # the two weight gradients (the 50265 x 768 one takes 310 us) go to the second stream and re-join at the end of the backward
+        # pass: they run under the fusion tower's latency-bound activation-gradient chain instead of in front of it
+        from .xroberta import _WgradStream
+        wg = _WgradStream(x.device)
+        wg.gemm_tn(dlogits, y, sv.dw, n=V, dbias=sv.db)
         # dgrad of the vocabulary projection: K = 50304 against a 960 x 768 output -- K is sliced over the grid instead of 90 workgroups
         # walking 786 K-tiles each, and the slices are summed in a fixed order (xfm_gemm_nt_ksplit): this activation gradient is rounded
         # to bf16 right here, so an order-dependent sum (fp32 atomics, rounds 1-3) made the whole backward below it bimodal
@@ -224,8 +228,9 @@ class _LMHeadCEFn(torch.autograd.Function):
         ln = head.layer_norm
         Fx.ln_bwd(dy, hact, mean, rstd, ln.weight, grad_view(ln.weight), grad_view(ln.bias), dx16=dhact)
         du = (dhact.float() * u.float()).to(BF16)  # u = gelu'(pre-activation), stored by the forward epilogue
-        Fx.gemm_tn(du, x, sd.dw, dbias=sd.db)
+        wg.gemm_tn(du, x, sd.dw, dbias=sd.db)
         dx = Fx.gemm_nt(du, sd.wt, n=sd.K)
+        wg.join_at_end()
         return dx, None, None, None
 
 

@@ -273,6 +273,22 @@ class _WgradStream:
         if self.on:
             self.main.wait_stream(self.side)
 
+    def join_at_end(self):
+        """Like join(), but the launch stream re-joins when the whole backward pass is over (an engine callback, as
+        model_pretrain._JoinAfterBackward): the weight gradients given to the second stream here need not finish before the NEXT node's
+        activation gradients start -- only before anyone reads the parameter gradients.  Only inside a backward pass."""
+        self.flush()
+        if self.on:
+            main, side, keep = self.main, self.side, self.keep
+
+            def rejoin():
+                main.wait_stream(side)
+                keep.clear()
+            torch.autograd.Variable._execution_engine.queue_callback(rejoin)
+            self.keep = []
+        else:
+            self.keep.clear()
+
     def join(self):
         if self.label is not None:
             _marks.mark(self.label + " chain end")
