@@ -31,6 +31,7 @@ BF16 = torch.bfloat16
 # packed fusion rows: exact layout of the hard-negative text block through ONE host read-back per step (default; measured 42.8 ->
 # 41.8 ms per step against worst-case room for that block, XFM_PACK_SYNC=0, which needs no sync at all)
 _PACK_SYNC = os.environ.get("XFM_PACK_SYNC", "1") != "0"
+_HOST_LAYOUT = os.environ.get("XFM_HOST_LAYOUT", "1") != "0"   # A/B knob: 0 = device-side layout ops + two pageable uploads (rounds 2-3)
 # cross-attention per image on contiguous query rows (the image-major layout makes them so) instead of the grouped kernels: measured
 # the same (9.84 vs 9.67 ms for the fusion encoder's fwd+bwd: the generic kernels size their grid for the fullest image), so off
 _LAST_ROWS = os.environ.get("XFM_LAST_LAYER_ROWS", "0") != "0"   # fusion tower: last layer only on the rows ITM / MLM read (measured neutral: off)
@@ -492,7 +493,7 @@ class XFMBase(nn.Module):
         (cross-attention per image on contiguous rows).  XFM_PACK_SYNC=0: no host sync at all -- four blocks in the reference's
         order, worst-case room and device-computed offsets for the block whose lengths follow the device-side draw."""
         from .ops import lm_head_ce
-        from .packing import Pack, image_major_layout, rows_gather
+        from .packing import Pack, image_major_fusion_layout, image_major_layout, rows_gather
         if neg_idx is None:
             image_neg_idx, text_neg_idx = self.get_hard_negatives(image_feat, text_feat, idx=idx)
         else:
@@ -524,10 +525,20 @@ class XFMBase(nn.Module):
             prune = _LAST_ROWS and not _XATTN_RANGES and M <= 64
             sel_off = list(range(3 * bs)) + [3 * bs + j * M for j in range(bs)]
             sel_len = [1] * (3 * bs) + [M] * bs
-            fpack, _, _, meta, ranges = image_major_layout(seq_len, seq_img, bs, pack.T, dev, extra=(seq_txt, seq_img, sel_off, sel_len))
-            pos_dev, seq_src, enc_index = meta[0].long(), meta[1].long(), meta[2].contiguous()
-            text_all = rows_gather(text_rows.detach(), fpack.gather_index(pack, seq_src))
-            start_of = fpack.start.index_select(0, pos_dev)                     # start row of every sequence, reference order
+            if pack.lens_host is not None and _HOST_LAYOUT:
+                # the whole layout (offsets, cross-attention row ranges, the row gather from the text tower's pack) on the host, ONE upload
+                src_start = [0]
+                for n_tok in pack.lens_host[:-1]:
+                    src_start.append(src_start[-1] + n_tok)
+                fpack, meta, ranges, gidx, start_of = image_major_fusion_layout(seq_len, seq_img, bs, pack.T, dev, src_start, seq_txt,
+                                                                                extra=(seq_txt, seq_img, sel_off, sel_len))
+                enc_index = meta[2]
+                text_all = rows_gather(text_rows.detach(), gidx)
+            else:
+                fpack, _, _, meta, ranges = image_major_layout(seq_len, seq_img, bs, pack.T, dev, extra=(seq_txt, seq_img, sel_off, sel_len))
+                pos_dev, seq_src, enc_index = meta[0].long(), meta[1].long(), meta[2].contiguous()
+                text_all = rows_gather(text_rows.detach(), fpack.gather_index(pack, seq_src))
+                start_of = fpack.start.index_select(0, pos_dev)                     # start row of every sequence, reference order
             out_rows = None
             if prune:
                 sel_rows = torch.cat([start_of[:3 * bs], (start_of[3 * bs:, None] + masked_pos.to(torch.int32)).reshape(-1)])
