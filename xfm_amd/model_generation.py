@@ -77,8 +77,8 @@ class XFMForVQA(XFMBase):
         return msg
 
     def _question_states(self, image, question):
-        image_embeds, image_atts = self.get_vision_embeds(image)
-        text_embeds = self.get_text_embeds(question.input_ids, question.attention_mask)
+        from .model_pretrain import towers_side_by_side
+        image_embeds, image_atts, text_embeds = towers_side_by_side(self, image, question.input_ids, question.attention_mask)
         return self.get_cross_embeds(image_embeds, image_atts, text_embeds=text_embeds, text_atts=question.attention_mask,
                                      is_pretrain=False)
 

@@ -22,8 +22,8 @@ class XFMForRetrieval(XFMBase):
         return msg
 
     def forward(self, image, text_ids, text_atts, idx=None, neg_idx=None):
-        image_embeds, image_atts = self.get_vision_embeds(image)
-        text_embeds = self.get_text_embeds(text_ids, text_atts)
+        from .model_pretrain import towers_side_by_side
+        image_embeds, image_atts, text_embeds = towers_side_by_side(self, image, text_ids, text_atts)
         image_feat, text_feat = self.get_features(image_embeds, text_embeds)
         loss_itc = self.get_contrastive_loss(image_feat, text_feat, idx=idx)
         loss_itm = self.get_matching_loss(image_embeds, image_atts, image_feat, text_ids, text_atts, text_feat, idx=idx,
