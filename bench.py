@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward(+all-reduce) only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fusion-probe", action="store_true", help="skip the stand-alone fusion-encoder fwd+bwd measurement (profiling runs)")
+    ap.add_argument("--host-time", action="store_true", help="also print (stderr) the host's enqueue time of one step against an idle GPU")
     ap.add_argument("--cpu-batch", type=int, default=0, help="units per CPU-baseline step (0 = the workload's bounded sample; pre-train: 8, SURVEY 8d)")
     ap.add_argument("--padded-rows", action="store_true", help="push the padding rows of the 30-token captions through the text / fusion "
                     "towers like the reference does (default: unpadded token rows, xfm_amd.packing)")
@@ -157,11 +158,23 @@ class GemmTimer:
                 return r
             return f
 
+        def timed_tn_group(items):
+            """One grouped weight-gradient launch (the deferred wgrads of a tower): one event pair, the summed 2MNK of its problems."""
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self.orig_tng(items)
+            e.record()
+            self.groups.append((len(items), sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items), s, e))
+            return r
+
         self.shapes = []
+        self.groups = []
         self.orig_tn = Fx.gemm_tn
+        self.orig_tng = Fx.gemm_tn_group
         self.orig_af, self.orig_ab = Fx.attn_fwd, Fx.attn_bwd
         Fx.gemm_nt = timed
         Fx.gemm_tn = timed_tn
+        Fx.gemm_tn_group = timed_tn_group
         Fx.attn_fwd = timed_attn("attn_fwd", self.orig_af)
         Fx.attn_bwd = timed_attn("attn_bwd", self.orig_ab)
         return self
@@ -169,6 +182,7 @@ class GemmTimer:
     def __exit__(self, *a):
         self.Fx.gemm_nt = self.orig
         self.Fx.gemm_tn = self.orig_tn
+        self.Fx.gemm_tn_group = self.orig_tng
         self.Fx.attn_fwd, self.Fx.attn_bwd = self.orig_af, self.orig_ab
 
     def by_shape(self):
@@ -219,6 +233,11 @@ class GemmTimer:
             a[0] += 1
             a[1] += s.elapsed_time(e)
             a[2] += fl
+        for n_items, fl, s, e in self.groups:   # grouped launches: one persistent kernel (+ fix-up) for a whole tower's weight gradients
+            a = fam.setdefault("gemm_tn_group_kernel (grouped weight gradients: whole 256x256 tiles + stream-K tail)", [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += s.elapsed_time(e)
+            a[2] += fl
         return fam
 
 
@@ -252,12 +271,18 @@ class FlopCounter:
                 return orig(*args, **kw)
             return f
 
-        Fx.gemm_nt, Fx.gemm_tn = nt, tn
+        def tng(items):
+            self.flop += sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)
+            return self.o_tng(items)
+
+        self.o_tng = Fx.gemm_tn_group
+        Fx.gemm_nt, Fx.gemm_tn, Fx.gemm_tn_group = nt, tn, tng
         Fx.attn_fwd, Fx.attn_bwd = att(1.0, self.o[2], 3), att(2.5, self.o[3], 9)
         return self
 
     def __exit__(self, *a):
         self.Fx.gemm_nt, self.Fx.gemm_tn, self.Fx.attn_fwd, self.Fx.attn_bwd = self.o
+        self.Fx.gemm_tn_group = self.o_tng
 
 
 def fusion_probe(model, B, host_batch, packed, iters=5):
@@ -648,6 +673,16 @@ def main():
             losses = step(timed_comm=True)
         barrier()
         elapsed = time.perf_counter() - t0
+        if args.host_time and rank == 0:   # the host's enqueue time of one step with an empty queue in front of it (never waits for a slot)
+            hs = []
+            for _ in range(8):
+                torch.cuda.synchronize()
+                h0 = time.perf_counter()
+                step()
+                hs.append((time.perf_counter() - h0) * 1e3)
+            torch.cuda.synchronize()
+            print(f"host enqueue per step ({args.workload}): min {min(hs):.1f} ms, median {sorted(hs)[4]:.1f} ms "
+                  f"against {elapsed / args.steps * 1e3:.1f} ms per free-running step", file=sys.stderr)
         if marks.ON and rank == 0:
             rows, n_avg = marks.mean_table()
             print(f"step marks (mean of the last {n_avg} steps)  | stream | queued by the host at ms | reached by the GPU at ms |", file=sys.stderr)
@@ -696,6 +731,9 @@ def main():
             for (kind, M, N, K, epi), (calls, ms) in sorted(gt.by_shape().items(), key=lambda kv: -kv[1][1]):
                 tf = "" if kind.startswith("attn") else f"{2.0 * M * N * K * calls / ms / 1e9:6.0f}TF"
                 f.write(f"{kind} M={M:6d} N={N:6d} K={K:6d} epi/bias={epi} calls={calls:3d} total={ms:7.3f}ms avg={ms / calls * 1e3:7.1f}us {tf}\n")
+            for n_items, fl, s_, e_ in gt.groups:
+                gms = s_.elapsed_time(e_)
+                f.write(f"tn_group: {n_items} weight gradients in one grouped launch  total={gms:7.3f}ms  {fl / gms / 1e9:6.0f}TF\n")
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     ms_per_step = elapsed / args.steps * 1e3
 
