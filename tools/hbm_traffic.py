@@ -13,7 +13,7 @@ import sys
 def family(name):
     if "gemm_nt" in name:
         return "gemm_nt"
-    if "gemm_tn" in name or "tn_reduce" in name:
+    if "gemm_tn" in name or "tn_reduce" in name or "tn_group_fixup" in name:
         return "gemm_tn"
     if "attn" in name:
         return "attn"

@@ -15,6 +15,8 @@ def family(name):
     n = name.replace("void ", "").split("(")[0]
     if "gemm_nt_256" in n or "gemm_tn_256" in n:
         return n
+    if "gemm_tn_group" in n:
+        return "gemm_tn_group_kernel (grouped weight gradients)"
     if "gemm_nt" in n:
         return "gemm_nt (small tiles)"
     if "gemm_tn" in n:
