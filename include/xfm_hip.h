@@ -28,7 +28,7 @@ extern "C" {
 #define XFM_E_LAUNCH (-2)
 #define XFM_E_UNSUPPORTED (-3)
 
-#define XFM_ABI_VERSION 6
+#define XFM_ABI_VERSION 7
 
 const char* xfm_last_error(void);
 int xfm_abi_version(void);

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # XFM_HIP_LIB: A/B a differently built library (kernel experiments); the default is the in-tree build.
 LIB_PATH = os.environ.get("XFM_HIP_LIB") or os.path.join(_HERE, "libxfm_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_void_p, c_int, c_long, c_float, c_u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint32
 
