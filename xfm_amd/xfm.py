@@ -513,6 +513,7 @@ class XFMBase(nn.Module):
             if neg_idx is not None:   # given by the caller: host data already
                 im, tn = [int(j) for j in neg_idx[0]], [int(j) for j in neg_idx[1]]
             else:
+                self.fusion_encoder.roberta.prefetch_cross_kv(image_embeds)   # (second stream: runs while the host waits below)
                 _marks.mark("negatives: read-back queued")
                 im, tn = torch.stack([image_neg_idx, text_neg_idx]).cpu().tolist()
                 _marks.mark("negatives: host has them")
