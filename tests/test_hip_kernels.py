@@ -1052,6 +1052,9 @@ def test_gemm_tn_batch_equals_separate_calls(M, N, K, nb):
     (1024, [(768, 3072)] * 22),                                            # 792 tiles: three whole waves + 24 tiles, pieces = whole tiles
     (2048 + 40, [(768, 768), (320, 256), (256, 768), (768, 200)]),         # ragged M (tail rows) and shapes the 256 x 256 pipeline refuses
     (1152, [(256, 256)] * 50),                                             # more problems than one launch's table holds
+    (1024, [(1024, 1024)] * 16),                                           # exactly one whole round of tiles: nothing is cut
+    (1024, [(256, 768)]),                                                  # three tiles of the shortest allowed M: pieces = whole tiles
+    (1024 + 63, [(512, 256), (256, 512)]),                                 # the last K-step holds 63 of its 64 rows
 ])
 def test_gemm_tn_group_whole_tiles_and_stream_k_tail(M, shapes):
     """Grouped weight gradients (the deferred wgrads of a tower in persistent launches): values against fp32 math with dW += and the
