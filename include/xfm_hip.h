@@ -149,7 +149,19 @@ typedef struct {
   uint32_t drop_thresh; float drop_scale; uint32_t seed_lo, seed_hi;
   const float* gelu_b;     /* non-NULL: the forward applied GELU after the affine; this is the LayerNorm bias (the pre-activation
                               xhat * w + b is rebuilt and dy is multiplied by gelu'(.) first) */
+  struct xfm_reduce_item_s* defer;  /* non-NULL: do NOT launch the column-sum reduce; describe it here instead.  The caller keeps `workspace`
+                              untouched until it has run the item through xfm_reduce_sets_batch (one launch for a whole tower's LayerNorms
+                              instead of one 7-us kernel behind each of them on the activation-gradient chain) */
 } xfm_ln_bwd_args;
+
+/* out[s][c] += sum over the nblocks rows of partial[s][.][c], s < nset: the deferred second half of xfm_layernorm_bwd. */
+typedef struct xfm_reduce_item_s {
+  const float* partial;    /* [nset][nblocks][D] */
+  float* out[4];           /* NULL = skip the set */
+  int nblocks, D, nset, reserved;
+} xfm_reduce_item;
+/* n items (HOST array) in launches of up to 56; same sums and the same atomics-at-the-end form as the per-call reduce. */
+int xfm_reduce_sets_batch(int n, const xfm_reduce_item* items, void* stream);
 
 int xfm_layernorm_fwd(const xfm_ln_fwd_args* a, int D, int mode, void* stream);
 long xfm_layernorm_bwd_workspace(int rows, int D, int mode);
@@ -351,6 +363,10 @@ typedef struct {        /* backward-only */
   int need_dprev;                                /* produce the gradient w.r.t. the layer input (dprev_a + dprev_b in bslab) */
   void* side_stream;
   float* ws_main; long ws_main_bytes; float* ws_side; long ws_side_bytes;
+  float* ln_ws; long ln_ws_stride;               /* non-NULL (with ln_items): the layer's three LayerNorm backward kernels write their column-sum
+                                                    partials to ln_ws + k * ln_ws_stride (floats, k = 0..2; each >= xfm_layernorm_bwd_workspace bytes)
+                                                    and launch no reduce; ... */
+  xfm_reduce_item* ln_items; int* ln_count;      /* ... they append their items to this HOST table instead (ln_items[*ln_count], count advanced) */
   int defer_wgrad;                               /* 1: launch NO weight-gradient GEMM -- the caller queues them (the dY / X operands sit at the
                                                     layout's offsets in bslab / slab, which it keeps alive) and runs the queue of the whole
                                                     tower as grouped launches (xfm_gemm_tn_group).  Bias gradients that ride on a weight

@@ -1088,6 +1088,45 @@ def test_gemm_tn_group_whole_tiles_and_stream_k_tail(M, shapes):
             assert torch.equal(dbi[i], dyi[i].float().sum(0)), f"integer dbias[{i}]"
 
 
+@pytest.mark.parametrize("rows", [37, 5261, 25216])
+def test_layernorm_backward_deferred_column_sums_equal_the_per_call_reduce(rows):
+    """xfm_ln_bwd_args.defer + xfm_reduce_sets_batch (ONE fold for all the LayerNorms of a tower) against the reduce kernel that follows
+    each backward kernel: same dx / dh, parameter gradients equal to the rounding of the final atomics; POST and layer-scale modes, several
+    calls in one queue, gradients accumulated on top of existing values."""
+    Fx = _fx()
+    D = 768
+    g = torch.Generator().manual_seed(rows)
+    mk = lambda *shape, sc=1.0, dt=BF16: (torch.randn(*shape, generator=g) * sc).to(dt).cuda()   # noqa: E731
+    w = mk(D, dt=F32) * 0.1 + 1.0
+    outs = {}
+    for mode in ("per call", "deferred"):
+        rq = Fx.ReduceQueue(torch.device("cuda"), 4 * (Fx._lib.load().xfm_layernorm_bwd_workspace(rows, D, 2) + 256)) if mode == "deferred" else None
+        torch.manual_seed(1)
+        dg, db, dbias, dls = (torch.full((D,), 0.25, dtype=F32, device="cuda") for _ in range(4))
+        res = []
+        for call in range(2):   # two POST calls and two layer-scale calls into the same gradients
+            gg = torch.Generator().manual_seed(100 + call)
+            r = lambda *shape, sc=1.0, dt=BF16: (torch.randn(*shape, generator=gg) * sc).to(dt).cuda()   # noqa: E731
+            dy, z = r(rows, D, sc=0.1), r(rows, D)
+            mean, rstd = z.float().mean(1).contiguous(), (z.float().var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+            res.append(Fx.ln_post_bwd(dy, z, mean, rstd, w, dg, db, dbias, drop=Fx.drop_params(0.1, 77 + call), defer=rq))
+            x_new, h = r(rows, D, dt=F32), r(rows, D)
+            dstream = r(rows, D, sc=0.1, dt=F32)
+            mean2, rstd2 = x_new.mean(1).contiguous(), (x_new.var(1, unbiased=False) + 1e-6).rsqrt().contiguous()
+            res.append((Fx.ln_ls_bwd(dy, dstream, x_new, mean2, rstd2, w, h, w, None, 1, dg, db, dbias, dls, defer=rq), dstream))
+        if rq is not None:
+            assert len(rq.items) == 4
+            rq.run()
+            rq.run()   # (a second run has nothing left to fold)
+        outs[mode] = (res, (dg, db, dbias, dls))
+    for a, b in zip(outs["per call"][0], outs["deferred"][0]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    for name, x, y in zip(("dgamma", "dbeta", "dbias", "dls"), outs["per call"][1], outs["deferred"][1]):
+        _close(y, x, 2e-6, "deferred " + name)
+        assert float((x - 0.25).abs().max()) > 1e-3, name   # (the reduce did add something)
+
+
 @pytest.mark.parametrize("C", [2, 3, 5, 10, 101, 1000])
 def test_small_ce_any_class_count_and_ignored_labels(C):
     """ops.small_ce = F.cross_entropy for every class count (the kernels read 4-column granules: widths that are not a multiple of 4 go

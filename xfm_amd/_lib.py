@@ -33,7 +33,12 @@ class LnBwdArgs(ctypes.Structure):
                 ("dh", c_void_p), ("dres", c_void_p), ("dstream", c_void_p),
                 ("h", c_void_p), ("ls_gamma", c_void_p), ("row_scale", c_void_p), ("partial", c_void_p),
                 ("rows", c_int), ("rows_per_sample", c_int),
-                ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32), ("gelu_b", c_void_p)]
+                ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32), ("gelu_b", c_void_p),
+                ("defer", c_void_p)]
+
+
+class ReduceItem(ctypes.Structure):   # xfm_reduce_item
+    _fields_ = [("partial", c_void_p), ("out", c_void_p * 4), ("nblocks", c_int), ("D", c_int), ("nset", c_int), ("reserved", c_int)]
 
 
 class CastItem(ctypes.Structure):
@@ -89,7 +94,7 @@ class RLayerIO(ctypes.Structure):
 class RLayerBwd(ctypes.Structure):
     _fields_ = [("bslab", _P), ("dy_a", _P), ("dy_b", _P), ("enc", _P), ("dkv", _P), ("dkv_ld", _L), ("denc32", _P),
                 ("need_dprev", _I), ("side_stream", _P), ("ws_main", _P), ("ws_main_bytes", _L), ("ws_side", _P), ("ws_side_bytes", _L),
-                ("defer_wgrad", _I)]
+                ("ln_ws", _P), ("ln_ws_stride", _L), ("ln_items", _P), ("ln_count", _P), ("defer_wgrad", _I)]
 
 
 class TnItem(ctypes.Structure):   # xfm_tn_item
@@ -131,6 +136,7 @@ SIGNATURES = {
     "xfm_colsum_workspace": (c_long, [c_int, c_int]),
     "xfm_colsum": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_long, c_void_p]),
     "xfm_layernorm_fwd": (c_int, [ctypes.POINTER(LnFwdArgs), c_int, c_int, c_void_p]),
+    "xfm_reduce_sets_batch": (c_int, [c_int, c_void_p, c_void_p]),
     "xfm_layernorm_bwd_workspace": (c_long, [c_int, c_int, c_int]),
     "xfm_layernorm_bwd": (c_int, [ctypes.POINTER(LnBwdArgs), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_long, c_void_p]),

@@ -237,6 +237,12 @@ class _TrunkFn(torch.autograd.Function):
         # the blocks' weight gradients are QUEUED and run as one grouped launch at the end of the trunk (or before each hand-over of a
         # gradient range to the data-parallel accelerator below): 48 projections x 9-36 output tiles walk whole tiles over all of M
         tn = wg.defer_tn if (_DEFER_WGRAD and dy.is_cuda) else wg.gemm_tn
+        # ... and so are the column-sum folds of the two LayerNorm backward kernels of a block (dgamma / dbeta / bias / layer-scale gradients)
+        rq = None
+        if _DEFER_LN and dy.is_cuda:
+            from . import _lib
+            rq = Fx.ReduceQueue(dy.device, 2 * len(blocks) * ((_lib.load().xfm_layernorm_bwd_workspace(M, D, 2) + 255) // 256 * 256))   # LN_LS
+            wg.defer_reduces(rq)
         for i in reversed(range(len(blocks))):
             blk, s = blocks[i], vit._slots[i]
             (y, dense, qkv, ctxv, lse, h1, x1, mean2, rstd2, y2, u, hact, h2, x2, meann, rstdn, dp1, dp2, dense_t, ctxv_lo, tiles) = ctx.saved[i]
@@ -248,13 +254,13 @@ class _TrunkFn(torch.autograd.Function):
             dg1 = g(blk.gamma_1) if blk.gamma_1 is not None else None
             dg2 = g(blk.gamma_2) if blk.gamma_2 is not None else None
             dh2 = Fx.ln_ls_bwd(dy, dstream, x2, meann, rstdn, nxt.weight, h2, g2, dp2, N, g(nxt.weight), g(nxt.bias),
-                               s["fc2"].db, dg2)
+                               s["fc2"].db, dg2, defer=rq)
             tn(dh2, hact, s["fc2"].dw)
             du = Fx.gemm_nt(dh2, s["fc2"].wt, epi=Fx.EPI_DGELU, aux=u, n=s["fc2"].K)
             tn(du, y2, s["fc1"].dw, dbias=s["fc1"].db)
             dy2 = Fx.gemm_nt(du, s["fc1"].wt, n=s["fc1"].K)
             dh1 = Fx.ln_ls_bwd(dy2, dstream, x1, mean2, rstd2, blk.norm2.weight, h1, g1, dp1, N, g(blk.norm2.weight),
-                               g(blk.norm2.bias), s["proj"].db, dg1)
+                               g(blk.norm2.bias), s["proj"].db, dg1, defer=rq)
             tn(dh1, ctxv, s["proj"].dw)
             dctx = Fx.gemm_nt(dh1, s["proj"].wt, n=s["proj"].K)
             dqkv = torch.empty_like(qkv)
@@ -325,6 +331,7 @@ _VIT_FUSED_BWD = __import__("os").environ.get("XFM_ATTN_VIT_BWD", "0") != "0"   
 # five overlapped 57-MB collectives (round 2: 4 -> 5 blocks = 142 MB behind two of 114 MB)
 # XFM_VIT_DEFER_WGRAD=0: one xfm_gemm_tn per projection as the backward reaches it (rounds 1-3) instead of the grouped launch
 _DEFER_WGRAD = __import__("os").environ.get("XFM_VIT_DEFER_WGRAD", "1") != "0"
+_DEFER_LN = __import__("os").environ.get("XFM_VIT_DEFER_LN", "1") != "0"   # A/B knob: one batched LayerNorm column-sum reduce for the trunk
 _WGRAD_GROUP_BLOCKS = int(__import__("os").environ.get("XFM_VIT_WGRAD_GROUP", "0"))   # blocks per grouped launch (0: the whole trunk at its end)
 _GRAD_CHUNK_BLOCKS = max(1, int(__import__("os").environ.get("XFM_VIT_GRAD_CHUNK", "2")))
 

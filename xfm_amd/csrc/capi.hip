@@ -105,6 +105,7 @@ int xfm_layernorm_fwd(const xfm_ln_fwd_args* a, int D, int mode, void* stream) {
   return xfm_ln_fwd_impl(*a, D, mode, ST(stream));
 }
 
+int xfm_reduce_sets_batch(int n, const xfm_reduce_item* items, void* stream) { return xfm_reduce_sets_batch_impl(n, items, ST(stream)); }
 long xfm_layernorm_bwd_workspace(int rows, int D, int mode) {
   const int nset = mode == XFM_LN_PLAIN ? 2 : (mode == XFM_LN_POST ? 3 : 4);
   return (long)nset * xfm_ln_bwd_grid(rows) * D * 4;

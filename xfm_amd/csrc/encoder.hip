@@ -245,11 +245,18 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
   const uint32_t c_att = io.seed_ctr + 1, c_h1 = io.seed_ctr + 2, c_att2 = io.seed_ctr + 3, c_h2 = io.seed_ctr + 4;
   const uint32_t c_h3 = cross ? io.seed_ctr + 5 : io.seed_ctr + 3;
   const bf16* y_in = cross ? S16(L.y2) : S16(L.y1);  // input of the feed-forward block
+  // LayerNorm backward column sums: folded right behind each kernel (b.ws_main), or -- b.ln_items -- left as partials in the caller's
+  // per-LayerNorm slices for ONE batched reduce over the whole tower (three 7-us kernels less per layer on this chain)
+  const bool ln_defer = b.ln_items != nullptr && b.ln_count != nullptr && b.ln_ws != nullptr;
+  auto ln_bwd = [&](LnBwd a, int k, float* dg, float* db, float* dbias) {
+    if (!ln_defer) return xfm_ln_bwd_impl(a, D, LN_POST, dg, db, dbias, nullptr, b.ws_main, b.ws_main_bytes, st);
+    a.defer = b.ln_items + (*b.ln_count)++;
+    return xfm_ln_bwd_impl(a, D, LN_POST, dg, db, dbias, nullptr, b.ln_ws + (long)k * b.ln_ws_stride, b.ln_ws_stride * 4, st);
+  };
   (void)c_att2;
 
   // ---- feed-forward block
-  RL_TRY(xfm_ln_bwd_impl(rl_ln_bwd(io, b.dy_a, b.dy_b, s, L.z3, L.m3, L.r3, p.ln3_w, G16(L.dh3), G16(L.dres3), c_h3), D, LN_POST,
-                         p.dln3_w, p.dln3_b, p.dbout, nullptr, b.ws_main, b.ws_main_bytes, st));
+  RL_TRY(ln_bwd(rl_ln_bwd(io, b.dy_a, b.dy_b, s, L.z3, L.m3, L.r3, p.ln3_w, G16(L.dh3), G16(L.dres3), c_h3), 0, p.dln3_w, p.dln3_b, p.dbout));
   RL_TRY(wgrad(G16(L.dh3), D, S16(L.hact), FF, p.dwout, FF, nullptr, R, D, FF));
   RL_TRY(xfm_gemm_nt_impl(G16(L.dh3), D, p.wout_t, p.ld_wout_t, G16(L.du), FF, nullptr, S16(L.u), FF, R, FF, D, EPI_DGELU, 0, st));
   RL_TRY(wgrad(G16(L.du), FF, y_in, D, p.dwi, D, p.dbi, R, FF, D));
@@ -258,8 +265,7 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
   const bf16* in_b = G16(L.dres3);
   // ---- cross-attention block
   if (cross) {
-    RL_TRY(xfm_ln_bwd_impl(rl_ln_bwd(io, in_a, in_b, s, L.z2, L.m2, L.r2, p.ln2_w, G16(L.dh2), G16(L.dres2), c_h2), D, LN_POST,
-                           p.dln2_w, p.dln2_b, p.dbo2, nullptr, b.ws_main, b.ws_main_bytes, st));
+    RL_TRY(ln_bwd(rl_ln_bwd(io, in_a, in_b, s, L.z2, L.m2, L.r2, p.ln2_w, G16(L.dh2), G16(L.dres2), c_h2), 1, p.dln2_w, p.dln2_b, p.dbo2));
     if (!batch3) RL_TRY(wgrad(G16(L.dh2), D, S16(L.c2), D, p.dwo2, D, nullptr, R, D, D));
     RL_TRY(xfm_gemm_nt_impl(G16(L.dh2), D, p.wo2_t, p.ld_wo2_t, G16(L.dc2), D, nullptr, nullptr, 0, R, D, D, EPI_BF16, 0, st));
     if (zf) (void)hipMemsetAsync(g + L.dq2, 0, (size_t)R * D * 2, st);
@@ -284,8 +290,7 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
     in_b = G16(L.dres2);
   }
   // ---- self-attention block
-  RL_TRY(xfm_ln_bwd_impl(rl_ln_bwd(io, in_a, in_b, s, L.z1, L.m1, L.r1, p.ln1_w, G16(L.dh1), G16(L.dres1), c_h1), D, LN_POST,
-                         p.dln1_w, p.dln1_b, p.dbo, nullptr, b.ws_main, b.ws_main_bytes, st));
+  RL_TRY(ln_bwd(rl_ln_bwd(io, in_a, in_b, s, L.z1, L.m1, L.r1, p.ln1_w, G16(L.dh1), G16(L.dres1), c_h1), 2, p.dln1_w, p.dln1_b, p.dbo));
   if (batch3) {
     const void* dys[3] = {G16(L.dh2), G16(L.dq2), G16(L.dh1)};
     const void* xs[3] = {S16(L.c2), S16(L.y1), S16(L.c1)};

@@ -402,6 +402,64 @@ __global__ __launch_bounds__(256) void reduce_sets_kernel(ReduceSets r) {
 }
 static int reduce_sets_groups(int nblocks) { return nblocks >= 64 * REDUCE_SETS_GROUPS ? REDUCE_SETS_GROUPS : 1; }
 
+// The same fold for a TABLE of deferred reduces (xfm_reduce_sets_batch): grid (max D / 64, 4 sets, items x REDUCE_SETS_GROUPS); an item
+// with few partial rows leaves most of its row groups empty.  One launch for the 36 LayerNorm backwards of a 12-layer tower.
+#define REDUCE_BATCH_MAX 56
+struct ReduceBatch { int n; xfm_reduce_item it[REDUCE_BATCH_MAX]; };
+__global__ __launch_bounds__(256) void reduce_sets_batch_kernel(ReduceBatch tb) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int s = blockIdx.y;
+  const int e = blockIdx.z / REDUCE_SETS_GROUPS, grp = blockIdx.z % REDUCE_SETS_GROUPS;
+  const xfm_reduce_item& r = tb.it[e];
+  float* out = (s < r.nset) ? r.out[s] : nullptr;
+  const int groups = r.nblocks >= 64 * REDUCE_SETS_GROUPS ? REDUCE_SETS_GROUPS : 1;   // (the per-call kernel's rule: same sums)
+  if (grp >= groups) return;
+  const int per = (r.nblocks + groups - 1) / groups;
+  const int b0 = grp * per;
+  int b1 = b0 + per;
+  b1 = b1 < r.nblocks ? b1 : r.nblocks;
+  float t = 0.f;
+  if (c < r.D && out != nullptr) {
+    const float* src = r.partial + (long)s * r.nblocks * r.D + c;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int b = b0 + sl;
+    for (; b + 12 < b1; b += 16) {
+      t0 += src[(long)b * r.D];
+      t1 += src[(long)(b + 4) * r.D];
+      t2 += src[(long)(b + 8) * r.D];
+      t3 += src[(long)(b + 12) * r.D];
+    }
+    for (; b < b1; b += 4) t0 += src[(long)b * r.D];
+    t = (t0 + t1) + (t2 + t3);
+  }
+  red[sl][cl] = t;
+  __syncthreads();
+  if (sl == 0 && c < r.D && out != nullptr && b0 < b1) {
+    const float v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    atomicAdd(out + c, v);   // (always: two items of one table may name the same destination -- a gradient shared by two LayerNorms)
+  }
+}
+int xfm_reduce_sets_batch_impl(int n, const xfm_reduce_item* items, hipStream_t st) {
+  XFM_REQUIRE(n >= 0 && (n == 0 || items != nullptr), "reduce_sets_batch: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += REDUCE_BATCH_MAX) {
+    ReduceBatch tb;
+    tb.n = n - i0 < REDUCE_BATCH_MAX ? n - i0 : REDUCE_BATCH_MAX;
+    int dmax = 0;
+    for (int i = 0; i < tb.n; ++i) {
+      tb.it[i] = items[i0 + i];
+      XFM_REQUIRE(tb.it[i].partial != nullptr && tb.it[i].nblocks > 0 && tb.it[i].D > 0 && tb.it[i].nset >= 1 && tb.it[i].nset <= 4,
+                  "reduce_sets_batch: bad item %d", i0 + i);
+      dmax = tb.it[i].D > dmax ? tb.it[i].D : dmax;
+    }
+    hipLaunchKernelGGL(reduce_sets_batch_kernel, dim3(cdiv(dmax, 64), 4, tb.n * REDUCE_SETS_GROUPS), dim3(256), 0, st, tb);
+    const int rc = xfm_check_launch("reduce_sets_batch");
+    if (rc != XFM_OK) return rc;
+  }
+  return XFM_OK;
+}
+
 int xfm_ln_bwd_grid(int rows) {
   static const int rpb = getenv("XFM_LN_BWD_ROWS") ? atoi(getenv("XFM_LN_BWD_ROWS")) : 8;  // tuning knob (8 measured: fusion tower 13.95 -> 13.56 ms)
   int blocks = cdiv(rows, rpb);  // rows per workgroup: enough waves per CU for an HBM-bound kernel at M = 7680
@@ -507,6 +565,10 @@ int xfm_ln_bwd_impl(LnBwd p, int D, int mode, float* dgamma, float* dbeta, float
 #undef LNB_CASE
   int rc = xfm_check_launch("ln_bwd");
   if (rc != XFM_OK) return rc;
+  if (p.defer != nullptr) {   // the caller folds the partials later, with the other LayerNorms of its tower (xfm_reduce_sets_batch)
+    *p.defer = xfm_reduce_item{workspace, {dgamma, dbeta, dbias, dls}, grid, D, nset, 0};
+    return XFM_OK;
+  }
   ReduceSets r{workspace, {dgamma, dbeta, dbias, dls}, grid, D};
   hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(D, 64), nset, reduce_sets_groups(grid)), dim3(256), 0, st, r);
   return xfm_check_launch("ln_bwd_reduce");

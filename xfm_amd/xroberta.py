@@ -204,6 +204,7 @@ class _WgradStream:
             self.side.wait_stream(self.main)  # arena state (zeroed grads, earlier kernels) is visible to the side stream
         self.keep = []
         self.queue = []
+        self.reduces = []
 
     def defer_tn(self, dy, x, dw, dbias=None):
         """Queue dw += dy^T @ x (dbias += column sums of dy) for the next flush(): everything queued -- all over the same M rows --
@@ -211,7 +212,30 @@ class _WgradStream:
         reduce per projection; the 48 weight gradients of the ViT trunk: 5.2 -> 3.9 ms).  The queue holds dy / x alive."""
         self.queue.append((dy, x, dw, dbias))
 
+    def defer_reduces(self, rq):
+        """A Fx.ReduceQueue (or a list of ReduceItems + the buffer they point into) whose folds run with the next flush()."""
+        self.reduces.append(rq)
+
+    def _run_reduces(self, reduces):
+        for rq in reduces:
+            if isinstance(rq, tuple):
+                Fx.reduce_sets_batch(rq[0])
+            else:
+                rq.run()
+
     def flush(self):
+        reduces = self.reduces
+        self.reduces = [r for r in reduces if not isinstance(r, tuple)]   # a ReduceQueue stays registered (more kernels will append to it)
+        if reduces and not self.queue:
+            if not self.on:
+                return self._run_reduces(reduces)
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            self.side.wait_event(ev)
+            self.keep.append(reduces)
+            with torch.cuda.stream(self.side):
+                self._run_reduces(reduces)
+            return
         if not self.queue:
             return
         items, self.queue = self.queue, []
@@ -219,14 +243,16 @@ class _WgradStream:
         for it in items:   # one grouped launch per distinct row count (a tower's projections share M; the K/V projections of the image states
             by_m.setdefault(it[0].shape[0], []).append(it)   # and the pruned last layer have their own)
         if not self.on:
+            self._run_reduces(reduces)
             for group in by_m.values():
                 Fx.gemm_tn_group(group)
             return
         ev = torch.cuda.Event()
         ev.record(self.main)
         self.side.wait_event(ev)
-        self.keep.append(items)
+        self.keep.append((items, reduces))
         with torch.cuda.stream(self.side):
+            self._run_reduces(reduces)
             for group in by_m.values():
                 Fx.gemm_tn_group(group)
 
@@ -691,6 +717,7 @@ def _view(slab, off, rows, cols, dtype=BF16):
 
 
 _KV_AHEAD = os.environ.get("XFM_KV_AHEAD", "1") != "0"   # A/B knob of RobertaModel.prefetch_cross_kv
+_RL_DEFER_LN = os.environ.get("XFM_RL_DEFER_LN", "1") != "0"   # A/B knob: one batched LayerNorm column-sum reduce per tower
 _RL_DEFER_WGRAD = os.environ.get("XFM_RL_DEFER_WGRAD", "1") != "0"
 
 
@@ -841,6 +868,15 @@ class _EncoderFnNative(torch.autograd.Function):
         # end (whole 256 x 256 tiles over all of M instead of 10 M-splits + a reduce per projection: the fusion + text towers' weight
         # gradients cost 2.8 ms of the step one by one under the activation-gradient chain, ~1.6 ms grouped)
         defer = _RL_DEFER_WGRAD and R >= 1024
+        # the LayerNorm backward kernels' column-sum folds (dgamma / dbeta / output-projection bias gradients): partials stay in per-call
+        # slices of one buffer and ONE batched reduce runs with the weight gradients, instead of a 7-us kernel behind each of the 3 per layer
+        ln_items = ln_count = ln_ws = None
+        if _RL_DEFER_LN:
+            from ._lib import ReduceItem
+            ln_stride = (lib.xfm_layernorm_bwd_workspace(io.R_alloc if io.R_alloc > 0 else R, D, 1) // 4 + 63) // 64 * 64   # LN_POST
+            ln_ws = torch.empty(max(3 * len(layers) * ln_stride, 1), dtype=F32, device=dy.device)
+            ln_items, ln_count = (ReduceItem * (3 * len(layers)))(), ctypes.c_int(0)
+            bw.ln_items, bw.ln_count, bw.ln_ws_stride = ctypes.addressof(ln_items), ctypes.addressof(ln_count), ln_stride
         for k in reversed(range(len(layers))):
             layer = layers[k]
             slab, x_in, kv, ctr, cross = ctx.saved[k]
@@ -862,6 +898,8 @@ class _EncoderFnNative(torch.autograd.Function):
             bw.bslab, bw.dy_a, bw.dy_b = bslab.data_ptr(), dy_a.data_ptr(), Fx._ptr(dy_b)
             bw.need_dprev = int(k > 0 or need_dx)
             bw.defer_wgrad = int(defer)
+            if ln_ws is not None:
+                bw.ln_ws = ln_ws.data_ptr() + k * 3 * ln_stride * 4
             _rl_touch(layer, arena, cross)
             check(lib.xfm_rlayer_bwd(ctypes.byref(_rlayer_params(layer, cfg)), ctypes.byref(io), ctypes.byref(bw), st), "rlayer_bwd")
             if defer:   # the layer's weight gradients join the tower's queue: operands at the layout's offsets of the two slabs (kept alive)
@@ -879,6 +917,8 @@ class _EncoderFnNative(torch.autograd.Function):
                 wg.defer_tn(Gv(L.dqkv, 3 * D), x_in[:R], sl["qkv"]._dw, sl["qkv"]._db)
             dy_a, dy_b = _view(bslab, L.dprev, R, D), _view(bslab, L.dres1, R, D)
             ctx.saved[k] = None
+        if ln_ws is not None and ln_count.value > 0:
+            wg.defer_reduces(([ln_items[i] for i in range(ln_count.value)], ln_ws))
         dx = (dy_a.float() + dy_b.float()).to(BF16) if need_dx else None
         if dx is not None and R < rows_full:
             dx = torch.cat([dx, torch.zeros((rows_full - R, D), dtype=dx.dtype, device=dx.device)], dim=0)
