@@ -155,6 +155,20 @@ class PatchEmbed(nn.Module):
         nn.init.kaiming_uniform_(self.proj.weight, a=math.sqrt(5))
 
 
+def _block_bias(vit, blk, H, N, ld, need_grad):
+    """(dense, dense_t, tiles) of one block's relative-position bias, as _TrunkFn.forward builds them."""
+    long_n = N > 256 and need_grad   # (long sequences: the dK/dV kernel reads the tiled transposed copy, no dense one)
+    dense = Fx.relpos_gather(blk.attn.relative_position_bias_table, vit._index32, H, N, ld, transposed=not long_n)
+    dense_t = tiles = None
+    if not long_n:
+        dense, dense_t = dense
+    if 64 < N <= 224:   # the batch-walking ViT-shape kernels (csrc/attention_vit.hip) read accumulator-layout copies
+        tiles = Fx.bias_tiles(dense, N, blk.attn.scale, fwd=True, bwd=_VIT_FUSED_BWD and need_grad)
+    elif N > 256 and need_grad:   # 384 / 480 px: the long-sequence backward kernels (csrc/attention_long.hip) read both copies
+        tiles = Fx.bias_tiles(dense, N, blk.attn.scale, fwd=True, bwd=True)
+    return dense, dense_t, tiles
+
+
 class _TrunkFn(torch.autograd.Function):
     """All transformer blocks + the final LayerNorm as one node.  x0: fp32 [B, N, D] -> bf16 [B, N, D]."""
 
@@ -172,21 +186,33 @@ class _TrunkFn(torch.autograd.Function):
         ctx.first = (x, mean, rstd)
         rel_pos = getattr(vit, "_rel_pos", True)      # models/vit.py (plain ViT): no relative-position bias,
         final_norm = vit._final_norm if hasattr(vit, "_final_norm") else vit.fc_norm
+        # the blocks' dense relative-position biases (table gather + accumulator-layout copies: two 5-us kernels per block) depend on the
+        # weights alone: all 24 launches go to the second stream up front and run under the first block's GEMMs
+        ahead = None
+        if rel_pos and x.is_cuda and _RELPOS_AHEAD:
+            from .xroberta import _WgradStream
+            pre = _WgradStream(x.device)
+            if pre.on:
+                ahead = []
+                with torch.cuda.stream(pre.side):
+                    for blk in blocks:
+                        ahead.append(_block_bias(vit, blk, H, N, ld, bool(ctx.needs_input_grad[0])))
+                    ev_bias = torch.cuda.Event()
+                    ev_bias.record(pre.side)
+                for triple in ahead:
+                    for t in triple[:2] + tuple(triple[2] or ()):
+                        if t is not None:
+                            t.record_stream(pre.main)
+                pre.main.wait_event(ev_bias)
         for i, blk in enumerate(blocks):
             s = vit._slots[i]
             g1 = blk.gamma_1 if blk.gamma_1 is not None else vit._ones   # ... and no layer scale (gamma = 1, no gradient)
             g2 = blk.gamma_2 if blk.gamma_2 is not None else vit._ones
             dense = dense_t = tiles = None
-            if rel_pos:
-                # (long sequences: the dK/dV kernel reads the tiled transposed copy built below, no dense one)
-                long_n = N > 256 and ctx.needs_input_grad[0]
-                dense = Fx.relpos_gather(blk.attn.relative_position_bias_table, vit._index32, H, N, ld, transposed=not long_n)
-                if not long_n:
-                    dense, dense_t = dense
-                if 64 < N <= 224:   # the batch-walking ViT-shape kernels (csrc/attention_vit.hip) read accumulator-layout copies
-                    tiles = Fx.bias_tiles(dense, N, blk.attn.scale, fwd=True, bwd=_VIT_FUSED_BWD and ctx.needs_input_grad[0])
-                elif N > 256 and ctx.needs_input_grad[0]:   # 384 / 480 px: the long-sequence backward kernels (csrc/attention_long.hip)
-                    tiles = Fx.bias_tiles(dense, N, blk.attn.scale, fwd=True, bwd=True)   # read both copies (dQ: query on the lane, dK/dV: key)
+            if ahead is not None:
+                dense, dense_t, tiles = ahead[i]
+            elif rel_pos:
+                dense, dense_t, tiles = _block_bias(vit, blk, H, N, ld, bool(ctx.needs_input_grad[0]))
             qkv = Fx.gemm_nt(y, s["qkv"].wb, s["qkv"].b)
             # long sequences keep the low half of O: the backward then takes delta from dO . (O + O_lo) instead of a first pass over
             # the keys (two of the dQ kernel's five matrix products: 355 -> 224 us per layer at 901 tokens for 24 us of forward)
@@ -272,12 +298,17 @@ class _TrunkFn(torch.autograd.Function):
             Fx.attn_bwd(dctx, qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ctxv, lse, dqkv[:, :D], dqkv[:, D:2 * D],
                         dqkv[:, 2 * D:], B, H, N, N, blk.attn.scale, bias=dense, dbias=ddense, bias_t=dense_t, o_lo=ctxv_lo,
                         bias_tiles=tiles if (_VIT_FUSED_BWD or N > 256) else None)
-            if dense is not None:
+            if dense is not None:   # the TABLE gradient from the dense bias gradient: a parameter gradient -- runs with the queued weight gradients
                 G = blk.attn.window_size[0]
+                dtab = g(blk.attn.relative_position_bias_table)
                 if N > 256 and blk.attn.window_size[0] == blk.attn.window_size[1] and N == G * G + 1:
-                    Fx.relpos_grid_grad(ddense, G, H, ld, g(blk.attn.relative_position_bias_table))   # 144 -> ~20 us at 901 tokens
+                    fn = lambda ddense=ddense, G=G, dtab=dtab: Fx.relpos_grid_grad(ddense, G, H, ld, dtab)   # noqa: E731  (144 -> ~20 us at 901 tokens)
                 else:
-                    Fx.relpos_scatter_sorted(ddense, vit._relpos_order, vit._relpos_start, H, N, ld, g(blk.attn.relative_position_bias_table))
+                    fn = lambda ddense=ddense, dtab=dtab: Fx.relpos_scatter_sorted(ddense, vit._relpos_order, vit._relpos_start, H, N, ld, dtab)   # noqa: E731
+                if tn is wg.defer_tn:
+                    wg.defer_call(fn, keep=(ddense_all,))
+                else:
+                    fn()
             tn(dqkv, y, s["qkv"].dw, dbias=s["qkv"].db)
             dy = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K)
             ctx.saved[i] = None
@@ -331,6 +362,7 @@ _VIT_FUSED_BWD = __import__("os").environ.get("XFM_ATTN_VIT_BWD", "0") != "0"   
 # five overlapped 57-MB collectives (round 2: 4 -> 5 blocks = 142 MB behind two of 114 MB)
 # XFM_VIT_DEFER_WGRAD=0: one xfm_gemm_tn per projection as the backward reaches it (rounds 1-3) instead of the grouped launch
 _DEFER_WGRAD = __import__("os").environ.get("XFM_VIT_DEFER_WGRAD", "1") != "0"
+_RELPOS_AHEAD = __import__("os").environ.get("XFM_VIT_RELPOS_AHEAD", "1") != "0"   # A/B knob: the blocks' dense biases built up front on the second stream
 _DEFER_LN = __import__("os").environ.get("XFM_VIT_DEFER_LN", "1") != "0"   # A/B knob: one batched LayerNorm column-sum reduce for the trunk
 _WGRAD_GROUP_BLOCKS = int(__import__("os").environ.get("XFM_VIT_WGRAD_GROUP", "0"))   # blocks per grouped launch (0: the whole trunk at its end)
 _GRAD_CHUNK_BLOCKS = max(1, int(__import__("os").environ.get("XFM_VIT_GRAD_CHUNK", "2")))

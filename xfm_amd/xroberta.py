@@ -212,13 +212,20 @@ class _WgradStream:
         reduce per projection; the 48 weight gradients of the ViT trunk: 5.2 -> 3.9 ms).  The queue holds dy / x alive."""
         self.queue.append((dy, x, dw, dbias))
 
+    def defer_call(self, fn, keep=()):
+        """fn() runs with the next flush() (second stream, after everything the launch stream holds then): parameter-gradient kernels
+        that nothing on the activation-gradient chain waits for (the relative-position table gradients of the ViT blocks)."""
+        self.reduces.append((fn, tuple(keep), None))
+
     def defer_reduces(self, rq):
         """A Fx.ReduceQueue (or a list of ReduceItems + the buffer they point into) whose folds run with the next flush()."""
         self.reduces.append(rq)
 
     def _run_reduces(self, reduces):
         for rq in reduces:
-            if isinstance(rq, tuple):
+            if isinstance(rq, tuple) and len(rq) == 3:
+                rq[0]()
+            elif isinstance(rq, tuple):
                 Fx.reduce_sets_batch(rq[0])
             else:
                 rq.run()
