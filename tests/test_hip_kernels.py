@@ -1053,6 +1053,7 @@ def test_gemm_tn_batch_equals_separate_calls(M, N, K, nb):
     (2048 + 40, [(768, 768), (320, 256), (256, 768), (768, 200)]),         # ragged M (tail rows) and shapes the 256 x 256 pipeline refuses
     (1152, [(256, 256)] * 50),                                             # more problems than one launch's table holds
     (1024, [(1024, 1024)] * 16),                                           # exactly one whole round of tiles: nothing is cut
+    (1024, [(1024, 1024)] * 31),                                           # 496 tiles: the last round is 94 % full and runs whole too
     (1024, [(256, 768)]),                                                  # three tiles of the shortest allowed M: pieces = whole tiles
     (1024 + 63, [(512, 256), (256, 512)]),                                 # the last K-step holds 63 of its 64 rows
 ])

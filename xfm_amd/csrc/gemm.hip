@@ -1845,6 +1845,9 @@ static bool tn_group_item_ok(const xfm_tn_item& it, int M) {   // (any M from 10
 }
 static void tn_group_plan(int tiles, int nk, int G, int& full, int& sk_wgs, long& R) {
   full = tiles / G * G;
+  // a last round that is at least 90 % full runs as whole tiles too: cutting it would even out the last 10 % of one round at the price
+  // of two partial planes + a fix-up pass for every tile of it (the fusion tower: 1512 tiles = 5 rounds + 232)
+  if ((tiles - full) * 10 >= G * 9) full = tiles;
   R = (long)(tiles - full) * nk;
   sk_wgs = 0;
   if (R > 0) {

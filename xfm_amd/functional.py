@@ -259,6 +259,8 @@ class ReduceQueue:
     folds are parameter gradients -- nothing on the activation-gradient chain waits for them -- and one 7-us kernel behind each of
     the 36 LayerNorms of a 12-layer tower is 0.3 ms of that chain."""
 
+    persistent = True   # (a _WgradStream keeps it registered across flushes)
+
     def __init__(self, device, nbytes_total):
         self.buf = torch.empty(max(int(nbytes_total) // 4, 1), dtype=F32, device=device)
         self.used = 0

@@ -178,6 +178,17 @@ class RobertaEncoder(nn.Module):
 from . import marks as _marks  # noqa: E402
 
 
+class _DeferredCall:
+    """One-shot work of a _WgradStream flush."""
+    persistent = False
+
+    def __init__(self, fn, keep=()):
+        self.fn, self.keep = fn, tuple(keep)
+
+    def run(self):
+        self.fn()
+
+
 class _WgradStream:
     """Weight-gradient GEMMs of a tower's backward on a second HIP stream.  dW only feeds the optimizer / all-reduce, so the
     dY^T X products need not sit on the activation-gradient critical path: at the fusion / text towers' sizes (M = 7680 / 1920 rows)
@@ -214,25 +225,21 @@ class _WgradStream:
 
     def defer_call(self, fn, keep=()):
         """fn() runs with the next flush() (second stream, after everything the launch stream holds then): parameter-gradient kernels
-        that nothing on the activation-gradient chain waits for (the relative-position table gradients of the ViT blocks)."""
-        self.reduces.append((fn, tuple(keep), None))
+        that nothing on the activation-gradient chain waits for (the relative-position table gradients of the ViT blocks, the batched
+        LayerNorm folds of the layer executor).  `keep`: the tensors it touches."""
+        self.reduces.append(_DeferredCall(fn, keep))
 
     def defer_reduces(self, rq):
-        """A Fx.ReduceQueue (or a list of ReduceItems + the buffer they point into) whose folds run with the next flush()."""
+        """A Fx.ReduceQueue: whatever LayerNorm backward kernels have queued on it is folded by every flush() until the join."""
         self.reduces.append(rq)
 
     def _run_reduces(self, reduces):
-        for rq in reduces:
-            if isinstance(rq, tuple) and len(rq) == 3:
-                rq[0]()
-            elif isinstance(rq, tuple):
-                Fx.reduce_sets_batch(rq[0])
-            else:
-                rq.run()
+        for work in reduces:
+            work.run()
 
     def flush(self):
         reduces = self.reduces
-        self.reduces = [r for r in reduces if not isinstance(r, tuple)]   # a ReduceQueue stays registered (more kernels will append to it)
+        self.reduces = [r for r in reduces if getattr(r, "persistent", False)]   # a ReduceQueue stays registered (more kernels will append to it)
         if reduces and not self.queue:
             if not self.on:
                 return self._run_reduces(reduces)
@@ -925,7 +932,8 @@ class _EncoderFnNative(torch.autograd.Function):
             dy_a, dy_b = _view(bslab, L.dprev, R, D), _view(bslab, L.dres1, R, D)
             ctx.saved[k] = None
         if ln_ws is not None and ln_count.value > 0:
-            wg.defer_reduces(([ln_items[i] for i in range(ln_count.value)], ln_ws))
+            folds = [ln_items[i] for i in range(ln_count.value)]
+            wg.defer_call(lambda: Fx.reduce_sets_batch(folds), keep=(ln_ws,))
         dx = (dy_a.float() + dy_b.float()).to(BF16) if need_dx else None
         if dx is not None and R < rows_full:
             dx = torch.cat([dx, torch.zeros((rows_full - R, D), dtype=dx.dtype, device=dx.device)], dim=0)
@@ -984,7 +992,8 @@ class RobertaModel(nn.Module):
         if arena._batch_event is not None:
             arena._batch_wait()
         pre = _WgradStream(enc.device)
-        self._kv_ahead = ((enc.data_ptr(), tuple(enc.shape), enc._version), {id(layer): pre.project(enc, layer._s["kv2"]) for layer in layers})
+        # (the entry holds `enc`: its memory cannot be handed to another tensor while the projections wait to be picked up)
+        self._kv_ahead = ((enc.data_ptr(), tuple(enc.shape), enc._version), {id(layer): pre.project(enc, layer._s["kv2"]) for layer in layers}, enc)
 
     def attach(self, arena):
         self._arena = arena
