@@ -191,7 +191,9 @@ class _LMHeadCEFn(torch.autograd.Function):
         y, mean, rstd = Fx.ln_fwd(hact, head.layer_norm.weight, head.layer_norm.bias, head.layer_norm.eps)
         ldl = (V + VOCAB_LD - 1) // VOCAB_LD * VOCAB_LD
         logits = torch.empty((R, ldl), dtype=F32, device=x.device)
-        Fx.gemm_nt(y, sv.wb, sv.b, epi=Fx.EPI_F32, out=logits, n=V)
+        # (few rows against the whole vocabulary: 4 x 197 tiles of 256 x 256 are three rounds of the persistent kernel -- 127 us against
+        # 148 us for the plan's 256 x 128 ring at 960 rows; below ~512 rows the plan's choice stands)
+        Fx.gemm_nt(y, sv.wb, sv.b, epi=Fx.EPI_F32, out=logits, n=V, tile_hint=5 if R >= 512 else 0)
         labels = labels.reshape(-1).contiguous()
         lse, loss_rows = Fx.ce_fwd(logits, V, labels)
         nvalid = (labels != -100).sum().clamp(min=1).to(F32)
