@@ -262,7 +262,8 @@ class _TrunkFn(torch.autograd.Function):
         ddense_all = None
         # the blocks' weight gradients are QUEUED and run as one grouped launch at the end of the trunk (or before each hand-over of a
         # gradient range to the data-parallel accelerator below): 48 projections x 9-36 output tiles walk whole tiles over all of M
-        tn = wg.defer_tn if (_DEFER_WGRAD and dy.is_cuda) else wg.gemm_tn
+        queued = _DEFER_WGRAD and dy.is_cuda
+        tn = wg.defer_tn if queued else wg.gemm_tn
         # ... and so are the column-sum folds of the two LayerNorm backward kernels of a block (dgamma / dbeta / bias / layer-scale gradients)
         rq = None
         if _DEFER_LN and dy.is_cuda:
@@ -305,7 +306,7 @@ class _TrunkFn(torch.autograd.Function):
                     fn = lambda ddense=ddense, G=G, dtab=dtab: Fx.relpos_grid_grad(ddense, G, H, ld, dtab)   # noqa: E731  (144 -> ~20 us at 901 tokens)
                 else:
                     fn = lambda ddense=ddense, dtab=dtab: Fx.relpos_scatter_sorted(ddense, vit._relpos_order, vit._relpos_start, H, N, ld, dtab)   # noqa: E731
-                if tn is wg.defer_tn:
+                if queued:
                     wg.defer_call(fn, keep=(ddense_all,))
                 else:
                     fn()

@@ -35,7 +35,13 @@ class _LinearSlotFn(torch.autograd.Function):
             dyp = torch.zeros((dy2.shape[0], pad), dtype=BF16, device=dy2.device)
             dyp[:, :s.N] = dy2
             dy2 = dyp
-        Fx.gemm_tn(dy2, ctx.x2, s.dw, n=s.N, dbias=s.db)
+        if dy2.is_cuda:   # the weight gradient leaves the chain: second stream, re-joined when the backward pass is over
+            from .xroberta import _WgradStream
+            wg = _WgradStream(dy2.device)
+            wg.gemm_tn(dy2, ctx.x2, s.dw, n=s.N, dbias=s.db)
+            wg.join_at_end()
+        else:
+            Fx.gemm_tn(dy2, ctx.x2, s.dw, n=s.N, dbias=s.db)
         dx = None
         if ctx.need_dx:
             if dy2.shape[1] % 64 == 0 and dy2.shape[1] <= s.wt.shape[1]:
