@@ -264,22 +264,21 @@ class ReduceQueue:
     def __init__(self, device, nbytes_total):
         self.buf = torch.empty(max(int(nbytes_total) // 4, 1), dtype=F32, device=device)
         self.used = 0
-        self.items = []
+        self.items = []    # ReduceItems not folded yet
+        self.extra = []    # overflow buffers (alive as long as the queue)
 
     def take(self, nbytes):
         n = (int(nbytes) // 4 + 63) // 64 * 64
-        if self.used + n > self.buf.numel():   # (sized by the caller for its tower; a stray extra call gets a buffer of its own)
-            extra = torch.empty(n, dtype=F32, device=self.buf.device)
-            self.items.append(extra)   # kept alive with the items (filtered out in run())
-            return extra
+        if self.used + n > self.buf.numel():   # (sized by the caller for its tower; a call beyond that gets a buffer of its own)
+            self.extra.append(torch.empty(n, dtype=F32, device=self.buf.device))
+            return self.extra[-1]
         out = self.buf[self.used:self.used + n]
         self.used += n
         return out
 
     def run(self):
         """Fold what has been queued since the last run (the buffer's slices are not reused: a fold may still be in flight)."""
-        items = [it for it in self.items if isinstance(it, _lib.ReduceItem)]
-        self.items = [it for it in self.items if not isinstance(it, _lib.ReduceItem)]
+        items, self.items = self.items, []
         if items:
             reduce_sets_batch(items)
 
