@@ -40,6 +40,7 @@ def _install_optimizer_hook():
     _hook_installed[0] = True
 
 _CAST_BATCH = os.environ.get("XFM_CAST_BATCH", "1") != "0"  # A/B knob: one batched refresh of the bf16 operand copies per step
+_CAST_CHUNKS = max(1, int(os.environ.get("XFM_CAST_CHUNKS", "6")))  # ... as this many launches in first-use order (1: one launch on the using stream)
 ALIGN = 256  # elements; arena segments are 1 KiB aligned (vector loads, per-block optimiser groups)
 
 
@@ -64,6 +65,7 @@ class LinearSlot:
         self._ver = None
         self._arena = None
         self._listed = False
+        self._chunk = 0      # which launch of the arena's batched refresh holds this slot (ParamArena._cast)
         self.need_t = True
 
     # bf16 operands are (re)built lazily, on first use after the arena version moved: slots a step never touches (the
@@ -79,7 +81,7 @@ class LinearSlot:
         if self._ver != a._manual_ver:
             a._cast(self)
         if a._batch_event is not None:
-            a._batch_wait()
+            a._batch_wait(self._chunk)
 
     # Gradient views are handed out through properties: every launch site that accumulates into the gradient arena asks for
     # `slot.dw` / `slot.db`, which is what marks the slot's parameters as LIVE (ParamArena.touch) -- the data-parallel exchange,
@@ -225,7 +227,9 @@ class ParamArena:
         self._table = None
         self._batch_ver = -1
         self._batch_event = None
-        self._batch_synced = set()
+        self._batch_events = []
+        self._batch_synced = {}
+        self._cast_stream = None
         self.params = [p for _, p in params]
         _ARENAS.add(self)
         _install_optimizer_hook()
@@ -234,16 +238,40 @@ class ParamArena:
     def _cast(self, slot):
         ver = self._manual_ver
         if _CAST_BATCH and slot._listed and self._batch_ver != ver and len(self._active) > 1:
+            # The refresh (0.5 ms of HBM traffic for ~290 M weights) runs as _CAST_CHUNKS launches over the slots IN THE ORDER OF THEIR
+            # FIRST USE, on a stream of its own, one event per launch: a tower starts as soon as the launch that holds its first layer
+            # is done (the ViT after ~0.15 ms instead of 0.5) and the later launches run under its first GEMMs.
             if self._table is None:
-                self._table = Fx.cast_table([(s.w, s._wb, s._wt) for s in self._active], self.device)
-            Fx.cast_transpose_batch(*self._table)
+                total = sum(s.w.numel() for s in self._active)
+                per, acc, chunks = total / max(1, min(_CAST_CHUNKS, len(self._active))), 0, [[]]
+                for s in self._active:
+                    if acc >= per * len(chunks) and len(chunks) < _CAST_CHUNKS:
+                        chunks.append([])
+                    chunks[-1].append(s)
+                    acc += s.w.numel()
+                for k, group in enumerate(chunks):
+                    for s in group:
+                        s._chunk = k
+                self._table = [Fx.cast_table([(s.w, s._wb, s._wt) for s in group], self.device) for group in chunks]
+            cur = torch.cuda.current_stream()
+            stream = cur
+            if len(self._table) > 1:
+                if self._cast_stream is None:
+                    self._cast_stream = torch.cuda.Stream(device=self.device)
+                stream = self._cast_stream
+                stream.wait_stream(cur)   # (the optimizer's update of the fp32 weights is in `cur`'s past)
+            self._batch_events = []
+            with torch.cuda.stream(stream):
+                for tbl in self._table:
+                    Fx.cast_transpose_batch(*tbl)
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    self._batch_events.append(ev)
             for s in self._active:
                 s._ver = ver
             self._batch_ver = ver
-            stream = torch.cuda.current_stream()
-            self._batch_event = torch.cuda.Event()
-            self._batch_event.record(stream)
-            self._batch_synced = {stream.cuda_stream}
+            self._batch_event = self._batch_events[-1]
+            self._batch_synced = {stream.cuda_stream: len(self._table) - 1}
             return
         slot._alloc()
         Fx.cast_transpose(slot.w, slot._wb, slot._wt)
@@ -253,11 +281,14 @@ class ParamArena:
             self._active.append(slot)
             self._table = None
 
-    def _batch_wait(self):
-        if Fx._stream() not in self._batch_synced:
-            stream = torch.cuda.current_stream()
-            stream.wait_event(self._batch_event)
-            self._batch_synced.add(stream.cuda_stream)
+    def _batch_wait(self, chunk=None):
+        """The current stream waits for launch `chunk` of the batched refresh (None: all of it); launches finish in order."""
+        if chunk is None:
+            chunk = len(self._batch_events) - 1
+        sid = Fx._stream()
+        if self._batch_synced.get(sid, -1) < chunk:
+            torch.cuda.current_stream().wait_event(self._batch_events[chunk])
+            self._batch_synced[sid] = chunk
 
     # bf16 caches are valid for one version; bumped by optimiser steps, load_state_dict and explicit bump()
     def version(self):

@@ -767,12 +767,9 @@ class _EncoderFnNative(torch.autograd.Function):
         layers = [model.encoder.layer[li] for li in range(lo, hi)]
         arena = layers[0]._s["qkv"]._arena
         ver = arena._manual_ver
-        for layer in layers:           # bf16 operand copies up to date (one batched cast launch when the arena version moved)
+        for layer in layers:           # bf16 operand copies up to date (the arena's batched refresh when its version moved) and visible here
             for slot in layer._s.values():
-                if slot._ver != ver:
-                    slot.wb
-        if arena._batch_event is not None:
-            arena._batch_wait()
+                slot._ensure()
         d_att, d_hid = Fx.drop_params(p_att, 1), Fx.drop_params(p_hid, 1)
         io = RLayerIO()
         io.R, io.B, io.T, io.Nenc, io.U = R, B, T, Nenc if enc is not None else 0, U
@@ -986,11 +983,8 @@ class RobertaModel(nn.Module):
         if not layers:
             return
         arena = layers[0]._s["kv2"]._arena
-        for layer in layers:   # bf16 operand copies up to date (one batched cast launch when the arena version moved)
-            if layer._s["kv2"]._ver != arena._manual_ver:
-                layer._s["kv2"].wb
-        if arena._batch_event is not None:
-            arena._batch_wait()
+        for layer in layers:   # bf16 operand copies up to date and visible on this stream
+            layer._s["kv2"]._ensure()
         pre = _WgradStream(enc.device)
         # (the entry holds `enc`: its memory cannot be handed to another tensor while the projections wait to be picked up)
         self._kv_ahead = ((enc.data_ptr(), tuple(enc.shape), enc._version), {id(layer): pre.project(enc, layer._s["kv2"]) for layer in layers}, enc)
