@@ -257,7 +257,8 @@ def test_collectives_through_rccl_in_a_group_of_one():
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_w1_worker.py")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    # (chunks of two blocks: the worker's 6-block ViT then hands over twice from inside its backward; the default of four is for 12 blocks)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", XFM_VIT_GRAD_CHUNK="2")
     r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=420, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("NCCL_W1 ")][-1]
