@@ -28,7 +28,7 @@ extern "C" {
 #define XFM_E_LAUNCH (-2)
 #define XFM_E_UNSUPPORTED (-3)
 
-#define XFM_ABI_VERSION 7
+#define XFM_ABI_VERSION 8
 
 const char* xfm_last_error(void);
 int xfm_abi_version(void);
@@ -134,6 +134,9 @@ typedef struct {
   float eps;
   uint32_t drop_thresh; float drop_scale; uint32_t seed_lo, seed_hi;  /* POST: dropout on h (thresh = p * 2^32) */
   int gelu;                /* y = GELU(LN(..)): the Linear -> LayerNorm -> GELU heads (xfm.py:115-121, model_classification.py:33-48) */
+  const float* res32;      /* POST: the residual in fp32 (replaces `res`): the un-rounded output of the previous LayerNorm -- the reference's
+                              autocast keeps LayerNorm outputs and the residual sum in fp32 (xroberta.py:300-304, 381-385) */
+  float* z32_out;          /* POST: the pre-norm sum in fp32 for the backward (z_out may then be NULL) */
 } xfm_ln_fwd_args;
 
 typedef struct {
@@ -152,6 +155,8 @@ typedef struct {
   struct xfm_reduce_item_s* defer;  /* non-NULL: do NOT launch the column-sum reduce; describe it here instead.  The caller keeps `workspace`
                               untouched until it has run the item through xfm_reduce_sets_batch (one launch for a whole tower's LayerNorms
                               instead of one 7-us kernel behind each of them on the activation-gradient chain) */
+  float* dres32;           /* POST: the gradient of the residual branch in fp32 (the next LayerNorm backward up the stream takes it as
+                              dy32); `dres` may then be NULL */
 } xfm_ln_bwd_args;
 
 /* out[s][c] += sum over the nblocks rows of partial[s][.][c], s < nset: the deferred second half of xfm_layernorm_bwd. */
@@ -300,6 +305,8 @@ typedef struct {
   int pos_mode; /* 0: RoBERTa pad-aware cumsum positions; 1: BERT absolute positions 0..T-1 (xbert.py:198-199) */
   const int* row_map; /* optional [B*T]: token (b,t) is written to / its gradient read from row row_map[b*T+t] of y / dy (packed,
                          unpadded rows); -1 skips the token (padding).  mean / rstd / pos_ids stay [B*T]. */
+  float* y32;         /* optional fp32 twin of y (same rows): the embedding output enters the encoder's fp32 residual stream un-rounded */
+  const float* dy32;  /* optional fp32 gradient added to dy (the residual-branch gradient of the first layer) */
 } xfm_embed_args;
 int xfm_embed_ln_fwd(const xfm_embed_args* a, int D, void* stream);
 long xfm_embed_ln_bwd_workspace(int rows, int D);
@@ -352,6 +359,11 @@ typedef struct {        /* geometry + per-call inputs shared by forward and back
   void* slab;                                    /* forward activations, xfm_rlayer_layout(...).fwd_bytes */
   const xfm_bf16* kv; long kv_ld;                /* cross: this layer's K|V projection of the image states [U*Nenc, >= 2D] */
   void* kv_event;                                /* hipEvent_t the main stream waits for before it reads kv (NULL: none) */
+  int f32_stream;                                /* 1: fp32 residual stream inside the layer (layout flag XFM_RL_F32_STREAM): every post-LN sum
+                                                    z_k = dropout(h_k) + y_{k-1} uses the UN-ROUNDED fp32 output of the previous LayerNorm and is
+                                                    kept in fp32 for the backward, whose residual-branch gradients are fp32 too -- what the
+                                                    reference's mixed precision does (LayerNorm and the residual add run in fp32) */
+  const float* x32;                              /* f32_stream: fp32 twin of x (the previous layer's y3_32) or NULL (x enters the stream as is) */
 } xfm_rlayer_io;
 
 typedef struct {        /* backward-only */
@@ -367,6 +379,8 @@ typedef struct {        /* backward-only */
                                                     partials to ln_ws + k * ln_ws_stride (floats, k = 0..2; each >= xfm_layernorm_bwd_workspace bytes)
                                                     and launch no reduce; ... */
   xfm_reduce_item* ln_items; int* ln_count;      /* ... they append their items to this HOST table instead (ln_items[*ln_count], count advanced) */
+  const float* dy_b32;                           /* f32_stream: the fp32 part of the gradient w.r.t. the layer output (the next layer's dres1) or
+                                                    NULL; dy_b must be NULL.  The gradient w.r.t. the layer input is dprev (bf16) + dres1 (fp32) */
   int defer_wgrad;                               /* 1: launch NO weight-gradient GEMM -- the caller queues them (the dY / X operands sit at the
                                                     layout's offsets in bslab / slab, which it keeps alive) and runs the queue of the whole
                                                     tower as grouped launches (xfm_gemm_tn_group).  Bias gradients that ride on a weight
@@ -378,9 +392,11 @@ typedef struct {        /* byte offsets inside slab / bslab (256-byte aligned) *
   long dh3, dres3, du, d1a, dh2, dres2, dc2, dq2, delta2, d2a, dh1, dres1, dc1, dqkv, delta1, dprev, bwd_bytes;
   long ws_main_bytes, ws_side_bytes;             /* workspace the backward wants on each stream */
   long c2lo;                                     /* forward slab: low half of the cross-attention output (O = c2 + c2lo to fp32-ish precision) */
+  long y1_32, y2_32, y3_32;                      /* XFM_RL_F32_STREAM: fp32 twins of y1 / y2 / y3 (-1 otherwise); z1-3 and dres1-3 are fp32 then */
 } xfm_rlayer_layout_t;
 
-int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int xq_max, int dropout,
+enum { XFM_RL_DROPOUT = 1, XFM_RL_F32_STREAM = 2 };   /* `flags` of xfm_rlayer_layout */
+int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int xq_max, int flags,
                       xfm_rlayer_layout_t* out);
 int xfm_rlayer_fwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, void* stream);
 int xfm_rlayer_bwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, const xfm_rlayer_bwd_args* b, void* stream);

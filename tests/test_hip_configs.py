@@ -10,7 +10,12 @@ run live on the same formula weights and synthetic batch:
   configs[3]  VQA fine-tune (VQA.py:35-72 -> model_generation.py:96-133): B = 24, 480 px (901 image tokens), k ~ U[1, 10] answers per
               question through the 12-layer causal decoder -- against `vqa_cfg.npz` (the reference at this shape): loss within 1e-3,
               every parameter gradient as above.
-(configs[1], ImageNet at B = 128, is test_hip_modules.test_classification_imagenet_at_batch_128_vs_oracle.)
+  configs[4]  the HEADLINE shape (bench.py's default workload: the full pre-training step at B = 64 per GPU, 224 px, 30 tokens, 12 + 12 +
+              12 layers) -- against `pretrain_cfg.npz`, the REFERENCE run at this very shape (both ViT passes, captured negatives, pre-drawn
+              MIM masks), through the bench's default path (packed rows, image-major layout, batched passes, deferred grouped weight
+              gradients): total loss within 1e-3, every parameter gradient by the module rule.
+(configs[1], ImageNet at B = 128, is test_hip_modules.test_classification_imagenet_at_batch_128_vs_oracle -- forward and backward against
+`imagenet_cfg.npz`.)
 The config-shape fixtures come from tools/oracle/gen_golden.py --only retrieval_cfg | vqa_cfg (the reference's vision tower run in
 chunks of images so that its fp32 activations fit the build container; same arithmetic); the oracle is held to them live."""
 import json
@@ -187,11 +192,10 @@ def test_retrieval_step_at_config_shape_vs_oracle():
     assert abs(float(itm) - rm) <= max(1e-2 * rm, 4.0 * abs(am - rm)), (float(itm), rm, am)
     assert abs(float(itc + itm) - (ri + rm)) <= 1e-3 * (ri + rm), (float(itc + itm), ri + rm)
     # every parameter gradient, by the module tests' rule (rel-L2 <= 8e-2, cosine >= 0.996), a tensor above it held to the reference's
-    # own autocast floor on that tensor x 1.5 (1 - cosine: x 2.3 = 1.5^2).  Measured: 621 tensors, worst rel-L2 0.105; 6 of them (fusion layers
-    # 0-5, where the text gradient of this fine-tuning step has crossed 12 + 12 bf16 layers) sit at 1.35-1.45 x their floor -- the
-    # text / fusion towers keep their LayerNorm outputs and residual stream in bf16, the reference's autocast keeps those in fp32;
-    # the 256-entry probe of a tensor against the floor's whole-tensor figure adds ~10 %.
-    _check_grads(z, "grad", m, min_rms=1e-6, abs_ok={"temp": 0.05, "itm_head.3.bias": 2e-3}, floor="floor", floor_err=1.5, floor_cos=2.3)
+    # own autocast floor on that tensor x 1.3 (1 - cosine: x 1.7 = 1.3^2) -- the bound every other fixture uses.  (Round 4 needed 1.5 / 2.3
+    # here: six fusion-layer tensors sat at 1.35-1.45 x their floor while the text / fusion towers kept LayerNorm outputs and the residual
+    # stream in bf16; since round 5 that stream is fp32, as in the reference's mixed precision: xroberta._F32_STREAM.)
+    _check_grads(z, "grad", m, min_rms=1e-6, abs_ok={"temp": 0.05, "itm_head.3.bias": 2e-3}, floor="floor")
     dead = _finite_and_complete(m, expect_zero=("vision_encoder.mask_token", "self.key.bias", "crossattention.self.key.bias"))
     # what takes no part (model_retrieval.py:25-36): the text tower's unused cross-attention blocks, the fusion tower's own embeddings
     # and LM heads (it is fed the text tower's states).  Every tower layer, both projections, the ITM head and the temperature train.
@@ -230,7 +234,38 @@ def test_vqa_step_at_config_shape_vs_oracle():
     assert abs(orc - ref) <= 2e-4 * abs(ref), (orc, ref)
     print(f"VQA B={B} {R}px answers={sum(x.k)}: loss {float(loss):.5f} vs reference {ref:.5f} (its bf16 autocast: {amp:.5f}), peak {peak:.1f} GiB")
     assert abs(float(loss) - ref) <= max(1e-3 * abs(ref), 2.0 * abs(amp - ref)), (float(loss), ref, amp)
-    _check_grads(z, "grad", m, min_rms=1e-6, floor="floor", floor_err=1.5, floor_cos=2.3)
+    _check_grads(z, "grad", m, min_rms=1e-6, floor="floor")
     dead = _finite_and_complete(m, expect_zero=("vision_encoder.mask_token", "key.bias"))
     assert all(_unused_by_design(k) for k in dead), [k for k in dead if not _unused_by_design(k)][:8]
     assert len(dead) < 0.35 * sum(1 for _ in m.parameters())
+
+
+def test_pretrain_step_at_headline_shape_vs_reference():
+    """configs[4] per GPU = the bench's default workload: `loss = model(image, text_ids, text_atts, text_ids_masked=..., masked_pos=...,
+    masked_ids=..., ret_mim_loss=True, data_source='image')` (Pretrain.py:61-91 -> model_pretrain.py:30-91) at B = 64, 224 px, 30 tokens,
+    full depth, on the path bench.py times: `text_lens` given (unpadded token rows in the text / fusion towers, the 4B fusion sequences
+    laid out image by image), batch_passes (one 2B-row ViT pass for the clean + MIM-masked views, one 4B-row fusion pass for ITM +
+    MLM), per-layer native executor, grouped weight gradients launched at the end of each tower's backward.  Checked against the
+    REFERENCE at this very shape (tools/oracle/gen_golden.py --only pretrain_cfg: both ViT passes in chunks of 8 images, the negatives
+    the reference drew, pre-drawn MIM masks, eval mode): four losses, total within 1e-3, every parameter gradient by the module rule
+    with the reference's own autocast floor (x 1.3 / 1.7); the live oracle is held to the fixture's losses too."""
+    from oracle import xfm_oracle as O
+    from golden_util import load
+    from test_hip_modules import _pretrain
+    import xfm_amd.xroberta as XR
+    import xfm_amd.beit2 as B2
+    _, meta = load("pretrain_cfg")
+    assert meta["B"] == 64 and meta["text_layers"] == meta["fusion_layers"] == meta["vit_depth"] == 12
+    # the bench's defaults, not a test-only configuration
+    assert XR._NATIVE_LAYERS and XR._RL_DEFER_WGRAD and XR._RL_DEFER_LN and B2._DEFER_WGRAD and XR._F32_STREAM
+    torch.cuda.reset_peak_memory_stats()
+    m, z, meta, report = _pretrain("pretrain_cfg", floor="floor", packed=True, returns=True)
+    torch.cuda.synchronize()
+    print(f"pretrain B=64: peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    b = syn.pretrain_batch(64, seed=meta["seed"])
+    masks = syn.mim_block_mask(64, 14, 75, seed=meta["seed"])
+    with torch.no_grad():   # (the oracle, live, against the fixture: the restatement is pinned at the headline shape too)
+        ref = O.pretrain_forward(_oracle_params(sd), O.default_cfg(12, 12, 12), b, meta["image_neg_idx"], meta["text_neg_idx"], masks)
+    for k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim"):
+        assert abs(float(ref[k]) - float(z[k])) <= 2e-4 * max(abs(float(z[k])), 1.0), (k, float(ref[k]), float(z[k]))

@@ -348,6 +348,50 @@ def test_layernorm_post_fwd_bwd_no_dropout():
     _close(dbias, dh.float().sum(0), 1e-4, "bias grad = colsum(dh)")
 
 
+def test_layernorm_post_fp32_stream_fwd_bwd():
+    """The fp32 residual stream of the text / fusion towers (xroberta._F32_STREAM): the residual is the previous LayerNorm's fp32
+    output, z and the twin of y stay fp32, the residual-branch gradient comes in and leaves in fp32 -- fp32-level agreement with torch
+    on everything that is not a bf16 tensor by contract (y, dh)."""
+    Fx = _fx()
+    rows, D = 261, 768
+    h, res = _rand((rows, D), seed=30), _rand((rows, D), 1.0, F32, seed=31)
+    w, b = _rand((D,), 1.0, F32, seed=32), _rand((D,), 0.3, F32, seed=33)
+    dy1, dy2 = _rand((rows, D), seed=34), _rand((rows, D), 1.0, F32, seed=35)
+    hr, rr = h.float().requires_grad_(True), res.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = _ln_ref(hr + rr, wr, br, 1e-5)
+    yr.backward(dy1.float() + dy2)
+    y, z, mean, rstd, y32 = Fx.ln_post_fwd(h, res, w, b, 1e-5, f32=True)
+    assert z.dtype == F32 and y32.dtype == F32 and y.dtype == BF16
+    _close(z, h.float() + res, 1e-6, "fp32 pre-norm sum")
+    _close(y32, yr, 2e-5, "fp32 twin of y")
+    assert torch.equal(y, y32.to(BF16)), "y is the rounding of its twin"
+    dg, db, dbias = (torch.zeros(D, device="cuda") for _ in range(3))
+    dh, dres = Fx.ln_post_bwd(dy1, z, mean, rstd, w, dg, db, dbias, dy2=dy2)
+    assert dres.dtype == F32 and dh.dtype == BF16
+    _close(dres, rr.grad, 2e-5, "fp32 residual-branch gradient")
+    assert torch.equal(dh, dres.to(BF16))
+    _close(dg, wr.grad, 1e-4, "dgamma")
+    _close(db, br.grad, 1e-4, "dbeta")
+    _close(dbias, dh.float().sum(0), 1e-4, "bias grad = colsum(dh)")
+    # a bf16 tower input enters the stream through its values; no incoming fp32 gradient on the tower's last LayerNorm
+    res16 = res.to(BF16)
+    y_b, z_b, m_b, r_b, y32_b = Fx.ln_post_fwd(h, res16, w, b, 1e-5, f32=True)
+    _close(z_b, h.float() + res16.float(), 1e-6, "bf16 input, fp32 sum")
+    dh_b, dres_b = Fx.ln_post_bwd(dy1, z_b, m_b, r_b, w, torch.zeros_like(dg), torch.zeros_like(db), torch.zeros_like(dbias))
+    hr2 = h.float().requires_grad_(True)
+    _ln_ref(hr2 + res16.float(), w, b, 1e-5).backward(dy1.float())
+    _close(dres_b, hr2.grad, 2e-5, "no fp32 gradient in")
+    # dropout: the twin carries the same mask
+    drop = Fx.drop_params(0.1, 4242)
+    y_d, z_d, _, _, _ = Fx.ln_post_fwd(h, res, w, b, 1e-5, drop, f32=True)
+    _, z_d16, _, _ = Fx.ln_post_fwd(h, res16, w, b, 1e-5, drop)
+    kept = ((z_d - res).abs() > 0) | (h.float() == 0)
+    rate = float(kept.float().mean())
+    assert abs(rate - 0.9) < 5e-3, rate
+    _close(z_d, z_d16.float() + (res - res16.float()), 2e-2, "same dropout stream as the bf16 form")
+
+
 def test_layernorm_post_dropout_mask_is_consistent_between_fwd_and_bwd():
     Fx = _fx()
     rows, D, p = 512, 768, 0.1
@@ -623,6 +667,34 @@ def test_embedding_layernorm_fwd_bwd():
     _close(dg, lw.grad, 1e-4, "dgamma")
     _close(db, lb.grad, 1e-4, "dbeta")
     assert float(dword[1].abs().max()) == 0.0 and float(dpos[1].abs().max()) == 0.0, "padding rows take no gradient"
+
+
+def test_embedding_fp32_twin_and_fp32_gradient():
+    """xfm_embed_args.y32 / dy32: the embedding output's fp32 twin is the un-rounded value of y, and an fp32 gradient on the twin's edge is
+    added to the bf16 one."""
+    Fx = _fx()
+    from xfm_amd import synthetic as syn
+    V, D, B, T = 1000, 768, 5, 30
+    b = syn.pretrain_batch(B, seed=3, with_image=False, vocab=V)
+    ids = b["text_ids"].cuda()
+    word, pos, typ = _rand((V, D), 0.1, F32, 90), _rand((64, D), 0.1, F32, 91), _rand((1, D), 0.1, F32, 92)
+    w, bb = _rand((D,), 1.0, F32, 93), _rand((D,), 0.3, F32, 94)
+    y, mean, rstd, pos_ids, y32 = Fx.embed_ln_fwd(ids, word, pos, typ, w, bb, 1e-5, 1, y32=True)
+    y0 = Fx.embed_ln_fwd(ids, word, pos, typ, w, bb, 1e-5, 1)[0]
+    assert torch.equal(y, y0) and torch.equal(y, y32.to(BF16))
+    dy, dy32 = _rand((B * T, D), seed=95), _rand((B * T, D), 1.0, F32, seed=96)
+    both = [torch.zeros_like(t) for t in (word, pos, typ.view(-1), w, bb)]
+    Fx.embed_ln_bwd(dy, ids, word, pos, typ, w, bb, 1e-5, 1, mean, rstd, pos_ids, *both, dy32=dy32)
+    parts = [torch.zeros_like(t) for t in (word, pos, typ.view(-1), w, bb)]
+    Fx.embed_ln_bwd(dy, ids, word, pos, typ, w, bb, 1e-5, 1, mean, rstd, pos_ids, *parts)
+    zero16 = torch.zeros_like(dy)
+    hi = dy32.to(BF16)
+    lo = (dy32 - hi.float()).to(BF16)      # dy32 ~ hi + lo: two more bf16-gradient calls reproduce the fp32 edge to 2^-16
+    for extra in (hi, lo):
+        Fx.embed_ln_bwd(extra, ids, word, pos, typ, w, bb, 1e-5, 1, mean, rstd, pos_ids, *parts)
+    del zero16
+    for got, ref, name in zip(both, parts, ("dword", "dpos", "dtype", "dgamma", "dbeta")):
+        _close(got, ref, 2e-4, name)
 
 
 def test_cross_entropy_fwd_bwd_ignore_index():

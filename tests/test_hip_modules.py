@@ -47,7 +47,9 @@ def _check_grads(z, prefix, module, name_prefix="", skip=("self.key.bias",), min
     floor: key prefix of the fixture's per-tensor mixed-precision floor (tools/oracle/gen_golden.py amp_floor: the reference's own
     bf16-autocast gradient against its fp32 gradient, [rel-L2, cosine]).  A tensor may then exceed the global tolerance only as far
     as the REFERENCE's 16-bit training arithmetic does on that same tensor: rel-L2 <= max(tol, 1.3 x floor), 1 - cos <= max(1 -
-    cos_tol, 1.7 x (1 - floor cos)); the margins cover the 256-entry probe against the floor's whole-tensor figure."""
+    cos_tol, 1.7 x (1 - floor cos)).  Fixtures generated since round 5 carry the floor ON THE PROBE'S OWN ENTRIES (floor[2:4]; the
+    reference's autocast noise reads 1.2-1.3 x its whole-tensor figure on the strided probe of the FFN output weights), older ones the
+    whole-tensor figure only (floor[0:2]); the margins cover the sampling noise of a 256-entry estimate."""
     bad, n, worst = [], 0, (0.0, 1.0)
     tol, cos_tol = tol or GRAD_TOL, cos_tol or COS_TOL
     params = dict(module.named_parameters())
@@ -78,7 +80,8 @@ def _check_grads(z, prefix, module, name_prefix="", skip=("self.key.bias",), min
         worst = (max(worst[0], err), min(worst[1], cos))
         tol_t, cos_t = tol, cos_tol
         if floor is not None and f"{floor}/{name}" in z.files:
-            fe, fc = (float(v) for v in z[f"{floor}/{name}"])
+            fl = [float(v) for v in z[f"{floor}/{name}"]]
+            fe, fc = fl[2:4] if len(fl) >= 4 else fl[:2]   # the reference's autocast error on the probe's own entries when the fixture has it
             tol_t, cos_t = max(tol, floor_err * fe), min(cos_tol, 1.0 - floor_cos * (1.0 - fc))
         if err > tol_t or cos < cos_t:
             bad.append((name, round(err, 4), round(cos, 5), round(tol_t, 4)))
@@ -586,16 +589,17 @@ def _pretrain_cfg(meta):
             "learnable_temp": True, "max_temp": 0.5, "min_temp": 0.001, "vision_depth": meta.get("vit_depth", 12)}
 
 
-def _pretrain(name, tol=None, cos_tol=None, batch_passes=True, packed=False, floor=None):
+def _pretrain(name, tol=None, cos_tol=None, batch_passes=True, packed=False, floor=None, returns=False):
     from xfm_amd.model_pretrain import XFM
     z, meta = load(name)
     B = meta["B"]
     m = XFM(dict(_pretrain_cfg(meta), batch_passes=batch_passes))
     _load_into(m, meta["spec"])
     m.cuda().finalize().eval()
-    hb = syn.pretrain_batch(B, seed=1234)
+    seed = meta.get("seed", 1234)
+    hb = syn.pretrain_batch(B, seed=seed)
     b = {k: v.cuda() for k, v in hb.items()}
-    masks = syn.mim_block_mask(B, 14, 75, seed=1234)
+    masks = syn.mim_block_mask(B, 14, 75, seed=seed)
     losses = m(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"], masked_pos=b["masked_pos"],
                masked_ids=b["masked_ids"], ret_mim_loss=True, data_source="image", ids_mask=masks,
                neg_idx=(meta["image_neg_idx"], meta["text_neg_idx"]), text_lens=hb["text_atts"].sum(1) if packed else None)
@@ -607,6 +611,8 @@ def _pretrain(name, tol=None, cos_tol=None, batch_passes=True, packed=False, flo
         total = total + losses[k]
         ref_total += ref
     print(json.dumps(report))
+    if "floor_loss_itm" in z.files:
+        print("reference under bf16 autocast:", {k: float(z["floor_" + k]) for k in report})
     # ITM is a 2-way CE over only 3B = 12 rows fed by bf16 tower outputs: its own tolerance is looser; the north-star
     # bound (total loss within 1e-3 rel) is asserted on the sum.
     ltol = {"loss_itc": 3e-3, "loss_itm": 3e-2, "loss_mlm": 3e-3, "loss_mim": 3e-3}
@@ -620,6 +626,8 @@ def _pretrain(name, tol=None, cos_tol=None, batch_passes=True, packed=False, flo
     for n, p in m.named_parameters():
         if n in unused:
             assert float(p._xfm_grad.abs().max()) == 0.0, f"{n} must receive no gradient"
+    if returns:
+        return m, z, meta, report
 
 
 def test_pretrain_step_small_vs_golden():

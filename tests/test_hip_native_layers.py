@@ -14,6 +14,15 @@ from xfm_amd.packing import Pack, pack_rows  # noqa: E402
 BF16 = torch.bfloat16
 
 
+@pytest.fixture(autouse=True, params=[True, False], ids=["f32stream", "bf16stream"])
+def _stream_mode(request):
+    """Both forms of the residual stream (xroberta._F32_STREAM: fp32, the default; bf16, the A/B knob) must agree between the paths."""
+    old = XR._F32_STREAM
+    XR._F32_STREAM = request.param
+    yield
+    XR._F32_STREAM = old
+
+
 def _model(layers, fusion_layer):
     torch.manual_seed(0)
     return XR.RobertaForMaskedLM(XR.RobertaConfig(num_hidden_layers=layers, fusion_layer=fusion_layer, vocab_size=4096)).cuda().finalize()

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # XFM_HIP_LIB: A/B a differently built library (kernel experiments); the default is the in-tree build.
 LIB_PATH = os.environ.get("XFM_HIP_LIB") or os.path.join(_HERE, "libxfm_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_void_p, c_int, c_long, c_float, c_u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint32
 
@@ -23,7 +23,8 @@ class LnFwdArgs(ctypes.Structure):
                 ("row_scale", c_void_p), ("w", c_void_p), ("b", c_void_p), ("x_out", c_void_p), ("z_out", c_void_p),
                 ("y", c_void_p), ("y32", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
                 ("rows", c_int), ("rows_per_sample", c_int), ("eps", c_float),
-                ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32), ("gelu", c_int)]
+                ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32), ("gelu", c_int),
+                ("res32", c_void_p), ("z32_out", c_void_p)]
 
 
 class LnBwdArgs(ctypes.Structure):
@@ -34,7 +35,7 @@ class LnBwdArgs(ctypes.Structure):
                 ("h", c_void_p), ("ls_gamma", c_void_p), ("row_scale", c_void_p), ("partial", c_void_p),
                 ("rows", c_int), ("rows_per_sample", c_int),
                 ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32), ("gelu_b", c_void_p),
-                ("defer", c_void_p)]
+                ("defer", c_void_p), ("dres32", c_void_p)]
 
 
 class ReduceItem(ctypes.Structure):   # xfm_reduce_item
@@ -67,7 +68,7 @@ class EmbedArgs(ctypes.Structure):
                 ("B", c_int), ("T", c_int), ("pad_id", c_int), ("eps", c_float),
                 ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32),
                 ("dy", c_void_p), ("dword", c_void_p), ("dpos", c_void_p), ("partial", c_void_p), ("pos_mode", c_int),
-                ("row_map", c_void_p)]
+                ("row_map", c_void_p), ("y32", c_void_p), ("dy32", c_void_p)]
 
 
 _P, _L, _I, _F, _U = c_void_p, c_long, c_int, c_float, c_u32
@@ -88,13 +89,13 @@ class RLayerIO(ctypes.Structure):
                 ("xq_start", _P), ("xq_len", _P), ("xq_max", _I),
                 ("causal", _I), ("zero_fill", _I), ("scale", _F),
                 ("att_thresh", _U), ("att_scale", _F), ("hid_thresh", _U), ("hid_scale", _F), ("seed_hi", _U), ("seed_ctr", _U),
-                ("x", _P), ("slab", _P), ("kv", _P), ("kv_ld", _L), ("kv_event", _P)]
+                ("x", _P), ("slab", _P), ("kv", _P), ("kv_ld", _L), ("kv_event", _P), ("f32_stream", _I), ("x32", _P)]
 
 
 class RLayerBwd(ctypes.Structure):
     _fields_ = [("bslab", _P), ("dy_a", _P), ("dy_b", _P), ("enc", _P), ("dkv", _P), ("dkv_ld", _L), ("denc32", _P),
                 ("need_dprev", _I), ("side_stream", _P), ("ws_main", _P), ("ws_main_bytes", _L), ("ws_side", _P), ("ws_side_bytes", _L),
-                ("ln_ws", _P), ("ln_ws_stride", _L), ("ln_items", _P), ("ln_count", _P), ("defer_wgrad", _I)]
+                ("ln_ws", _P), ("ln_ws_stride", _L), ("ln_items", _P), ("ln_count", _P), ("dy_b32", _P), ("defer_wgrad", _I)]
 
 
 class TnItem(ctypes.Structure):   # xfm_tn_item
@@ -105,7 +106,7 @@ class RLayerLayout(ctypes.Structure):
     _fields_ = [(n, _L) for n in ("qkv", "c1", "lse1", "h", "z1", "m1", "r1", "y1", "q2", "c2", "lse2", "z2", "m2", "r2", "y2", "hact", "u",
                                   "z3", "m3", "r3", "y3", "fwd_bytes",
                                   "dh3", "dres3", "du", "d1a", "dh2", "dres2", "dc2", "dq2", "delta2", "d2a", "dh1", "dres1", "dc1", "dqkv",
-                                  "delta1", "dprev", "bwd_bytes", "ws_main_bytes", "ws_side_bytes", "c2lo")]
+                                  "delta1", "dprev", "bwd_bytes", "ws_main_bytes", "ws_side_bytes", "c2lo", "y1_32", "y2_32", "y3_32")]
 
 
 class AdamWArgs(ctypes.Structure):

@@ -99,7 +99,8 @@ int xfm_layernorm_fwd(const xfm_ln_fwd_args* a, int D, int mode, void* stream) {
   NOTNULL(a, "layernorm_fwd");
   XFM_REQUIRE(a->w && a->b && a->y && a->mean && a->rstd, "layernorm_fwd: null operand");
   XFM_REQUIRE(mode != XFM_LN_PLAIN || a->x32 || a->x16, "layernorm_fwd: PLAIN needs x32 or x16");
-  XFM_REQUIRE(mode != XFM_LN_POST || (a->h && a->res && a->z_out), "layernorm_fwd: POST needs h, res, z_out");
+  XFM_REQUIRE(mode != XFM_LN_POST || (a->h && (a->res || a->res32) && (a->z_out || a->z32_out)),
+              "layernorm_fwd: POST needs h, res or res32, z_out or z32_out");
   XFM_REQUIRE(mode != XFM_LN_LS || (a->x32 && a->h && a->ls_gamma && a->x_out && a->rows_per_sample > 0),
               "layernorm_fwd: LS needs x32, h, ls_gamma, x_out, rows_per_sample");
   return xfm_ln_fwd_impl(*a, D, mode, ST(stream));
@@ -115,6 +116,7 @@ int xfm_layernorm_bwd(const xfm_ln_bwd_args* a, int D, int mode, float* dgamma, 
   NOTNULL(a, "layernorm_bwd");
   XFM_REQUIRE(a->dy1 && a->mean && a->rstd && a->w && (a->x32 || a->x16), "layernorm_bwd: null operand");
   XFM_REQUIRE(mode != XFM_LN_POST || a->dh, "layernorm_bwd: POST needs dh");
+  XFM_REQUIRE(mode == XFM_LN_POST || a->dres32 == nullptr, "layernorm_bwd: dres32 is a POST output");
   XFM_REQUIRE(mode != XFM_LN_LS || (a->dh && a->dstream && a->h && a->ls_gamma && a->rows_per_sample > 0),
               "layernorm_bwd: LS needs dh, dstream, h, ls_gamma, rows_per_sample");
   return xfm_ln_bwd_impl(*a, D, mode, dgamma, dbeta, dbias, dls, workspace, workspace_bytes, ST(stream));
@@ -218,9 +220,9 @@ int xfm_rows_scatter_add(const xfm_bf16* src, const int* index, int R, int D, fl
   return xfm_rows_scatter_add_impl(src, index, R, D, dst32, ST(stream));
 }
 
-int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int xq_max, int dropout,
+int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int xq_max, int flags,
                       xfm_rlayer_layout_t* out) {
-  return xfm_rlayer_layout_impl(R, B, T, D, H, FF, has_cross, Nenc, U, xq_max, dropout, out);
+  return xfm_rlayer_layout_impl(R, B, T, D, H, FF, has_cross, Nenc, U, xq_max, flags, out);
 }
 int xfm_rlayer_fwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, void* stream) {
   XFM_REQUIRE(p != nullptr && io != nullptr, "rlayer_fwd: null argument struct");

@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs p) {
       const int e = (i * 64 + lane) * 4;
       const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w + e), bv = *reinterpret_cast<const f32x4*>(p.b + e);
       bf16x4 o;
+      f32x4 o32;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float yv = (v[i][j] - mu) * rstd * wv[j] + bv[j];
@@ -355,8 +356,10 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs p) {
           yv = rng_keep(rng_u32(rkey, (uint32_t)(e + j)), p.drop_thresh) ? yv * p.drop_scale : 0.f;
         }
         o[j] = f2bf(yv);
+        o32[j] = yv;
       }
       *reinterpret_cast<bf16x4*>(p.y + (long)orow * D + e) = o;
+      if (p.y32 != nullptr) *reinterpret_cast<f32x4*>(p.y32 + (long)orow * D + e) = o32;
     }
   }
 }
@@ -393,9 +396,11 @@ __global__ __launch_bounds__(256) void emb_bwd_kernel(EmbArgs p) {
       const f32x4 d = *reinterpret_cast<const f32x4*>(p.type + e);
       const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.w + e);
       const bf16x4 g = *reinterpret_cast<const bf16x4*>(p.dy + (long)orow * D + e);
+      f32x4 g32 = {0.f, 0.f, 0.f, 0.f};
+      if (p.dy32 != nullptr) g32 = *reinterpret_cast<const f32x4*>(p.dy32 + (long)orow * D + e);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float gv = bf2f(g[j]);
+        float gv = bf2f(g[j]) + g32[j];
         if (p.drop_thresh != 0u) {
           gv = rng_keep(rng_u32(rkey, (uint32_t)(e + j)), p.drop_thresh) ? gv * p.drop_scale : 0.f;
         }

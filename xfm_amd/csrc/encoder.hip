@@ -21,36 +21,42 @@ typedef xfm_rlayer_layout_t RLL;
 
 static long al256(long x) { return (x + 255) & ~255L; }
 
-int xfm_rlayer_layout_impl(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int xq_max, int dropout, RLL* o) {
+int xfm_rlayer_layout_impl(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int xq_max, int flags, RLL* o) {
   XFM_REQUIRE(R > 0 && B > 0 && T > 0 && D > 0 && H > 0 && FF > 0 && o != nullptr, "rlayer_layout: bad geometry");
+  const int dropout = flags & XFM_RL_DROPOUT;
+  const bool f32s = (flags & XFM_RL_F32_STREAM) != 0;   // fp32 residual stream: z_k and the residual-branch gradients are fp32, y_k has an fp32 twin
   const long statld = (T + 3) / 4 * 4;
   const long rd = (long)R * D * 2, stat = (long)B * H * statld * 4, rvec = (long)R * 4;
+  const long rz = f32s ? 2 * rd : rd;
   // cross-attention row statistics: per sequence, or per image in range mode
   const long xstat = xq_max > 0 ? (long)U * H * ((xq_max + 3) / 4 * 4) * 4 : stat;
   long off = 0;
   auto take = [&](long bytes) { const long r = off; off += al256(bytes); return r; };
   o->qkv = take(3 * rd); o->c1 = take(rd); o->lse1 = take(stat); o->h = take(rd);
-  o->z1 = take(rd); o->m1 = take(rvec); o->r1 = take(rvec); o->y1 = take(rd);
+  o->z1 = take(rz); o->m1 = take(rvec); o->r1 = take(rvec); o->y1 = take(rd);
+  o->y1_32 = f32s ? take(2 * rd) : -1;
   if (has_cross) {
     o->q2 = take(rd); o->c2 = take(rd); o->lse2 = take(xstat);
     o->c2lo = take(rd);   // what the bf16 rounding of c2 lost: the backward gets delta = dO . (O + Olo) without a sweep over the keys
-    o->z2 = take(rd); o->m2 = take(rvec); o->r2 = take(rvec); o->y2 = take(rd);
+    o->z2 = take(rz); o->m2 = take(rvec); o->r2 = take(rvec); o->y2 = take(rd);
+    o->y2_32 = f32s ? take(2 * rd) : -1;
   } else {
-    o->q2 = o->c2 = o->c2lo = o->lse2 = o->z2 = o->m2 = o->r2 = o->y2 = -1;
+    o->q2 = o->c2 = o->c2lo = o->lse2 = o->z2 = o->m2 = o->r2 = o->y2 = o->y2_32 = -1;
   }
   o->hact = take((long)R * FF * 2); o->u = take((long)R * FF * 2);
-  o->z3 = take(rd); o->m3 = take(rvec); o->r3 = take(rvec); o->y3 = take(rd);
+  o->z3 = take(rz); o->m3 = take(rvec); o->r3 = take(rvec); o->y3 = take(rd);
+  o->y3_32 = f32s ? take(2 * rd) : -1;
   o->fwd_bytes = off;
   off = 0;
-  o->dh3 = take(rd); o->dres3 = dropout ? take(rd) : o->dh3;
+  o->dh3 = take(rd); o->dres3 = f32s ? take(2 * rd) : (dropout ? take(rd) : o->dh3);
   o->du = take((long)R * FF * 2); o->d1a = take(rd);
   if (has_cross) {
-    o->dh2 = take(rd); o->dres2 = dropout ? take(rd) : o->dh2;
+    o->dh2 = take(rd); o->dres2 = f32s ? take(2 * rd) : (dropout ? take(rd) : o->dh2);
     o->dc2 = take(rd); o->dq2 = take(rd); o->delta2 = take(xstat); o->d2a = take(rd);
   } else {
     o->dh2 = o->dres2 = o->dc2 = o->dq2 = o->delta2 = o->d2a = -1;
   }
-  o->dh1 = take(rd); o->dres1 = dropout ? take(rd) : o->dh1;
+  o->dh1 = take(rd); o->dres1 = f32s ? take(2 * rd) : (dropout ? take(rd) : o->dh1);
   o->dc1 = take(rd); o->dqkv = take(3 * rd); o->delta1 = take(stat); o->dprev = take(rd);
   o->bwd_bytes = off;
   o->ws_main_bytes = (long)3 * xfm_ln_bwd_grid(R) * D * 4;
@@ -120,12 +126,18 @@ static AttnArgs rl_cross_attn(const RLP& p, const RLIO& io, const RLL& L, char* 
   return a;
 }
 
-static LnFwd rl_ln_fwd(const RLIO& io, const bf16* h, const bf16* res, const float* w, const float* b, char* s, long z, long y, long m,
-                       long r, float eps, uint32_t ctr) {
+static LnFwd rl_ln_fwd(const RLIO& io, const bf16* h, const bf16* res, const float* res32, const float* w, const float* b, char* s, long z,
+                       long y, long y32, long m, long r, float eps, uint32_t ctr) {
   LnFwd f;
   memset(&f, 0, sizeof(f));
   f.h = h; f.res = res; f.w = w; f.b = b;
-  f.z_out = reinterpret_cast<bf16*>(s + z); f.y = reinterpret_cast<bf16*>(s + y);
+  if (io.f32_stream) {   // fp32 residual stream: fp32 z for the backward, fp32 twin of y for the next residual; a layer input without an
+    f.res32 = res32;     // fp32 twin (res32 NULL) enters the stream through its bf16 values
+    f.z32_out = reinterpret_cast<float*>(s + z); f.y32 = reinterpret_cast<float*>(s + y32);
+  } else {
+    f.z_out = reinterpret_cast<bf16*>(s + z);
+  }
+  f.y = reinterpret_cast<bf16*>(s + y);
   f.mean = reinterpret_cast<float*>(s + m); f.rstd = reinterpret_cast<float*>(s + r);
   f.rows = io.R; f.rows_per_sample = 1; f.eps = eps;
   rl_drop(io.hid_thresh, io.hid_scale, io.seed_hi, ctr, f.drop_thresh, f.drop_scale, f.seed_lo, f.seed_hi);
@@ -148,7 +160,8 @@ int xfm_rlayer_fwd_impl(const RLP& p, const RLIO& io, hipStream_t st) {
   const bool cross = rl_cross(p, io);
   RLL L;
   RL_TRY(xfm_rlayer_layout_impl(io.R_alloc > 0 ? io.R_alloc : io.R, io.B_alloc > 0 ? io.B_alloc : io.B, io.T, p.D, p.H, p.FF, p.has_cross,
-                                io.Nenc, io.U, io.xq_start != nullptr ? io.xq_max : 0, io.hid_thresh != 0u, &L));
+                                io.Nenc, io.U, io.xq_start != nullptr ? io.xq_max : 0,
+                                (io.hid_thresh != 0u ? XFM_RL_DROPOUT : 0) | (io.f32_stream ? XFM_RL_F32_STREAM : 0), &L));
   char* s = reinterpret_cast<char*>(io.slab);
   const int R = io.R, D = p.D, FF = p.FF;
   const bool zf = io.zero_fill && io.seq_start != nullptr;
@@ -160,8 +173,10 @@ int xfm_rlayer_fwd_impl(const RLP& p, const RLIO& io, hipStream_t st) {
   if (zf) (void)hipMemsetAsync(s + L.c1, 0, (size_t)R * D * 2, st);
   RL_TRY(xfm_attn_fwd_impl(rl_self_attn(p, io, L, s), st));
   RL_TRY(xfm_gemm_nt_impl(B16(L.c1), D, p.wo, D, h, D, p.bo, nullptr, 0, R, D, D, EPI_BF16, 0, st));
-  RL_TRY(xfm_ln_fwd_impl(rl_ln_fwd(io, h, io.x, p.ln1_w, p.ln1_b, s, L.z1, L.y1, L.m1, L.r1, p.eps, io.seed_ctr + 2), D, LN_POST, st));
+  auto F32 = [&](long off) { return io.f32_stream ? reinterpret_cast<const float*>(s + off) : nullptr; };
+  RL_TRY(xfm_ln_fwd_impl(rl_ln_fwd(io, h, io.x, io.x32, p.ln1_w, p.ln1_b, s, L.z1, L.y1, L.y1_32, L.m1, L.r1, p.eps, io.seed_ctr + 2), D, LN_POST, st));
   const bf16* y = B16(L.y1);
+  const float* y32 = F32(L.y1_32);
   uint32_t ctr3 = io.seed_ctr + 3;
   // ---- cross-attention block (xroberta.py:431-458)
   if (cross) {
@@ -170,14 +185,15 @@ int xfm_rlayer_fwd_impl(const RLP& p, const RLIO& io, hipStream_t st) {
     if (zf) (void)hipMemsetAsync(s + L.c2, 0, (size_t)R * D * 2, st);
     RL_TRY(xfm_attn_fwd_impl(rl_cross_attn(p, io, L, s), st));
     RL_TRY(xfm_gemm_nt_impl(B16(L.c2), D, p.wo2, D, h, D, p.bo2, nullptr, 0, R, D, D, EPI_BF16, 0, st));
-    RL_TRY(xfm_ln_fwd_impl(rl_ln_fwd(io, h, y, p.ln2_w, p.ln2_b, s, L.z2, L.y2, L.m2, L.r2, p.eps, io.seed_ctr + 4), D, LN_POST, st));
+    RL_TRY(xfm_ln_fwd_impl(rl_ln_fwd(io, h, y, y32, p.ln2_w, p.ln2_b, s, L.z2, L.y2, L.y2_32, L.m2, L.r2, p.eps, io.seed_ctr + 4), D, LN_POST, st));
     y = B16(L.y2);
+    y32 = F32(L.y2_32);
     ctr3 = io.seed_ctr + 5;
   }
   // ---- feed-forward block (xroberta.py:460-473): GELU fused into the first GEMM, gelu'(x) kept for the backward
   RL_TRY(xfm_gemm_nt_impl(y, D, p.wi, D, B16(L.hact), FF, p.bi, B16(L.u), FF, R, FF, D, EPI_GELU, 0, st));
   RL_TRY(xfm_gemm_nt_impl(B16(L.hact), FF, p.wout, FF, h, D, p.bout, nullptr, 0, R, D, FF, EPI_BF16, 0, st));
-  RL_TRY(xfm_ln_fwd_impl(rl_ln_fwd(io, h, y, p.ln3_w, p.ln3_b, s, L.z3, L.y3, L.m3, L.r3, p.eps, ctr3), D, LN_POST, st));
+  RL_TRY(xfm_ln_fwd_impl(rl_ln_fwd(io, h, y, y32, p.ln3_w, p.ln3_b, s, L.z3, L.y3, L.y3_32, L.m3, L.r3, p.eps, ctr3), D, LN_POST, st));
   return XFM_OK;
 }
 
@@ -194,14 +210,22 @@ static hipEvent_t rl_event() {
   return ring[next++ & 255u];
 }
 
-static LnBwd rl_ln_bwd(const RLIO& io, const bf16* dy1, const bf16* dy2, char* s, long z, long m, long r, const float* w, bf16* dh,
-                       bf16* dres, uint32_t ctr) {
+static LnBwd rl_ln_bwd(const RLIO& io, const bf16* dy1, const void* dy2, char* s, long z, long m, long r, const float* w, bf16* dh,
+                       void* dres, uint32_t ctr) {
   LnBwd g;
   memset(&g, 0, sizeof(g));
-  g.dy1 = dy1; g.dy2 = dy2;
-  g.x16 = reinterpret_cast<const bf16*>(s + z);
+  g.dy1 = dy1;
+  if (io.f32_stream) {   // the residual-branch gradient travels in fp32 from LayerNorm to LayerNorm (dy2 may be NULL: the tower's last layer)
+    g.dy32 = reinterpret_cast<const float*>(dy2);
+    g.x32 = reinterpret_cast<const float*>(s + z);
+    g.dres32 = reinterpret_cast<float*>(dres);
+  } else {
+    g.dy2 = reinterpret_cast<const bf16*>(dy2);
+    g.x16 = reinterpret_cast<const bf16*>(s + z);
+    g.dres = reinterpret_cast<bf16*>(dres);
+  }
   g.mean = reinterpret_cast<const float*>(s + m); g.rstd = reinterpret_cast<const float*>(s + r);
-  g.w = w; g.dh = dh; g.dres = dres;
+  g.w = w; g.dh = dh;
   g.rows = io.R; g.rows_per_sample = 1;
   rl_drop(io.hid_thresh, io.hid_scale, io.seed_hi, ctr, g.drop_thresh, g.drop_scale, g.seed_lo, g.seed_hi);
   return g;
@@ -214,7 +238,8 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
   XFM_REQUIRE(!cross || (b.enc != nullptr && b.dkv != nullptr), "rlayer_bwd: cross-attention needs enc and dkv");
   RLL L;
   RL_TRY(xfm_rlayer_layout_impl(io.R_alloc > 0 ? io.R_alloc : io.R, io.B_alloc > 0 ? io.B_alloc : io.B, io.T, p.D, p.H, p.FF, p.has_cross,
-                                io.Nenc, io.U, io.xq_start != nullptr ? io.xq_max : 0, io.hid_thresh != 0u, &L));
+                                io.Nenc, io.U, io.xq_start != nullptr ? io.xq_max : 0,
+                                (io.hid_thresh != 0u ? XFM_RL_DROPOUT : 0) | (io.f32_stream ? XFM_RL_F32_STREAM : 0), &L));
   XFM_REQUIRE(b.ws_main_bytes >= L.ws_main_bytes && (L.ws_side_bytes == 0 || (b.ws_side != nullptr && b.ws_side_bytes >= L.ws_side_bytes)),
               "rlayer_bwd: workspaces too small");
   char* s = reinterpret_cast<char*>(io.slab);
@@ -256,16 +281,18 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
   (void)c_att2;
 
   // ---- feed-forward block
-  RL_TRY(ln_bwd(rl_ln_bwd(io, b.dy_a, b.dy_b, s, L.z3, L.m3, L.r3, p.ln3_w, G16(L.dh3), G16(L.dres3), c_h3), 0, p.dln3_w, p.dln3_b, p.dbout));
+  XFM_REQUIRE(!io.f32_stream || b.dy_b == nullptr, "rlayer_bwd: with the fp32 stream the second gradient is dy_b32");
+  RL_TRY(ln_bwd(rl_ln_bwd(io, b.dy_a, io.f32_stream ? (const void*)b.dy_b32 : (const void*)b.dy_b, s, L.z3, L.m3, L.r3, p.ln3_w, G16(L.dh3),
+                          g + L.dres3, c_h3), 0, p.dln3_w, p.dln3_b, p.dbout));
   RL_TRY(wgrad(G16(L.dh3), D, S16(L.hact), FF, p.dwout, FF, nullptr, R, D, FF));
   RL_TRY(xfm_gemm_nt_impl(G16(L.dh3), D, p.wout_t, p.ld_wout_t, G16(L.du), FF, nullptr, S16(L.u), FF, R, FF, D, EPI_DGELU, 0, st));
   RL_TRY(wgrad(G16(L.du), FF, y_in, D, p.dwi, D, p.dbi, R, FF, D));
   RL_TRY(xfm_gemm_nt_impl(G16(L.du), FF, p.wi_t, p.ld_wi_t, G16(L.d1a), D, nullptr, nullptr, 0, R, D, FF, EPI_BF16, 0, st));
   const bf16* in_a = G16(L.d1a);
-  const bf16* in_b = G16(L.dres3);
+  const void* in_b = g + L.dres3;
   // ---- cross-attention block
   if (cross) {
-    RL_TRY(ln_bwd(rl_ln_bwd(io, in_a, in_b, s, L.z2, L.m2, L.r2, p.ln2_w, G16(L.dh2), G16(L.dres2), c_h2), 1, p.dln2_w, p.dln2_b, p.dbo2));
+    RL_TRY(ln_bwd(rl_ln_bwd(io, in_a, in_b, s, L.z2, L.m2, L.r2, p.ln2_w, G16(L.dh2), g + L.dres2, c_h2), 1, p.dln2_w, p.dln2_b, p.dbo2));
     if (!batch3) RL_TRY(wgrad(G16(L.dh2), D, S16(L.c2), D, p.dwo2, D, nullptr, R, D, D));
     RL_TRY(xfm_gemm_nt_impl(G16(L.dh2), D, p.wo2_t, p.ld_wo2_t, G16(L.dc2), D, nullptr, nullptr, 0, R, D, D, EPI_BF16, 0, st));
     if (zf) (void)hipMemsetAsync(g + L.dq2, 0, (size_t)R * D * 2, st);
@@ -287,10 +314,10 @@ int xfm_rlayer_bwd_impl(const RLP& p, const RLIO& io, const RLB& b, hipStream_t 
       RL_TRY(xfm_gemm_nt_impl(b.dkv, b.dkv_ld, p.wkv2_t, p.ld_wkv2_t, b.denc32, D, nullptr, nullptr, 0, io.U * io.Nenc, D, 2 * D, EPI_F32_ACC, 0, side));
     RL_TRY(xfm_gemm_nt_impl(G16(L.dq2), D, p.wq2_t, p.ld_wq2_t, G16(L.d2a), D, nullptr, nullptr, 0, R, D, D, EPI_BF16, 0, st));
     in_a = G16(L.d2a);
-    in_b = G16(L.dres2);
+    in_b = g + L.dres2;
   }
   // ---- self-attention block
-  RL_TRY(ln_bwd(rl_ln_bwd(io, in_a, in_b, s, L.z1, L.m1, L.r1, p.ln1_w, G16(L.dh1), G16(L.dres1), c_h1), 2, p.dln1_w, p.dln1_b, p.dbo));
+  RL_TRY(ln_bwd(rl_ln_bwd(io, in_a, in_b, s, L.z1, L.m1, L.r1, p.ln1_w, G16(L.dh1), g + L.dres1, c_h1), 2, p.dln1_w, p.dln1_b, p.dbo));
   if (batch3) {
     const void* dys[3] = {G16(L.dh2), G16(L.dq2), G16(L.dh1)};
     const void* xs[3] = {S16(L.c2), S16(L.y1), S16(L.c1)};

@@ -55,8 +55,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
         }
       } else if (MODE == LN_POST) {
         const bf16x4 hh = *reinterpret_cast<const bf16x4*>(p.h + base + e);
-        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res + base + e);
+        float rv[4];
+        if (p.res32 != nullptr) {  // fp32 residual stream: the previous LayerNorm's un-rounded output (what the reference's autocast keeps)
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res32 + base + e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rv[j] = rr[j];
+        } else {
+          const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res + base + e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rv[j] = bf2f(rr[j]);
+        }
         bf16x4 zz;
+        f32x4 z32;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float hv = bf2f(hh[j]);
@@ -64,10 +74,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
             const uint32_t r = rng_u32(rkey, (uint32_t)(e + j));
             hv = rng_keep(r, p.drop_thresh) ? hv * p.drop_scale : 0.f;
           }
-          v[i][j] = hv + bf2f(rr[j]);
+          v[i][j] = hv + rv[j];
           zz[j] = f2bf(v[i][j]);
+          z32[j] = v[i][j];
         }
-        *reinterpret_cast<bf16x4*>(p.z_out + base + e) = zz;
+        if (p.z_out != nullptr) *reinterpret_cast<bf16x4*>(p.z_out + base + e) = zz;
+        if (p.z32_out != nullptr) *reinterpret_cast<f32x4*>(p.z32_out + base + e) = z32;
       } else {
         const f32x4 a = *reinterpret_cast<const f32x4*>(p.x32 + base + e);
         const bf16x4 hh = *reinterpret_cast<const bf16x4*>(p.h + base + e);
@@ -332,6 +344,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
         col_add4(2, i, a2);
         *reinterpret_cast<bf16x4*>(p.dh + base + e) = oh;
         if (p.dres != nullptr && p.dres != p.dh) *reinterpret_cast<bf16x4*>(p.dres + base + e) = orr;
+        if (p.dres32 != nullptr) *reinterpret_cast<f32x4*>(p.dres32 + base + e) = f32x4{dz[0], dz[1], dz[2], dz[3]};  // fp32 gradient stream
       } else {
         const f32x4 ds = ds_in[MODE == LN_LS ? i : 0];
         const bf16x4 hh = h_in[MODE == LN_LS ? i : 0];

@@ -206,18 +206,30 @@ def ln_fwd(x, w, b, eps, y32=False, gelu=False):
     return (y, mean, rstd, yf) if y32 else (y, mean, rstd)
 
 
-def ln_post_fwd(h, res, w, b, eps, drop=(0, 1.0, 0, 0)):
-    """POST: z = dropout(h) + res; y = LN(z) -> (y, z, mean, rstd), all but stats bf16."""
+def ln_post_fwd(h, res, w, b, eps, drop=(0, 1.0, 0, 0), f32=False):
+    """POST: z = dropout(h) + res; y = LN(z) -> (y, z, mean, rstd), all but stats bf16.
+    f32 (the fp32 residual stream of the text / fusion towers): `res` may be fp32 (the previous LayerNorm's un-rounded output) or bf16
+    (a tower input), z is kept in fp32 and the result is (y, z fp32, mean, rstd, y fp32)."""
     _dev(h)
     rows, D = h.shape
-    assert h.is_contiguous() and res.is_contiguous() and h.dtype == BF16 and res.dtype == BF16
+    assert h.is_contiguous() and res.is_contiguous() and h.dtype == BF16 and res.dtype == (F32 if f32 and res.dtype == F32 else BF16)
     y, mean, rstd = _ln_out(rows, D, h.device)
-    z = torch.empty_like(h)
-    a = LnFwdArgs(h=h.data_ptr(), res=res.data_ptr(), w=w.data_ptr(), b=b.data_ptr(), z_out=z.data_ptr(), y=y.data_ptr(),
+    a = LnFwdArgs(h=h.data_ptr(), w=w.data_ptr(), b=b.data_ptr(), y=y.data_ptr(),
                   mean=mean.data_ptr(), rstd=rstd.data_ptr(), rows=rows, rows_per_sample=1, eps=eps,
                   drop_thresh=drop[0], drop_scale=drop[1], seed_lo=drop[2], seed_hi=drop[3])
+    if res.dtype == F32:
+        a.res32 = res.data_ptr()
+    else:
+        a.res = res.data_ptr()
+    if f32:
+        z = torch.empty((rows, D), dtype=F32, device=h.device)
+        y32 = torch.empty((rows, D), dtype=F32, device=h.device)
+        a.z32_out, a.y32 = z.data_ptr(), y32.data_ptr()
+    else:
+        z = torch.empty_like(h)
+        a.z_out = z.data_ptr()
     check(_lib.load().xfm_layernorm_fwd(ctypes.byref(a), D, LN_POST, _stream()), "layernorm_fwd(post)")
-    return y, z, mean, rstd
+    return (y, z, mean, rstd, y32) if f32 else (y, z, mean, rstd)
 
 
 def ln_ls_fwd(x, h, ls_gamma, row_scale, rows_per_sample, w, b, eps, x_out=None):
@@ -301,13 +313,20 @@ def ln_bwd(dy, x, mean, rstd, w, dgamma, dbeta, dy2=None, dy32=None, dx32=None, 
 
 
 def ln_post_bwd(dy, z, mean, rstd, w, dgamma, dbeta, dbias, dy2=None, drop=(0, 1.0, 0, 0), defer=None):
-    """POST backward -> (dh, dres) bf16 (same tensor when dropout is off); dgamma/dbeta/dbias += ."""
+    """POST backward -> (dh, dres) bf16 (same tensor when dropout is off); dgamma/dbeta/dbias += .
+    fp32 stream (z is fp32): dy2, if given, is the fp32 residual-branch gradient of the LayerNorm above; dres comes back in fp32."""
     rows, D = z.shape
-    dh = torch.empty_like(z)
-    dres = dh if drop[0] == 0 else torch.empty_like(z)
-    a = LnBwdArgs(dy1=dy.data_ptr(), dy2=_ptr(dy2), x16=z.data_ptr(), mean=mean.data_ptr(), rstd=rstd.data_ptr(),
-                  w=w.data_ptr(), dh=dh.data_ptr(), dres=dres.data_ptr(), rows=rows, rows_per_sample=1,
+    dh = torch.empty((rows, D), dtype=BF16, device=z.device)
+    a = LnBwdArgs(dy1=dy.data_ptr(), mean=mean.data_ptr(), rstd=rstd.data_ptr(),
+                  w=w.data_ptr(), dh=dh.data_ptr(), rows=rows, rows_per_sample=1,
                   drop_thresh=drop[0], drop_scale=drop[1], seed_lo=drop[2], seed_hi=drop[3])
+    if z.dtype == F32:
+        assert dy2 is None or dy2.dtype == F32
+        dres = torch.empty((rows, D), dtype=F32, device=z.device)
+        a.x32, a.dy32, a.dres32 = z.data_ptr(), _ptr(dy2), dres.data_ptr()
+    else:
+        dres = dh if drop[0] == 0 else torch.empty_like(z)
+        a.x16, a.dy2, a.dres = z.data_ptr(), _ptr(dy2), dres.data_ptr()
     _ln_bwd_call(a, D, LN_POST, dgamma, dbeta, dbias, None, z.device, defer)
     return dh, dres
 
@@ -558,8 +577,9 @@ def _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop, pos_mode=0):
                      seed_lo=drop[2], seed_hi=drop[3])
 
 
-def embed_ln_fwd(ids, word, pos, typ, w, b, eps, pad_id, drop=(0, 1.0, 0, 0), pos_mode=0, row_map=None, out_rows=None):
-    """row_map (int32 [B*T], -1 = skip) + out_rows: write the tokens to packed rows of a [out_rows, D] output."""
+def embed_ln_fwd(ids, word, pos, typ, w, b, eps, pad_id, drop=(0, 1.0, 0, 0), pos_mode=0, row_map=None, out_rows=None, y32=False):
+    """row_map (int32 [B*T], -1 = skip) + out_rows: write the tokens to packed rows of a [out_rows, D] output.
+    y32: also return the fp32 twin of y (the un-rounded values, for the encoder's fp32 residual stream)."""
     _dev(ids)
     assert ids.dtype == torch.int64 and ids.is_contiguous()
     B, T = ids.shape
@@ -567,25 +587,28 @@ def embed_ln_fwd(ids, word, pos, typ, w, b, eps, pad_id, drop=(0, 1.0, 0, 0), po
     if row_map is not None:
         assert row_map.dtype == torch.int32 and row_map.numel() == B * T and row_map.is_contiguous()
         y = torch.zeros((out_rows, D), dtype=BF16, device=ids.device)
+        yf = torch.zeros((out_rows, D), dtype=F32, device=ids.device) if y32 else None
     else:
         y = torch.empty((B * T, D), dtype=BF16, device=ids.device)
+        yf = torch.empty((B * T, D), dtype=F32, device=ids.device) if y32 else None
     mean = torch.empty(B * T, dtype=F32, device=ids.device)
     rstd = torch.empty(B * T, dtype=F32, device=ids.device)
     pos_ids = torch.empty(B * T, dtype=torch.int32, device=ids.device)
     a = _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop, pos_mode)
     a.row_map = _ptr(row_map)
-    a.y, a.mean, a.rstd, a.pos_ids = y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), pos_ids.data_ptr()
+    a.y, a.mean, a.rstd, a.pos_ids, a.y32 = y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), pos_ids.data_ptr(), _ptr(yf)
     check(_lib.load().xfm_embed_ln_fwd(ctypes.byref(a), D, _stream()), "embed_ln_fwd")
-    return y, mean, rstd, pos_ids
+    return (y, mean, rstd, pos_ids, yf) if y32 else (y, mean, rstd, pos_ids)
 
 
 def embed_ln_bwd(dy, ids, word, pos, typ, w, b, eps, pad_id, mean, rstd, pos_ids, dword, dpos, dtype_, dgamma, dbeta,
-                 drop=(0, 1.0, 0, 0), pos_mode=0, row_map=None):
+                 drop=(0, 1.0, 0, 0), pos_mode=0, row_map=None, dy32=None):
+    """dy32: optional fp32 gradient (same rows) added to dy."""
     D = word.shape[1]
     a = _embed_args(ids, word, pos, typ, w, b, eps, pad_id, drop, pos_mode)
     a.row_map = _ptr(row_map)
     a.mean, a.rstd, a.pos_ids = mean.data_ptr(), rstd.data_ptr(), pos_ids.data_ptr()
-    a.dy, a.dword, a.dpos = dy.data_ptr(), dword.data_ptr(), dpos.data_ptr()
+    a.dy, a.dword, a.dpos, a.dy32 = dy.data_ptr(), dword.data_ptr(), dpos.data_ptr(), _ptr(dy32)
     lib = _lib.load()
     ws = workspace(lib.xfm_embed_ln_bwd_workspace(a.B * a.T, D), dy.device)
     check(lib.xfm_embed_ln_bwd(ctypes.byref(a), D, _ptr(dgamma), _ptr(dbeta), _ptr(dtype_), ws.data_ptr(), ws.numel() * 4,
@@ -593,8 +616,11 @@ def embed_ln_bwd(dy, ids, word, pos, typ, w, b, eps, pad_id, mean, rstd, pos_ids
 
 
 def rows_gather(src, index, out=None):
-    """out[r, :] = src[index[r], :] (zero row where index[r] < 0); src bf16 [*, D] contiguous, index int32 [R]."""
+    """out[r, :] = src[index[r], :] (zero row where index[r] < 0); src bf16 (or fp32) [*, D] contiguous, index int32 [R]."""
     _dev(src)
+    if src.dtype == F32:   # an fp32 row of D values is a bf16 row of 2 D elements to a row copy
+        assert out is None or out.dtype == F32
+        return rows_gather(src.view(BF16), index, None if out is None else out.view(BF16)).view(F32)
     assert src.dtype == BF16 and src.dim() == 2 and src.is_contiguous() and index.dtype == torch.int32 and index.is_contiguous()
     R, D = index.numel(), src.shape[1]
     if out is None:

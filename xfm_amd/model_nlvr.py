@@ -5,6 +5,7 @@ import torch.nn.functional as F
 
 from .ops import small_ce
 from .xfm import XFMBase, build_mlp
+from .xroberta import rowwise
 
 
 class XFMForNLVR(XFMBase):
@@ -25,7 +26,7 @@ class XFMForNLVR(XFMBase):
         statement = self.get_text_embeds(text_ids, text_atts)
         n = targets.size(0)
         assert image_embeds.size(0) == 2 * n, "two images per statement"
-        fused_cls = self.get_cross_embeds(image_embeds, image_atts, text_embeds=statement.repeat(2, 1, 1), text_atts=text_atts.repeat(2, 1),
+        fused_cls = self.get_cross_embeds(image_embeds, image_atts, text_embeds=rowwise(lambda t: t.repeat(2, 1, 1), statement), text_atts=text_atts.repeat(2, 1),
                                           is_pretrain=False)[:, 0, :]
         pair = torch.cat((fused_cls[:n], fused_cls[n:]), dim=-1)   # [B, 2 * width]: (first image | second image)
         assert pair.shape[-1] == self.text_width * 2

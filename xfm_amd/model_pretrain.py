@@ -49,6 +49,20 @@ class _JoinAfterBackward(torch.autograd.Function):
         return g, None, None
 
 
+def _rejoin(t, main, side):
+    """A tower output computed on `side`, consumed on `main` from here on (main already waits for side): the allocator learns about
+    the second stream, the backward re-joins at its end.  The fp32 twin (xroberta.twin_of) follows."""
+    from .xroberta import rowwise, twin_of
+    if t is None:
+        return None
+    t.record_stream(main)
+    if twin_of(t) is not None:
+        twin_of(t).record_stream(main)
+    if t.requires_grad:
+        t = rowwise(lambda u: _JoinAfterBackward.apply(u, main, side), t)
+    return t
+
+
 def towers_side_by_side(model, image, text_ids, text_atts):
     """(image_embeds, image_atts, text_embeds) of a fine-tuning model with the text tower on a second HIP stream, as the pre-training
     step does it: queued first, it runs under the ViT's chip-filling kernels, and autograd replays its backward on the same stream --
@@ -64,10 +78,7 @@ def towers_side_by_side(model, image, text_ids, text_atts):
         text_embeds = model.get_text_embeds(text_ids, text_atts)
     image_embeds, image_atts = model.get_vision_embeds(image)
     main.wait_stream(side)
-    text_embeds.record_stream(main)
-    if text_embeds.requires_grad:
-        text_embeds = _JoinAfterBackward.apply(text_embeds, main, side)
-    return image_embeds, image_atts, text_embeds
+    return image_embeds, image_atts, _rejoin(text_embeds, main, side)
 
 
 class XFM(XFMBase):
@@ -149,11 +160,7 @@ class XFM(XFMBase):
         if data_source != 'imagenet':
             if text_stream is not None:  # re-join: the text features are consumed on the main stream from here on
                 main.wait_stream(text_stream)
-                for t in (text_embeds, mlm_embeds):
-                    if t is not None:
-                        t.record_stream(main)
-                if text_embeds.requires_grad:
-                    text_embeds = _JoinAfterBackward.apply(text_embeds, main, text_stream)
+                text_embeds, mlm_embeds = _rejoin(text_embeds, main, text_stream), _rejoin(mlm_embeds, main, text_stream)
             elif self.batch_passes and both_passes:
                 text_embeds, mlm_embeds = self.get_text_embeds_with_masked(text_ids, text_atts, text_ids_masked, pack=pack)
             else:

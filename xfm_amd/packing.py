@@ -183,10 +183,16 @@ class _RowsGatherFn(torch.autograd.Function):
         rows = rows.contiguous()
         ctx.n, ctx.dtype = rows.shape[0], rows.dtype
         ctx.index = index
+        if rows.dtype == F32:   # (the fp32 twin of a tower output: gathered as it is)
+            return Fx.rows_gather(rows, index)
         return Fx.rows_gather(rows if rows.dtype == BF16 else rows.to(BF16), index)
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.dtype == F32:
+            keep = ctx.index >= 0
+            acc = torch.zeros((ctx.n, dy.shape[1]), dtype=F32, device=dy.device)
+            return acc.index_add_(0, ctx.index.clamp_min(0).long(), dy.float() * keep[:, None]), None
         dy = (dy if dy.dtype == BF16 else dy.to(BF16)).contiguous()
         acc = torch.zeros((ctx.n, dy.shape[1]), dtype=F32, device=dy.device)
         Fx.rows_scatter_add(dy, ctx.index, acc)

@@ -25,7 +25,7 @@ from . import marks as _marks
 from .arena import LinearSlot, ParamArena
 from .beit2 import _Affine, beit_base_patch16
 from .ops import itc_loss, layer_norm, linear_slot, row_normalize, small_ce
-from .xroberta import RobertaConfig, RobertaForMaskedLM, _Lin
+from .xroberta import RobertaConfig, RobertaForMaskedLM, _Lin, rowwise
 
 BF16 = torch.bfloat16
 # packed fusion rows: exact layout of the hard-negative text block through ONE host read-back per step (default; measured 42.8 ->
@@ -368,7 +368,7 @@ class XFMBase(nn.Module):
         both = self.text_encoder.bert(torch.cat([text_ids, text_ids_masked], dim=0), attention_mask=torch.cat([text_atts, text_atts], dim=0),
                                       encoder_hidden_states=None, encoder_attention_mask=None, return_dict=True,
                                       grad_batch=bs).last_hidden_state
-        return both[:bs], both[bs:].detach()
+        return rowwise(lambda t: t[:bs], both), rowwise(lambda t: t[bs:].detach(), both)
 
     def get_features(self, image_embeds=None, text_embeds=None):
         out = []
@@ -390,7 +390,7 @@ class XFMBase(nn.Module):
         if text_embeds is None:
             return enc(text_ids, attention_mask=text_atts, encoder_hidden_states=image_embeds,
                        encoder_attention_mask=image_atts, return_dict=True, **kw).last_hidden_state
-        encoder_embeds = text_embeds.detach() if is_pretrain else text_embeds
+        encoder_embeds = rowwise(lambda t: t.detach(), text_embeds) if is_pretrain else text_embeds
         return enc(encoder_embeds=encoder_embeds, attention_mask=text_atts, encoder_hidden_states=image_embeds,
                    encoder_attention_mask=image_atts, return_dict=True, **kw).last_hidden_state
 
@@ -464,7 +464,7 @@ class XFMBase(nn.Module):
             text_neg_idx = torch.as_tensor(neg_idx[1], dtype=torch.long, device=image_embeds.device)
         bs = image_feat.size(0)
         # rows [0,B): positives ; [B,2B): (negative image, text) ; [2B,3B): (image, negative text)   xfm.py:781-793
-        text_all = torch.cat([text_embeds, text_embeds, text_embeds.index_select(0, text_neg_idx)], dim=0)
+        text_all = rowwise(lambda t: torch.cat([t, t, t.index_select(0, text_neg_idx)], dim=0), text_embeds)
         text_atts_all = torch.cat([text_atts, text_atts, text_atts.index_select(0, text_neg_idx)], dim=0)
         from .functional import attn_grouped_ok
         if _DEDUP_IMAGES and image_embeds.is_cuda and attn_grouped_ok(text_all.shape[1], image_embeds.shape[1]):
@@ -534,11 +534,12 @@ class XFMBase(nn.Module):
                 fpack, meta, ranges, gidx, start_of = image_major_fusion_layout(seq_len, seq_img, bs, pack.T, dev, src_start, seq_txt,
                                                                                 extra=(seq_txt, seq_img, sel_off, sel_len))
                 enc_index = meta[2]
-                text_all = rows_gather(text_rows.detach(), gidx)
+                text_all = rowwise(lambda t: rows_gather(t.detach(), gidx), text_rows)
             else:
                 fpack, _, _, meta, ranges = image_major_layout(seq_len, seq_img, bs, pack.T, dev, extra=(seq_txt, seq_img, sel_off, sel_len))
                 pos_dev, seq_src, enc_index = meta[0].long(), meta[1].long(), meta[2].contiguous()
-                text_all = rows_gather(text_rows.detach(), fpack.gather_index(pack, seq_src))
+                gidx = fpack.gather_index(pack, seq_src)
+                text_all = rowwise(lambda t: rows_gather(t.detach(), gidx), text_rows)
                 start_of = fpack.start.index_select(0, pos_dev)                     # start row of every sequence, reference order
             out_rows = None
             if prune:
@@ -560,7 +561,8 @@ class XFMBase(nn.Module):
             fpack = Pack.concat([(lens, n_rows, lh), (lens, n_rows, lh), (lens.index_select(0, text_neg_idx), bs * t_max, None),
                                  (lens, n_rows, lh)], pack.T)
             seq_src = torch.cat([ar, ar, text_neg_idx, ar + bs])             # sequence of the text tower's pack each fusion row copies
-            text_all = rows_gather(text_rows.detach(), fpack.gather_index(pack, seq_src))   # is_pretrain: the text states are detached
+            gidx = fpack.gather_index(pack, seq_src)
+            text_all = rowwise(lambda t: rows_gather(t.detach(), gidx), text_rows)   # is_pretrain: the text states are detached
             enc_index = torch.cat([ar, image_neg_idx, ar, ar]).to(torch.int32)
             seq = self.fusion_encoder.bert(encoder_embeds=text_all, attention_mask=None, encoder_hidden_states=image_embeds,
                                            encoder_attention_mask=image_atts, return_dict=True, encoder_batch_index=enc_index,
@@ -595,12 +597,12 @@ class XFMBase(nn.Module):
                 mlm_embeds = self.get_text_embeds(text_ids_masked, text_atts)
             if self.detach_text_forMLM:
                 mlm_embeds = mlm_embeds.detach()
-        itm_text = text_embeds.detach() if is_pretrain else text_embeds
+        itm_text = rowwise(lambda t: t.detach(), text_embeds) if is_pretrain else text_embeds
         # every fusion row attends to one of the B unique images: project K/V once per image and layer and let the
         # attention kernels gather them by index (the reference re-projects the duplicated image rows 4x, xfm.py:781-793)
         ar = torch.arange(bs, device=image_embeds.device)
         enc_index = torch.cat([ar, image_neg_idx, ar, ar]).to(torch.int32)
-        text_all = torch.cat([itm_text, itm_text, itm_text.index_select(0, text_neg_idx), mlm_embeds], dim=0)
+        text_all = rowwise(lambda a, b: torch.cat([a, a, a.index_select(0, text_neg_idx), b], dim=0), itm_text, mlm_embeds)
         text_atts_all = torch.cat([text_atts, text_atts, text_atts.index_select(0, text_neg_idx), text_atts], dim=0)
         self._ready()
         seq = self.fusion_encoder.bert(encoder_embeds=text_all, attention_mask=text_atts_all, encoder_hidden_states=image_embeds,

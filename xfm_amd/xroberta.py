@@ -78,33 +78,80 @@ class RobertaEmbeddings(nn.Module):
         self.p_drop = config.hidden_dropout_prob
 
 
+_F32_STREAM = os.environ.get("XFM_F32_STREAM", "1") != "0"
+"""The residual stream of the text / fusion towers in fp32 (A/B knob; 0 = the bf16 stream of rounds 1-4).  The reference trains in mixed
+precision: its Linears produce 16-bit outputs, but LayerNorm and the residual add run in fp32 (apex O1 / autocast lists), so every
+post-LN sum `LayerNorm(dropout(h) + x)` (xroberta.py:300-304, 381-385) sees the UN-ROUNDED output of the previous LayerNorm and the
+gradient of the residual branch travels in fp32 too.  With the stream on, every tower hand-over is a (bf16, fp32) pair: the bf16 tensor
+feeds the GEMMs, its fp32 twin the next residual add; the two are separate autograd edges (bf16 gradient from the GEMM side, fp32 from
+the LayerNorm side)."""
+
+
+def twin_of(t):
+    """The fp32 twin of a tower output (None when there is none)."""
+    return getattr(t, "_xfm_f32", None) if _F32_STREAM else None
+
+
+def with_twin(t, t32):
+    """Attach the fp32 twin to a tower output / to a row-wise image of one (cat / index_select / gather of both)."""
+    if t32 is not None and _F32_STREAM:
+        t._xfm_f32 = t32
+    return t
+
+
+def rowwise(fn, *tensors):
+    """fn applied to tower outputs AND, when every one of them has one, to their fp32 twins: for the row-wise glue between towers
+    (torch.cat / index_select / detach / row gathers), so the twin follows the rows into the next tower."""
+    out = fn(*tensors)
+    twins = [twin_of(t) for t in tensors]
+    if all(tw is not None for tw in twins):
+        with_twin(out, fn(*twins))
+    return out
+
+
 class _EmbedFn(torch.autograd.Function):
+    """-> (y bf16, y fp32 twin or None).  The twin exists when the fp32 stream is on; its gradient (fp32) is added to y's."""
+
     @staticmethod
     def forward(ctx, anchor, emb, input_ids, drop, owner, pack=None):
         ids = input_ids.contiguous()
         ctx.owner = owner if ctx.needs_input_grad[0] else None
         if ctx.owner is not None:
             arena_note_use(owner)
+        ctx.set_materialize_grads(False)
         ln = emb.LayerNorm
         row_map = None if pack is None else pack.row_map()  # packed (unpadded) output rows, xfm_amd.packing
-        y, mean, rstd, pos_ids = Fx.embed_ln_fwd(ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
-                                                 emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps,
-                                                 emb.padding_idx, drop, getattr(emb, "pos_mode", 0), row_map=row_map,
-                                                 out_rows=None if pack is None else pack.cap)
+        out = Fx.embed_ln_fwd(ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
+                              emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps,
+                              emb.padding_idx, drop, getattr(emb, "pos_mode", 0), row_map=row_map,
+                              out_rows=None if pack is None else pack.cap, y32=_F32_STREAM)
+        y, mean, rstd, pos_ids = out[:4]
+        y32 = out[4] if _F32_STREAM else None
         ctx.emb, ctx.saved, ctx.drop, ctx.row_map = emb, (ids, mean, rstd, pos_ids), drop, row_map
-        return y if pack is not None else y.view(ids.shape[0], ids.shape[1], -1)
+        if pack is None:
+            y = y.view(ids.shape[0], ids.shape[1], -1)
+            y32 = None if y32 is None else y32.view(ids.shape[0], ids.shape[1], -1)
+        return y, y32
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy32=None):
         emb = ctx.emb
         ids, mean, rstd, pos_ids = ctx.saved
         ln = emb.LayerNorm
+        if dy is None and dy32 is None:
+            return None, None, None, None, None, None
+        if dy is None:
+            dy = torch.zeros(dy32.shape, dtype=BF16, device=dy32.device)
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        if dy2.dtype != BF16:
+            dy2 = dy2.to(BF16)
+        if dy32 is not None:
+            dy32 = dy32.reshape(-1, dy32.shape[-1]).contiguous()
         Fx.embed_ln_bwd(dy2, ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
                         emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps, emb.padding_idx, mean, rstd, pos_ids,
                         grad_view(emb.word_embeddings.weight), grad_view(emb.position_embeddings.weight),
                         grad_view(emb.token_type_embeddings.weight).view(-1), grad_view(ln.weight), grad_view(ln.bias), ctx.drop,
-                        getattr(emb, "pos_mode", 0), row_map=ctx.row_map)
+                        getattr(emb, "pos_mode", 0), row_map=ctx.row_map, dy32=dy32)
         if ctx.owner is not None:
             arena_note_grad(ctx.owner)
         return None, None, None, None, None, None
@@ -340,19 +387,58 @@ class _WgradStream:
             _marks.mark(self.label + " end")
 
 
+def _grad_pair(dy, dy32, f32):
+    """The two gradient edges of a tower output (bf16 tensor, fp32 twin) as the (dy_a bf16, dy_b) pair the layer loop starts from:
+    dy_b is the fp32 part with the fp32 stream on (None when nobody read the twin), None otherwise."""
+    if dy is None and dy32 is None:
+        raise RuntimeError("encoder backward without a gradient")
+    if dy is None:
+        dy = torch.zeros(dy32.shape, dtype=BF16, device=dy32.device)
+    dy_a = dy.contiguous()
+    if dy_a.dtype != BF16:
+        dy_a = dy_a.to(BF16)
+    if dy32 is None:
+        return dy_a, None
+    if f32:
+        return dy_a, dy32.contiguous()
+    return (dy_a.float() + dy32).to(BF16), None
+
+
+def _input_grads(dy_a, dy_b, need_dx, twin_in, rows_full):
+    """Gradient w.r.t. the tower input from the last layer's (dprev bf16, residual-branch gradient): with an fp32 twin on the input the
+    two leave on their own edges, un-rounded; otherwise they are summed and rounded once to the input's bf16."""
+    if not need_dx:
+        return None, None
+    if twin_in and dy_b is not None and dy_b.dtype == F32:
+        dx, dx32 = dy_a, dy_b
+    else:
+        dx, dx32 = (dy_a.float() + dy_b.float()).to(BF16), None
+    pad = rows_full - dx.shape[0]
+    if pad > 0:   # (a backward over the first sequences of the batch: the other rows took no gradient)
+        dx = torch.cat([dx, torch.zeros((pad, dx.shape[1]), dtype=dx.dtype, device=dx.device)], dim=0)
+        if dx32 is not None:
+            dx32 = torch.cat([dx32, torch.zeros((pad, dx32.shape[1]), dtype=F32, device=dx32.device)], dim=0)
+    return dx, dx32
+
+
 class _EncoderFn(torch.autograd.Function):
-    """Layers [lo, hi) of a RobertaEncoder.  x: bf16 [B*T, D]; enc: bf16 [B*N, D] or None."""
+    """Layers [lo, hi) of a RobertaEncoder.  x: bf16 [B*T, D]; x32: its fp32 twin or None; enc: bf16 [B*N, D] or None.
+    -> (y bf16, y fp32 twin or None): see _F32_STREAM."""
 
     @staticmethod
-    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index, grad_batch=None, pack=None, xq=None):
+    def forward(ctx, x, x32, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index, grad_batch=None, pack=None, xq=None):
         cfg = model.config
+        f32 = _F32_STREAM
+        ctx.set_materialize_grads(False)
         D, H = cfg.hidden_size, cfg.num_attention_heads
         scale = 1.0 / math.sqrt(D // H)
         p_att = cfg.attention_probs_dropout_prob if training else 0.0
         p_hid = cfg.hidden_dropout_prob if training else 0.0
-        need_dx, need_denc = x.requires_grad, (enc is not None and enc.requires_grad)
+        need_dx, need_denc = x.requires_grad or (x32 is not None and x32.requires_grad), (enc is not None and enc.requires_grad)
         saved = []
         x = x.contiguous()
+        xres = x32.contiguous() if (f32 and x32 is not None) else x   # what the first residual add reads
+        ctx.twin_in = f32 and x32 is not None
         qp = None if pack is None else pack.pair  # packed token rows: x is [pack.cap, D], sequences at (start, len)
         zf = pack is not None and not pack.exact  # slack rows exist: attention outputs must be zero there
         if pack is not None and (key_keep is not None or causal):
@@ -382,7 +468,8 @@ class _EncoderFn(torch.autograd.Function):
                                           causal=causal, drop=d_att, q_pack=qp, k_pack=qp, zero_fill=zf)
             h1 = Fx.gemm_nt(c1, s["o"].wb, s["o"].b)
             ln1 = att.output.LayerNorm
-            y1, z1, m1, r1 = Fx.ln_post_fwd(h1, x, ln1.weight, ln1.bias, ln1.eps, d_h1)
+            y1, z1, m1, r1, *tw = Fx.ln_post_fwd(h1, xres, ln1.weight, ln1.bias, ln1.eps, d_h1, f32=f32)
+            yres = tw[0] if f32 else y1
             rec = {"x": x, "qkv": qkv, "c1": c1, "lse1": lse1, "z1": z1, "m1": m1, "r1": r1, "y1": y1, "d_att": d_att, "d_h1": d_h1}
             y2 = y1
             if layer.has_cross_attention and enc is not None:
@@ -404,16 +491,18 @@ class _EncoderFn(torch.autograd.Function):
                     c2lo = None
                 h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
                 ln2 = co.output.LayerNorm
-                y2, z2, m2, r2 = Fx.ln_post_fwd(h2, y1, ln2.weight, ln2.bias, ln2.eps, d_h2)
+                y2, z2, m2, r2, *tw = Fx.ln_post_fwd(h2, yres, ln2.weight, ln2.bias, ln2.eps, d_h2, f32=f32)
+                yres = tw[0] if f32 else y2
                 rec.update(q2=q2, kv=kv, c2=c2, c2lo=c2lo, lse2=lse2, z2=z2, m2=m2, r2=r2, y2=y2, d_att2=d_att2, d_h2=d_h2)
             d_h3 = Fx.drop_params(p_hid, _next_seed())
             hact, u = Fx.gemm_nt(y2, s["i"].wb, s["i"].b, epi=Fx.EPI_GELU)
             h3 = Fx.gemm_nt(hact, s["out"].wb, s["out"].b)
             ln3 = layer.output.LayerNorm
-            y3, z3, m3, r3 = Fx.ln_post_fwd(h3, y2, ln3.weight, ln3.bias, ln3.eps, d_h3)
+            y3, z3, m3, r3, *tw = Fx.ln_post_fwd(h3, yres, ln3.weight, ln3.bias, ln3.eps, d_h3, f32=f32)
             rec.update(hact=hact, u=u, z3=z3, m3=m3, r3=r3, d_h3=d_h3, cross=co is not None)
             saved.append(rec)
             x = y3
+            xres = tw[0] if f32 else y3
         ctx.saved, ctx.model, ctx.enc = saved, model, enc
         if grad_batch is not None and (enc is not None or not 0 < grad_batch <= B):
             raise ValueError("grad_batch is for self-attention-only passes: 0 < grad_batch <= batch")
@@ -422,16 +511,18 @@ class _EncoderFn(torch.autograd.Function):
         ctx.noted = need_dx or need_denc
         if ctx.noted:
             arena_note_use(model)
-        return x
+        return x, (xres if f32 else None)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy32=None):
         model, enc = ctx.model, ctx.enc
         lo, hi, causal, B, T, Nenc, key_keep, enc_keep, need_dx, need_denc, scale, enc_index, groups, grad_batch = ctx.meta
         cfg = model.config
         D, H = cfg.hidden_size, cfg.num_attention_heads
         g = grad_view
-        dy_a, dy_b = dy.contiguous(), None
+        f32 = _F32_STREAM
+        dy_a, dy_b = _grad_pair(dy, dy32, f32)
+        dy = dy_a
         wg = _WgradStream(dy.device, "fusion bwd" if enc is not None else "text bwd")
         B_full = B
         pack = ctx.pack
@@ -444,6 +535,7 @@ class _EncoderFn(torch.autograd.Function):
             if pack is not None:
                 pack = pack.head(B)
             dy_a = dy_a[:G]
+            dy_b = None if dy_b is None else dy_b[:G]
             key_keep = None if key_keep is None else key_keep[:B]
             for rec in ctx.saved:
                 for k, v in list(rec.items()):
@@ -526,9 +618,7 @@ class _EncoderFn(torch.autograd.Function):
             if li > lo or need_dx:
                 dy_a, dy_b = Fx.gemm_nt(dqkv, s["qkv"].wt, n=s["qkv"].K), dres1
             ctx.saved[li - lo] = None
-        dx = (dy_a.float() + dy_b.float()).to(BF16) if need_dx else None
-        if dx is not None and B < B_full:
-            dx = torch.cat([dx, torch.zeros((rows_full - dx.shape[0], dx.shape[1]), dtype=dx.dtype, device=dx.device)], dim=0)
+        dx, dx32 = _input_grads(dy_a, dy_b, need_dx, ctx.twin_in, rows_full)
         denc = None
         if concat_k:
             wt_cat = torch.cat([model.encoder.layer[li]._s["kv2"].wt[:, :2 * D] for li in cross_layers], dim=1)  # [D_enc, layers*2D]
@@ -540,7 +630,7 @@ class _EncoderFn(torch.autograd.Function):
         wg.join()  # the weight gradients are complete in main-stream order before the tower's all-reduce / the optimizer
         if ctx.noted:
             arena_note_grad(model)
-        return (dx, denc) + (None,) * 14
+        return (dx, dx32, denc) + (None,) * 14
 
 
 
@@ -556,8 +646,11 @@ class _LastLayerRowsFn(torch.autograd.Function):
     Output: [S, D].  Backward: the selected rows' gradients are scatter-added into the full-row gradient, next to dK/dV . W_kv."""
 
     @staticmethod
-    def forward(ctx, x, enc, model, li, B, T, Nenc, training, enc_index, pack, rows, sel, Tq):
+    def forward(ctx, x, x32, enc, model, li, B, T, Nenc, training, enc_index, pack, rows, sel, Tq):
         cfg = model.config
+        f32 = _F32_STREAM
+        ctx.set_materialize_grads(False)
+        ctx.twin_in = f32 and x32 is not None
         D, H = cfg.hidden_size, cfg.num_attention_heads
         scale = 1.0 / math.sqrt(D // H)
         p_att = cfg.attention_probs_dropout_prob if training else 0.0
@@ -574,11 +667,13 @@ class _LastLayerRowsFn(torch.autograd.Function):
         wqkv, bqkv = s["qkv"].wb, s["qkv"].b
         kvs = Fx.gemm_nt(x, wqkv[D:3 * D], bqkv[D:3 * D])                      # K | V of every row
         xs = Fx.rows_gather(x, rows)
+        xres = Fx.rows_gather(x32.contiguous(), rows) if ctx.twin_in else xs   # the selected rows' residual, un-rounded when the twin exists
         qs = Fx.gemm_nt(xs, wqkv[:D], bqkv[:D])                                # Q of the selected rows
         c1, lse1 = Fx.attn_fwd(qs, kvs[:, :D], kvs[:, D:], B, H, Tq, T, scale, drop=d_att, q_pack=sel, k_pack=kp, zero_fill=False)
         h1 = Fx.gemm_nt(c1, s["o"].wb, s["o"].b)
         ln1 = layer.attention.output.LayerNorm
-        y1, z1, m1, r1 = Fx.ln_post_fwd(h1, xs, ln1.weight, ln1.bias, ln1.eps, d_h1)
+        y1, z1, m1, r1, *tw = Fx.ln_post_fwd(h1, xres, ln1.weight, ln1.bias, ln1.eps, d_h1, f32=f32)
+        yres = tw[0] if f32 else y1
         rec = dict(x=x, xs=xs, kvs=kvs, qs=qs, c1=c1, lse1=lse1, z1=z1, m1=m1, r1=r1, y1=y1, d_att=d_att, d_h1=d_h1, cross=cross)
         y2 = y1
         if cross:
@@ -589,34 +684,36 @@ class _LastLayerRowsFn(torch.autograd.Function):
                                          lo=True)
             h2 = Fx.gemm_nt(c2, s["o2"].wb, s["o2"].b)
             ln2 = layer.crossattention.output.LayerNorm
-            y2, z2, m2, r2 = Fx.ln_post_fwd(h2, y1, ln2.weight, ln2.bias, ln2.eps, d_h2)
+            y2, z2, m2, r2, *tw = Fx.ln_post_fwd(h2, yres, ln2.weight, ln2.bias, ln2.eps, d_h2, f32=f32)
+            yres = tw[0] if f32 else y2
             rec.update(q2=q2, kv=kv, c2=c2, c2lo=c2lo, lse2=lse2, z2=z2, m2=m2, r2=r2, y2=y2, d_att2=d_att2, d_h2=d_h2)
         d_h3 = Fx.drop_params(p_hid, _next_seed())
         hact, u = Fx.gemm_nt(y2, s["i"].wb, s["i"].b, epi=Fx.EPI_GELU)
         h3 = Fx.gemm_nt(hact, s["out"].wb, s["out"].b)
         ln3 = layer.output.LayerNorm
-        y3, z3, m3, r3 = Fx.ln_post_fwd(h3, y2, ln3.weight, ln3.bias, ln3.eps, d_h3)
+        y3, z3, m3, r3, *tw = Fx.ln_post_fwd(h3, yres, ln3.weight, ln3.bias, ln3.eps, d_h3, f32=f32)
         rec.update(hact=hact, u=u, z3=z3, m3=m3, r3=r3, d_h3=d_h3)
         ctx.rec, ctx.model, ctx.enc, ctx.layer = rec, model, enc, layer
-        ctx.meta = (B, T, Nenc, scale, groups, kp, rows, sel, Tq, x.requires_grad, enc is not None and enc.requires_grad)
-        ctx.noted = x.requires_grad or (enc is not None and enc.requires_grad)
+        need_dx = x.requires_grad or (x32 is not None and x32.requires_grad)
+        ctx.meta = (B, T, Nenc, scale, groups, kp, rows, sel, Tq, need_dx, enc is not None and enc.requires_grad)
+        ctx.noted = need_dx or (enc is not None and enc.requires_grad)
         if ctx.noted:
             arena_note_use(model)
-        return y3
+        return y3, (tw[0] if f32 else None)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy32=None):
         model, enc, layer, r = ctx.model, ctx.enc, ctx.layer, ctx.rec
         B, T, Nenc, scale, groups, kp, rows, sel, Tq, need_dx, need_denc = ctx.meta
         cfg = model.config
         D, H = cfg.hidden_size, cfg.num_attention_heads
         g, s = grad_view, layer._s
-        dy_a = dy.contiguous()
-        if dy_a.dtype != BF16:
-            dy_a = dy_a.to(BF16)
+        dy_a, dy_b = _grad_pair(dy, dy32, _F32_STREAM)
+        dy = dy_a
         wg = _WgradStream(dy.device, "fusion bwd" if enc is not None else "text bwd")
         ln3 = layer.output.LayerNorm
-        dh3, dres3 = Fx.ln_post_bwd(dy_a, r["z3"], r["m3"], r["r3"], ln3.weight, g(ln3.weight), g(ln3.bias), s["out"].db, drop=r["d_h3"])
+        dh3, dres3 = Fx.ln_post_bwd(dy_a, r["z3"], r["m3"], r["r3"], ln3.weight, g(ln3.weight), g(ln3.bias), s["out"].db, dy2=dy_b,
+                                    drop=r["d_h3"])
         wg.gemm_tn(dh3, r["hact"], s["out"].dw)
         du = Fx.gemm_nt(dh3, s["out"].wt, epi=Fx.EPI_DGELU, aux=r["u"], n=s["out"].K)
         y2 = r["y2"] if r["cross"] else r["y1"]
@@ -653,18 +750,24 @@ class _LastLayerRowsFn(torch.autograd.Function):
         dw, db = s["qkv"].dw, s["qkv"].db
         wg.gemm_tn(dqs, r["xs"], dw[:D], dbias=db[:D])
         wg.gemm_tn(dkvs, r["x"], dw[D:3 * D], dbias=db[D:3 * D])
-        dx = None
+        dx, dxt = None, None
         if need_dx:
             wt = s["qkv"].wt
             dx32 = Fx.gemm_nt(dkvs, wt[:, D:3 * D], epi=Fx.EPI_F32, n=s["qkv"].K)           # through K / V: every row
             Fx.rows_scatter_add(Fx.gemm_nt(dqs, wt[:, :D], n=s["qkv"].K), rows, dx32)     # through Q and the residual: selected rows
-            Fx.rows_scatter_add(dres1, rows, dx32)
+            if dres1.dtype == F32:   # fp32 stream: the residual-branch gradient of the selected rows stays fp32 ...
+                if ctx.twin_in:      # ... and leaves on the twin's edge
+                    dxt = torch.zeros_like(dx32).index_add_(0, rows.long(), dres1)
+                else:
+                    dx32.index_add_(0, rows.long(), dres1)
+            else:
+                Fx.rows_scatter_add(dres1, rows, dx32)
             dx = dx32.to(BF16)
         wg.join()
         if ctx.noted:
             arena_note_grad(model)
         ctx.rec = None
-        return (dx, denc) + (None,) * 11
+        return (dx, dxt, denc) + (None,) * 11
 
 
 _NATIVE_LAYERS = os.environ.get("XFM_NATIVE_LAYERS", "1") != "0"  # A/B knob: one C-ABI call per RobertaLayer (csrc/encoder.hip)
@@ -742,16 +845,20 @@ class _EncoderFnNative(torch.autograd.Function):
     being bound by the Python interpreter.  Cross-attention goes through the grouped kernels (encoder_batch_index required)."""
 
     @staticmethod
-    def forward(ctx, x, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index, grad_batch=None, pack=None, xq=None):
+    def forward(ctx, x, x32, enc, model, key_keep, enc_keep, lo, hi, causal, B, T, Nenc, training, enc_index, grad_batch=None, pack=None, xq=None):
         from . import _lib
         from ._lib import RLayerIO, RLayerLayout, check
         import ctypes
         lib = _lib.load()
         cfg = model.config
+        f32 = _F32_STREAM
+        ctx.set_materialize_grads(False)
+        ctx.twin_in = f32 and x32 is not None
+        xt = x32.contiguous() if ctx.twin_in else None
         D, H, FF = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size
         p_att = cfg.attention_probs_dropout_prob if training else 0.0
         p_hid = cfg.hidden_dropout_prob if training else 0.0
-        need_dx, need_denc = x.requires_grad, (enc is not None and enc.requires_grad)
+        need_dx, need_denc = x.requires_grad or (x32 is not None and x32.requires_grad), (enc is not None and enc.requires_grad)
         x = x.contiguous()
         R = x.shape[0]
         if pack is not None and (key_keep is not None or causal):
@@ -784,13 +891,14 @@ class _EncoderFnNative(torch.autograd.Function):
         io.causal, io.scale = int(causal), 1.0 / math.sqrt(D // H)
         io.att_thresh, io.att_scale, io.hid_thresh, io.hid_scale = d_att[0], d_att[1], d_hid[0], d_hid[1]
         io.seed_hi = torch.initial_seed() & 0xFFFFFFFF
+        io.f32_stream = int(f32)
         layouts = {}
 
         def layout(cross):
             if cross not in layouts:
                 L = RLayerLayout()
-                check(lib.xfm_rlayer_layout(R, B, T, D, H, FF, int(cross), io.Nenc, U, io.xq_max if xq is not None else 0, int(p_hid > 0),
-                                            ctypes.byref(L)), "rlayer_layout")
+                check(lib.xfm_rlayer_layout(R, B, T, D, H, FF, int(cross), io.Nenc, U, io.xq_max if xq is not None else 0,
+                                            int(p_hid > 0) | (2 if f32 else 0), ctypes.byref(L)), "rlayer_layout")
                 layouts[cross] = L
             return layouts[cross]
 
@@ -813,6 +921,7 @@ class _EncoderFnNative(torch.autograd.Function):
             ctr = _seed_counter[0]
             _seed_counter[0] += 5 if cross else 3
             io.x, io.slab, io.seed_ctr = x.data_ptr(), slab.data_ptr(), ctr & 0xFFFFFFFF
+            io.x32 = Fx._ptr(xt)
             kv = None
             if cross:
                 kv, ev = kv_ready.pop(id(layer))
@@ -820,18 +929,19 @@ class _EncoderFnNative(torch.autograd.Function):
             else:
                 io.kv, io.kv_event = 0, 0
             check(lib.xfm_rlayer_fwd(ctypes.byref(_rlayer_params(layer, cfg)), ctypes.byref(io), st), "rlayer_fwd")
-            saved.append((slab, x, kv, ctr, cross))
+            saved.append((slab, x, kv, ctr, cross, xt))
             x = _view(slab, L.y3, R, D)
+            xt = _view(slab, L.y3_32, R, D, F32) if f32 else None
         ctx.saved, ctx.model, ctx.enc, ctx.io, ctx.layouts, ctx.pack = saved, model, enc, io, layouts, pack
         ctx.keep = (groups, xq, key_keep, enc_keep)   # device arrays the io struct points at
         ctx.meta = (lo, hi, B, T, Nenc, U, key_keep, need_dx, need_denc, groups, grad_batch, p_hid > 0)
         ctx.noted = need_dx or need_denc
         if ctx.noted:
             arena_note_use(model)
-        return x
+        return x, xt
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy32=None):
         from . import _lib
         from ._lib import RLayerBwd, check
         import ctypes
@@ -842,15 +952,16 @@ class _EncoderFnNative(torch.autograd.Function):
         D = cfg.hidden_size
         layers = [model.encoder.layer[li] for li in range(lo, hi)]
         arena = layers[0]._s["qkv"]._arena
-        dy_a, dy_b = dy.contiguous(), None
-        if dy_a.dtype != BF16:
-            dy_a = dy_a.to(BF16)
+        f32 = bool(io.f32_stream)
+        dy_a, dy_b = _grad_pair(dy, dy32, f32)
+        dy = dy_a
         rows_full, R = dy_a.shape[0], dy_a.shape[0]
         if grad_batch is not None and grad_batch < B:
             # only the first `grad_batch` sequences carry gradient: the backward walks the row prefix of the saved activations
             R = grad_batch * T if pack is None else pack.rows_of_head(grad_batch)
             io.R_alloc, io.B_alloc, io.R, io.B = rows_full, B, R, grad_batch
             dy_a = dy_a[:R]
+            dy_b = None if dy_b is None else dy_b[:R]
             if pack is not None:
                 io.zero_fill = int(not pack.head(grad_batch).exact)
         wg = _WgradStream(dy.device, "fusion bwd" if enc is not None else "text bwd")
@@ -890,11 +1001,12 @@ class _EncoderFnNative(torch.autograd.Function):
             bw.ln_items, bw.ln_count, bw.ln_ws_stride = ctypes.addressof(ln_items), ctypes.addressof(ln_count), ln_stride
         for k in reversed(range(len(layers))):
             layer = layers[k]
-            slab, x_in, kv, ctr, cross = ctx.saved[k]
+            slab, x_in, kv, ctr, cross, xt_in = ctx.saved[k]
             L = ctx.layouts[cross]
             bslab = torch.empty(L.bwd_bytes, dtype=torch.uint8, device=dy.device)
-            keep.append((bslab, slab, x_in, kv, dy_a, dy_b))
+            keep.append((bslab, slab, x_in, kv, dy_a, dy_b, xt_in))
             io.x, io.slab, io.seed_ctr = x_in.data_ptr(), slab.data_ptr(), ctr & 0xFFFFFFFF
+            io.x32 = Fx._ptr(xt_in)
             if cross:
                 io.kv, io.kv_ld, io.kv_event = kv.data_ptr(), kv.stride(0), 0
                 if concat_k:
@@ -906,7 +1018,8 @@ class _EncoderFnNative(torch.autograd.Function):
                     bw.dkv, bw.dkv_ld = dkv.data_ptr(), dkv.stride(0)
             else:
                 io.kv = 0
-            bw.bslab, bw.dy_a, bw.dy_b = bslab.data_ptr(), dy_a.data_ptr(), Fx._ptr(dy_b)
+            bw.bslab, bw.dy_a = bslab.data_ptr(), dy_a.data_ptr()
+            bw.dy_b, bw.dy_b32 = (0, Fx._ptr(dy_b)) if f32 else (Fx._ptr(dy_b), 0)
             bw.need_dprev = int(k > 0 or need_dx)
             bw.defer_wgrad = int(defer)
             if ln_ws is not None:
@@ -926,14 +1039,12 @@ class _EncoderFnNative(torch.autograd.Function):
                     wg.defer_tn(dkv_v, enc, sl["kv2"]._dw, sl["kv2"]._db)   # (dK|dV comes from the side stream: the flush runs there too)
                 wg.defer_tn(Gv(L.dh1, D), Sv(L.c1, D), sl["o"]._dw)
                 wg.defer_tn(Gv(L.dqkv, 3 * D), x_in[:R], sl["qkv"]._dw, sl["qkv"]._db)
-            dy_a, dy_b = _view(bslab, L.dprev, R, D), _view(bslab, L.dres1, R, D)
+            dy_a, dy_b = _view(bslab, L.dprev, R, D), _view(bslab, L.dres1, R, D, F32 if f32 else BF16)
             ctx.saved[k] = None
         if ln_ws is not None and ln_count.value > 0:
             folds = [ln_items[i] for i in range(ln_count.value)]
             wg.defer_call(lambda: Fx.reduce_sets_batch(folds), keep=(ln_ws,))
-        dx = (dy_a.float() + dy_b.float()).to(BF16) if need_dx else None
-        if dx is not None and R < rows_full:
-            dx = torch.cat([dx, torch.zeros((rows_full - R, D), dtype=dx.dtype, device=dx.device)], dim=0)
+        dx, dx32 = _input_grads(dy_a, dy_b, need_dx, ctx.twin_in, rows_full)
         denc = None
         if concat_k:
             wt_cat = torch.cat([layer._s["kv2"].wt[:, :2 * D] for layer in cross_layers], dim=1)
@@ -946,7 +1057,7 @@ class _EncoderFnNative(torch.autograd.Function):
         del keep
         if ctx.noted:
             arena_note_grad(model)
-        return (dx, denc) + (None,) * 14
+        return (dx, dx32, denc) + (None,) * 14
 
 
 class RobertaModel(nn.Module):
@@ -1023,14 +1134,18 @@ class RobertaModel(nn.Module):
                 raise ValueError("You have to specify either input_ids or inputs_embeds")
             B, T = input_ids.shape
             drop = Fx.drop_params(cfg.hidden_dropout_prob if self.training else 0.0, _next_seed())
-            x = _EmbedFn.apply(self.embeddings.word_embeddings.weight, self.embeddings, input_ids, drop, self, pack)
+            x, x32 = _EmbedFn.apply(self.embeddings.word_embeddings.weight, self.embeddings, input_ids, drop, self, pack)
         else:
             if pack is not None:
                 assert encoder_embeds.dim() == 2 and encoder_embeds.shape[0] == pack.cap, "packed encoder_embeds are [pack.cap, D] rows"
                 B, T = pack.B, pack.T
             else:
                 B, T = encoder_embeds.shape[:2]
-            x = encoder_embeds if encoder_embeds.dtype == BF16 else encoder_embeds.to(BF16)
+            x32 = twin_of(encoder_embeds)   # the producing tower's fp32 twin, if this is its output (or a row-wise image of it: with_twin)
+            if encoder_embeds.dtype == BF16:
+                x = encoder_embeds
+            else:   # fp32 states from outside: they ARE the un-rounded stream
+                x, x32 = encoder_embeds.to(BF16), (encoder_embeds if encoder_embeds.dtype == F32 and _F32_STREAM else None)
         if pack is not None:
             assert (B, T) == (pack.B, pack.T)
             attention_mask = None  # implied by the lengths: keys past a sequence's end do not exist
@@ -1055,6 +1170,7 @@ class RobertaModel(nn.Module):
         else:
             raise ValueError(f"mode {mode} is not supported")
         y = x.reshape(B * T, -1) if pack is None else x
+        y32 = None if x32 is None else (x32.reshape(B * T, -1) if pack is None else x32)
         if hi > lo:
             # one native call per layer whenever cross-attention (if any) can take the grouped kernels; else kernel by kernel
             xq = None
@@ -1070,14 +1186,17 @@ class RobertaModel(nn.Module):
                 assert enc is None or (encoder_batch_index is not None and Fx.attn_grouped_ok(int(output_rows[3]), Nenc))
                 hi -= 1
             if hi > lo:
-                y = fn.apply(y, enc, self, key_keep, enc_keep, lo, hi, bool(is_decoder), B, T, Nenc, self.training,
-                             encoder_batch_index if enc is not None else None, grad_batch, pack, xq)
+                y, y32 = fn.apply(y, y32, enc, self, key_keep, enc_keep, lo, hi, bool(is_decoder), B, T, Nenc, self.training,
+                                  encoder_batch_index if enc is not None else None, grad_batch, pack, xq)
             if output_rows is not None:
                 rows, sel_start, sel_len, tq = output_rows
-                y = _LastLayerRowsFn.apply(y, enc, self, hi, B, T, Nenc, self.training, encoder_batch_index if enc is not None else None,
-                                           pack, rows.to(torch.int32).contiguous(),
-                                           (sel_start.to(torch.int32).contiguous(), sel_len.to(torch.int32).contiguous()), int(tq))
-        return SimpleNamespace(last_hidden_state=y.view(B, T, -1) if pack is None else y, pooler_output=None, past_key_values=None,
+                y, y32 = _LastLayerRowsFn.apply(y, y32, enc, self, hi, B, T, Nenc, self.training,
+                                                encoder_batch_index if enc is not None else None,
+                                                pack, rows.to(torch.int32).contiguous(),
+                                                (sel_start.to(torch.int32).contiguous(), sel_len.to(torch.int32).contiguous()), int(tq))
+        if pack is None:
+            y, y32 = y.view(B, T, -1), (None if y32 is None else y32.view(B, T, -1))
+        return SimpleNamespace(last_hidden_state=with_twin(y, y32), pooler_output=None, past_key_values=None,
                                hidden_states=None, attentions=None, cross_attentions=None)
 
 
