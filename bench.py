@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="units per GPU (0 = the workload's configured batch; pre-train: 64, the north-star's)")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward(+all-reduce) only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clocks", action="store_true", help="skip the clock / power sample under load (40 more steps after the timed region)")
     ap.add_argument("--no-fusion-probe", action="store_true", help="skip the stand-alone fusion-encoder fwd+bwd measurement (profiling runs)")
     ap.add_argument("--host-time", action="store_true", help="also print (stderr) the host's enqueue time of one step against an idle GPU")
     ap.add_argument("--cpu-batch", type=int, default=0, help="units per CPU-baseline step (0 = the workload's bounded sample; pre-train: 8, SURVEY 8d)")
@@ -582,6 +583,59 @@ def wl_glue(args, device, rank):
 BUILDERS = {"pretrain": wl_pretrain, "imagenet": wl_imagenet, "retrieval": wl_retrieval, "vqa": wl_vqa, "glue": wl_glue}
 
 
+def kernel_tree_hash():
+    """sha1 over the kernel sources (xfm_amd/csrc/* + the public header): profiles written by tools/hbm_traffic.py carry it, so a
+    committed PMC profile that no longer describes the kernels in the tree says so in the bench line instead of going stale silently."""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, "xfm_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + [os.path.join("..", "..", "include", "xfm_hip.h")]:
+        path = os.path.join(csrc, f)
+        if os.path.isfile(path) and f.endswith((".hip", ".h")):
+            with open(path, "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def sample_clocks(run_step, n_steps=40):
+    """Shader / memory clock and socket power UNDER the step's load, outside the timed region: rocm-smi is read by a helper thread
+    while `n_steps` more steps run (a box that measures 8 % slower than its neighbours can then be explained from its own record).
+    Returns a dict of whatever rocm-smi reports for device 0 with 'clk' / 'power' / 'use' / 'temp' in its name, or a note."""
+    import shutil
+    import subprocess
+    import threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return {"note": "rocm-smi not found"}
+    res = {}
+
+    def read():
+        time.sleep(0.25)   # let the queue fill
+        try:
+            r = subprocess.run([exe, "--showclocks", "--showpower", "--showuse", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
+            d = json.loads(r.stdout)
+            card = d.get("card0") or next(iter(d.values()))
+            res.update({k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "fclk", "socclk", "power", "gpu use", "junction", "edge"))})
+        except Exception as e:   # noqa: BLE001 -- a diagnostic field must never fail the bench line
+            res["note"] = f"rocm-smi failed: {type(e).__name__}: {e}"
+
+    th = threading.Thread(target=read)
+    th.start()
+    t0 = time.perf_counter()
+    done = 0
+    while th.is_alive() or done < n_steps:
+        run_step()
+        done += 1
+        if done % 8 == 0:
+            torch.cuda.synchronize()   # keep the host within a few steps of the GPU: the sample must fall inside the busy period
+        if time.perf_counter() - t0 > 30:
+            break
+    th.join()
+    torch.cuda.synchronize()
+    res["sampled_under_load_steps"] = done
+    return res
+
+
 def device_identity(device):
     p = torch.cuda.get_device_properties(device)
     for attr in ("uuid",):
@@ -611,8 +665,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     backend = os.environ.get("XFM_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # XFM_DDP_FORCE=1 at N = 1 (no multi-GPU node to hand): a process group of ONE rank on RCCL, and the accelerator's N > 1 code path
+    # runs for real -- live-set agreement, arena all-reduces launched from the tower hooks and the ViT chunk hand-over on the
+    # communication stream, one grouped weight-gradient launch per handed-over chunk, the ITC all-gather.  The line's `distributed`
+    # object says what RCCL saw; the value is a 1-GPU throughput WITH the data-parallel machinery's compute-side costs.
+    forced = world == 1 and os.environ.get("XFM_DDP_FORCE", "0") == "1"
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29671")
         dist.init_process_group(backend, world_size=world, rank=rank)
 
     from xfm_amd import marks
@@ -637,7 +697,7 @@ def main():
         marks.mark("step begin")
         total, parts = forward(wrapped, j)
         marks.mark("forward end")
-        if timed_comm and world > 1:  # end of backward -> gradient all-reduce complete, on the launch stream
+        if timed_comm and (world > 1 or forced):  # end of backward -> gradient all-reduce complete, on the launch stream
             acc.timing = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             comm_events.append(acc.timing)
         acc.backward_step(total, optimizer)
@@ -699,13 +759,14 @@ def main():
 
     # distributed self-description: how many ranks RCCL actually connected and on how many distinct devices
     rccl = None
-    if world > 1:
+    if world > 1 or forced:
         ids = [None] * world
         dist.all_gather_object(ids, device_identity(device))
         rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "distinct_devices": len(set(ids)),
                 "exchange_dtype": acc.exchange_dtype, "exchange_bytes": ex_stats["exchange_bytes"],
                 "exchange_calls": ex_stats["exchange_calls"], "overlapped_bytes": ex_stats["overlapped_bytes"],
                 "exposed_comm_ms": round(sum(exposed) / max(len(exposed), 1), 3),
+                "forced_group_of_one": forced, "vit_grad_chunk_blocks": int(os.environ.get("XFM_VIT_GRAD_CHUNK", "4")),
                 "exposed_comm_note": "HIP events on the launch stream: end of this rank's backward -> its last gradient all-reduce has "
                                      "landed (mean over the timed steps, rank 0); the overlapped part of the exchange ran under backward"}
 
@@ -743,6 +804,9 @@ def main():
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath):
                 break
+        for name5 in ("round5_hbm_traffic.json",):
+            if os.path.exists(os.path.join(ROOT, "profiles", name5)):
+                name, tpath = name5, os.path.join(ROOT, "profiles", name5)
         if os.path.exists(tpath):  # PMC passes are separate rocprofv3 runs of this same command (profiles/README.md)
             with open(tpath) as f:
                 tj = json.load(f)
@@ -756,6 +820,10 @@ def main():
                                f"(tail-split row blocks included), from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in profiles/{name} " \
                                "(2 x FETCH_SIZE + WRITE_SIZE, KB; tools/pmc_traffic.sh); Infinity-Cache hits are counted; algorithmic bytes " \
                                f"per launch (A + B + C once) average {dom_bytes / max(dom_n, 1):.3e}"
+                prof_hash, tree_hash = tj.get("kernel_tree_hash"), kernel_tree_hash()
+                traffic_note += (f"; profile taken on kernel tree {prof_hash}, this run's tree is {tree_hash}"
+                                 + ("" if prof_hash == tree_hash else " -- the kernels have changed since the profile (or it predates the stamp): "
+                                    "indicative only, re-run tools/pmc_traffic.sh"))
     if rank == 0:
         gf = wl["gflop"]
         step_tf_exec = executed_flop / (ms_per_step * 1e-3) / 1e12
@@ -807,12 +875,14 @@ def main():
         }
         if rccl is not None:
             out["distributed"] = rccl
-        if pretrain and not args.no_fusion_probe and world == 1:  # single-rank only: its backward would launch unmatched gradient collectives
+        if world == 1 and not forced and not args.no_clocks:
+            out["clocks_under_load"] = sample_clocks(step)
+        if pretrain and not args.no_fusion_probe and world == 1 and not forced:  # single-rank only: its backward would launch unmatched gradient collectives
             out["fusion_encoder_fwd_bwd"] = fusion_probe(model, B, host[0], packed=not args.padded_rows)
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and not forced:  # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(model, wl, args.cpu_batch or wl["cpu_batch"], args.cpu_threads)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -405,7 +405,9 @@ int xfm_rlayer_bwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, const xf
  * launches (matmul through the vendor BLAS, softmax, nll_loss, fills, multinomial):
  *   rownorm      y = x / max(|x|_2, 1e-12) per row (F.normalize, xfm.py:617-620), fp32 [R, E], E % 64 == 0, E <= 1024; inv = 1 / norm
  *   itc          logits = I . T^T / temp over N gathered rows; loss = (CE(logits, arange) + CE(logits^T, arange)) / 2 (xfm.py:699-703);
- *                fwd: lse [2N] (rows of logits, then rows of logits^T), loss_sum[0] += the loss; bwd: dI, dT (fully written) and
+ *                fwd: lse [4N] (statistics of the rows of logits, then of logits^T; behind them the 2N rows' loss terms),
+ *                loss_sum [2], zeroed by the caller: [0] += the loss, summed over the row terms in a fixed order by the block that takes
+ *                the last ticket of the integer counter at [1] (bit-reproducible); bwd: dI, dT (fully written) and
  *                dtemp[0] += for the upstream gradient g[0]
  *                idx != NULL (int64 [N], the gathered image ids of the retrieval fine-tuning step, xfm.py:705-713): soft labels -- the
  *                positives of row r are the rows with the same id, weight 1 / cnt_r each; fwd writes cnt [N], bwd reads it

@@ -32,7 +32,7 @@ def run(meta, force, exchange="fp32"):
     cfg = {"use_beit_v2": True, "image_res": 224, "patch_size": 16, "local_attn_depth": -1, "text_encoder": "roberta-base",
            "text_num_hidden_layers": meta["text_layers"], "text_fusion_start_at": meta["text_layers"],
            "fusion_num_hidden_layers": meta["fusion_layers"], "fusion_fusion_start_at": 0, "embed_dim": 256, "temp": 0.07,
-           "learnable_temp": True, "max_temp": 0.5, "min_temp": 0.001, "vision_depth": 6}
+           "learnable_temp": True, "max_temp": 0.5, "min_temp": 0.001, "vision_depth": 12}   # 12 blocks: the DEFAULT chunk of four hands over twice
     m = XFM(cfg)
     sd = syn.formula_state_dict(m.state_dict())
     m.load_state_dict(sd, strict=True)
@@ -46,6 +46,20 @@ def run(meta, force, exchange="fp32"):
     stats, grads = [], None
     snaps, identity = [], {"ranges": 0, "bad": 0}
     if force:
+        # Poison the ordering the exchange must respect: the LM head's vocabulary weight gradient (50265 x 768, inside the fusion tower's
+        # arena range, launched on the weight-gradient side stream and re-joined only at the end of the backward pass) is held back by a
+        # ~10 ms spin on that stream.  An exchange of the fusion range that does not wait for the side stream snapshots the range
+        # before the gradient lands, and the identity check below fails deterministically.
+        from xfm_amd import xroberta as XR
+        orig_tn = XR._WgradStream.gemm_tn
+
+        def slow_tn(self, dy, x, dw, **kw):
+            if self.on and dw.shape[0] >= 50000:
+                with torch.cuda.stream(self.side):
+                    torch.cuda._sleep(20_000_000)
+            return orig_tn(self, dy, x, dw, **kw)
+
+        XR._WgradStream.gemm_tn = slow_tn
         orig = acc._exchange
 
         def snapshotting(a, b, async_ok=True):   # runs under torch.cuda.stream(comm stream): the clone is ordered before the collective
@@ -75,6 +89,8 @@ def run(meta, force, exchange="fp32"):
             grads = m._arena.grad.clone()
         acc.optimizer_step(opt, m)
     torch.cuda.synchronize()
+    if force:
+        XR._WgradStream.gemm_tn = orig_tn
     layout = [(m._arena.names[id(p)],) + tuple(m._arena.offsets[id(p)]) for p in m._arena.params]
     return m._arena.data.clone(), first_grads, stats, str(acc._op), sum(b_ - a for a, b_ in acc.live_ranges()), identity, layout
 

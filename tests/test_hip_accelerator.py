@@ -257,8 +257,11 @@ def test_collectives_through_rccl_in_a_group_of_one():
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_w1_worker.py")
-    # (chunks of two blocks: the worker's 6-block ViT then hands over twice from inside its backward; the default of four is for 12 blocks)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", XFM_VIT_GRAD_CHUNK="2")
+    # (the shipped defaults: a 12-block ViT handing over chunks of four blocks, each hand-over launching the chunk's grouped weight
+    # gradients; the worker also holds the LM head's weight gradient back on its side stream so that an exchange that does not wait
+    # for that stream fails the identity check)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.pop("XFM_VIT_GRAD_CHUNK", None)
     r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=420, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("NCCL_W1 ")][-1]

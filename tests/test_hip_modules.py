@@ -395,31 +395,42 @@ def test_classification_imagenet_branch_vs_golden(tmp_path):
 
 
 def test_classification_imagenet_at_batch_128_vs_oracle(tmp_path):
-    """BASELINE configs[1]'s real batch (Imagenet.py:437-492, batch 128 per GPU at 224 px, 12-block tower): predictions and the loss
-    against the CPU oracle's forward on the same formula weights.  (Gradients at full depth are pinned by the B = 4 fixture above.)"""
+    """BASELINE configs[1]'s real batch (Imagenet.py:437-492, batch 128 per GPU at 224 px, 12-block tower), forward AND backward:
+    predictions, loss and every parameter gradient against `imagenet_cfg.npz` -- the REFERENCE run at this very shape
+    (tools/oracle/gen_golden.py --only imagenet_cfg: models.model_classification.XFMForClassification, fp32, vision tower in chunks of
+    8 images) -- with the reference's own bf16-autocast floor per tensor; the live CPU oracle is held to the fixture's predictions too.
+    M = 25216 token rows through the 256 x 256 GEMMs, the 197-token attention forward / backward pair and the grouped weight gradients:
+    the model-level gradient check at the ViT's headline row count."""
     from oracle import xfm_oracle as O
     from xfm_amd.model_classification import XFMForClassification
-    _, meta = load("classification_imagenet")
+    z, meta = load("imagenet_cfg")
     spec = meta["spec"]
     m = XFMForClassification(_cls_cfg(meta, vision_config=_beit_checkpoint_config(spec, tmp_path), task_name="imagenet", num_labels=1000))
     sd = _load_into(m, spec)
     m.cuda().finalize().eval()
-    B = 128
+    B = meta["B"]
+    assert B == 128
     image = syn.gaussian("imagenet128.image", (B, 3, 224, 224))
-    g = torch.Generator().manual_seed(11)
-    targets = torch.randint(0, 1000, (B,), generator=g)
+    targets = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(11))
+    assert targets.tolist() == meta["targets"]
     with torch.no_grad():
         pred = m(image.cuda(), None, None, targets.cuda(), train=False).float().cpu()
-        loss = float(m(image.cuda(), None, None, targets.cuda(), train=True))
         ref = O.classification_forward(sd, O.default_cfg(vit_depth=12), image, None, None, deep_head=True).float()
     assert pred.shape == ref.shape == (B, 1000)
+    from golden_util import check
+    check(z, "pred_imagenet", ref, atol=2e-5, rtol=2e-4, what="oracle vs reference at B = 128: ")
+    _check_out(z, "pred_imagenet", pred)
     err = float((pred - ref).norm() / ref.norm())
-    assert err <= OUT_TOL, err
-    ref_loss = float(torch.nn.functional.cross_entropy(ref, targets))
-    assert abs(loss - ref_loss) <= 2e-3 * abs(ref_loss), (loss, ref_loss)
     per_row = ((pred - ref).norm(dim=1) / ref.norm(dim=1)).max()
-    assert float(per_row) <= 2 * OUT_TOL, float(per_row)
-    print(f"ImageNet B=128: logits rel-L2 {err:.4f}, worst row {float(per_row):.4f}, loss {loss:.5f} vs {ref_loss:.5f}")
+    assert err <= OUT_TOL and float(per_row) <= 2 * OUT_TOL, (err, float(per_row))
+    loss = m(image.cuda(), None, None, targets.cuda(), train=True)
+    ref_loss, amp_loss = float(z["loss_imagenet"]), float(z["amp_loss_imagenet"])
+    assert abs(float(loss) - ref_loss) <= 1e-3 * abs(ref_loss), (float(loss), ref_loss)
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f"ImageNet B=128: logits rel-L2 {err:.4f}, worst row {float(per_row):.4f}, loss {float(loss):.5f} vs reference {ref_loss:.5f} "
+          f"(its bf16 autocast: {amp_loss:.5f})")
+    _check_grads(z, "grad", m, min_rms=1e-6, floor="floor")
 
 
 def test_classification_multimodal_and_text_branches_vs_golden(tmp_path):

@@ -58,7 +58,7 @@ def fwd_bwd(fixed):
 
 
 for step in range(4):
-    err = float("nan")
+    err = None   # (checked on steps 0 and 1 only: the later steps run in training mode, where the hand-averaged reference would draw other masks)
     if step < 2:  # step 0: plain sweep after backward (live ranges unknown yet); step 1: the overlapped, chunked exchange
         # (a) what the exchange must produce: every rank's LOCAL gradient (accelerator told it is alone), averaged by hand
         acc.world_size, acc._dist = 1, False
@@ -81,7 +81,7 @@ for step in range(4):
     same_everywhere(model._arena.data, f"step {step}: parameters after the optimizer step")
     live = sum(b - a for a, b in acc._ranges)
     print(f"rank {rank} step {step}: losses {[round(float(v), 4) for v in losses.values()]} live {live}/{model._arena.numel} "
-          f"grad-norm {float(acc.last_grad_norm):.4f} exchange-vs-mean-of-locals {err:.2e} "
+          f"grad-norm {float(acc.last_grad_norm):.4f} exchange-vs-mean-of-locals {'n/a (training-mode step: replica identity only)' if err is None else format(err, '.2e')} "
           f"ranges sent from inside backward {[(b - a) // 2 ** 20 for a, b in acc.overlapped_ranges]} Mi-elements", flush=True)
 dist.barrier()
 if rank == 0:

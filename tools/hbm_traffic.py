@@ -44,7 +44,11 @@ def main():
     fetch_dir, write_dir, steps = sys.argv[1], sys.argv[2], float(sys.argv[3])
     fetch, calls = load(fetch_dir, "FETCH_SIZE")
     write, _ = load(write_dir, "WRITE_SIZE")
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_traffic.sh) -- python3 bench.py --steps 2 "
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_tree_hash
+    out = {"kernel_tree_hash": kernel_tree_hash(),
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_traffic.sh) -- python3 bench.py --steps 2 "
                      "--warmup 1 --no-cpu-baseline; averaged over the steps of the run (warm-up + timed + instrumented)",
            "correction": "read bytes = 2 x FETCH_SIZE (gfx950 counts 128-B requests of wide coalesced reads as 64 B), write bytes = "
                          "WRITE_SIZE; KB -> bytes x1024 (MI355X_MICROARCH.md, HBM)",

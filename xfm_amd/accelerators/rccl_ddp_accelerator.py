@@ -30,6 +30,9 @@ from .. import functional as Fx
 from .accelerator import Accelerator
 
 
+_DRY = os.environ.get("XFM_DDP_DRY", "0") == "1"
+
+
 class _Wrapped(torch.nn.Module):
     """`.module` holder so callers written against DDP (Pretrain.py:261-263) keep working."""
 
@@ -144,7 +147,8 @@ class RCCLDDPAccelerator(Accelerator):
             self._cuts = sorted({r[0] for _, _, r in self._towers} | {r[1] for _, _, r in self._towers})
             self._t = [0] * len(arena._units)
             if use_cuda:
-                self._comm_stream = torch.cuda.Stream()
+                # XFM_COMM_PRIO (A/B knob): HIP priority of the communication stream
+                self._comm_stream = torch.cuda.Stream(priority=int(os.environ.get("XFM_COMM_PRIO", "0")))
                 self._install_tower_hooks(model)
             if optimizer is not None:
                 self._hook_optimizer(optimizer)
@@ -229,6 +233,8 @@ class RCCLDDPAccelerator(Accelerator):
     def _exchange(self, a, b, async_ok=True):
         """All-reduce (mean) of arena.grad[a:b] on the current stream."""
         g = self.arena.grad[a:b]
+        if _DRY:   # measurement knob: every hook, flush and stream wait of the N > 1 path, no collective (what does the MACHINERY cost?)
+            return
         self.stats["exchange_calls"] += 1
         self.stats["exchange_bytes"] += (b - a) * (2 if self.exchange_dtype == "bf16" else 4)
         if self.exchange_dtype == "bf16":
@@ -246,6 +252,16 @@ class RCCLDDPAccelerator(Accelerator):
         self._comm_stream.wait_stream(cur)
         if extra_stream is not None:  # weight-gradient GEMMs of the range still in flight on their own stream
             self._comm_stream.wait_stream(extra_stream)
+        # Parameter gradients are also written on the weight-gradient side streams (xroberta._WgradStream: one per launch stream) by
+        # launch sites that re-join only at the END of the backward pass (join_at_end: the LM head's two weight gradients, whose
+        # parameters lie inside the fusion tower's range; ops._LinearSlotFn).  A range leaves only with its gradients final, so the
+        # exchange waits for everything those streams hold at this point, whichever stream the writer used -- not just the one whose
+        # FIFO happens to be shared with the tower (advisor finding, round 4).
+        from ..xroberta import _WgradStream
+        dev = self.arena.grad.device.index
+        for (d, _), side in list(_WgradStream._streams.items()):
+            if d == dev and side is not extra_stream:
+                self._comm_stream.wait_stream(side)
         with torch.cuda.stream(self._comm_stream):
             for a, b in _clip(self._ranges, *rng):
                 self._exchange(a, b)

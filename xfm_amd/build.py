@@ -6,8 +6,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libxfm_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "layernorm.hip", "attention.hip", "attention_vit.hip", "elementwise.hip", "encoder.hip", "losses.hip", "common.h",
-           os.path.join("..", "..", "include", "xfm_hip.h")]
+def _sources():
+    """Every file the single translation unit (capi.hip) can include: whatever sits in csrc/ plus the public header -- listed from the
+    directory, so a new kernel file cannot be forgotten here (round 4: attention_long.hip was, and is_stale() missed edits to it)."""
+    files = [f for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    return files + [os.path.join("..", "..", "include", "xfm_hip.h")]
 
 
 def _hipcc():
@@ -21,7 +24,7 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in _sources())
 
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-inline-asm"]

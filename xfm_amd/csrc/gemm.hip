@@ -36,6 +36,10 @@ struct GemmNT {
   int k_splits; // small-tile kernels, EPI_F32_ACC only: gridDim.y K-slices, fp32 atomics into C (1 = off)
   int k_rot;    // 256 x 256 kernel: column phases of the K rotation (0 / 1 = every tile starts at K-tile 0)
   long split_stride;  // EPI_F32 with k_splits > 1: K-slice y stores its partial tile to C + y * split_stride (elements), plain stores
+  int skew_from, skew_ticks;  // persistent 256 x 256 kernel: workgroup i >= skew_from starts (i - skew_from) / (grid - skew_from) * skew_ticks
+                              // later (10-ns ticks of the constant clock); 0 = all at once.  See launch_nt_256.
+  long long* dbg;             // diagnostic (XFM_GEMM_DBG_PTR, tools/tile_timeline.py): wave 0 of every workgroup writes 10-ns timestamps
+                              // [tile index, start, K loop done, epilogue done] per tile it walks; NULL in every product call
 };
 
 // LDS swizzles (16-B chunk index XOR) for 128-B tile rows read with ds_read_b128.
@@ -572,6 +576,12 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g, int tiles) {
   } while (0)
 
   int v = blockIdx.x, m0, n0;
+  if (PERSIST && g.skew_ticks > 0 && (int)blockIdx.x >= g.skew_from) {
+    // start-time skew (launch_nt_256): the workgroups that walk one tile fewer than the others start late, spread over one tile time
+    const long long t0 = wall_clock64();
+    const long long d = (long long)g.skew_ticks * ((int)blockIdx.x - g.skew_from) / ((int)gridDim.x - g.skew_from);
+    while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+  }
   tile_origin(v, m0, n0);
   tile_offsets(m0, n0);
   // prologue: units 0..D-1 in flight
@@ -579,7 +589,12 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g, int tiles) {
   for (int s = 0; s < D; ++s) issue(s);
   bool stores_behind = false;  // NS output stores of the previous tile were issued after the units 0..D-1 of this one
 
+  int dbg_n = 0;
   while (true) {
+    if (g.dbg != nullptr && tid == 0) {
+      long long* d = g.dbg + ((long)blockIdx.x * 8 + dbg_n) * 4;
+      d[0] = v; d[1] = wall_clock64();
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -638,6 +653,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g, int tiles) {
       XFM_BAR();
     }
     if (wr == 0) XFM_BAR();  // both groups are past their last LDS read
+    if (g.dbg != nullptr && tid == 0) g.dbg[((long)blockIdx.x * 8 + dbg_n) * 4 + 2] = wall_clock64();
     const int cm0 = m0, cn0 = n0;
     // The bias goes out BEFORE the next tile's staging loads and is waited for with a count that leaves exactly those in flight
     // (loads return in order): this wave's 64 values, into the last ring slot (free until P2 of the next tile's first K-tile).
@@ -665,6 +681,10 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmNT g, int tiles) {
     wait_units<0, D>(ahead);
     if (g.bias == nullptr) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     gemm_epilogue<MT, NT, EPI>(g, acc, cm0 + wr * 128, cn0 + wc * 64, lr, lg, lds_bias);
+    if (g.dbg != nullptr && tid == 0) {
+      g.dbg[((long)blockIdx.x * 8 + dbg_n) * 4 + 3] = wall_clock64();
+      dbg_n = dbg_n < 7 ? dbg_n + 1 : 7;
+    }
     if (!more) break;
     XFM_FENCE();
     // exactly NS stores per lane only when every lane stored every (mt, np) with one 16-B (2 x 16-B for fp32) instruction
@@ -684,7 +704,8 @@ static void launch_nt_256_as(const GemmNT& g, int grid, int tiles, hipStream_t s
   hipLaunchKernelGGL((gemm_nt_256_kernel<E, P, D>), dim3(grid), dim3(512), smem, st, g, tiles);
 }
 
-static int launch_nt_256(const GemmNT& g, int epi, hipStream_t st) {
+static int launch_nt_256(const GemmNT& g_in, int epi, hipStream_t st) {
+  GemmNT g = g_in;
   const int tiles = cdiv(g.M, 256) * cdiv(g.N, 256);
   if ((unsigned long)g.M * (unsigned long)g.lda >= (1ul << 32) || (unsigned long)g.N * (unsigned long)g.ldb >= (1ul << 32)) {
     xfm_set_error("gemm_nt: operand too large for the 256x256 kernel's 32-bit element offsets");
@@ -697,6 +718,24 @@ static int launch_nt_256(const GemmNT& g, int epi, hipStream_t st) {
   static const int cus = xfm_cu_count();
   const bool persist = persist_env && cus >= 8 && tiles > cus;
   const int grid = persist ? cus & ~7 : tiles;
+  // Start-time skew.  A round of 256 tiles ends with every CU storing its 128 KB (256 KB with gelu') of output at the same moment:
+  // 33 - 66 MB that drain at the chip's write bandwidth (7 - 15 us) while no matrix core works, and the next tile's staging loads
+  // queue behind the store acknowledgements (in-order vmcnt).  tools/kstep_probe.py: 1.4 - 1.5 us per K-step but 8 - 9 us of fixed cost
+  // per round.  The workgroups that walk one tile FEWER than the others (tiles % grid != 0) can start up to one tile time later for
+  // free; spread over that time they stay out of step with the rest for the whole launch, and the stores of one group drain under the
+  // K loops of the others.  XFM_GEMM_SKEW_US: the spread in microseconds per K-step of the problem (0 = off).
+  static const float skew_env = getenv("XFM_GEMM_SKEW_US") ? (float)atof(getenv("XFM_GEMM_SKEW_US")) : 0.f;
+  g.skew_from = 0;
+  g.skew_ticks = 0;
+  g.dbg = nullptr;
+  {
+    const char* dp = getenv("XFM_GEMM_DBG_PTR");   // (read per launch: the tool sets it around the one call it wants a timeline of)
+    if (dp != nullptr && dp[0] != 0) g.dbg = reinterpret_cast<long long*>(strtoull(dp, nullptr, 0));
+  }
+  if (persist && skew_env > 0.f && tiles % grid != 0) {
+    g.skew_from = tiles % grid;
+    g.skew_ticks = (int)(skew_env * 100.f * (float)(g.K / 64));
+  }
 #define XFM_256_CASE(E)                                                                 \
   case E:                                                                               \
     if (d_env == 5) {                                                                   \

@@ -70,16 +70,25 @@ __global__ __launch_bounds__(256) void itc_fwd_kernel(const float* __restrict__ 
     pos = block_add256(pos, red);
     npos = block_add256(npos, red);
   }
+  // The loss is the sum of the 2N row terms in a FIXED order (a float atomicAdd per block made two runs of the same step differ in the
+  // last bit of loss_itc): every block parks its term behind the statistics (lse[2N + block]); the block that takes the last ticket
+  // (loss_sum[1], an integer counter the caller zeroed with loss_sum[0]) adds them up with a fixed tree.
+  __shared__ int last;
   if (threadIdx.x == 0) {
     const float l = mx + __logf(s);
     lse[blockIdx.x] = l;
-    if (idx != nullptr) {
-      if (rows) cnt[r] = npos;
-      atomicAdd(loss_sum, (l - pos / npos) / (2.0f * N));
-    } else {
-      atomicAdd(loss_sum, (l - lg[r]) / (2.0f * N));
-    }
+    if (idx != nullptr && rows) cnt[r] = npos;
+    lse[2 * N + blockIdx.x] = (idx != nullptr ? (l - pos / npos) : (l - lg[r])) / (2.0f * N);
+    __threadfence();
+    last = atomicAdd(reinterpret_cast<int*>(loss_sum) + 1, 1) == 2 * N - 1;
   }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float t = 0.f;
+  for (int j = threadIdx.x; j < 2 * N; j += 256) t += __builtin_nontemporal_load(lse + 2 * N + j);
+  t = block_add256(t, red);
+  if (threadIdx.x == 0) loss_sum[0] += t;
 }
 
 // blocks [0, N): dI_i and the temperature gradient; blocks [N, 2N): dT_j.  With L = logits, G_ij = softmax_row(L)_ij +

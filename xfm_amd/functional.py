@@ -673,12 +673,12 @@ def itc_fwd(image_feat, text_feat, temp, idx=None):
     assert image_feat.dtype == F32 and text_feat.dtype == F32 and image_feat.is_contiguous() and text_feat.is_contiguous()
     assert text_feat.shape == (N, E) and temp.dtype == F32 and temp.numel() == 1
     idx = _idx64(idx, N)
-    lse = torch.empty(2 * N, dtype=F32, device=image_feat.device)
+    lse = torch.empty(4 * N, dtype=F32, device=image_feat.device)   # [0, 2N): row statistics; [2N, 4N): the rows' loss terms
     cnt = torch.empty(N, dtype=F32, device=image_feat.device) if idx is not None else None
-    loss = torch.zeros(1, dtype=F32, device=image_feat.device)
+    loss = torch.zeros(2, dtype=F32, device=image_feat.device)      # [0] the loss, [1] the kernel's ticket counter
     check(_lib.load().xfm_itc_fwd(image_feat.data_ptr(), text_feat.data_ptr(), temp.data_ptr(), N, E, lse.data_ptr(), loss.data_ptr(),
                                   _ptr(idx), _ptr(cnt), _stream()), "itc_fwd")
-    return loss, lse, cnt
+    return loss[:1], lse[:2 * N], cnt
 
 
 def itc_bwd(image_feat, text_feat, temp, lse, g, idx=None, cnt=None):

@@ -126,19 +126,28 @@ _PINNED = {}
 
 def _upload_i32(arr, device):
     """One int32 host array -> device through a ring of pinned staging buffers (a pageable upload blocks the host and goes through a
-    bounce buffer; this one is a plain asynchronous copy on the current stream).  The ring is 8 deep: a buffer is rewritten eight
-    uploads later, long after its copy ran (the host never runs more than a step or two ahead of the stream)."""
+    bounce buffer; this one is a plain asynchronous copy on the current stream).  The ring is 8 deep; every slot carries the event of
+    its last copy and the host waits for it before rewriting the slot (normally long past: eight uploads ago) -- a path without a
+    per-step host sync (caller-supplied negatives, XFM_PACK_SYNC=0) can run ahead of the stream, and a rewritten staging buffer would
+    upload the NEXT step's layout indices silently."""
     if device.type != "cuda":
         return torch.from_numpy(arr).to(device)
     n = int(arr.size)
     key = (device.index, max(1024, 1 << (n - 1).bit_length()))
     ring = _PINNED.get(key)
     if ring is None:
-        ring = _PINNED[key] = [[torch.empty(key[1], dtype=torch.int32).pin_memory() for _ in range(8)], 0]
-    buf = ring[0][ring[1]]
-    ring[1] = (ring[1] + 1) % 8
+        ring = _PINNED[key] = [[torch.empty(key[1], dtype=torch.int32).pin_memory() for _ in range(8)], 0, [None] * 8]
+    slot = ring[1]
+    buf = ring[0][slot]
+    ring[1] = (slot + 1) % 8
+    if ring[2][slot] is not None:
+        ring[2][slot].synchronize()
     buf[:n].numpy()[:] = arr.reshape(-1)
-    return buf[:n].to(device, non_blocking=True)
+    out = buf[:n].to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    ring[2][slot] = ev
+    return out
 
 
 def image_major_fusion_layout(seq_len, seq_img, n_images, T, device, src_start, seq_src, extra=()):

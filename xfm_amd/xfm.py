@@ -434,13 +434,6 @@ class XFMBase(nn.Module):
         idx = idx.view(-1, 1)
         assert idx.size(0) == image_feat.size(0)
         idx_all = allgather(idx)
-        if not image_feat_all.is_cuda:   # (CPU: the gloo tests of the data-parallel glue)
-            logits = image_feat_all @ text_feat_all.t() / self.temp
-            pos_idx = torch.eq(idx_all, idx_all.t()).float()
-            labels = pos_idx / pos_idx.sum(1, keepdim=True)
-            loss_i2t = -torch.sum(F.log_softmax(logits, dim=1) * labels, dim=1).mean()
-            loss_t2i = -torch.sum(F.log_softmax(logits.t(), dim=1) * labels, dim=1).mean()
-            return (loss_i2t + loss_t2i) / 2
         return itc_loss(image_feat_all, text_feat_all, self.temp, idx=idx_all.reshape(-1))
 
     def get_hard_negatives(self, image_feat, text_feat, idx=None):

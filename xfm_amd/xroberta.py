@@ -370,6 +370,12 @@ class _WgradStream:
 
             def rejoin():
                 main.wait_stream(side)
+                # the callback runs on the thread (and current stream) that called backward(): if this node ran on another stream (the
+                # text tower's, replayed by autograd), that caller -- the optimizer, the gradient norm, the final all-reduce -- must wait
+                # for these weight gradients too, whatever order the end-of-backward callbacks run in
+                cur = torch.cuda.current_stream(main.device)
+                if cur != main:
+                    cur.wait_stream(side)
                 keep.clear()
             torch.autograd.Variable._execution_engine.queue_callback(rejoin)
             self.keep = []
