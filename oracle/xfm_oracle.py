@@ -126,6 +126,18 @@ def beit_forward(P, pre, image, depth=12, heads=12, ids_mask=None, drop_path=Non
     return beit_pool_tail(P, pre, x, eps)
 
 
+def beit_region_outputs(full, idx_to_group_img, image_atts):
+    """The region call form, beit2.py:467-475 (reached through xfm.py:574-597 get_vision_embeds(image, image_atts, idx_to_group_img)):
+    `full` = the tower's ordinary output for the n distinct images [n, 1 + P, D]; every one of the bs samples picks its image
+    (idx_to_group_img [bs]) and pools ITS OWN pseudo-cls as the image_atts-weighted mean of the normalised patch rows
+    (image_atts [bs, 1 + P]; column 0 belongs to the cls slot and is not used) -> ([bs, 1 + P, D], full)."""
+    x = full[:, 1:, :]
+    x_bs = torch.gather(x, 0, idx_to_group_img.view(-1, 1, 1).expand(-1, x.shape[1], x.shape[2]))
+    w = image_atts[:, 1:].unsqueeze(2).to(x.dtype)
+    cls = (w * x_bs).sum(dim=1, keepdim=True) / w.sum(dim=1, keepdim=True)
+    return torch.cat([cls, x_bs], dim=1), full
+
+
 # --------------------------------------------------------------------------------------
 # Plain ViT  (models/vit.py; SURVEY row V0, unused by the shipped configs)
 # --------------------------------------------------------------------------------------
@@ -298,6 +310,16 @@ def bert_lm_head(P, pre, x, eps=1e-12):
     """BertLMPredictionHead xbert.py:663-697: transform (dense -> GELU -> LayerNorm) then decoder + shared bias."""
     h = _ln(P, pre + "transform.LayerNorm", gelu_erf(_lin(P, pre + "transform.dense", x)), eps)
     return F.linear(h, P[pre + "decoder.weight"], P[pre + "bias"])
+
+
+def bert_causal_lm_loss(P, input_ids, att, enc, enc_att, labels, num_layers, reduction="none", pre="", fusion_layer=0):
+    """BertLMHeadModel.forward xbert.py:1262-1347 (the answer decoder of a bert-named VQA model, model_generation.py:52-54): causal
+    self mask, cross-attention from layer `fusion_layer` on, cls.predictions head, logits[:, :-1] vs labels[:, 1:], summed per
+    sequence for reduction='none'.  Returns (loss rows, unshifted logits)."""
+    seq = bert_model(P, pre + "bert.", input_ids, att, enc, enc_att, num_layers=num_layers, fusion_layer=fusion_layer, causal=True)
+    logits = bert_lm_head(P, pre + "cls.predictions.", seq)
+    loss = F.cross_entropy(logits[:, :-1, :].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1), reduction=reduction)
+    return (loss.view(input_ids.shape[0], -1).sum(1) if reduction == "none" else loss), logits
 
 
 def bert_mlm_loss(P, seq_out, masked_pos, labels):

@@ -262,7 +262,8 @@ def test_pretrain_step_at_headline_shape_vs_reference():
     m, z, meta, report = _pretrain("pretrain_cfg", floor="floor", packed=True, returns=True)
     torch.cuda.synchronize()
     print(f"pretrain B=64: peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
-    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    from golden_util import state_from_spec
+    sd = state_from_spec(meta["spec"])   # the formula weights the model was loaded with
     b = syn.pretrain_batch(64, seed=meta["seed"])
     masks = syn.mim_block_mask(64, 14, 75, seed=meta["seed"])
     with torch.no_grad():   # (the oracle, live, against the fixture: the restatement is pinned at the headline shape too)

@@ -124,6 +124,15 @@ def test_beit_tower_vs_golden():
     _check_out(z, "out_masked", ym)
     (ym.float() * cot).sum().backward()
     _check_grads(z, "grad_masked", m)
+    # the region call form (beit2.py:467-475; through XFMBase.get_vision_embeds: xfm.py:574-597)
+    m._arena.zero_grad()
+    idx, atts = syn.region_case(B)
+    yr, yfull = m(image, idx_to_group_img=idx.cuda(), image_atts=atts.cuda())
+    _check_out(z, "out_region", yr)
+    _check_out(z, "out_region_full", yfull)
+    cot_r = syn.symmetric("beit.cot_region", tuple(yr.shape), 1.0).cuda()
+    ((yr.float() * cot_r).sum() + 0.5 * (yfull.float() * cot).sum()).backward()
+    _check_grads(z, "grad_region", m)
 
 
 def test_beit_tower_at_384px_vs_oracle():
@@ -256,6 +265,43 @@ def test_causal_lm_answer_decoder_vs_golden():
     _check_grads(z, "grad", m)
     err, cos = rel_l2(z, "grad_in/question_states", enc.grad)
     assert err <= GRAD_TOL and cos >= COS_TOL, (err, cos)
+
+
+def test_bert_causal_lm_answer_decoder_vs_golden():
+    """xbert.BertLMHeadModel: the answer decoder XFMForVQA builds for a bert-named text encoder (model_generation.py:52-54,
+    xbert.py:1235-1347) -- the causal_lm_2L case on the BERT stack, fixture from the reference's own class."""
+    from xfm_amd.xbert import BertConfig, BertLMHeadModel
+    z, meta = load("bert_causal_lm_2L")
+    B, L, S = meta["B"], meta["L"], meta["S"]
+    m = BertLMHeadModel(BertConfig(num_hidden_layers=meta["layers"], fusion_layer=0, encoder_width=768))
+    ours = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+    assert ours == meta["spec"]
+    _load_into(m, meta["spec"])
+    m.cuda().finalize().eval()
+    ids, atts, enc_atts = (torch.tensor(meta[k]).cuda() for k in ("ids", "atts", "enc_atts"))
+    enc = syn.gaussian("causal.question_states", (B, S, 768), 0.7).cuda().requires_grad_(True)
+    weights = (syn.gaussian("causal.weights", (B,), 1.0).abs() + 0.1).cuda()
+    with torch.no_grad():
+        full = m(ids, attention_mask=atts, encoder_hidden_states=enc, encoder_attention_mask=enc_atts)
+        assert m(ids, attention_mask=atts, encoder_hidden_states=enc, encoder_attention_mask=enc_atts, return_logits=True).shape == (B, L - 1, 30522)
+    _check_out(z, "logits", full.logits)
+    res = m(ids, attention_mask=atts, encoder_hidden_states=enc, encoder_attention_mask=enc_atts,
+            labels=ids.masked_fill(ids == 0, -100), return_dict=True, reduction="none")
+    ref_rows = torch.from_numpy(z["loss_rows"])
+    assert torch.allclose(res.loss.float().cpu(), ref_rows, rtol=3e-3, atol=3e-3), (res.loss, ref_rows)
+    loss = (weights * res.loss).sum() / B
+    ref = float(z["loss"])
+    assert abs(float(loss) - ref) <= 2e-3 * abs(ref), (float(loss), ref)
+    loss.backward()
+    _check_grads(z, "grad", m)
+    err, cos = rel_l2(z, "grad_in/question_states", enc.grad)
+    assert err <= GRAD_TOL and cos >= COS_TOL, (err, cos)
+    # and XFMForVQA picks it for a bert-named text encoder
+    from xfm_amd.model_generation import XFMForVQA
+    vqa = XFMForVQA({"use_beit_v2": True, "image_res": 224, "patch_size": 16, "local_attn_depth": -1, "text_encoder": "bert-base-uncased",
+                     "text_num_hidden_layers": 1, "text_fusion_start_at": 1, "fusion_num_hidden_layers": 1, "fusion_fusion_start_at": 0,
+                     "embed_dim": 256, "temp": 0.07, "vision_depth": 1, "pad_token_id": 0, "decoder_fusion_start_at": 0, "num_dec_layers": 1})
+    assert type(vqa.text_decoder).__name__ == "BertLMHeadModel" and "text_decoder.cls.predictions.decoder.weight" in vqa.state_dict()
 
 
 def test_xbert_variant_vs_golden():

@@ -53,6 +53,16 @@ def test_beit_blocks_and_mask_path():
     check(z, "out_masked", ym, ATOL, RTOL)
     (ym * cot).sum().backward()
     _check_grads(z, "grad_masked", P)
+    # the region call form (beit2.py:467-475): per-sample pooled cls over a region mask, samples sharing images
+    for v in P.values():
+        v.grad = None
+    idx, atts = syn.region_case(B)
+    yr, yfull = O.beit_region_outputs(O.beit_forward(P, "", image, depth=depth), idx, atts)
+    check(z, "out_region", yr, ATOL, RTOL)
+    check(z, "out_region_full", yfull, ATOL, RTOL)
+    cot_r = syn.symmetric("beit.cot_region", tuple(yr.shape), 1.0)
+    ((yr * cot_r).sum() + 0.5 * (yfull * cot).sum()).backward()
+    _check_grads(z, "grad_region", P)
 
 
 def test_roberta_text_tower_and_mlm_head():
@@ -127,6 +137,24 @@ def test_causal_lm_answer_decoder():
     rows, logits = O.causal_lm_loss(P, ids, atts, enc, enc_atts, ids.masked_fill(ids == 1, -100), meta["layers"])
     assert np.allclose(rows.detach().numpy(), z["loss_rows"], rtol=1e-5, atol=1e-4)
     # the reference returns the UNSHIFTED logits in .logits
+    loss = (weights * rows).sum() / B
+    assert abs(float(loss) - float(z["loss"])) < 1e-4
+    loss.backward()
+    _check_grads(z, "grad", P)
+    check(z, "grad_in/question_states", enc.grad, ATOL, RTOL)
+
+
+def test_bert_causal_lm_answer_decoder():
+    """xbert.BertLMHeadModel (model_generation.py:52-54), fixture from the reference's own class."""
+    z, meta = load("bert_causal_lm_2L")
+    B, L, S = meta["B"], meta["L"], meta["S"]
+    P = _params(meta["spec"])
+    ids, atts, enc_atts = (torch.tensor(meta[k]) for k in ("ids", "atts", "enc_atts"))
+    enc = syn.gaussian("causal.question_states", (B, S, 768), 0.7).requires_grad_(True)
+    weights = syn.gaussian("causal.weights", (B,), 1.0).abs() + 0.1
+    rows, logits = O.bert_causal_lm_loss(P, ids, atts, enc, enc_atts, ids.masked_fill(ids == 0, -100), meta["layers"])
+    assert np.allclose(rows.detach().numpy(), z["loss_rows"], rtol=1e-5, atol=1e-4)
+    check(z, "logits", logits, ATOL, RTOL)
     loss = (weights * rows).sum() / B
     assert abs(float(loss) - float(z["loss"])) < 1e-4
     loss.backward()

@@ -128,6 +128,15 @@ def gen_beit(depth=2, B=4):
     pack("out_masked", ym, out)
     (ym * cot).sum().backward()
     grads_of(m, out, "grad_masked")
+    # the region call form (beit2.py:467-475): 6 samples over the 4 images, ragged region masks
+    m.zero_grad()
+    idx, atts = syn.region_case(B)
+    yr, yfull = m(image, idx_to_group_img=idx, image_atts=atts)
+    pack("out_region", yr, out)
+    pack("out_region_full", yfull, out)
+    cot_r = syn.symmetric("beit.cot_region", tuple(yr.shape), 1.0)
+    ((yr * cot_r).sum() + 0.5 * (yfull * cot).sum()).backward()
+    grads_of(m, out, "grad_region")
     save(f"beit_{depth}blk", out, {"spec": spec_of(m), "B": B, "depth": depth})
 
 
@@ -259,6 +268,43 @@ BERT_BASE_CONFIG = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12,
                         hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
                         max_position_embeddings=512, type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-12,
                         pad_token_id=0)
+
+
+def gen_bert_causal_lm(layers=2, B=6, L=9, S=30):
+    """The answer decoder of a bert-named VQA model (model_generation.py:52-54 -> xbert.BertLMHeadModel, xbert.py:1235-1347): BERT
+    embeddings, causal self mask, cross-attention in every layer, BertOnlyMLMHead, shifted CE with reduction='none', per-sequence
+    weighted sum -- the same case as causal_lm_2L on the xbert stack ([PAD] = 0)."""
+    from models.xbert import BertConfig, BertLMHeadModel
+    torch.manual_seed(0)
+    cfg = BertConfig(**BERT_BASE_CONFIG)
+    cfg.num_hidden_layers, cfg.fusion_layer, cfg.encoder_width = layers, 0, 768
+    m = BertLMHeadModel(cfg)
+    load_formula(m)
+    m.eval()
+    b = syn.pretrain_batch(B, seed=13, with_image=False, vocab=30522)
+    ids = b["text_ids"][:, :L].clone()
+    ids[ids == 0] = 5   # (the RoBERTa-style generator's <s> = 0 is [PAD] here)
+    atts = torch.ones(B, L, dtype=torch.long)
+    for r, n in enumerate([9, 4, 7, 3, 9, 5][:B]):  # ragged answers, padded with [PAD] = 0
+        atts[r, n:] = 0
+        ids[r, n:] = 0
+    enc = syn.gaussian("causal.question_states", (B, S, 768), 0.7).requires_grad_(True)
+    enc_atts = torch.ones(B, S, dtype=torch.long)
+    enc_atts[1, 20:] = 0
+    enc_atts[4, 11:] = 0
+    weights = syn.gaussian("causal.weights", (B,), 1.0).abs() + 0.1
+    out = {}
+    res = m(ids, attention_mask=atts, encoder_hidden_states=enc, encoder_attention_mask=enc_atts,
+            labels=ids.masked_fill(ids == 0, -100), return_dict=True, reduction="none")
+    out["loss_rows"] = res.loss.detach().numpy().astype(np.float32)
+    loss = (weights * res.loss).sum() / B
+    out["loss"] = np.asarray(float(loss))
+    pack("logits", res.logits, out)
+    loss.backward()
+    grads_of(m, out, "grad")
+    pack("grad_in/question_states", enc.grad, out)
+    save(f"bert_causal_lm_{layers}L", out, {"spec": spec_of(m), "B": B, "L": L, "S": S, "layers": layers,
+                                            "ids": ids.tolist(), "atts": atts.tolist(), "enc_atts": enc_atts.tolist()})
 
 
 def gen_xbert(layers=2, B=4):
@@ -955,7 +1001,7 @@ def main():
     torch.set_num_threads(int(os.environ.get("GEN_THREADS", "8")))
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval, "harness": gen_harness, "checkpoint_vqa": gen_checkpoint_vqa, "grounding": gen_grounding,
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "bert_causal_lm": lambda: gen_bert_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval, "harness": gen_harness, "checkpoint_vqa": gen_checkpoint_vqa, "grounding": gen_grounding,
             "retrieval_384": lambda: gen_retrieval(B=8, res=384, T=40, name="retrieval_384"),
             "vqa_480": lambda: gen_vqa(res=480, name="vqa_480")}
     cfg_jobs = {"retrieval_cfg": gen_retrieval_cfg, "vqa_cfg": gen_vqa_cfg, "pretrain_cfg": gen_pretrain_cfg, "imagenet_cfg": gen_imagenet_cfg}   # config-shape fixtures: minutes of CPU each, only on request

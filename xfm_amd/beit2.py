@@ -336,6 +336,19 @@ class _TrunkFn(torch.autograd.Function):
         return dstream.view(B, N, D), None, None
 
 
+def region_outputs(full, idx_to_group_img, image_atts):
+    """The region call form's per-sample output (beit2.py:467-475): sample i reads the normalised patch rows of image
+    idx_to_group_img[i] and pools its own pseudo-cls as their image_atts-weighted mean (fp32 sums, one rounding to the tower's
+    bf16).  A row gather and a [bs, P] x [bs, P, D] contraction on a handful of samples: device-side glue (differentiable ATen ops on
+    the HIP tensors), no tower kernel involved."""
+    idx = idx_to_group_img.to(device=full.device, dtype=torch.long).view(-1)
+    x_bs = full[:, 1:, :].index_select(0, idx)
+    w = image_atts.to(device=full.device)[:, 1:].to(torch.float32)
+    assert w.shape == x_bs.shape[:2], "image_atts is [bs, 1 + patches]"
+    cls = torch.einsum("bp,bpd->bd", w, x_bs.float()) / w.sum(dim=1, keepdim=True)
+    return torch.cat([cls.to(full.dtype).unsqueeze(1), x_bs], dim=1)
+
+
 class _TokensFn(torch.autograd.Function):
     """x0 = cat(cls, where(mask, mask_token, tok[b mod Bt])) in fp32; the cls / mask-token gradients are accumulated straight into
     the gradient arena."""
@@ -478,8 +491,10 @@ class VisionTransformer(OwnsArena, nn.Module):
         the token assembly, but each runs the trunk as its own pass -- view 0 on the current stream, view 1 on `split_stream` -- and
         the result is the pair (out0, out1) instead of one [2B, N, D] tensor; out1 lives on `split_stream` (the caller joins).
         Autograd replays each pass's backward on its forward stream."""
-        if idx_to_group_img is not None or image_atts is not None:
-            raise NotImplementedError("region / grouped-image path (beit2.py:467-475) is outside the hot-path scope")
+        if (idx_to_group_img is None) != (image_atts is None):
+            raise ValueError("the region call form takes idx_to_group_img AND image_atts (beit2.py:467-475)")
+        if idx_to_group_img is not None and (do_mask or split_stream is not None):
+            raise ValueError("the region call form has no masked view (beit2.py:467-475)")
         self._ready()
         B = x.shape[0]
         D = self.embed_dim
@@ -515,6 +530,8 @@ class VisionTransformer(OwnsArena, nn.Module):
             x0.record_stream(split_stream)
             return (out0, out1), ids_mask
         out = _TrunkFn.apply(x0, self, dp)           # bf16 [B, N, D]: fc_norm on every row, then row 0 <- mean of the patch rows
+        if idx_to_group_img is not None:
+            return region_outputs(out, idx_to_group_img, image_atts), out
         return (out, ids_mask) if do_mask else out
 
 

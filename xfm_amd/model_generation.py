@@ -36,13 +36,16 @@ class XFMForVQA(XFMBase):
         assert isinstance(config['pad_token_id'], int)
         self.pad_token_id = config['pad_token_id']
         config_enc = self.text_encoder.config
-        if 'roberta' not in config['text_encoder']:
-            raise NotImplementedError("the BERT answer decoder (xbert.BertLMHeadModel, model_generation.py:54) is not built; "
-                                      "use a roberta text_encoder")
+        roberta = 'roberta' in config['text_encoder']
+        if roberta:
+            cfg_cls, dec_cls = RobertaConfig, RobertaForCausalLM
+        else:   # bert-named text encoders decode with xbert.BertLMHeadModel (model_generation.py:52-54)
+            from .xbert import BertConfig, BertLMHeadModel
+            cfg_cls, dec_cls = BertConfig, BertLMHeadModel
         if 'text_config' in config:
-            config_dec = RobertaConfig(**config['text_config'])
+            config_dec = cfg_cls(**config['text_config'])
         elif os.path.exists(os.path.join(config['text_encoder'], 'config.json')):
-            config_dec = RobertaConfig.from_json_file(os.path.join(config['text_encoder'], 'config.json'))
+            config_dec = cfg_cls.from_json_file(os.path.join(config['text_encoder'], 'config.json'))
         else:
             config_dec = copy.deepcopy(config_enc)
         config_dec.encoder_width = config_enc.hidden_size
@@ -50,7 +53,7 @@ class XFMForVQA(XFMBase):
         config_dec.num_hidden_layers = config['num_dec_layers']
         self.cross_encoder_width = config_enc.encoder_width  # = vision width
         self.dec_encoder_width = config_enc.hidden_size
-        self.text_decoder = RobertaForCausalLM(config=config_dec)
+        self.text_decoder = dec_cls(config=config_dec)
         if self.dec_encoder_width != self.cross_encoder_width:
             self.init_params = ['text_decoder.' + n for n, _ in self.text_decoder.named_parameters()
                                 if ('crossattention.self.key' in n) or ('crossattention.self.value' in n)]

@@ -199,3 +199,20 @@ def vqa_batch(batch_size, seed=1234, image_res=480, max_tokens=40, max_answers=1
         o += n
     return NS(image=b["image"], q_ids=b["text_ids"], q_atts=b["text_atts"], k=k, a_ids=ans["text_ids"], a_atts=ans["text_atts"],
               weights=torch.from_numpy(w.astype(np.float32)))
+
+
+def region_case(n_images, grid=14):
+    """Inputs of the vision tower's region call form (beit2.py:467-475): bs = n_images + 2 samples over n_images images
+    (`idx_to_group_img` [bs], some images used twice) and a ragged region mask per sample (`image_atts` [bs, 1 + grid^2] of 0 / 1: a
+    rectangle of patches, column 0 = the cls slot, always 1)."""
+    bs = n_images + 2
+    idx = torch.tensor([(3 * i + 1) % n_images for i in range(bs)], dtype=torch.long)
+    atts = torch.zeros(bs, 1 + grid * grid, dtype=torch.long)
+    atts[:, 0] = 1
+    for i in range(bs):
+        y0, x0 = (2 * i) % (grid - 4), (3 * i + 1) % (grid - 5)
+        h, w = 3 + i % 4, 4 + (2 * i) % 5
+        m = torch.zeros(grid, grid, dtype=torch.long)
+        m[y0:y0 + h, x0:x0 + w] = 1
+        atts[i, 1:] = m.reshape(-1)
+    return idx, atts

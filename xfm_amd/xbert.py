@@ -6,7 +6,9 @@ Same layer stack and kernels as `xfm_amd.xroberta` (state_dict keys of a layer a
   * BertSelfAttention (xbert.py:296-301, 329-330) scales the scores after QK^T unless `config.fp16`; the HIP attention
     kernel applies the scale to the fp32 scores in either case, so both orderings are served by the one kernel;
   * BertForMaskedLM (xbert.py:1523-1618): `.bert` is an attribute (not a method), one head `cls.predictions`
-    (transform.dense -> GELU -> transform.LayerNorm -> decoder + shared bias, xbert.py:663-697), no causal head.
+    (transform.dense -> GELU -> transform.LayerNorm -> decoder + shared bias, xbert.py:663-697);
+  * BertLMHeadModel (xbert.py:1235-1347): the causal answer decoder of a bert-named VQA model (model_generation.py:54) -- `bert` +
+    `cls`, causal self-attention mask, next-token shift, `reduction='none'` CE summed per sequence.
 """
 import json
 from types import SimpleNamespace
@@ -135,3 +137,63 @@ class BertForMaskedLM(OwnsArena, nn.Module):
             return SimpleNamespace(loss=None, logits=logits, hidden_states=None, attentions=None)
         loss, logits = lm_head_ce(seq.reshape(-1, seq.shape[-1]), head, labels.reshape(-1), 'mean')
         return SimpleNamespace(loss=loss, logits=logits[:, :V].view(Bq, Tq, V), hidden_states=None, attentions=None)
+
+
+class BertLMHeadModel(OwnsArena, nn.Module):
+    """Causal decoder with cross-attention to encoder states on the BERT-flavoured stack (xbert.py:1235-1347): what
+    model_generation.py:54 builds as `text_decoder` for a bert-named text encoder.  Same fused stack and LM-head node as
+    xroberta.RobertaForCausalLM; the state_dict keys are the reference's (`bert.*`, `cls.predictions.*`).  Label smoothing
+    (xbert.py:1336-1337, LabelSmoothSoftmaxCEV1) is used by no XFM task model: > 0 raises.  Generation (beam search, past_key_values)
+    is outside the hot-path scope, as for the RoBERTa decoder."""
+
+    def __init__(self, config, label_smoothing=0.0):
+        super().__init__()
+        if label_smoothing > 0:
+            raise NotImplementedError("label smoothing (xbert.py:1336-1337) is not used on the XFM path")
+        self.config = config
+        self.bert = BertModel(config, add_pooling_layer=False)
+        self.cls = BertOnlyMLMHead(config)
+        self.label_smoothing = label_smoothing
+        self._arena = None
+
+    def linear_slots(self, prefix=""):
+        return self.bert.linear_slots(prefix + "bert.") + self.cls.predictions.linear_slots(prefix + "cls.predictions.")
+
+    def attach(self, arena):
+        self._arena = arena
+        self.bert.attach(arena)
+
+    def finalize(self, device=None):
+        device = device or self.cls.predictions.bias.device
+        self.attach(ParamArena(self, self.linear_slots(), device))
+        self._own_arena = True
+        return self
+
+    def get_output_embeddings(self):
+        return self.cls.predictions.decoder
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
+                inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None, labels=None, past_key_values=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, is_decoder=True,
+                reduction='mean', mode='multi_modal', return_logits=False):
+        if past_key_values is not None or use_cache:
+            raise NotImplementedError("incremental decoding caches (generation) are outside the hot-path scope")
+        outputs = self.bert(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, position_ids=position_ids,
+                            head_mask=head_mask, inputs_embeds=inputs_embeds, encoder_hidden_states=encoder_hidden_states,
+                            encoder_attention_mask=encoder_attention_mask, is_decoder=is_decoder, mode=mode)
+        seq = outputs.last_hidden_state
+        head = self.cls.predictions
+        V = self.config.vocab_size
+        B, T = seq.shape[:2]
+        if return_logits or labels is None:
+            logits = lm_head_logits(seq.reshape(-1, seq.shape[-1]), head).view(B, T, V)
+            if return_logits:
+                return logits[:, :-1, :].contiguous()
+            return SimpleNamespace(loss=None, logits=logits, hidden_states=seq, past_key_values=None, attentions=None,
+                                   cross_attentions=None)
+        shifted, lab = seq[:, :-1, :], labels[:, 1:]   # next-token prediction (xbert.py:1331-1333)
+        loss, logits = lm_head_ce(shifted.reshape(-1, seq.shape[-1]), head, lab.reshape(-1), reduction)
+        if reduction == 'none':
+            loss = loss.view(B, -1).sum(1)
+        return SimpleNamespace(loss=loss, logits=logits[:, :V].view(B, T - 1, V), hidden_states=seq, past_key_values=None,
+                               attentions=None, cross_attentions=None)

@@ -334,9 +334,15 @@ class XFMBase(nn.Module):
 
     # ---- towers ---------------------------------------------------------------------------------
     def get_vision_embeds(self, image, image_atts=None, idx_to_group_img=None, do_mask=False, ids_mask=None, split_stream=None):
-        if idx_to_group_img is not None:
-            raise NotImplementedError("region path (xfm.py:574-597) is outside the hot-path scope")
         self._ready()
+        if idx_to_group_img is not None:   # fewer images than samples (xfm.py:574-597)
+            idx = idx_to_group_img.to(image.device).view(-1)
+            if image_atts is None:     # every sample sees its whole image: the tower's output, one copy per sample
+                image_embeds_fullatts = self.vision_encoder(image).index_select(0, idx)
+                return image_embeds_fullatts, _ones_mask(image_embeds_fullatts)
+            assert image_atts.size(0) == idx.size(0)
+            image_embeds, image_embeds_fullatts = self.vision_encoder(image, idx_to_group_img=idx, image_atts=image_atts)
+            return image_embeds, image_atts, image_embeds_fullatts.index_select(0, idx)
         if do_mask:
             image_embeds, id_masked = self.vision_encoder(image, do_mask=True, ids_mask=ids_mask, split_stream=split_stream)
             if isinstance(image_embeds, tuple):   # two views as two passes (the second one on `split_stream`)
