@@ -54,8 +54,10 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # (defaults: 2.5 s of timed steps behind 15 warm-up steps -- a fresh process on a fresh box needs ~10 steps before the caching
+    # allocator has its blocks and the clocks have settled: 20 steps behind 5 read 1-1.5 ms per step slower than the steady state)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--batch", type=int, default=0, help="units per GPU (0 = the workload's configured batch; pre-train: 64, the north-star's)")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward(+all-reduce) only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -293,6 +295,8 @@ def fusion_probe(model, B, host_batch, packed, iters=5):
     afterwards.  Two fractions of the MFMA peak are reported: by the FLOPs the REFERENCE spends on these 4B padded sample-passes
     (35.32 GFLOP each: throughput credit for work this build avoids -- K/V projected once per image, no padding rows) and by the
     FLOPs the kernels here actually execute (hardware utilisation)."""
+    from xfm_amd.arena import grads_ready
+    grads_ready()   # (this probe runs backward passes outside the accelerator: behind the last step's asynchronous zero_grad)
     from xfm_amd.packing import Pack
     dev = next(model.parameters()).device
     g = torch.Generator(device="cpu").manual_seed(7)

@@ -156,6 +156,7 @@ def test_loop_text_then_image_steps_match_torch_adamw_replay():
     assert grp["weight_decay"] == 0.05
     want = params0["text_encoder.roberta.embeddings.word_embeddings.weight"][row] * (1 - grp["lr"] * 0.05) ** 3
     assert torch.allclose(we[row].detach(), want.cuda(), rtol=1e-6, atol=1e-9)
+    acc.grads_ready()   # (the step's zero_grad runs on its own stream, under the next forward: readers outside the accelerator wait for it)
     assert float(arena.grad.abs().max()) == 0.0  # zeroed for the next step
 
 
@@ -221,6 +222,7 @@ def test_resume_from_optimizer_state_dict_is_bit_identical():
 
     def third_step(model, optimizer, accelerator):
         accelerator._step += 1
+        accelerator.grads_ready()   # (a hand-written gradient goes in behind the previous step's asynchronous zero_grad)
         model._arena.grad.copy_(G)
         accelerator.optimizer_step(optimizer, model)
         torch.cuda.synchronize()

@@ -31,6 +31,11 @@ from .accelerator import Accelerator
 
 
 _DRY = os.environ.get("XFM_DDP_DRY", "0") == "1"
+# The step's optimizer.zero_grad() (1.46 GB of fills over the live gradient ranges, ~0.3 ms at HBM speed) on a stream of its own,
+# behind the AdamW kernels that read the gradients: nothing reads or writes a gradient again before the NEXT backward pass, so the
+# fills run under the next step's forward instead of at the end of the serial optimizer tail; backward_step (and every accelerator
+# entry that touches the gradient arena) waits for them.  A/B knob.
+_ASYNC_ZERO = os.environ.get("XFM_ASYNC_ZERO", "1") != "0"
 
 
 class _Wrapped(torch.nn.Module):
@@ -110,6 +115,7 @@ class RCCLDDPAccelerator(Accelerator):
         self._use = {}
         self._op = dist.ReduceOp.SUM
         self.timing = None         # (start, end) torch.cuda.Event pair a caller installs to time the exposed part of the exchange
+        self._zero_stream = None   # the optimizer step's zero_grad runs here (_zero_async)
 
     # ------------------------------------------------------------------------------------------ set-up
     def set_seed(self):
@@ -277,6 +283,7 @@ class RCCLDDPAccelerator(Accelerator):
         self._sync_now = (self._step % self.accum) == 0 and sync is not False
         self._done_ranges = []
         arena = self.arena
+        self._grads_ready()
         if arena is not None:
             arena.reattach()  # a caller's optimizer.zero_grad(set_to_none=True) must not detach .grad from the arena
         self._overlap_ok = (self._dist and self._sync_now and arena is not None and self._comm_stream is not None
@@ -334,8 +341,32 @@ class RCCLDDPAccelerator(Accelerator):
             for a, b in self._ranges:
                 arena.grad[a:b].mul_(1.0 / self.world_size)
 
+    def grads_ready(self):
+        """The current stream may touch the gradient arena: a pending asynchronous zero_grad (optimizer_step) has to land first.
+        Called by every accelerator entry; callers that read or write `.grad` themselves right after optimizer_step call it too."""
+        from ..arena import grads_ready
+        if self.arena is not None and self.arena.grad.is_cuda:
+            grads_ready(self.arena.grad.device)
+
+    _grads_ready = grads_ready
+
+    def _zero_async(self):
+        arena = self.arena
+        if not (_ASYNC_ZERO and arena.grad.is_cuda):
+            return arena.zero_grad(self._ranges)
+        from ..arena import _PENDING_ZERO
+        if self._zero_stream is None:
+            self._zero_stream = torch.cuda.Stream()
+        self._zero_stream.wait_stream(torch.cuda.current_stream())   # the optimizer kernels have read the gradients
+        with torch.cuda.stream(self._zero_stream):
+            arena.zero_grad(self._ranges)
+            ev = torch.cuda.Event()
+            ev.record(self._zero_stream)
+        _PENDING_ZERO[arena.grad.device.index] = ev
+
     def zero_grad(self):
         if self.arena is not None:
+            self._grads_ready()
             self.arena.zero_grad(self.live_ranges())
 
     def _grad_norm_sq(self):
@@ -356,6 +387,7 @@ class RCCLDDPAccelerator(Accelerator):
             optimizer.zero_grad()
             return float(total)
         arena.reattach()
+        self._grads_ready()
         self.live_ranges()
         fused = arena.grad.is_cuda and self.fused_optimizer and _is_adamw(optimizer)
         if not fused:
@@ -378,7 +410,7 @@ class RCCLDDPAccelerator(Accelerator):
         arena.bump()
         # (xfm_adamw can zero the gradients in its own sweep -- `zero_grad` -- but the fourth store stream costs the kernel more than
         # the separate fills: 837 vs 625 + 170 us per step, measured round 4)
-        arena.zero_grad(self._ranges)
+        self._zero_async()
         self.last_grad_norm = norm  # device tensor: no host sync on the step path
         return norm
 

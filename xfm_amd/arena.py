@@ -121,6 +121,21 @@ class OwnsArena:
             super().zero_grad(set_to_none=set_to_none)
 
 
+_PENDING_ZERO = {}   # device index -> torch.cuda.Event of an asynchronous zero_grad still to land (RCCLDDPAccelerator._zero_async)
+
+
+def grads_ready(device=None):
+    """Make the current stream wait for a pending asynchronous zero_grad of the gradient arena(s) on `device` (default: current).  The
+    accelerator calls it before every backward / optimizer step; code that reads or writes parameter gradients on its own right after
+    an accelerator step (a probe, a test) calls it first.  No-op when nothing is pending."""
+    if not _PENDING_ZERO:
+        return
+    dev = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    ev = _PENDING_ZERO.pop(dev, None)
+    if ev is not None:
+        torch.cuda.current_stream(dev).wait_event(ev)
+
+
 def grad_of(p):
     """Gradient view of a parameter inside its arena (re-attached if a caller dropped .grad); marks the parameter live -- every
     kernel launch site that accumulates a parameter gradient gets its destination through here or through slot.dw / slot.db."""
@@ -345,6 +360,8 @@ class ParamArena:
     def zero_grad(self, ranges=None):
         """ranges: the (start, end) arena ranges of live parameters (dead ranges are never written and stay zero); None = everything."""
         if ranges is None:
+            if self.grad.is_cuda:
+                grads_ready(self.grad.device)
             self.grad.zero_()
         else:
             for a, b in ranges:

@@ -251,6 +251,9 @@ class _WgradStream:
         if label is not None:
             _marks.mark(label + " begin")
         self.main = torch.cuda.current_stream(device)
+        if label is not None:   # a tower's backward starts: its gradient writes must follow a pending asynchronous zero_grad (arena.grads_ready)
+            from .arena import grads_ready
+            grads_ready(device)
         self.on = _WgradStream.enabled
         if self.on:
             # one side stream per LAUNCH stream: the text tower's backward runs on its own stream next to the ViT's, and its small
