@@ -246,6 +246,35 @@ def test_resume_from_optimizer_state_dict_is_bit_identical():
         assert torch.equal(a[n], b[n]), f"{n} differs after resume"
 
 
+def test_gradient_norm_shares_taken_inside_backward_equal_the_pass_after_it(monkeypatch):
+    """XFM_EARLY_NORM (accelerator._early_sumsq): from the step after the live set has settled, the text and fusion towers' share of
+    the clip norm is taken on their weight-gradient side stream as soon as their backward is over, the rest after backward -- same
+    kernel over the same ranges, summed in range order: the norm the optimizer clips with equals the one a single pass after backward
+    computes on the very same gradient arena, bit for bit, and the early shares are really in use."""
+    import xfm_amd.accelerators.rccl_ddp_accelerator as A
+    from xfm_amd import functional as Fx
+    z, meta = load("pretrain_small")
+    m, wrapped, opt, acc = _build(meta)
+    B = meta["B"]
+    taken = []
+    for step in range(3):
+        b = {k: v.cuda() for k, v in syn.pretrain_batch(B, seed=300 + step).items()}
+        masks = syn.mim_block_mask(B, 14, 75, seed=300 + step)
+        losses = wrapped(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"], masked_pos=b["masked_pos"],
+                         masked_ids=b["masked_ids"], ret_mim_loss=True, data_source="image", ids_mask=masks,
+                         neg_idx=([(i + 1) % B for i in range(B)], [(i + 2) % B for i in range(B)]))
+        acc.backward_step(losses["loss_itc"] + losses["loss_itm"] + losses["loss_mlm"] + losses["loss_mim"], opt)
+        taken.append(len(acc._norm_early))
+        torch.cuda.synchronize()
+        ref = torch.zeros(1, device="cuda")
+        for a, b_ in acc.live_ranges():
+            Fx.sumsq(m._arena.grad[a:b_], ref)
+        norm = acc.optimizer_step(opt, m)
+        assert torch.equal(norm.reshape(1), ref.sqrt()), (step, float(norm), float(ref.sqrt()))
+    assert taken[0] == 0 and taken[1] >= 2 and taken[2] >= 2, taken   # step 0 discovers the live set; then both towers' ranges leave early
+    assert A._EARLY_NORM
+
+
 def test_collectives_through_rccl_in_a_group_of_one():
     """The N > 1 branches on hardware before a multi-GPU node is available: a process group of ONE rank on backend 'nccl' (= RCCL)
     with FORCE_COLLECTIVES, three pre-training steps (tests/nccl_w1_worker.py).  The live-set agreement, the arena broadcast, the

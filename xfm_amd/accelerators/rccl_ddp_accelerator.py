@@ -36,6 +36,11 @@ _DRY = os.environ.get("XFM_DDP_DRY", "0") == "1"
 # fills run under the next step's forward instead of at the end of the serial optimizer tail; backward_step (and every accelerator
 # entry that touches the gradient arena) waits for them.  A/B knob.
 _ASYNC_ZERO = os.environ.get("XFM_ASYNC_ZERO", "1") != "0"
+# The squared gradient norm of a tower's arena ranges as soon as the tower's backward (and, at N > 1, its all-reduce) is over: the text
+# and fusion towers (70 % of the live gradient bytes) are final while the ViT backward still runs, so their share of the clip norm's
+# read pass over the gradients leaves the serial optimizer tail.  Same kernel, same ranges, same order of the final sum: the norm is
+# bit-identical to the one computed after backward.  A/B knob.
+_EARLY_NORM = os.environ.get("XFM_EARLY_NORM", "1") != "0"
 
 
 class _Wrapped(torch.nn.Module):
@@ -116,6 +121,8 @@ class RCCLDDPAccelerator(Accelerator):
         self._op = dist.ReduceOp.SUM
         self.timing = None         # (start, end) torch.cuda.Event pair a caller installs to time the exposed part of the exchange
         self._zero_stream = None   # the optimizer step's zero_grad runs here (_zero_async)
+        self._norm_early = {}      # (a, b) live range -> (sum of squares [1], event): computed from inside backward (_early_sumsq)
+        self._early_norm_ok = False
 
     # ------------------------------------------------------------------------------------------ set-up
     def set_seed(self):
@@ -220,8 +227,11 @@ class RCCLDDPAccelerator(Accelerator):
         rec = self._use[id(node)]
         rec[0] += delta
         # overlap needs a live set every rank already agrees on (i.e. from the second step with a given loss mix on)
-        if delta < 0 and rec[0] == 0 and rec[2] is not None and self._overlap_ok:
-            self._launch(rec[2])
+        if delta < 0 and rec[0] == 0 and rec[2] is not None:
+            if self._overlap_ok:
+                self._launch(rec[2])
+            elif self._early_norm_ok and not self._dist:
+                self._early_sumsq(rec[2])
 
     def _on_blocks_done(self, vit, lo, hi, wgrad):
         """Blocks [lo, hi) of the vision trunk have passed their backward (called from the trunk's backward; `wgrad` is its
@@ -269,10 +279,40 @@ class RCCLDDPAccelerator(Accelerator):
             if d == dev and side is not extra_stream:
                 self._comm_stream.wait_stream(side)
         with torch.cuda.stream(self._comm_stream):
+            n_before = len(self._pending)
             for a, b in _clip(self._ranges, *rng):
                 self._exchange(a, b)
                 self.stats["overlapped_bytes"] += (b - a) * (2 if self.exchange_dtype == "bf16" else 4)
+            if self._early_norm_ok:   # the exchanged gradients of this range are final once its collectives are: their share of the norm now
+                for w in self._pending[n_before:]:
+                    w.wait()          # (stream-ordered: the communication stream, not the host, waits)
+                self._sumsq_ranges(_clip(self._ranges, *rng))
         self._done_ranges.append(rng)
+
+    def _sumsq_ranges(self, ranges):
+        """Sum of squares of each WHOLE live range in `ranges`, on the current stream, parked with an event for _grad_norm_sq."""
+        whole = set(self._ranges)
+        for a, b in ranges:
+            if (a, b) not in whole:   # (a tower boundary that cuts a live range: left to the pass after backward)
+                continue
+            acc = torch.zeros(1, dtype=torch.float32, device=self.arena.grad.device)
+            Fx.sumsq(self.arena.grad[a:b], acc)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._norm_early[(a, b)] = (acc, ev)
+
+    def _early_sumsq(self, rng):
+        """N = 1: a tower's backward is over (its weight gradients have been joined into the current stream): its ranges' share of the
+        gradient norm runs on the tower's weight-gradient side stream (behind whatever that stream still holds for the tower, e.g. the LM
+        head's weight gradients that re-join at the end of backward) while the launch stream goes on with the next tower's backward."""
+        from ..xroberta import _WgradStream
+        cur = torch.cuda.current_stream()
+        side = _WgradStream._streams.get((self.arena.grad.device.index, cur.cuda_stream))
+        if side is None:
+            return self._sumsq_ranges(_clip(self._ranges, *rng))
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._sumsq_ranges(_clip(self._ranges, *rng))
 
     # ------------------------------------------------------------------------------------------ step
     def backward_step(self, loss, optimizer, sync=None):
@@ -288,10 +328,16 @@ class RCCLDDPAccelerator(Accelerator):
             arena.reattach()  # a caller's optimizer.zero_grad(set_to_none=True) must not detach .grad from the arena
         self._overlap_ok = (self._dist and self._sync_now and arena is not None and self._comm_stream is not None
                             and arena.live_ver == self._agreed_ver and self._agreed_ver >= 0)
+        # (the norm's early shares need the same settled live set; they are taken on the backward that the optimizer step follows)
+        self._norm_early = {}
+        self._early_norm_ok = (_EARLY_NORM and self._sync_now and arena is not None and arena.grad.is_cuda and self.clip > 0
+                               and self.fused_optimizer and arena.live_ver == self._agreed_ver and self._agreed_ver >= 0
+                               and (self._overlap_ok or not self._dist))
         if self._sync_now:
             self.stats = {"exchange_bytes": 0, "exchange_calls": 0, "overlapped_bytes": 0}
         loss.backward()
         self._overlap_ok = False
+        self._early_norm_ok = False
         if self._dist and self._sync_now:
             if self.timing is not None and self._comm_stream is not None:   # bench.py: end of backward -> all-reduce done
                 self.timing[0].record()
@@ -372,8 +418,15 @@ class RCCLDDPAccelerator(Accelerator):
     def _grad_norm_sq(self):
         """Over the live ranges only: parameters that never receive a gradient are zero (and stay zero), no need to read them."""
         out = torch.zeros(1, dtype=torch.float32, device=self.arena.grad.device)
-        for a, b in self._ranges:
-            Fx.sumsq(self.arena.grad[a:b], out)
+        early, self._norm_early = self._norm_early, {}
+        cur = torch.cuda.current_stream()
+        for a, b in self._ranges:   # (range order either way: out = ((0 + s_0) + s_1) + ... whether s_i was taken early or is taken here)
+            hit = early.get((a, b))
+            if hit is None:
+                Fx.sumsq(self.arena.grad[a:b], out)
+            else:
+                cur.wait_event(hit[1])
+                out += hit[0]
         return out
 
     def optimizer_step(self, optimizer, model, grad_norm: float = 0.0):
