@@ -26,8 +26,10 @@ def timeit(fn, iters):
 def main():
     M = N = int(os.environ.get("MN", "4096"))
     res = {}
-    for K in (256, 512, 1024, 2048):
-        for mode in ("hot", "ic"):
+    modes = tuple(os.environ.get("MODES", "hot,ic").split(","))   # (MODES=hot / MODES=ic: one operand regime per process, for the PMC passes)
+    ks = tuple(int(k) for k in os.environ.get("KS", "256,512,1024,2048").split(","))
+    for K in ks:
+        for mode in modes:
             nbuf = 1 if mode == "hot" else max(2, int(96e6 / ((M + N) * K * 2)))
             g = torch.Generator(device="cuda").manual_seed(K)
             As = [torch.randn(M, K, device="cuda", generator=g).bfloat16() for _ in range(nbuf)]
@@ -41,7 +43,9 @@ def main():
                 Fx.gemm_nt(As[i], Bs[i], out=out, tile_hint=5)
             res[(K, mode)] = timeit(run, 200)
             print(f"M=N={M} K={K:5d} {mode:4s}: {res[(K, mode)]:7.2f} us  ({nbuf} operand sets)", flush=True)
-    for mode in ("hot", "ic"):
+    for mode in modes:
+        if len(ks) < 4:
+            break
         print(f"{mode}: K-step from 256->512: {(res[(512, mode)] - res[(256, mode)]) / 4:.3f} us; 512->1024: {(res[(1024, mode)] - res[(512, mode)]) / 8:.3f} us; "
               f"1024->2048: {(res[(2048, mode)] - res[(1024, mode)]) / 16:.3f} us")
 
