@@ -845,6 +845,7 @@ def _view(slab, off, rows, cols, dtype=BF16):
 _KV_AHEAD = os.environ.get("XFM_KV_AHEAD", "1") != "0"   # A/B knob of RobertaModel.prefetch_cross_kv
 _RL_DEFER_LN = os.environ.get("XFM_RL_DEFER_LN", "1") != "0"   # A/B knob: one batched LayerNorm column-sum reduce per tower
 _RL_DEFER_WGRAD = os.environ.get("XFM_RL_DEFER_WGRAD", "1") != "0"
+_TOWER_JOIN_END = os.environ.get("XFM_TOWER_JOIN_END", "0") != "0"
 
 
 class _EncoderFnNative(torch.autograd.Function):
@@ -1062,7 +1063,10 @@ class _EncoderFnNative(torch.autograd.Function):
         elif need_denc:
             wg.sync_side()
             denc = denc32.to(BF16)
-        wg.join()
+        if _TOWER_JOIN_END:   # (A/B knob: the tower's queued weight gradients re-join at the END of the backward pass instead of here)
+            wg.join_at_end()
+        else:
+            wg.join()
         del keep
         if ctx.noted:
             arena_note_grad(model)
