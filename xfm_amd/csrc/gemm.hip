@@ -919,6 +919,8 @@ static int ksplit_plan(int M, int N, int K, int* nk_per_out) {
     if (sp > K / 1024) sp = K / 1024;
     if (sp < 1) sp = 1;
   }
+  static const int force_env = getenv("XFM_KSPLIT_FORCE") ? atoi(getenv("XFM_KSPLIT_FORCE")) : 0;   // experiment knob
+  if (force_env > 0 && force_env <= K / 64) sp = force_env;
   const int nk_all = K / 64, nk_per = cdiv(nk_all, sp);
   *nk_per_out = nk_per;
   return cdiv(nk_all, nk_per);  // slices that own at least one K-tile
@@ -946,7 +948,8 @@ int xfm_gemm_nt_ksplit_impl(const void* A, long lda, const void* B, long ldb, vo
   // k_splits = the slices that own K-tiles; the kernel re-derives nk_per = ceil(nk_all / k_splits) <= the planned one, under which
   // exactly those slices stay non-empty, so every plane of the workspace is written in full
   XFM_REQUIRE(cdiv(K / 64, cdiv(K / 64, slices)) == slices, "gemm_nt_ksplit: slice plan mismatch");
-  int rc = launch_nt<64, 128, 3>(g, EPI_F32, st);
+  static const int tile_env = getenv("XFM_KSPLIT_TILE") ? atoi(getenv("XFM_KSPLIT_TILE")) : 0;   // experiment knob: 1 = 128 x 128 tiles
+  int rc = tile_env == 1 ? launch_nt<128, 128, 3>(g, EPI_F32, st) : launch_nt<64, 128, 3>(g, EPI_F32, st);
   if (rc != XFM_OK) return rc;
   hipLaunchKernelGGL(ksplit_reduce_kernel, dim3(cdiv((long)M * N / 8, 256)), dim3(256), 0, st, ws, slices, (long)M * N, M, N, out, ldo, out_bf16);
   return xfm_check_launch("ksplit_reduce");
