@@ -887,6 +887,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model, wl, args.cpu_batch or wl["cpu_batch"], args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1 or forced:
+        from xfm_amd.accelerators import rccl_ddp_accelerator as _A
+        if _A._HOST_TIMES and rank == 0:
+            ht = sorted(_A._HOST_TIMES)
+            print(f"host time per all_reduce call: n {len(ht)}, median {ht[len(ht) // 2]:.3f} ms, p90 {ht[int(len(ht) * 0.9)]:.3f} ms, max {ht[-1]:.3f} ms, "
+                  f"sum per step {sum(ht) / max(counter[0], 1):.2f} ms", file=sys.stderr)
         dist.barrier()
         dist.destroy_process_group()
 

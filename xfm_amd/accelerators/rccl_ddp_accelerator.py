@@ -31,6 +31,10 @@ from .accelerator import Accelerator
 
 
 _DRY = os.environ.get("XFM_DDP_DRY", "0") == "1"
+# first-use order of the step's streams at set_up when collectives are on (see _touch_streams; measured in an RCCL group of one,
+# profiles/round5_forced_collectives.md: the text tower's backward starts at 19.6 ms instead of 30.3 ms, step -0.4 ms)
+_STREAM_TOUCH_DIST = "nccl,text,wmain,wtext,cast,zero,comm"
+_HOST_TIMES = [] if os.environ.get("XFM_DDP_HOST_TIMES", "0") == "1" else None   # diagnostic: host milliseconds per all_reduce call
 # The step's optimizer.zero_grad() (1.46 GB of fills over the live gradient ranges, ~0.3 ms at HBM speed) on a stream of its own,
 # behind the AdamW kernels that read the gradients: nothing reads or writes a gradient again before the NEXT backward pass, so the
 # fills run under the next step's forward instead of at the end of the serial optimizer tail; backward_step (and every accelerator
@@ -153,7 +157,10 @@ class RCCLDDPAccelerator(Accelerator):
         self.model = model
         arena = getattr(model, "_arena", None)
         self.arena = arena
-        if self._dist:
+        # (data parallel: first-use order of the step's streams chosen so that RCCL's stream does not share a hardware queue with the
+        # text tower's stream or with the ViT's weight-gradient stream -- _touch_streams; N = 1: the step's natural order is fine)
+        touch = os.environ.get("XFM_STREAM_TOUCH", _STREAM_TOUCH_DIST if self._dist else "") if (use_cuda and arena is not None) else ""
+        if self._dist and "nccl" not in touch:
             self.broadcast()
         if arena is not None:
             self._towers = self._tower_ranges(model)
@@ -163,10 +170,60 @@ class RCCLDDPAccelerator(Accelerator):
                 # XFM_COMM_PRIO (A/B knob): HIP priority of the communication stream
                 self._comm_stream = torch.cuda.Stream(priority=int(os.environ.get("XFM_COMM_PRIO", "0")))
                 self._install_tower_hooks(model)
+            if touch:
+                self._touch_streams(touch, local_rank)
             if optimizer is not None:
                 self._hook_optimizer(optimizer)
                 self._adopt_optimizer_state(optimizer)  # a resumed optimizer.load_state_dict() precedes set_up (Pretrain.py:437-447)
         return _Wrapped(model), optimizer, lr_scheduler
+
+    def _touch_streams(self, order, local_rank):
+        """HIP deals a process's streams onto its few hardware queues (GPU_MAX_HW_QUEUES = 4) in the order of their FIRST USE, and
+        streams that share a queue run in submission order: a kernel behind another stream's pending event wait is stuck even though
+        its own stream is free (rocprofv3 Queue_Id, tools/queue_roles.py: with the natural first-use order RCCL's stream and the text
+        tower's share a queue, and the text backward starts 11 ms late behind a collective that waits for a hand-over event).  Here
+        every stream of the step is created and used once, in an order chosen for the sharing it produces; `nccl` stands for the
+        set-up broadcast (ProcessGroupNCCL's first collective = its stream's first use)."""
+        from ..model_pretrain import _side_stream
+        from ..xroberta import _WgradStream
+        dev = torch.device("cuda", local_rank)
+        main = torch.cuda.current_stream(dev)
+
+        def wside(of):
+            key = (dev.index, of.cuda_stream)
+            if key not in _WgradStream._streams:
+                _WgradStream._streams[key] = torch.cuda.Stream(device=dev, priority=_WgradStream.priority)
+            return _WgradStream._streams[key]
+
+        for name in [t.strip() for t in order.split(",") if t.strip()]:
+            if name == "nccl":
+                if self._dist:
+                    self.broadcast()
+                continue
+            if name == "text":
+                st = _side_stream(dev)
+            elif name == "wmain":
+                st = wside(main)
+            elif name == "wtext":
+                st = wside(_side_stream(dev))
+            elif name == "cast":
+                if self.arena._cast_stream is None:
+                    self.arena._cast_stream = torch.cuda.Stream(device=dev)
+                st = self.arena._cast_stream
+            elif name == "zero":
+                if self._zero_stream is None:
+                    self._zero_stream = torch.cuda.Stream()
+                st = self._zero_stream
+            elif name == "comm":
+                st = self._comm_stream
+            elif name == "pad":
+                st = torch.cuda.Stream()
+                self._pads = getattr(self, "_pads", []) + [st]
+            else:
+                raise ValueError(f"XFM_STREAM_TOUCH: unknown stream '{name}'")
+            with torch.cuda.stream(st):
+                torch.zeros(64, device=dev).add_(1.0)   # (a first kernel: the stream gets its hardware queue now)
+        torch.cuda.synchronize(dev)
 
     def broadcast(self):
         """rank 0's weights to everyone: one collective over the parameter arena instead of 771 (ddp_accelerator.py:73-74)."""
@@ -259,7 +316,13 @@ class RCCLDDPAccelerator(Accelerator):
             w.wait()  # stream-ordered for RCCL (the host does not block); the unpack follows on this stream
             g.copy_(buf)
         elif async_ok and self._comm_stream is not None:
-            self._pending.append(dist.all_reduce(g, op=self._op, async_op=True))
+            if _HOST_TIMES is not None:
+                import time
+                t0 = time.perf_counter()
+                self._pending.append(dist.all_reduce(g, op=self._op, async_op=True))
+                _HOST_TIMES.append((time.perf_counter() - t0) * 1e3)
+            else:
+                self._pending.append(dist.all_reduce(g, op=self._op, async_op=True))
         else:
             dist.all_reduce(g, op=self._op)
 
