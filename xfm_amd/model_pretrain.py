@@ -10,6 +10,7 @@ _PACK_ROWS = os.environ.get("XFM_PACK_ROWS", "1") != "0"  # A/B knob: `text_lens
 # A/B (profiles/round3_mim_stream.md): the MIM-masked view of the images as its own ViT pass on a second stream, under the latency-bound
 # fusion tower, instead of batched with the clean view as one 2B-row pass
 _MIM_STREAM = os.environ.get("XFM_MIM_STREAM", "0") != "0"
+_TEXT_AFTER_VIT = os.environ.get("XFM_TEXT_AFTER_VIT", "0") != "0"   # A/B knob, see forward_multimodal
 _SIDE_STREAMS = {}
 _MIM_STREAMS = {}
 
@@ -125,10 +126,8 @@ class XFM(XFMBase):
             from .packing import Pack
             lens = [int(x) for x in (text_lens.tolist() if torch.is_tensor(text_lens) else text_lens)]
             pack = Pack.from_lens(lens + lens, text_ids.shape[1], image.device)   # 2B sequences: clean | masked
-        if data_source != 'imagenet' and self.batch_passes and image.is_cuda and _TEXT_STREAM_ON:
-            main = torch.cuda.current_stream(image.device)
-            text_stream = _side_stream(image.device)
-            text_stream.wait_stream(main)
+        def text_pass():
+            nonlocal text_embeds, mlm_embeds
             with torch.cuda.stream(text_stream):
                 _marks.mark("text fwd begin")
                 if both_passes:
@@ -136,6 +135,18 @@ class XFM(XFMBase):
                 else:
                     text_embeds = self.get_text_embeds(text_ids, text_atts)
                 _marks.mark("text fwd end")
+
+        text_late = False
+        if data_source != 'imagenet' and self.batch_passes and image.is_cuda and _TEXT_STREAM_ON:
+            main = torch.cuda.current_stream(image.device)
+            text_stream = _side_stream(image.device)
+            text_stream.wait_stream(main)   # (what the launch stream holds NOW: the previous step; not the ViT pass queued below)
+            # _TEXT_AFTER_VIT: the text pass is QUEUED after the ViT pass (it still runs beside it, on its own stream): autograd replays
+            # backward nodes in reverse order of creation, so the text tower's backward is then queued BEFORE the ViT's and runs beside
+            # the fusion tower's latency-bound backward chain instead of beneath the ViT's chip-filling GEMMs
+            text_late = _TEXT_AFTER_VIT and torch.is_grad_enabled()
+            if not text_late:
+                text_pass()
         _marks.mark("vit fwd begin")
         if self.batch_passes and do_mim and self.do_image_mask:
             B = image.shape[0]
@@ -157,6 +168,8 @@ class XFM(XFMBase):
         else:
             image_embeds, image_atts = self.get_vision_embeds(image)
         _marks.mark("vit fwd end")
+        if text_late:
+            text_pass()
         if data_source != 'imagenet':
             if text_stream is not None:  # re-join: the text features are consumed on the main stream from here on
                 main.wait_stream(text_stream)
