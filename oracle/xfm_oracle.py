@@ -498,10 +498,13 @@ def classification_forward(P, cfg, image, text_ids, text_atts, deep_head):
 # --------------------------------------------------------------------------------------
 # XFMForVQA (models/model_generation.py) and XFMForNLVR (models/model_nlvr.py)
 # --------------------------------------------------------------------------------------
-def fused_question_states(P, cfg, image, q_ids, q_atts):
+def fused_question_states(P, cfg, image, q_ids, q_atts, idx_to_group_img=None):
     """model_generation.py:94,103-110: image through the vision tower, question through the bare text tower, then the fusion
-    tower's cross-attention to the image (is_pretrain=False: nothing detached)."""
+    tower's cross-attention to the image (is_pretrain=False: nothing detached).  idx_to_group_img: fewer images than samples, every
+    sample reads the whole output of its image (xfm.py:577-588)."""
     emb = beit_forward(P, "vision_encoder.", image, depth=cfg["vit_depth"])
+    if idx_to_group_img is not None:
+        emb = torch.gather(emb, 0, idx_to_group_img.view(-1, 1, 1).expand(-1, emb.shape[1], emb.shape[2]))
     atts = torch.ones(emb.shape[:2], dtype=torch.long)
     txt = roberta_model(P, "text_encoder.", input_ids=q_ids, att=q_atts, num_layers=cfg["text_layers"], fusion_layer=cfg["text_layers"])
     return roberta_model(P, "fusion_encoder.roberta.", att=q_atts, encoder_embeds=txt, enc=emb, enc_att=atts,
@@ -654,7 +657,8 @@ def bbox_loss(output_coord, target_bbox, is_image=None):
     return loss_bbox.sum() / num_boxes, loss_giou.sum() / num_boxes
 
 
-def grounding_forward(P, cfg, image, text_ids, text_atts):
-    """XFMForGrounding.forward model_grounding.py:50-62 -> output_coord [B, 4] (predict_bbox xfm.py:843-854, is_pretrain=False)."""
-    states = fused_question_states(P, cfg, image, text_ids, text_atts)  # the same image / text / fusion composition as the VQA model
+def grounding_forward(P, cfg, image, text_ids, text_atts, idx_to_group_img=None):
+    """XFMForGrounding.forward model_grounding.py:50-62 -> output_coord [B, 4] (predict_bbox xfm.py:843-854, is_pretrain=False).
+    idx_to_group_img (XFMForGroundingDomainPretrain, model_grounding.py:26-33): sample i reads image idx_to_group_img[i] (xfm.py:577-588)."""
+    states = fused_question_states(P, cfg, image, text_ids, text_atts, idx_to_group_img=idx_to_group_img)
     return build_mlp_forward(P, "bbox_head.", states[:, 0, :]).sigmoid()

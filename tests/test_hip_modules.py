@@ -619,6 +619,24 @@ def test_grounding_model_vs_golden():
     _check_grads(z, "grad", m, min_rms=1e-6)
 
 
+def test_grounding_domain_pretrain_model_vs_golden():
+    """model_grounding.XFMForGroundingDomainPretrain (model_grounding.py:12-33): five (expression, box) samples over three images through
+    one vision pass (`idx_to_group_img`, the region call form's whole-image branch), `is_image`-weighted L1 + GIoU."""
+    from xfm_amd.model_grounding import XFMForGroundingDomainPretrain
+    z, meta = load("grounding_domain")
+    m = XFMForGroundingDomainPretrain(_pretrain_cfg(meta))
+    ours = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+    assert ours == meta["spec"]
+    _load_into(m, meta["spec"])
+    m.cuda().finalize().eval()
+    b = {k: v.cuda() for k, v in syn.pretrain_batch(meta["bs"], seed=98).items()}
+    idx, target, is_image = (torch.tensor(meta[k]).cuda() for k in ("idx", "target", "is_image"))
+    l1, giou = m(b["image"][:meta["n_images"]], b["text_ids"], b["text_atts"], idx, target, is_image=is_image)
+    assert abs(float(l1) - float(z["loss_bbox"])) < 2e-2 and abs(float(giou) - float(z["loss_giou"])) < 2e-2
+    (l1 + giou).backward()
+    _check_grads(z, "grad", m, min_rms=1e-6)
+
+
 def test_nlvr_model_vs_golden():
     from xfm_amd.model_nlvr import XFMForNLVR
     z, meta = load("nlvr_small")

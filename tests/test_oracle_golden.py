@@ -302,6 +302,20 @@ def test_retrieval_evaluation_rerank_and_recall():
         assert abs(got['r_mean'] - ((100.0 / 3 + 200.0) / 3 + (75.0 + 200.0) / 3) / 2) < 1e-9
 
 
+def test_grounding_domain_pretrain_model():
+    """XFMForGroundingDomainPretrain (model_grounding.py:12-33): several samples per image through one vision pass."""
+    z, meta = load("grounding_domain")
+    P = _params(meta["spec"])
+    cfg = O.default_cfg(text_layers=meta["text_layers"], fusion_layers=meta["fusion_layers"], vit_depth=meta.get("vit_depth", 12))
+    b = syn.pretrain_batch(meta["bs"], seed=98)
+    idx, target, is_image = torch.tensor(meta["idx"]), torch.tensor(meta["target"]), torch.tensor(meta["is_image"])
+    coord = O.grounding_forward(P, cfg, b["image"][:meta["n_images"]], b["text_ids"], b["text_atts"], idx_to_group_img=idx)
+    l1, giou = O.bbox_loss(coord, target, is_image)
+    assert abs(float(l1) - float(z["loss_bbox"])) < 2e-5 and abs(float(giou) - float(z["loss_giou"])) < 2e-5
+    (l1 + giou).backward()
+    _check_grads(z, "grad", P)
+
+
 def test_grounding_model_and_box_losses():
     z, meta = load("grounding_small")
     P = _params(meta["spec"])

@@ -962,6 +962,33 @@ def gen_grounding(B=3):
                                   "unused": unused})
 
 
+def gen_grounding_domain(n_images=3):
+    """models/model_grounding.py XFMForGroundingDomainPretrain: bs = n_images + 2 (expression, box) samples over n_images images
+    (`idx_to_group_img`, every sample on its whole image), `is_image` weighting of the box losses."""
+    from models.model_grounding import XFMForGroundingDomainPretrain
+    ref_shim.init_single_process_group()
+    torch.manual_seed(0)
+    cfg = ref_shim.pretrain_config(text_layers=2, fusion_layers=2)
+    with shallow_vit():
+        m = XFMForGroundingDomainPretrain(cfg)
+    load_formula(m)
+    m.eval()
+    bs = n_images + 2
+    b = syn.pretrain_batch(bs, seed=98)
+    idx, _ = syn.region_case(n_images)
+    target = torch.tensor([[0.5, 0.3, 0.4, 0.4], [0.45, 0.3, 0.2, 0.3], [0.55, 0.4, 0.5, 0.5], [0.45, 0.55, 0.9, 0.8], [0.4, 0.5, 0.3, 0.6]][:bs])
+    is_image = torch.tensor([0, 1, 0, 0, 1][:bs])
+    out = {}
+    loss_bbox, loss_giou = m(b["image"][:n_images], b["text_ids"], b["text_atts"], idx, target, is_image=is_image)
+    out["loss_bbox"], out["loss_giou"] = np.asarray(float(loss_bbox.detach())), np.asarray(float(loss_giou.detach()))
+    print("grounding_domain", float(loss_bbox), float(loss_giou), flush=True)
+    (loss_bbox + loss_giou).backward()
+    grads_of(m, out)
+    unused = [n for n, p in m.named_parameters() if p.grad is None]
+    save("grounding_domain", out, {"spec": spec_of(m), "n_images": n_images, "bs": bs, "idx": idx.tolist(), "target": target.tolist(),
+                                   "is_image": is_image.tolist(), "text_layers": 2, "fusion_layers": 2, "vit_depth": SHALLOW, "unused": unused})
+
+
 def gen_harness():
     """optim.py create_optimizer's four parameter groups on the reference pre-training model, and scheduler.py's linear schedule.
     (transformers 5.x dropped `transformers.optimization.AdamW`; it is aliased to torch.optim.AdamW -- an API alias, the grouping
@@ -1001,7 +1028,7 @@ def main():
     torch.set_num_threads(int(os.environ.get("GEN_THREADS", "8")))
     ref_shim.install()
     jobs = {"beit": lambda: gen_beit(2), "roberta_text": lambda: gen_roberta_text(2), "fusion": lambda: gen_fusion(2),
-            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "bert_causal_lm": lambda: gen_bert_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval, "harness": gen_harness, "checkpoint_vqa": gen_checkpoint_vqa, "grounding": gen_grounding,
+            "pretrain_small": lambda: gen_pretrain("pretrain_small", 2, 2), "causal_lm": lambda: gen_causal_lm(2), "bert_causal_lm": lambda: gen_bert_causal_lm(2), "xbert": lambda: gen_xbert(2), "vit": lambda: gen_vit(2), "retrieval": lambda: gen_retrieval(), "checkpoint": lambda: gen_checkpoint(), "classification": lambda: gen_classification(), "vqa": gen_vqa, "nlvr": gen_nlvr, "retrieval_eval": gen_retrieval_eval, "harness": gen_harness, "checkpoint_vqa": gen_checkpoint_vqa, "grounding": gen_grounding, "grounding_domain": gen_grounding_domain,
             "retrieval_384": lambda: gen_retrieval(B=8, res=384, T=40, name="retrieval_384"),
             "vqa_480": lambda: gen_vqa(res=480, name="vqa_480")}
     cfg_jobs = {"retrieval_cfg": gen_retrieval_cfg, "vqa_cfg": gen_vqa_cfg, "pretrain_cfg": gen_pretrain_cfg, "imagenet_cfg": gen_imagenet_cfg}   # config-shape fixtures: minutes of CPU each, only on request

@@ -29,8 +29,24 @@ class XFMForGrounding(XFMBase):
 
 
 class XFMForGroundingDomainPretrain(XFMBase):
-    """model_grounding.py:12-33 needs the region path (`idx_to_group_img`: several boxes per image through one vision pass), which is
-    outside the hot-path scope."""
+    """model_grounding.py:12-33: several (expression, box) samples per image through ONE vision pass -- `idx_to_group_img` [bs] names
+    each sample's image (the region call form without region masks, xfm.py:577-588: every sample sees its whole image); box regression
+    from the fused [CLS], L1 + GIoU with the `is_image` weighting."""
 
     def __init__(self, config):
-        raise NotImplementedError("XFMForGroundingDomainPretrain runs the region path (xfm.py:574-597, idx_to_group_img); use XFMForGrounding")
+        super().__init__(config, load_vision_params=False, load_text_params=False, use_contrastive_loss=False,
+                         use_matching_loss=False, use_mlm_loss=False, use_bbox_loss=True)
+        self.init_params = []
+
+    def load_pretrained(self, ckpt_rpath, config):
+        state_dict = load_pretrained(self, ckpt_rpath, config, is_eval=False, load_text=True)
+        msg = self.load_state_dict(state_dict, strict=False)
+        if self._arena is not None:
+            self._arena.bump()
+        return msg
+
+    def forward(self, image, text_ids, text_atts, idx_to_group_img, target_bbox, is_image=None):
+        image_embeds_fullatts, _ = self.get_vision_embeds(image, idx_to_group_img=idx_to_group_img)
+        text_embeds = self.get_text_embeds(text_ids, text_atts)
+        output_coord = self.predict_bbox(image_embeds_fullatts, text_ids, text_atts, text_embeds, is_pretrain=False)
+        return self.get_bbox_loss(output_coord, target_bbox, is_image=is_image)
