@@ -64,6 +64,44 @@ __global__ __launch_bounds__(512) void probe_a(const char* g, float* out, int it
   out[blockIdx.x * 512 + tid] = s;
 }
 
+// variant A2: variant A with the fragment reads of the NEXT k-substep issued before the MFMAs of the current one (two register sets),
+// so that a wave's own LDS latency hides under its own MFMAs instead of relying on the SIMD's other wave
+__global__ __launch_bounds__(512) void probe_a2(const char* g, float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 2, wc = w & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+  for (int i = tid; i < 4 * IMG / 4; i += 512) reinterpret_cast<float*>(lds)[i] = 0.001f * (i & 255);
+  __syncthreads();
+  f32x4 acc[8][4];
+  for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  bf16x8 xa[2][8], wb[2][4];
+  auto load = [&](int buf, const char* A, const char* B, int ks) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) xa[buf][m] = *reinterpret_cast<const bf16x8*>(A + off(wr * 128 + m * 16 + lr, ks * 4 + lg));
+#pragma unroll
+    for (int n = 0; n < 4; ++n) wb[buf][n] = *reinterpret_cast<const bf16x8*>(B + off(wc * 64 + n * 16 + lr, ks * 4 + lg));
+  };
+  load(0, lds, lds + IMG, 0);
+  for (int it = 0; it < iters; ++it) {
+    const char* A = lds + (it & 1) * 2 * IMG;
+    const char* An = lds + ((it + 1) & 1) * 2 * IMG;
+    load(1, A, A + IMG, 1);
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0][n], xa[0][m], acc[m][n], 0, 0, 0);
+    __builtin_amdgcn_s_barrier();   // (the image pair of the next iteration is "ready": where the real kernel's barrier sits)
+    load(0, An, An + IMG, 0);
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1][n], xa[1][m], acc[m][n], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+  out[blockIdx.x * 512 + tid] = s + (float)xa[0][0][0];
+}
+
 template <int DMA>
 __global__ __launch_bounds__(256) void probe_b(const char* g, float* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -146,7 +184,9 @@ int main() {
   hipFuncSetAttribute((const void*)probe_b<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   hipFuncSetAttribute((const void*)probe_b<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   const double flop = 2.0 * 256 * 256 * 64;
-  struct { const char* name; float ms; } r[6];
+  hipFuncSetAttribute((const void*)probe_a2, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  struct { const char* name; float ms; } r[7];
+  r[6] = {"A2 variant A, next k-substep's fragments read before the current MFMAs", time_ms([&] { hipLaunchKernelGGL(probe_a2, dim3(grid), dim3(512), smem, 0, g, out, iters); })};
   r[4] = {"C  8 waves, MFMAs on register operands only         ", time_ms([&] { hipLaunchKernelGGL(probe_c, dim3(grid), dim3(512), 0, 0, out, iters); })};
   r[5] = {"C  ... on 32 CUs only (one workgroup per 8 CUs)      ", time_ms([&] { hipLaunchKernelGGL(probe_c, dim3(32), dim3(512), 0, 0, out, iters); })};
   r[0] = {"A  8 waves, 128 x 64 per wave, 16x16x32, LDS only ", time_ms([&] { hipLaunchKernelGGL(probe_a<0>, dim3(grid), dim3(512), smem, 0, g, out, iters); })};
