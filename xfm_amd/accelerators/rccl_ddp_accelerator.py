@@ -471,7 +471,7 @@ class RCCLDDPAccelerator(Accelerator):
             arena.zero_grad(self._ranges)
             ev = torch.cuda.Event()
             ev.record(self._zero_stream)
-        _PENDING_ZERO[arena.grad.device.index] = ev
+        _PENDING_ZERO[arena.grad.device.index] = [ev, {self._zero_stream.cuda_stream}]
 
     def zero_grad(self):
         if self.arena is not None:

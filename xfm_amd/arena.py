@@ -121,19 +121,24 @@ class OwnsArena:
             super().zero_grad(set_to_none=set_to_none)
 
 
-_PENDING_ZERO = {}   # device index -> torch.cuda.Event of an asynchronous zero_grad still to land (RCCLDDPAccelerator._zero_async)
+_PENDING_ZERO = {}   # device index -> [event of the last asynchronous zero_grad (RCCLDDPAccelerator._zero_async), ids of the streams that wait for it]
 
 
 def grads_ready(device=None):
-    """Make the current stream wait for a pending asynchronous zero_grad of the gradient arena(s) on `device` (default: current).  The
-    accelerator calls it before every backward / optimizer step; code that reads or writes parameter gradients on its own right after
-    an accelerator step (a probe, a test) calls it first.  No-op when nothing is pending."""
+    """Make the current stream wait for the last asynchronous zero_grad of the gradient arena(s) on `device` (default: current).  The
+    accelerator calls it before every backward / optimizer step, every tower's backward calls it on ITS stream, and code that reads or
+    writes parameter gradients on its own right after an accelerator step (a probe, a test) calls it first.  Every stream waits once
+    per zero_grad (a wait for an event that has long fired is free); no-op when there has been none."""
     if not _PENDING_ZERO:
         return
     dev = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
-    ev = _PENDING_ZERO.pop(dev, None)
-    if ev is not None:
-        torch.cuda.current_stream(dev).wait_event(ev)
+    rec = _PENDING_ZERO.get(dev)
+    if rec is None:
+        return
+    cur = torch.cuda.current_stream(dev)
+    if cur.cuda_stream not in rec[1]:
+        cur.wait_event(rec[0])
+        rec[1].add(cur.cuda_stream)
 
 
 def grad_of(p):
