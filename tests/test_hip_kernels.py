@@ -1221,6 +1221,51 @@ def test_small_ce_any_class_count_and_ignored_labels(C):
     assert float(x.grad[::5].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,H,S,use_bias", [
+    (5, 12, 197, True),     # the 224-px ViT: 7 key-tile pairs, Q / dO through LDS, query groups of 3 + 3 + 3 + 2 + 2 tiles
+    (3, 2, 100, True),      # 4 pairs
+    (2, 3, 250, True),      # 8 pairs: fragments stay in registers
+    (3, 2, 40, False),      # waves without a key tile; no bias
+])
+def test_short_attention_backward_delta_from_output(B, H, S, use_bias, monkeypatch):
+    """The short-sequence dQ kernel's opt-in form (XFM_ATTN_SHORT_PRE=1, csrc/attention.hip attn_bwd_dq_short_kernel<.., PRE = true>):
+    the softmax-gradient row term delta_i = dO_i . (O_i + Olo_i) from the forward's output halves instead of the exchange of
+    sum_j P_ij dP_ij between the key-range waves.  Held to the same tolerances against fp32 math as the default form, and to the
+    default form's own results within bf16 noise; the returned delta to dO . O."""
+    Fx = _fx()
+    D = H * 64
+    scale = 0.125
+    qkv = _rand((B * S, 3 * D), seed=350 + S)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    ld = (S + 15) // 16 * 16
+    bias = None
+    if use_bias:
+        bias = torch.full((H, S, ld), float("nan"), dtype=F32, device="cuda")
+        bias[:, :, :S] = _rand((H, S, S), 1.0, F32, seed=352)
+    dout = _rand((B * S, D), seed=353)
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    br = bias[:, :, :S].clone().requires_grad_(True) if use_bias else None
+    _attn_ref(qr, kr, vr, B, H, S, S, scale, br).backward(dout.float())
+    o, lse, o_lo = Fx.attn_fwd(q, k, v, B, H, S, S, scale, bias=bias, lo=True)
+    got = {}
+    for pre in ("0", "1"):
+        monkeypatch.setenv("XFM_ATTN_SHORT_PRE", pre)   # (read per call)
+        dqkv = torch.full((B * S, 3 * D), float("nan"), dtype=BF16, device="cuda")
+        dbias = torch.zeros_like(bias).nan_to_num(0.0) if use_bias else None
+        delta = Fx.attn_bwd(dout, q, k, v, o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, S, S, scale, bias=bias, dbias=dbias, o_lo=o_lo)
+        torch.cuda.synchronize()
+        got[pre] = (dqkv.float(), None if dbias is None else dbias.clone(), delta.clone())
+        _close(dqkv[:, :D], qr.grad, 2e-2, "dq")
+        _close(dqkv[:, D:2 * D], kr.grad, 2e-2, "dk")
+        _close(dqkv[:, 2 * D:], vr.grad, 2e-2, "dv")
+        if use_bias:
+            _close(dbias[:, :, :S], br.grad, 2e-2, "dbias")
+            assert float(dbias[:, :, S:].abs().max() if ld > S else 0.0) == 0.0
+    want_delta = (dout.float() * (o.float() + o_lo.float())).view(B, S, H, 64).sum(-1).permute(0, 2, 1)
+    _close(got["1"][2][:, :, :S], want_delta, 1e-4, "delta from the output halves")
+    _close(got["1"][0], got["0"][0], 1e-2, "dqkv, the two forms")
+
+
 @pytest.mark.parametrize("mode", ["0", "3"])   # XFM_ATTN_VIT_BWD: 0 = split dQ + dK/dV kernels (default), 3 = single-pass kernel (13 tiles)
 @pytest.mark.parametrize("tiled", [True, False])
 @pytest.mark.parametrize("B,H,S,use_bias", [

@@ -2,6 +2,8 @@
 csrc/attention_vit.hip vs the general ones (XFM_ATTN_VIT=0).  Usage: [B=128] python tools/bench_attn_vit.py [iters]"""
 import os, sys
 os.environ.setdefault("XFM_ATTN_VIT_BWD", "0")
+if os.environ.get("LO", "0") == "1":
+    os.environ.setdefault("XFM_ATTN_SHORT_PRE", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from xfm_amd import functional as Fx
@@ -22,12 +24,21 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
 
 
+LO = os.environ.get("LO", "0") == "1"   # keep the low half of O: the backward takes delta from dO . (O + O_lo)
+o_lo = None
+
+
 def fwd():
+    global o_lo
+    if LO:
+        o, lse, o_lo = Fx.attn_fwd(q, k, v, B, H, N, N, 0.125, bias=bias, bias_tiles=tiles, lo=True)
+        return o, lse
     return Fx.attn_fwd(q, k, v, B, H, N, N, 0.125, bias=bias, bias_tiles=tiles)
 
 
-def bwd(o, lse):
-    Fx.attn_bwd(dout, q, k, v, o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, N, N, 0.125, bias=bias, dbias=dbias, bias_t=bias_t, bias_tiles=tiles)
+def bwd(o, lse, phase=0, delta=None):
+    return Fx.attn_bwd(dout, q, k, v, o, lse, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, N, N, 0.125, bias=bias, dbias=dbias, bias_t=bias_t,
+                       bias_tiles=tiles, o_lo=o_lo, phase=phase, delta=delta)
 
 
 for _ in range(3):
@@ -47,6 +58,19 @@ for _ in range(iters):
 e.record()
 torch.cuda.synchronize()
 tb = s.elapsed_time(e) / iters * 1e3
+split = ""
+if os.environ.get("XFM_ATTN_VIT_BWD", "0") == "0":   # the split pair: each kernel on its own (phase 1 = dQ + delta + dbias, phase 2 = dK / dV)
+    dl = bwd(o, lse, phase=1)
+    ts = []
+    for ph in (1, 2):
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(iters):
+            bwd(o, lse, phase=ph, delta=dl if ph == 2 else None)
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) / iters * 1e3)
+    split = f" (dQ {ts[0]:.1f} + dK/dV {ts[1]:.1f})"
 gf = 4.0 * B * H * N * N * 64 / 1e9
-print(f"XFM_ATTN_VIT={os.environ.get('XFM_ATTN_VIT', '1')} BWD={os.environ.get('XFM_ATTN_VIT_BWD')} B={B}: fwd {tf:.1f} us ({gf / tf * 1e3:.0f} TFLOP/s), bwd {tb:.1f} us ({2.5 * gf / tb * 1e3:.0f} TFLOP/s); "
+print(f"LO={int(LO)} XFM_ATTN_VIT={os.environ.get('XFM_ATTN_VIT', '1')} BWD={os.environ.get('XFM_ATTN_VIT_BWD')} B={B}: fwd {tf:.1f} us ({gf / tf * 1e3:.0f} TFLOP/s), bwd {tb:.1f} us{split} ({2.5 * gf / tb * 1e3:.0f} TFLOP/s); "
       f"checksum {float(o.float().abs().sum()):.4e} {float(dqkv.float().abs().sum()):.4e} {float(dbias.abs().sum()) if dbias is not None else 0.0:.4e}")

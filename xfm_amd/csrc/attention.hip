@@ -9,6 +9,7 @@
 //
 // Layouts: q/k/v/o are addressed as ptr[(b*S + s)*row_stride + h*64 + d], i.e. straight out of / into the fused
 // projection GEMM buffers ([B*S, 3*768] for self-attention, [B*Sk, 2*768] for the cross-attention K/V).
+#include <type_traits>
 #include "common.h"
 #include <stdlib.h>
 
@@ -544,6 +545,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
 #define VB_KBUF (ATTN_RES_MAX * ATTN_TILE)
 #define VB_EXCH(QT) ((QT) * 16 * 512)
 #define VB_LDS(QT) (4 * VB_KBUF + VB_EXCH(QT) + (QT) * 4 * 16 * 4)
+#define VB_LDS_QL(QT, NP) (4 * (2 * (NP) * 2048) + (QT) * (NP) * 1024 + (QT) * 4 * 16 * 4 + 2 * (QT) * 2 * 2048)   // Q / dO through LDS (PRE, NP <= 7)
 
 // rows [0, nrows) of a [*, 64] bf16 operand into consecutive 64-row tiles (direct-to-LDS, same image as stage_slot's tiles).
 // Issued as inline asm on purpose: when the compiler sees a direct-to-LDS load it drains it (s_waitcnt vmcnt(0)) in front of
@@ -582,11 +584,23 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <int QT, int NP>
-__global__ __launch_bounds__(QT * 256) void attn_bwd_dq_short_kernel(AttnArgs a, int nb_per_block, int G) {
+// PRE: the row term delta_i = dO_i . (O_i + Olo_i) is taken from the forward's output (a.o, a.o_lo) at the top of an entry, from
+// fragments fetched one entry ahead -- no delta exchange, no second barrier, and dS leaves in the same phase as the scores.
+// !PRE (no o_lo): delta_i = sum_j P_ij dP_ij from the very P and dP that form dS, exchanged between the four key-range waves.
+template <int QT, int NP, bool PRE, bool DBG>
+__global__ __launch_bounds__(QT * 256) void attn_bwd_dq_short_kernel(AttnArgs a, int nb_per_block, int G, long long* dbg) {
   constexpr int NW = QT * 4;
+  // QL (PRE and <= 14 key tiles): the Q / dO tiles of the workgroup's queries come through LDS too -- 4 QT one-KB pieces per entry instead
+  // of four fragment loads in each of the 4 QT waves (every key-range wave of a query tile fetched the same rows) -- in the room
+  // that 28-KB K / V buffers leave.  The vector-memory path moves ~64 B/clk per CU and every wave-load holds its wave at issue
+  // while the queue is full: the loads, not the arithmetic, set the entry period (tools/attn_timeline.py).
+  constexpr bool QL = PRE && NP <= 7;
+  constexpr int KBUF = QL ? 2 * NP * 2048 : VB_KBUF;           // one K or V image
+  constexpr int EXQ = QL ? NP * 1024 : 16 * 512;               // dS exchange of one query tile
+  constexpr int QIMG = QT * 2 * 2048;                          // Q tiles | dO tiles of one entry (QL)
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // (w through readfirstlane: the tile counts below are wave-uniform and the compiler must know it -- see the entry loop)
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
   const int qt = w >> 2, kw = w & 3;
   // 1-D grid, logical id = group + G * (head + H * batch slice), an XCD takes a contiguous range of logical ids: the G groups of one
@@ -608,8 +622,9 @@ __global__ __launch_bounds__(QT * 256) void attn_bwd_dq_short_kernel(AttnArgs a,
   const int qc = qi < sq ? qi : sq - 1;
 
   char* const sK0 = lds;
-  char* const ex = lds + 4 * VB_KBUF;
-  float* const dred = reinterpret_cast<float*>(ex + VB_EXCH(QT));
+  char* const ex = lds + 4 * KBUF;
+  float* const dred = reinterpret_cast<float*>(ex + QT * EXQ);
+  char* const qimg = reinterpret_cast<char*>(dred) + QT * 4 * 16 * 4;   // (QL) two Q | dO images
 
   // LDS addressing.  A 16-row tile t of an image starts 2048 B after tile t-1 (four to a 64-row, 8 KB staging tile) and the XOR
   // swizzle of a row depends on (row >> 1) & 7 only, i.e. not on the tile: every fragment address is ONE per-lane offset plus a
@@ -618,10 +633,17 @@ __global__ __launch_bounds__(QT * 256) void attn_bwd_dq_short_kernel(AttnArgs a,
   const int rf0 = lr * 128 + ((lg ^ sw_r) << 4), rf1 = lr * 128 + (((4 + lg) ^ sw_r) << 4);  // row fragments, k-steps 0 / 1
   const int tr_row = 4 * lg + (lr >> 2), tr_col = kw * 16 + 4 * (lr & 3);                   // transposed fragment of d-tile kw
   const int tro = tr_row * 128 + ((((tr_col >> 3) ^ ((tr_row >> 1) & 7))) << 4) + (tr_col & 7) * 2;
-  const int ex_w = ((qt * 16 + kt0) * 64 + lane) * 8, ex_r = (qt * 16 * 64 + lane) * 8;
+  // dS exchange of a query tile: key tiles in PAIRS, 16 B per lane and pair -- a lane's values of tile 2p in the low, of tile 2p + 1 in
+  // the high 8 bytes: the dQ loop reads a pair as ONE ds_read_b128 (256 B/clk; the two 8-byte reads 512 B apart it used to take
+  // were fused by the compiler into ds_read2st64_b64, 128 B/clk, and made its phase LDS-bound), and the value read IS the MFMA operand.
+  char* const ex_q = ex + qt * EXQ + lane * 16;
+  auto ex_slot = [&](int tile) { return ex_q + ((tile >> 1) << 10) + ((tile & 1) << 3); };
+  // key tiles past the last one stay zero for the whole kernel (the dQ loop runs over NP pairs)
+  for (int i = tid; i < QT * EXQ / 16; i += NW * 64) reinterpret_cast<u32x4*>(ex)[i] = u32x4{0, 0, 0, 0};
 
-  // Softmax in the exponent of 2 with the row constants folded into the accumulator the score MFMAs start from:
-  //   S' = K.q + (bias - lse) / scale,  P = exp2(S' * scale * log2 e)   (no subtraction, no select: keys past Sk carry bias -1e30)
+  // Softmax in the exponent of 2, the bias folded into the accumulator the score MFMAs start from and the row's log-sum-exp into the
+  // exponent's fma:  S' = K.q + bias / scale,  P = exp2(S' * scale * log2 e - lse * log2 e)   (no subtraction, no select: keys past Sk
+  // carry bias -1e30, query rows past Sq carry lse = +1e30)
   const float inv_scale = 1.0f / a.scale, c2 = a.scale * 1.44269504088896341f;
   f32x4 bvs[4], dsacc[4];
 #pragma unroll
@@ -635,152 +657,362 @@ __global__ __launch_bounds__(QT * 256) void attn_bwd_dq_short_kernel(AttnArgs a,
   }
 
   // batch-invariant per-lane byte offsets; an entry adds one scalar stride to the (scalar) base pointers
-  const int q_off = (int)(((long)qc * a.q_rs + h * 64 + 8 * lg) * 2), do_off = (int)(((long)qc * a.do_rs + h * 64 + 8 * lg) * 2);
-  const int dq_off = (int)(((long)qi * a.dq_rs + h * 64 + kw * 16 + 4 * lg) * 2), stat_off = (int)((long)h * a.stat_ld + qc);
+  // (unsigned 32-bit lane offsets against SCALAR per-entry base pointers: every access is `global_* v_off, s[base]`; as signed offsets
+  // the loop-strength reducer turned each into a per-lane 64-bit pointer carried round the loop, 26 VGPRs of them)
+  const unsigned q_off = (unsigned)(((long)qc * a.q_rs + h * 64 + 8 * lg) * 2), do_off = (unsigned)(((long)qc * a.do_rs + h * 64 + 8 * lg) * 2);
+  // (PRE: wave kw takes a QUARTER of the row's 64 columns of O / O_lo -- the 4 of this lane's 16 dO columns with index
+  // 32 (kw >> 1) + 8 lg + 4 (kw & 1) + 0..3 -- so the four key-range waves together read O once, not four times)
+  const unsigned do_q4 = (unsigned)(((long)qc * a.do_rs + h * 64 + 32 * (kw >> 1) + 8 * lg + 4 * (kw & 1)) * 2);
+  const unsigned o_off = PRE ? (unsigned)(((long)qc * a.o_rs + h * 64 + 32 * (kw >> 1) + 8 * lg + 4 * (kw & 1)) * 2) : 0u;
+  const unsigned dq_off = (unsigned)(((long)(qvalid ? qi : 0) * a.dq_rs + h * 64 + kw * 16 + 4 * lg) * 2), stat_off = (unsigned)((long)h * a.stat_ld + qc);
   const long q_bs = (long)sq * a.q_rs * 2, do_bs = (long)sq * a.do_rs * 2, dq_bs = (long)sq * a.dq_rs * 2, stat_bs = (long)a.H * a.stat_ld;
+  const long o_bs = (long)sq * a.o_rs * 2;
   const long k_bs = (long)sk * a.k_rs * 2, v_bs = (long)sk * a.v_rs * 2;
-  // this wave's pieces of a K / V image (<= 3 of the 8-per-chunk direct-to-LDS instructions): source offset per lane, LDS offset
-  // per wave.  At least NP / 2 chunks are staged (rows past Sk repeat the last key) so that every tile the dQ loop reads is finite.
-  int k_off[3], v_off[3];
-  unsigned pc_dst[3];
-  const int chunks = (sk + 63) >> 6;
-  const int n_pc = (chunks > NP / 2 ? chunks : NP / 2) * 8;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int j = w + i * NW;
-    const int r = (j & 7) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ swz_a(r);
-    int gr = (j >> 3) * 64 + r;
-    gr = gr < sk ? gr : sk - 1;
-    k_off[i] = (int)(((long)gr * a.k_rs + h * 64 + c * 8) * 2);
-    v_off[i] = (int)(((long)gr * a.v_rs + h * 64 + c * 8) * 2);
-    pc_dst[i] = (unsigned)__builtin_amdgcn_readfirstlane((j >> 3) * ATTN_TILE + (j & 7) * 1024);
-  }
-  auto stage_kv = [&](int b, int buf) {
-    const char* kb = reinterpret_cast<const char*>(a.k) + (long)b * k_bs;
-    const char* vb = reinterpret_cast<const char*>(a.v) + (long)b * v_bs;
-    const unsigned dk = (unsigned)(uintptr_t)LDS_PTR(void, sK0) + (unsigned)buf * VB_KBUF, dv = dk + 2 * VB_KBUF;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      if (w + i * NW < n_pc) {  // (inline asm: see stage_rows)
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(kb + k_off[i]), "s"(dk + pc_dst[i]) : "memory", "m0");
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vb + v_off[i]), "s"(dv + pc_dst[i]) : "memory", "m0");
-      }
-    }
-  };
-
+  // this wave's pieces of a K / V image (<= 3 of the 1-KB, 8-row direct-to-LDS instructions): source offset per lane, LDS offset per
+  // wave.  The 2 NP tiles the dQ loop reads are staged (rows past Sk repeat the last key: finite, their dS is zero).
   const int b_begin = zslice * nb_per_block;
   int b_end = b_begin + nb_per_block;
   b_end = b_end < a.B ? b_end : a.B;
-  // Q / dO fragments and the log-sum-exp of the NEXT entry are fetched while the current one computes (a load issued at the top
-  // of an entry and waited for there costs the whole HBM latency per entry: every wave of the CU sits behind the same barrier)
+  // Running (scalar) base pointers instead of `base + b * stride` at every use: the staging / fetch cursors point at the entry being
+  // REQUESTED (one ahead of the entry computed), pdelta at the entry computed, pdq at the one before it (whose dQ is stored late);
+  // one 64-bit add each per entry (the multiplications were ~100 scalar instructions per entry in a kernel that is issue-bound).
+  const char *pk = reinterpret_cast<const char*>(a.k) + (long)b_begin * k_bs, *pv = reinterpret_cast<const char*>(a.v) + (long)b_begin * v_bs;
+  const char *pq = reinterpret_cast<const char*>(a.q) + (long)b_begin * q_bs, *pdo = reinterpret_cast<const char*>(a.dout) + (long)b_begin * do_bs;
+  const char *po = PRE ? reinterpret_cast<const char*>(a.o) + (long)b_begin * o_bs : nullptr;
+  const char *plo = PRE ? reinterpret_cast<const char*>(a.o_lo) + (long)b_begin * o_bs : nullptr;
+  const float* plse = a.lse + (long)b_begin * stat_bs;
+  float* pdelta = a.delta + (long)b_begin * stat_bs;
+  char* pdq = reinterpret_cast<char*>(a.dq) + (long)(b_begin - 1) * dq_bs;
+  // (diagnostic build only: bit 3 of the pointer's low bits pins every request on the slice's first entry -- the whole walk then runs
+  // from cache, which prices the memory side of the entry period; results are garbage)
+  const bool pin = DBG && ((uintptr_t)dbg & 8) != 0;
+  auto advance = [&]() {
+    if (DBG && pin) return;
+    pk += k_bs; pv += v_bs; pq += q_bs; pdo += do_bs; plse += stat_bs;
+    if constexpr (PRE) { po += o_bs; plo += o_bs; }
+  };
+  unsigned pc_dst[3];
+  constexpr int n_pc = 4 * NP;
+  static_assert(n_pc <= 3 * NW, "three pieces per wave");
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = w + i * NW;
+    pc_dst[i] = (unsigned)__builtin_amdgcn_readfirstlane((j >> 3) * ATTN_TILE + (j & 7) * 1024);
+  }
+  unsigned k_offs[3] = {0, 0, 0}, v_offs[3] = {0, 0, 0};
+  if constexpr (!PRE) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int j = w + i * NW;
+      const int r = (j & 7) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz_a(r);
+      int gr = (j >> 3) * 64 + r;
+      gr = gr < sk ? gr : sk - 1;
+      k_offs[i] = (unsigned)(((long)gr * a.k_rs + h * 64 + c * 8) * 2);
+      v_offs[i] = (unsigned)(((long)gr * a.v_rs + h * 64 + c * 8) * 2);
+    }
+  }
+  auto stage_piece = [&](int b, int buf, int i) {   // K and V piece i of this wave (inline asm: see stage_rows)
+    if (w + i * NW < n_pc) {
+      unsigned k_off, v_off;
+      if constexpr (PRE) {
+        // (the lane offsets are recomputed per piece from an opaque copy of the lane id -- a dozen integer instructions -- instead of
+        // living in six VGPRs for the whole kernel: with the O quarters in flight the scores' bias tile would be spilled for them)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int j = w + i * NW;
+        const int r = (j & 7) * 8 + (ln >> 3);
+        const int c = (ln & 7) ^ swz_a(r);
+        int gr = (j >> 3) * 64 + r;
+        gr = gr < sk ? gr : sk - 1;
+        k_off = (unsigned)(((long)gr * a.k_rs + h * 64 + c * 8) * 2);
+        v_off = (unsigned)(((long)gr * a.v_rs + h * 64 + c * 8) * 2);
+      } else {
+        k_off = k_offs[i];
+        v_off = v_offs[i];
+      }
+      const char* kb = pk;
+      const char* vb = pv;
+      const unsigned dk = (unsigned)(uintptr_t)LDS_PTR(void, sK0) + (unsigned)buf * KBUF, dv = dk + 2 * KBUF;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(k_off), "s"(kb), "s"(dk + pc_dst[i]) : "memory", "m0");
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(v_off), "s"(vb), "s"(dv + pc_dst[i]) : "memory", "m0");
+    }
+  };
+  auto stage_kv = [&](int b, int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) stage_piece(b, buf, i);
+  };
+
+  // Q / dO (/ O, O_lo) fragments and the log-sum-exp of the NEXT entry are fetched while the current one computes (a load issued at
+  // the top of an entry and waited for there costs the whole HBM latency per entry: every wave of the CU sits behind the same barrier)
   bf16x8 qf0, qf1, df0, df1;
+  bf16x4 oq, lq, dq4;
+  bf16x4 dq_hold = bf16x4{0, 0, 0, 0};   // this wave's dQ of the entry just finished (stored one entry later)
   float lse_n = 0.f;
+  // (QL) piece w of the 4 QT: 8 query rows of Q (w < 2 QT) or dO into image `buf`, rows past Sq repeat the last one
+  auto stage_q = [&](int b, int buf) {
+    if (w < 4 * QT) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int isd = w >= 2 * QT ? 1 : 0, jj = w - isd * 2 * QT;
+      const int r = (jj & 1) * 8 + (ln >> 3);
+      const int c = (ln & 7) ^ swz_a(r);
+      int gr = q0 - qt * 16 + (jj >> 1) * 16 + r;
+      gr = gr < sq ? gr : sq - 1;
+      const unsigned off = (unsigned)(((long)gr * (isd ? a.do_rs : a.q_rs) + h * 64 + c * 8) * 2);
+      const char* base = isd ? pdo : pq;
+      const unsigned dst = (unsigned)(uintptr_t)LDS_PTR(void, qimg) + (unsigned)(buf * QIMG + isd * (QT * 2048) + jj * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory", "m0");
+    }
+  };
   auto fetch_q = [&](int b) {
-    const char* qp = reinterpret_cast<const char*>(a.q) + (long)b * q_bs + q_off;
-    const char* dop = reinterpret_cast<const char*>(a.dout) + (long)b * do_bs + do_off;
-    qf0 = *reinterpret_cast<const bf16x8*>(qp);
-    qf1 = *reinterpret_cast<const bf16x8*>(qp + 64);
-    df0 = *reinterpret_cast<const bf16x8*>(dop);
-    df1 = *reinterpret_cast<const bf16x8*>(dop + 64);
-    lse_n = a.lse[(long)b * stat_bs + stat_off];
+    if constexpr (!QL) {
+      const char* qp = pq + q_off;   // (scalar base + zero-extended lane offset)
+      const char* dop = pdo + do_off;
+      qf0 = *reinterpret_cast<const bf16x8*>(qp);
+      qf1 = *reinterpret_cast<const bf16x8*>(qp + 64);
+      df0 = *reinterpret_cast<const bf16x8*>(dop);
+      df1 = *reinterpret_cast<const bf16x8*>(dop + 64);
+    } else {   // the dO quarter that meets this wave's O quarter (the row's fragments themselves arrive through LDS)
+      dq4 = *reinterpret_cast<const bf16x4*>(pdo + do_q4);
+    }
+    if constexpr (PRE) {
+      const char* op = po + o_off;
+      const char* lp = plo + o_off;
+      oq = *reinterpret_cast<const bf16x4*>(op);
+      lq = *reinterpret_cast<const bf16x4*>(lp);
+    }
+    lse_n = plse[stat_off];
   };
   if (b_begin < b_end) {
     stage_kv(b_begin, 0);
+    if constexpr (QL) stage_q(b_begin, 0);
     fetch_q(b_begin);
+    advance();
   }
-  for (int b = b_begin; b < b_end; ++b) {
-    const int cur = (b - b_begin) & 1;
-    const char* sK = sK0 + cur * VB_KBUF;
-    // everything up to the fetches of this entry must have landed.  (The compiler cannot see this wait: the empty asm makes it place
-    // its own wait for the fetched registers HERE, before this entry's direct-to-LDS loads are issued, rather than at their first
-    // use, where a counted wait would also drain those.)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(qf0), "+v"(qf1), "+v"(df0), "+v"(df1), "+v"(lse_n));
-    const float lse_s = (qvalid ? lse_n : 1.0e30f) * inv_scale;  // rows past Sq: P = exp2(-huge) = 0
-    lds_barrier();  // K(b), V(b) have landed; every wave is done with entry b-1 (its K / V buffers, the exchange tiles)
-    if (b + 1 < b_end) stage_kv(b + 1, cur ^ 1);
+  const int dbg_wave = (int)((uintptr_t)dbg & 7);   // (the stamping wave, 0..7, rides in the low bits of the 256-B aligned diagnostic pointer)
+  dbg = reinterpret_cast<long long*>((uintptr_t)dbg & ~(uintptr_t)15);
+  // The number of key tiles of a wave (nt, 0..4) is a run-time, wave-uniform value.  Written as `if (t < nt)` inside the tile loops it
+  // made every tile its own exec-masked basic block -- read, wait, MFMA, read, wait, MFMA: 16 LDS round trips in series.  So the whole
+  // walk is straight-line code per tile COUNT (NT; -1 = a wave without a query tile: barriers and its share of the staging only),
+  // picked by ONE scalar branch per kernel.  (A switch per phase inside one loop made the register allocator merge five versions of
+  // the score registers: 38 spilled VGPRs.)
+  auto walk = [&](auto NTc) {
+    constexpr int NT = decltype(NTc)::value;
+    constexpr bool ACT = NT >= 0;
+    constexpr int NTS = NT > 0 ? NT : 1;
+    for (int b = b_begin; b < b_end; ++b) {
+      const int cur = (b - b_begin) & 1;
+      const char* sK = sK0 + cur * KBUF;
+      // diagnostic (XFM_ATTN_DBG_PTR, tools/attn_timeline.py): one wave stamps the phases of every entry (10-ns clock); NULL in every product call
+      long long* const dbe = DBG && dbg != nullptr && tid == dbg_wave * 64 && b - b_begin < 32 ? dbg + ((long)blockIdx.x * 32 + (b - b_begin)) * 16 : nullptr;
+      if (DBG && dbe) dbe[0] = wall_clock64();
+      // everything up to the fetches of this entry must have landed.  (The compiler cannot see this wait: the empty asm makes it place
+      // its own wait for the fetched registers HERE, before this entry's direct-to-LDS loads are issued, rather than at their first
+      // use, where a counted wait would also drain those.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // dQ of the PREVIOUS entry leaves here, behind the wait: vmcnt counts stores too (until L2 has them), and a store issued at the
+      // end of an entry made this wait, a few instructions later, sit out its whole acknowledgement
+      if constexpr (ACT) {
+        if (b > b_begin && qvalid) *reinterpret_cast<bf16x4*>(pdq + dq_off) = dq_hold;
+      }
+      if constexpr (!QL) asm volatile("" : "+v"(qf0), "+v"(qf1), "+v"(df0), "+v"(df1));
+      else asm volatile("" : "+v"(dq4));
+      asm volatile("" : "+v"(lse_n));
+      if constexpr (PRE) asm volatile("" : "+v"(oq), "+v"(lq));
+      const float nlse = qvalid ? -lse_n * 1.44269504088896341f : -1.0e30f;  // rows past Sq: P = exp2(-huge) = 0
+      float delta = 0.f;
+      if constexpr (PRE && ACT) {
+        // this wave's quarter of dO . (O + O_lo): packed bf16 dot products with fp32 accumulation; the four quarters meet in LDS
+        bf16x2 d0, d1;
+        if constexpr (QL) {
+          d0 = bf16x2{dq4[0], dq4[1]};
+          d1 = bf16x2{dq4[2], dq4[3]};
+        } else {
+          const bf16x8 dh = (kw & 2) ? df1 : df0;
+          d0 = (kw & 1) ? bf16x2{dh[4], dh[5]} : bf16x2{dh[0], dh[1]};
+          d1 = (kw & 1) ? bf16x2{dh[6], dh[7]} : bf16x2{dh[2], dh[3]};
+        }
+        float t0 = __builtin_amdgcn_fdot2_f32_bf16(d0, bf16x2{oq[0], oq[1]}, 0.f, false);
+        float t1 = __builtin_amdgcn_fdot2_f32_bf16(d1, bf16x2{oq[2], oq[3]}, 0.f, false);
+        t0 = __builtin_amdgcn_fdot2_f32_bf16(d0, bf16x2{lq[0], lq[1]}, t0, false);
+        t1 = __builtin_amdgcn_fdot2_f32_bf16(d1, bf16x2{lq[2], lq[3]}, t1, false);
+        const float part = group4_sum(t0 + t1);
+        if (lg == 0) dred[(qt * 16 + lr) * 4 + kw] = part;
+      }
+      if (DBG && dbe) dbe[1] = wall_clock64();
+      lds_barrier();  // K(b), V(b) have landed; every wave is done with entry b-1 (its K / V buffers, the exchange tiles)
+      if (DBG && dbe) dbe[2] = wall_clock64();
+      if constexpr (PRE && ACT) {
+        const f32x4 dq4 = *reinterpret_cast<const f32x4*>(dred + (qt * 16 + lr) * 4);
+        delta = (dq4[0] + dq4[1]) + (dq4[2] + dq4[3]);
+        if (kw == 0 && lg == 0 && qvalid) pdelta[stat_off] = delta;
+      }
+      const bool more = b + 1 < b_end;
+      if constexpr (QL) {
+        // everything of the next entry is requested HERE, a whole entry ahead of its use: its Q / dO pieces, the small per-lane loads
+        // (their registers are free: this entry's went into delta and nlse above), then K / V
+        if (more) {
+          stage_q(b + 1, cur ^ 1);
+          fetch_q(b + 1);
+        }
+        if constexpr (ACT) {
+          const char* qi_ = qimg + cur * QIMG + qt * 2048;
+          qf0 = *reinterpret_cast<const bf16x8*>(qi_ + rf0);
+          qf1 = *reinterpret_cast<const bf16x8*>(qi_ + rf1);
+          df0 = *reinterpret_cast<const bf16x8*>(qi_ + QT * 2048 + rf0);
+          df1 = *reinterpret_cast<const bf16x8*>(qi_ + QT * 2048 + rf1);
+        }
+      }
+      // (placing the K / V pieces between the tiles of the score phase instead -- one K + V piece per tile -- measured the same entry period
+      // with ~50 more scalar instructions per entry; all of them go out here)
+      if (more) stage_kv(b + 1, cur ^ 1);
+      if (DBG && dbe) dbe[8] = wall_clock64();
 
-    f32x4 st[4], dp[4];
-    float dpart = 0.f;
-    if (wave_active) {
-      const char* ka = sK + kt0 * 2048;
+      f32x4 st[NTS], dp[NTS];
+      if constexpr (ACT) {
+        const char* ka = sK + kt0 * 2048;
+        float dpart = 0.f;
+        // fragments of tile t + 1 are requested before the MFMAs of tile t (two tiles' worth, 32 VGPRs, in flight)
+        bf16x8 fr[2][4];
+        auto frags = [&](int t, bf16x8 (&f)[4]) {
+          f[0] = *reinterpret_cast<const bf16x8*>(ka + t * 2048 + rf0);
+          f[1] = *reinterpret_cast<const bf16x8*>(ka + t * 2048 + rf1);
+          f[2] = *reinterpret_cast<const bf16x8*>(ka + 2 * KBUF + t * 2048 + rf0);
+          f[3] = *reinterpret_cast<const bf16x8*>(ka + 2 * KBUF + t * 2048 + rf1);
+        };
+        auto mfmas = [&](int t) {
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[t & 1][0], qf0, bvs[t], 0, 0, 0);
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[t & 1][1], qf1, st[t], 0, 0, 0);
+          dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[t & 1][2], df0, dp[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[t & 1][3], df1, dp[t], 0, 0, 0);
+        };
+        if constexpr (PRE) {
+          // Software pipeline with scheduling fences between the steps: the K (V) fragments of tile t + 1 are requested as soon as the
+          // score (dP) MFMAs of tile t have read theirs (16 VGPRs of fragments), and the exponentials / dS of tile t - 1 are written
+          // after the MFMAs of tile t and execute beside them (two tiles of scores live).  A free schedule hoists every read and MFMA
+          // to the top and spills the bias tiles, whose reloads (vmcnt) would wait behind the K / V prefetch.
+          bf16x8 fk[2], fv[2];
+          if constexpr (NT > 0) {
+            fk[0] = *reinterpret_cast<const bf16x8*>(ka + rf0);
+            fk[1] = *reinterpret_cast<const bf16x8*>(ka + rf1);
+            fv[0] = *reinterpret_cast<const bf16x8*>(ka + 2 * KBUF + rf0);
+            fv[1] = *reinterpret_cast<const bf16x8*>(ka + 2 * KBUF + rf1);
+          }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (t < nt) {
+          for (int t = 0; t <= NT; ++t) {
+            if (t < NT) {
+              st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[0], qf0, bvs[t], 0, 0, 0);
+              st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[1], qf1, st[t], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if (t + 1 < NT) {
+                fk[0] = *reinterpret_cast<const bf16x8*>(ka + (t + 1) * 2048 + rf0);
+                fk[1] = *reinterpret_cast<const bf16x8*>(ka + (t + 1) * 2048 + rf1);
+              }
+              dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+              dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[0], df0, dp[t], 0, 0, 0);
+              dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[1], df1, dp[t], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if (t + 1 < NT) {
+                fv[0] = *reinterpret_cast<const bf16x8*>(ka + 2 * KBUF + (t + 1) * 2048 + rf0);
+                fv[1] = *reinterpret_cast<const bf16x8*>(ka + 2 * KBUF + (t + 1) * 2048 + rf1);
+              }
+            }
+            if (t > 0) {
+              bf16x4 pk;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) st[t][r] = bvs[t][r] - lse_s;
-          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(ka + t * 2048 + rf0), qf0, st[t], 0, 0, 0);
-          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(ka + t * 2048 + rf1), qf1, st[t], 0, 0, 0);
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(ka + 2 * VB_KBUF + t * 2048 + rf0), df0, dp[t], 0, 0, 0);
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(ka + 2 * VB_KBUF + t * 2048 + rf1), df1, dp[t], 0, 0, 0);
-        }
-      }
+              for (int r = 0; r < 4; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(st[t - 1][r], c2, nlse));
+                const float ds = pv * (dp[t - 1][r] - delta);
+                dsacc[t - 1][r] += ds;
+                pk[r] = f2bf(ds);
+              }
+              *reinterpret_cast<bf16x4*>(ex_slot(kt0 + t - 1)) = pk;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          if constexpr (NT > 0) frags(0, fr[0]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (t < nt) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(st[t][r] * c2);
-            st[t][r] = pv;
-            dpart = fmaf(pv, dp[t][r], dpart);
+          for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) frags(t + 1, fr[(t + 1) & 1]);
+            mfmas(t);
+            __builtin_amdgcn_sched_barrier(0xF);   // (ALU and MFMA instructions may cross, memory instructions may not)
           }
         }
-      }
-      dpart = group4_sum(dpart);
-      if (lg == 0) dred[(qt * 4 + kw) * 16 + lr] = dpart;
-    }
-    if (b + 1 < b_end) fetch_q(b + 1);  // (here, not at the top: this entry's fragments are dead now and lend their registers)
-    lds_barrier();  // delta partials are in
-    // delta_i = sum_j P_ij dP_ij from the SAME P and dP that form dS, so that sum_j dS_ij = 0 holds to fp32 rounding
-    const float delta = (dred[(qt * 4 + 0) * 16 + lr] + dred[(qt * 4 + 1) * 16 + lr]) + (dred[(qt * 4 + 2) * 16 + lr] + dred[(qt * 4 + 3) * 16 + lr]);
-    if (wave_active && kw == 0 && lg == 0 && qvalid) a.delta[(long)b * stat_bs + stat_off] = delta;
-    if (wave_active) {
+        if constexpr (!PRE) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (t < nt) {
-          bf16x4 pk;
+          for (int t = 0; t < NT; ++t) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float ds = st[t][r] * (dp[t][r] - delta);
-            dsacc[t][r] += ds;
-            pk[r] = f2bf(ds);
+            for (int r = 0; r < 4; ++r) {
+              const float pv = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, nlse));
+              st[t][r] = pv;
+              dpart = fmaf(pv, dp[t][r], dpart);
+            }
           }
-          *reinterpret_cast<bf16x4*>(ex + ex_w + t * 512) = pk;
+          dpart = group4_sum(dpart);
+          if (lg == 0) dred[(qt * 4 + kw) * 16 + lr] = dpart;
         }
       }
-    }
-    lds_barrier();  // the query tile's dS tiles of all keys are in
-    if (wave_active) {
-      // dQ^T[d, q] = sum_keys K^T[d, key] dS^T[key, q] for d-tile kw, two key tiles per MFMA.  Straight-line over NP pairs (tiles past
-      // the last one contribute zeros) so that the LDS reads of several pairs are in flight together; two chains of dependent MFMAs.
-      const char* kb = sK + tro;
-      f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      if (DBG && dbe) dbe[3] = wall_clock64();
+      if constexpr (!QL) if (more) fetch_q(b + 1);  // (here, not at the top: this entry's fragments are dead now and lend their registers)
+      if constexpr (!PRE) {
+        lds_barrier();  // delta partials are in
+        if (DBG && dbe) dbe[4] = wall_clock64();
+        if constexpr (ACT) {
+          // delta_i = sum_j P_ij dP_ij from the SAME P and dP that form dS, so that sum_j dS_ij = 0 holds to fp32 rounding
+          delta = (dred[(qt * 4 + 0) * 16 + lr] + dred[(qt * 4 + 1) * 16 + lr]) + (dred[(qt * 4 + 2) * 16 + lr] + dred[(qt * 4 + 3) * 16 + lr]);
+          if (kw == 0 && lg == 0 && qvalid) pdelta[stat_off] = delta;
 #pragma unroll
-      for (int s2 = 0; s2 < NP; ++s2) {
-        bf16x4 lo = *reinterpret_cast<const bf16x4*>(ex + ex_r + (2 * s2) * 512);
-        bf16x4 hi = *reinterpret_cast<const bf16x4*>(ex + ex_r + (2 * s2 + 1) * 512);
-        if (2 * s2 >= KT) lo = bf16x4{0, 0, 0, 0};
-        if (2 * s2 + 1 >= KT) hi = bf16x4{0, 0, 0, 0};
-        bf16x8 pf;
+          for (int t = 0; t < NT; ++t) {
+            bf16x4 pk;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { pf[j] = lo[j]; pf[4 + j] = hi[j]; }
-        union { struct { s16x4 a, b; } s; bf16x8 v; } kf;
-        kf.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, kb + (2 * s2) * 2048));
-        kf.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, kb + (2 * s2 + 1) * 2048));
-        acc2[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, pf, acc2[s2 & 1], 0, 0, 0);
-        if ((s2 & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four pairs' fragments in flight at a time
+            for (int r = 0; r < 4; ++r) {
+              const float ds = st[t][r] * (dp[t][r] - delta);
+              dsacc[t][r] += ds;
+              pk[r] = f2bf(ds);
+            }
+            *reinterpret_cast<bf16x4*>(ex_slot(kt0 + t)) = pk;
+          }
+        }
+      } else if (DBG && dbe) dbe[4] = wall_clock64();
+      if (DBG && dbe) dbe[5] = wall_clock64();
+      lds_barrier();  // the query tile's dS tiles of all keys are in
+      if (DBG && dbe) dbe[6] = wall_clock64();
+      if constexpr (ACT) {
+        // dQ^T[d, q] = sum_keys K^T[d, key] dS^T[key, q] for d-tile kw, two key tiles per MFMA.  Straight-line over NP pairs (tiles past
+        // the last one hold zeros) so that the LDS reads of several pairs are in flight together; two chains of dependent MFMAs.
+        const char* kb = sK + tro;
+        f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s2 = 0; s2 < NP; ++s2) {
+          const bf16x8 pf = *reinterpret_cast<const bf16x8*>(ex_q + s2 * 1024);
+          union { struct { s16x4 a, b; } s; bf16x8 v; } kf;
+          kf.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, kb + (2 * s2) * 2048));
+          kf.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, kb + (2 * s2 + 1) * 2048));
+          acc2[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, pf, acc2[s2 & 1], 0, 0, 0);
+          if ((s2 & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four pairs' fragments in flight at a time
+        }
+        const f32x4 acc = acc2[0] + acc2[1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dq_hold[r] = f2bf(acc[r] * a.scale);
       }
-      const f32x4 acc = acc2[0] + acc2[1];
-      if (qvalid) {
-        bf16x4 ov;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = f2bf(acc[r] * a.scale);
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(a.dq) + (long)b * dq_bs + dq_off) = ov;
-      }
+      if (DBG && dbe) dbe[7] = wall_clock64();
+      advance();
+      pdelta += stat_bs;
+      pdq += dq_bs;
     }
+  };
+  if (!wave_active) walk(std::integral_constant<int, -1>{});
+  else switch (nt) {
+    case 4: walk(std::integral_constant<int, 4>{}); break;
+    case 3: walk(std::integral_constant<int, 3>{}); break;
+    case 2: walk(std::integral_constant<int, 2>{}); break;
+    case 1: walk(std::integral_constant<int, 1>{}); break;
+    default: walk(std::integral_constant<int, 0>{}); break;
   }
+  if (qvalid && b_begin < b_end) *reinterpret_cast<bf16x4*>(pdq + dq_off) = dq_hold;
 
   if (a.dbias != nullptr) {  // flush sum_b dS: a wave-private LDS transpose makes every atomic wave-instruction one run of keys of one row
     __syncthreads();
@@ -819,7 +1051,7 @@ __global__ __launch_bounds__(VK_KT * 256) void attn_bwd_dkv_short_kernel(AttnArg
   constexpr int NW = VK_KT * 4, IMG = VK_IMG(NP), EXCH = VK_EXCH(NP), PIECES = 4 * NP;  // 1-KB (8-row) pieces per image
   constexpr int NPC = (PIECES + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: see the dQ kernel)
   const int lr = lane & 15, lg = lane >> 4;
   const int ktl = w >> 2, qw = w & 3;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);  // (see the dQ kernel: the groups of one (head, batch slice) share an XCD)
@@ -847,7 +1079,10 @@ __global__ __launch_bounds__(VK_KT * 256) void attn_bwd_dkv_short_kernel(AttnArg
   const int rf0 = lr * 128 + ((lg ^ sw_r) << 4), rf1 = lr * 128 + (((4 + lg) ^ sw_r) << 4);
   const int tr_row = 4 * lg + (lr >> 2), tr_col = qw * 16 + 4 * (lr & 3);
   const int tro = tr_row * 128 + ((((tr_col >> 3) ^ ((tr_row >> 1) & 7))) << 4) + (tr_col & 7) * 2;
-  const int ex_w = ((ktl * 2 * NP + qt0) * 64 + lane) * 8, ex_r = (ktl * 2 * NP * 64 + lane) * 8;
+  // P / dS exchange of a key tile: query tiles in PAIRS, 16 B per lane and pair (tile 2p in the low, 2p + 1 in the high 8 bytes): the
+  // dK / dV loop reads a pair as ONE ds_read_b128 -- the MFMA operand as it stands -- instead of a ds_read2st64_b64 at half the LDS rate
+  const int ex_r = ktl * (2 * NP * 512) + lane * 16;
+  auto ex_slot = [&](int tile) { return ex_r + ((tile >> 1) << 10) + ((tile & 1) << 3); };
 
   for (int i = tid; i < 2 * EXCH / 16; i += NW * 64) reinterpret_cast<u32x4*>(exP)[i] = u32x4{0, 0, 0, 0};  // tiles past the last query stay zero
 
@@ -928,36 +1163,43 @@ __global__ __launch_bounds__(VK_KT * 256) void attn_bwd_dkv_short_kernel(AttnArg
     lds_barrier();  // Q(b), dO(b), statistics(b) have landed; every wave is done with entry b-1
     if (b + 1 < b_end) stage_q(b + 1, cur ^ 1);
 
-    f32x4 st[4], dp[4];
-    if (wave_active) {
+    // (straight-line code per tile count, one scalar branch: see the dQ kernel)
+    auto scores = [&](auto NTc) {
+      constexpr int NT = decltype(NTc)::value;
+      f32x4 st[NT > 0 ? NT : 1], dp[NT > 0 ? NT : 1];
       const char* qa = sQ + qt0 * 2048;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (t < nqt) {
-          const f32x4 lsv = *reinterpret_cast<const f32x4*>(sL + (qt0 + t) * 16 + 4 * lg);
-          dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 lsv = *reinterpret_cast<const f32x4*>(sL + (qt0 + t) * 16 + 4 * lg);
+        dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) st[t][r] = fmaf(-lsv[r], inv_scale, bvs[t][r]);
-          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qa + t * 2048 + rf0), kf0, st[t], 0, 0, 0);
-          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qa + t * 2048 + rf1), kf1, st[t], 0, 0, 0);
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qa + 2 * IMG + t * 2048 + rf0), vf0, dp[t], 0, 0, 0);
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qa + 2 * IMG + t * 2048 + rf1), vf1, dp[t], 0, 0, 0);
-        }
+        for (int r = 0; r < 4; ++r) st[t][r] = fmaf(-lsv[r], inv_scale, bvs[t][r]);
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qa + t * 2048 + rf0), kf0, st[t], 0, 0, 0);
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qa + t * 2048 + rf1), kf1, st[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qa + 2 * IMG + t * 2048 + rf0), vf0, dp[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qa + 2 * IMG + t * 2048 + rf1), vf1, dp[t], 0, 0, 0);
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (t < nqt) {
-          const f32x4 dlv = *reinterpret_cast<const f32x4*>(sL + 256 + (qt0 + t) * 16 + 4 * lg);
-          bf16x4 pp, ps;
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 dlv = *reinterpret_cast<const f32x4*>(sL + 256 + (qt0 + t) * 16 + 4 * lg);
+        bf16x4 pp, ps;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(st[t][r] * c2);
-            pp[r] = f2bf(pv);
-            ps[r] = f2bf(pv * (dp[t][r] - dlv[r]));
-          }
-          *reinterpret_cast<bf16x4*>(exP + ex_w + t * 512) = pp;
-          *reinterpret_cast<bf16x4*>(exP + EXCH + ex_w + t * 512) = ps;
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(st[t][r] * c2);
+          pp[r] = f2bf(pv);
+          ps[r] = f2bf(pv * (dp[t][r] - dlv[r]));
         }
+        *reinterpret_cast<bf16x4*>(exP + ex_slot(qt0 + t)) = pp;
+        *reinterpret_cast<bf16x4*>(exP + EXCH + ex_slot(qt0 + t)) = ps;
+      }
+    };
+    if (wave_active) {
+      switch (nqt) {
+        case 4: scores(std::integral_constant<int, 4>{}); break;
+        case 3: scores(std::integral_constant<int, 3>{}); break;
+        case 2: scores(std::integral_constant<int, 2>{}); break;
+        case 1: scores(std::integral_constant<int, 1>{}); break;
+        default: break;
       }
     }
     if (b + 1 < b_end) fetch_k(b + 1);  // (this entry's K / V fragments are dead: the next ones take their registers)
@@ -968,18 +1210,15 @@ __global__ __launch_bounds__(VK_KT * 256) void attn_bwd_dkv_short_kernel(AttnArg
       f32x4 av[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, ak[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int s2 = 0; s2 < NP; ++s2) {
-        union { struct { bf16x4 a, b; } s; bf16x8 v; } pf, sf;
         union { struct { s16x4 a, b; } s; bf16x8 v; } qf, df;
-        pf.s.a = *reinterpret_cast<const bf16x4*>(exP + ex_r + (2 * s2) * 512);
-        pf.s.b = *reinterpret_cast<const bf16x4*>(exP + ex_r + (2 * s2 + 1) * 512);
-        sf.s.a = *reinterpret_cast<const bf16x4*>(exP + EXCH + ex_r + (2 * s2) * 512);
-        sf.s.b = *reinterpret_cast<const bf16x4*>(exP + EXCH + ex_r + (2 * s2 + 1) * 512);
+        const bf16x8 pfv = *reinterpret_cast<const bf16x8*>(exP + ex_r + s2 * 1024);
+        const bf16x8 sfv = *reinterpret_cast<const bf16x8*>(exP + EXCH + ex_r + s2 * 1024);
         df.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, qb + 2 * IMG + (2 * s2) * 2048));
         df.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, qb + 2 * IMG + (2 * s2 + 1) * 2048));
         qf.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, qb + (2 * s2) * 2048));
         qf.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, qb + (2 * s2 + 1) * 2048));
-        av[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df.v, pf.v, av[s2 & 1], 0, 0, 0);
-        ak[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf.v, sf.v, ak[s2 & 1], 0, 0, 0);
+        av[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df.v, pfv, av[s2 & 1], 0, 0, 0);
+        ak[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf.v, sfv, ak[s2 & 1], 0, 0, 0);
         if ((s2 & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two pairs' fragments in flight at a time
       }
       if (kvalid) {
@@ -2031,8 +2270,13 @@ int xfm_attn_bwd_impl(const AttnArgs& a_in, hipStream_t st) {
   } else if (short_dq) {
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_short_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, VB_LDS(3));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_short_kernel<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, VB_LDS(3));
+#define XFM_DQS_BYTES(NP, PRE) ((PRE) && (NP) <= 7 ? VB_LDS_QL(3, NP) : VB_LDS(3))
+#define XFM_DQS_ATTR(NP, PRE) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_short_kernel<3, NP, PRE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XFM_DQS_BYTES(NP, PRE))
+      XFM_DQS_ATTR(4, false); XFM_DQS_ATTR(7, false); XFM_DQS_ATTR(8, false);
+      XFM_DQS_ATTR(4, true); XFM_DQS_ATTR(7, true); XFM_DQS_ATTR(8, true);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_short_kernel<3, 7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, XFM_DQS_BYTES(7, false));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_short_kernel<3, 7, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, XFM_DQS_BYTES(7, true));
+#undef XFM_DQS_ATTR
       attr_set = true;
     }
     // (query groups x heads) workgroups per batch slice; slices so that one round of <= 256 workgroups covers the batch
@@ -2043,8 +2287,29 @@ int xfm_attn_bwd_impl(const AttnArgs& a_in, hipStream_t st) {
     z = z < 1 ? 1 : (z > a.B ? a.B : z);
     const int nb = cdiv(a.B, z);
     const dim3 grid(groups * a.H * cdiv(a.B, nb));
-    if (a.Sk <= 128) hipLaunchKernelGGL((attn_bwd_dq_short_kernel<3, 4>), grid, dim3(768), VB_LDS(3), st, a, nb, groups);
-    else hipLaunchKernelGGL((attn_bwd_dq_short_kernel<3, 8>), grid, dim3(768), VB_LDS(3), st, a, nb, groups);
+    long long* dbg = nullptr;
+    {
+      const char* dp = getenv("XFM_ATTN_DBG_PTR");   // (read per launch: tools/attn_timeline.py sets it around the one call it wants a timeline of)
+      if (dp != nullptr && dp[0] != 0) dbg = reinterpret_cast<long long*>(strtoull(dp, nullptr, 0));   // (| stamping wave, 0..11)
+    }
+    // NP = key-tile pairs the dQ loop runs over.  XFM_ATTN_SHORT_PRE=1 (opt-in): the row term delta from dO . (O + O_lo) when the forward
+    // kept the low half of O -- one barrier and the delta exchange less per entry, Q / dO through LDS, and MEASURED SLOWER (dQ 121 us
+    // against 97.5 at B = 128, 197 tokens: profiles/round5_attn_short.md), so the exchange form stays the default
+    const char* pe = getenv("XFM_ATTN_SHORT_PRE");   // (read per call: the tests switch it inside one process)
+    const bool pre_env = pe != nullptr && atoi(pe) != 0;
+    const bool pre = pre_env && a.o != nullptr && a.o_lo != nullptr;
+#define XFM_DQS_LAUNCH(NP)                                                                                                      \
+  do {                                                                                                                          \
+    if (pre) hipLaunchKernelGGL((attn_bwd_dq_short_kernel<3, NP, true, false>), grid, dim3(768), XFM_DQS_BYTES(NP, true), st, a, nb, groups, dbg);    \
+    else hipLaunchKernelGGL((attn_bwd_dq_short_kernel<3, NP, false, false>), grid, dim3(768), XFM_DQS_BYTES(NP, false), st, a, nb, groups, dbg);      \
+  } while (0)
+    if (dbg != nullptr && a.Sk > 128 && a.Sk <= 224) {   // the stamped build exists for the ViT shape only (tools/attn_timeline.py)
+      if (pre) hipLaunchKernelGGL((attn_bwd_dq_short_kernel<3, 7, true, true>), grid, dim3(768), XFM_DQS_BYTES(7, true), st, a, nb, groups, dbg);
+      else hipLaunchKernelGGL((attn_bwd_dq_short_kernel<3, 7, false, true>), grid, dim3(768), XFM_DQS_BYTES(7, false), st, a, nb, groups, dbg);
+    } else if (a.Sk <= 128) XFM_DQS_LAUNCH(4);
+    else if (a.Sk <= 224) XFM_DQS_LAUNCH(7);
+    else XFM_DQS_LAUNCH(8);
+#undef XFM_DQS_LAUNCH
   } else if (a.dbias != nullptr && res && plain) {
     // batch entries whose dS one workgroup sums before touching HBM.  The kernel holds 230+ VGPRs (sum_b dS of four chunks), i.e.
     // one workgroup per CU: of 4 and 8 entries take the one with fewer (rounds of 256 workgroups) x entries, ties to 8
