@@ -20,6 +20,8 @@ dbias = torch.zeros_like(bias)
 tiles = Fx.bias_tiles(bias, N, 0.125) if os.environ.get("TILED", "1") == "1" else None
 if os.environ.get("NOBIAS") == "1":
     bias = bias_t = dbias = tiles = None
+if os.environ.get("DBIAS", "1") == "0":   # bias, but no bias gradient
+    dbias = None
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
 

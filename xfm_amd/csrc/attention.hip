@@ -202,7 +202,7 @@ __device__ __forceinline__ float delta_from_out(const AttnArgs& a, long row, int
 template <bool RES, bool PLAIN>
 __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), nthreads = blockDim.x;
   const int lr = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   long qbase, kbase;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a, int nb_per
   constexpr bool DBIAS = NKC > 0;
   constexpr int NACC = DBIAS ? NKC : 1;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), nthreads = blockDim.x;
   const int lr = lane & 15, lg = lane >> 4;
   const int h = blockIdx.y;
   const int q0 = (blockIdx.x * (nthreads >> 6) + w) * 16;
@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(VK_KT * 256) void attn_bwd_dkv_short_kernel(AttnArg
 template <bool RES, bool PLAIN>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthreads = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), nthreads = blockDim.x;
   const int lr = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int kvb = a.kv_index ? a.kv_index[b] : b;
@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs a) {
 template <bool PACK, bool MASK, bool DROP>
 __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int g = blockIdx.z, h = blockIdx.y;
   const int tq = (a.Sq + 15) / 16, rpp = nw / tq;  // waves per row, rows per pass
@@ -1540,7 +1540,7 @@ __global__ __launch_bounds__(512, 4) void xattn_fwd_kernel(AttnArgs a) {
 template <bool MASK, bool DROP>
 __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int g = blockIdx.z, h = blockIdx.y;
   const int rstart = a.grp_start[g], nrows = a.grp_start[g + 1] - rstart;
@@ -1674,7 +1674,7 @@ __global__ __launch_bounds__(512, 4) void xattn_dq_kernel(AttnArgs a) {
 template <bool DROP>
 __global__ __launch_bounds__(1024) void xattn_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int g = blockIdx.z, h = blockIdx.y;
   const int rstart = a.grp_start[g], nrows = a.grp_start[g + 1] - rstart;
@@ -1819,7 +1819,7 @@ __device__ __forceinline__ void xs_barrier() {
 }
 __global__ __launch_bounds__(512, 2) void xattn_fwd_stream_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int g = blockIdx.z, h = blockIdx.y;
   const int rstart = a.grp_start[g], nrows = a.grp_start[g + 1] - rstart;
@@ -1936,7 +1936,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_stream_kernel(AttnArgs a) {
 // of the kernels above), then dS and dQ -- unless the forward left o_lo (one sweep).
 __global__ __launch_bounds__(512, 2) void xattn_dq_stream_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int g = blockIdx.z, h = blockIdx.y;
   const int rstart = a.grp_start[g], nrows = a.grp_start[g + 1] - rstart;

@@ -335,7 +335,7 @@ static int launch_attn_fwd_vit(const AttnArgs& a, hipStream_t st) {
 #define V3_OFF_ST (V3_OFF_EX + 2 * V3_EXCH)    // 2 x { lse / scale [32] | delta [32] }
 #define V3_LDS (V3_OFF_ST + 2 * 256)
 
-template <bool HAS_BIAS>
+template <bool HAS_BIAS, bool DBIAS>
 __global__ __launch_bounds__(512) void attn_bwd_vit3_kernel(AttnArgs a, VitMap vm) {
   constexpr int KT = V3_KT, NP = V3_NP;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -429,12 +429,12 @@ __global__ __launch_bounds__(512) void attn_bwd_vit3_kernel(AttnArgs a, VitMap v
     if (lane < 32) ss[lane] = p * 32 + lane < S ? ls * inv_scale : 1.0e30f;
   };
 
-  f32x4 dsacc[KT][2];
+  f32x4 dsacc[DBIAS ? KT : 1][2];
 #pragma unroll
-  for (int i = 0; i < KT; ++i) dsacc[i][0] = dsacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < (DBIAS ? KT : 1); ++i) dsacc[i][0] = dsacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   // sum_b dS of this wave's 32 keys leaves through a wave-private 1-KB transpose in exchange buffer `xs` (idle when this runs)
   auto flush = [&](int hh, int xs) {
-    if (a.dbias == nullptr || !owner) return;
+    if (!DBIAS || a.dbias == nullptr || !owner) return;
     float* scr = reinterpret_cast<float*>(ex + xs * V3_EXCH + w * 1024);
     const int col = lane & 31, key = kt0 * 16 + col;
     float* const dst0 = a.dbias + (long)hh * S * a.bias_ld + key;
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(512) void attn_bwd_vit3_kernel(AttnArgs a, VitMap v
                 for (int r = 0; r < 4; ++r) {
                   const float pv = __builtin_amdgcn_exp2f(sc[r] * c2);
                   const float ds = pv * dp[r];
-                  dsacc[qt < KT ? qt : 0][t][r] += ds;
+                  if (DBIAS) dsacc[qt < KT ? qt : 0][t][r] += ds;
                   pp[u][t][r] = f2bf(pv);
                   ps[u][t][r] = f2bf(ds);
                 }
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(512) void attn_bwd_vit3_kernel(AttnArgs a, VitMap v
       // transposition scratch takes the other one
       flush(h, par ^ 1);
 #pragma unroll
-      for (int i = 0; i < KT; ++i) dsacc[i][0] = dsacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < (DBIAS ? KT : 1); ++i) dsacc[i][0] = dsacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       lds_barrier_v();
     }
     h = hn;
@@ -670,7 +670,8 @@ static bool attn_vit3_shape(const AttnArgs& a) {
 
 static int launch_attn_bwd_vit3(const AttnArgs& a, hipStream_t st) {
   const VitMap vm = vit_map(a.B, a.H);
-  if (a.bias != nullptr) vit_launch<7>(attn_bwd_vit3_kernel<true>, V3_LDS, dim3(vm.grid), dim3(512), st, a, vm);
-  else vit_launch<8>(attn_bwd_vit3_kernel<false>, V3_LDS, dim3(vm.grid), dim3(512), st, a, vm);
+  if (a.bias != nullptr && a.dbias != nullptr) vit_launch<7>(attn_bwd_vit3_kernel<true, true>, V3_LDS, dim3(vm.grid), dim3(512), st, a, vm);
+  else if (a.bias != nullptr) vit_launch<9>(attn_bwd_vit3_kernel<true, false>, V3_LDS, dim3(vm.grid), dim3(512), st, a, vm);
+  else vit_launch<8>(attn_bwd_vit3_kernel<false, false>, V3_LDS, dim3(vm.grid), dim3(512), st, a, vm);
   return xfm_check_launch("attn_bwd_vit3");
 }
