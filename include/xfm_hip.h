@@ -446,6 +446,29 @@ int xfm_adamw(const xfm_adamw_args* a, void* stream);
 #define XFM_SUMSQ_WORKSPACE_FLOATS 1024
 int xfm_sumsq(const float* x, long n, float* out, float* workspace, void* stream);
 
+/* ---- Data-parallel exchange over RCCL / xGMI ------------------------------------------------------------------------
+ * What the reference does through torch.distributed: the gradient all-reduce of DistributedDataParallel
+ * (accelerators/ddp_accelerator.py:34-98, apex_ddp_accelerator.py:34-110), the feature AllGather of the contrastive loss
+ * (models/xfm.py:17-50), the parameter broadcast at wrap time -- for a host without torch.distributed.  One
+ * communicator per process (one process per GPU); every call is enqueued on the caller's HIP stream and returns at once; nothing is
+ * allocated or synchronised.  librccl is resolved at the first call (dlopen: inside a PyTorch process that is the RCCL torch already
+ * mapped); XFM_E_UNSUPPORTED when it cannot be loaded.  The Python host (accelerators/rccl_ddp_accelerator.py) keeps using
+ * torch.distributed's "nccl" backend, which IS RCCL; xfm_amd/dp.py wraps these for hosts that do not.
+ *   rank 0: xfm_dp_unique_id(id) -> hand the XFM_DP_ID_BYTES bytes to every rank (file, socket, environment) ->
+ *   every rank, with its device current: xfm_dp_init(id, rank, world, &comm) -> ... -> xfm_dp_finalize(comm). */
+#define XFM_DP_ID_BYTES 128
+enum { XFM_DP_F32 = 0, XFM_DP_BF16 = 1, XFM_DP_I32 = 2 };
+enum { XFM_DP_SUM = 0, XFM_DP_AVG = 1, XFM_DP_MAX = 2 };
+int xfm_dp_unique_id(void* id);
+int xfm_dp_init(const void* id, int rank, int world, void** comm);
+/* in place over one bucket (a range of the flat gradient arena): buf[i] = op over ranks; XFM_DP_AVG is the mean DistributedDataParallel
+ * takes (ReduceOp.AVG: one pass, no separate division) */
+int xfm_dp_bucket_allreduce(void* comm, void* buf, long n, int dtype, int op, void* stream);
+/* recv[r * n_per_rank + i] = rank r's send[i]  (models/xfm.py:17-50: the forward of AllGather; its backward is the caller's slice) */
+int xfm_dp_allgather(void* comm, const void* send, void* recv, long n_per_rank, int dtype, void* stream);
+int xfm_dp_broadcast(void* comm, void* buf, long n, int dtype, int root, void* stream);
+int xfm_dp_finalize(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

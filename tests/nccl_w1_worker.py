@@ -1,10 +1,12 @@
 """Worker of test_hip_accelerator.test_collectives_through_rccl_in_a_group_of_one (run as a child process with a time limit, so that
-an RCCL bring-up problem cannot hang the test process).  Three runs of the same three pre-training steps on cuda:0:
+an RCCL bring-up problem cannot hang the test process).  Four runs of the same three pre-training steps on cuda:0:
   A  no process group (the plain W = 1 path);
   B  backend 'nccl' (RCCL), world_size 1, FORCE_COLLECTIVES: agreement MAX all-reduce, ITC all_gather with slice backward,
      arena broadcast, ReduceOp.AVG all-reduces issued from the tower hooks / the ViT chunk hand-over on the communication
      stream, fp32 exchange;
-  C  the same with the bf16 wire format (pack -> all-reduce -> unpack on the communication stream).
+  C  the same with the bf16 wire format (pack -> all-reduce -> unpack on the communication stream);
+  D  as B with XFM_DP_NATIVE: the gradient ranges leave through the library's own communicator (xfm_dp_bucket_allreduce, on the
+     communication stream itself) instead of ProcessGroupNCCL.
 Mean over one rank is the identity: every range that leaves through RCCL -- from the tower hooks and the ViT chunk hand-over inside
 backward, or from the sweep after it -- must come back BIT FOR BIT (fp32) or as exactly its bf16 rounding (bf16 wire format); the
 worker snapshots each range on the communication stream right before its collective and compares after the step.  Run-to-run the
@@ -26,8 +28,10 @@ from xfm_amd import pretrain_loop as PL  # noqa: E402
 from xfm_amd import synthetic as syn  # noqa: E402
 
 
-def run(meta, force, exchange="fp32"):
+def run(meta, force, exchange="fp32", native=False):
     from xfm_amd.accelerators import RCCLDDPAccelerator
+    from xfm_amd.accelerators import rccl_ddp_accelerator as A
+    A._NATIVE = bool(native)   # (the module reads XFM_DP_NATIVE at import; the worker switches it per run)
     from xfm_amd.model_pretrain import XFM
     cfg = {"use_beit_v2": True, "image_res": 224, "patch_size": 16, "local_attn_depth": -1, "text_encoder": "roberta-base",
            "text_num_hidden_layers": meta["text_layers"], "text_fusion_start_at": meta["text_layers"],
@@ -118,10 +122,12 @@ def main():
     dist.init_process_group("nccl", world_size=1, rank=0)
     pb, gb, sb, op, _, id_fp32, _ = run(meta, True)
     pc, gc, sc, _, _, id_bf16, _ = run(meta, True, "bf16")
+    pd, gd, sd, _, _, id_native, _ = run(meta, True, "fp32", native=True)   # the gradient ranges through the C-ABI's own communicator
     dist.barrier()
     dist.destroy_process_group()
     out = {"backend": "nccl", "op": op, "live_elems": live,
-           "identity_fp32": id_fp32, "identity_bf16": id_bf16,
+           "identity_fp32": id_fp32, "identity_bf16": id_bf16, "identity_native": id_native,
+           "first_step_grad_rel_l2_native": float((gd - ga).norm() / ga.norm()),
            "first_step_grad_rel_l2_vs_no_collectives": float((gb - ga).norm() / ga.norm()),
            "first_step_grad_rel_l2_bf16_wire": float((gc - ga).norm() / ga.norm()),
            "param_rel_l2_after_3_steps": float((pb - pa).norm() / pa.norm()),

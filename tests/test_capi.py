@@ -65,6 +65,21 @@ def test_argument_errors_are_reported_not_crashed():
     assert rc == -1
 
 
+def test_rccl_entry_points_report_argument_errors():
+    """xfm_dp_*: no communicator -> an error code and a message, never a crash (XFM_E_ARG; XFM_E_UNSUPPORTED where librccl.so cannot be
+    loaded -- the library itself must load without it: it is resolved at the first xfm_dp_* call, not at link time)."""
+    from xfm_amd import _lib
+    lib = _lib.load()
+    rc = lib.xfm_dp_bucket_allreduce(None, None, 16, 0, 1, None)
+    assert rc in (-1, -3) and lib.xfm_last_error()
+    rc = lib.xfm_dp_init(None, 0, 1, None)
+    assert rc in (-1, -3)
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH if hasattr(_lib, "LIB_PATH") else os.path.join(ROOT, "xfm_amd", "libxfm_hip.so")],
+                            capture_output=True, text=True).stdout
+    assert "rccl" not in needed   # no link-time dependency on RCCL
+
+
 def test_product_path_refuses_cpu_tensors():
     from xfm_amd import _lib, functional as Fx
     a = torch.zeros(4, 64, dtype=torch.bfloat16)

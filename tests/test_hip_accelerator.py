@@ -301,6 +301,9 @@ def test_collectives_through_rccl_in_a_group_of_one():
     assert "AVG" in out["op"]
     assert out["identity_fp32"]["ranges"] >= 15 and out["identity_fp32"]["bad"] == 0, out["identity_fp32"]
     assert out["identity_bf16"]["ranges"] >= 15 and out["identity_bf16"]["bad"] == 0, out["identity_bf16"]
+    # XFM_DP_NATIVE: the same ranges through xfm_dp_bucket_allreduce (include/xfm_hip.h), launched on the communication stream
+    assert out["identity_native"]["ranges"] >= 15 and out["identity_native"]["bad"] == 0, out["identity_native"]
+    assert out["first_step_grad_rel_l2_native"] < 1e-6, out
     # two runs of the same step differ by the float atomics of the small weight-gradient path only: 1e-8 of the gradient norm.  (Round
     # 3 saw 1.1e-3 once in ~20 runs: the LM-head activation gradient was summed over its K-slices with fp32 atomics and then rounded
     # to bf16 -- a rounding flip of one element that the backward below it amplified.  That sum is in a fixed order now,
@@ -313,3 +316,20 @@ def test_collectives_through_rccl_in_a_group_of_one():
     assert out["stats_bf16"][2]["exchange_bytes"] == 2 * out["live_elems"]
     # bf16 wire format: one rounding of each exchanged gradient
     assert out["first_step_grad_rel_l2_bf16_wire"] < 4e-3 and out["param_rel_l2_after_3_steps"] < 1e-2, out
+
+
+def test_rccl_entry_points_of_the_c_abi_in_a_group_of_one():
+    """include/xfm_hip.h xfm_dp_{unique_id, init, bucket_allreduce, allgather, broadcast, finalize} (the exchange a host
+    without torch.distributed binds; ddp_accelerator.py:34-98, models/xfm.py:17-50): a communicator of ONE rank on cuda:0 in a child
+    process (tests/dp_w1_worker.py).  Sum, mean and max over one rank, the gather and the broadcast are the identity: every buffer
+    comes back bit for bit, on a side stream ordered by stream semantics only."""
+    import json
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_w1_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("DP_W1 ")][-1][len("DP_W1 "):])
+    assert out["checks"] == 10 and out["bad"] == 0, out

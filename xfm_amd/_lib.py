@@ -166,6 +166,12 @@ SIGNATURES = {
     "xfm_ce_bwd": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p]),
     "xfm_adamw": (c_int, [ctypes.POINTER(AdamWArgs), c_void_p]),
     "xfm_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "xfm_dp_unique_id": (c_int, [c_void_p]),
+    "xfm_dp_init": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "xfm_dp_bucket_allreduce": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "xfm_dp_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "xfm_dp_broadcast": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "xfm_dp_finalize": (c_int, [c_void_p]),
     "xfm_rlayer_layout": (c_int, [c_int] * 11 + [ctypes.POINTER(RLayerLayout)]),
     "xfm_rlayer_fwd": (c_int, [ctypes.POINTER(RLayerParams), ctypes.POINTER(RLayerIO), c_void_p]),
     "xfm_rlayer_bwd": (c_int, [ctypes.POINTER(RLayerParams), ctypes.POINTER(RLayerIO), ctypes.POINTER(RLayerBwd), c_void_p]),

@@ -39,6 +39,11 @@ _HOST_TIMES = [] if os.environ.get("XFM_DDP_HOST_TIMES", "0") == "1" else None  
 # behind the AdamW kernels that read the gradients: nothing reads or writes a gradient again before the NEXT backward pass, so the
 # fills run under the next step's forward instead of at the end of the serial optimizer tail; backward_step (and every accelerator
 # entry that touches the gradient arena) waits for them.  A/B knob.
+# XFM_DP_NATIVE=1 (opt-in): the gradient ranges leave through the library's own communicator (include/xfm_hip.h xfm_dp_bucket_allreduce,
+# xfm_amd/dp.py) instead of ProcessGroupNCCL -- the collective then runs ON the communication stream it is launched from (torch's
+# runs on ProcessGroupNCCL's internal stream and hands back an event).  torch.distributed still carries the bootstrap (the unique id), the
+# live-set agreement, the set-up broadcast and the ITC all_gather.
+_NATIVE = os.environ.get("XFM_DP_NATIVE", "0") != "0"
 _ASYNC_ZERO = os.environ.get("XFM_ASYNC_ZERO", "1") != "0"
 # The squared gradient norm of a tower's arena ranges as soon as the tower's backward (and, at N > 1, its all-reduce) is over: the text
 # and fusion towers (70 % of the live gradient bytes) are final while the ViT backward still runs, so their share of the clip norm's
@@ -123,6 +128,7 @@ class RCCLDDPAccelerator(Accelerator):
         self._done_ranges = []
         self._use = {}
         self._op = dist.ReduceOp.SUM
+        self._native = None        # xfm_amd.dp.NativeComm when XFM_DP_NATIVE=1 (set_up)
         self.timing = None         # (start, end) torch.cuda.Event pair a caller installs to time the exposed part of the exchange
         self._zero_stream = None   # the optimizer step's zero_grad runs here (_zero_async)
         self._norm_early = {}      # (a, b) live range -> (sum of squares [1], event): computed from inside backward (_early_sumsq)
@@ -152,6 +158,12 @@ class RCCLDDPAccelerator(Accelerator):
         _xfm.FORCE_COLLECTIVES = bool(self.force and self._dist)
         # RCCL averages in the collective itself (no extra pass over the 1.4 GB of live gradients)
         self._op = dist.ReduceOp.AVG if (self._dist and dist.get_backend() == "nccl") else dist.ReduceOp.SUM
+        self._native = None
+        if _NATIVE and self._dist and use_cuda and dist.get_backend() == "nccl":
+            from ..dp import NativeComm
+            box = [NativeComm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self._native = NativeComm(box[0], rank, dist.get_world_size())
         if hasattr(model, "finalize"):
             model.finalize()
         self.model = model
@@ -310,7 +322,14 @@ class RCCLDDPAccelerator(Accelerator):
             return
         self.stats["exchange_calls"] += 1
         self.stats["exchange_bytes"] += (b - a) * (2 if self.exchange_dtype == "bf16" else 4)
-        if self.exchange_dtype == "bf16":
+        if self._native is not None:   # on the current (= communication) stream; nothing to wait for afterwards
+            if self.exchange_dtype == "bf16":
+                buf = g.to(torch.bfloat16)
+                self._native.all_reduce(buf, "avg")
+                g.copy_(buf)
+            else:
+                self._native.all_reduce(g, "avg")
+        elif self.exchange_dtype == "bf16":
             buf = g.to(torch.bfloat16)
             w = dist.all_reduce(buf, op=self._op, async_op=True)
             w.wait()  # stream-ordered for RCCL (the host does not block); the unpack follows on this stream

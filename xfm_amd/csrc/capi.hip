@@ -36,6 +36,7 @@ int xfm_cu_count() {
 #include "elementwise.hip"
 #include "encoder.hip"
 #include "losses.hip"
+#include "dp.hip"
 
 #define ST(s) ((hipStream_t)(s))
 #define NOTNULL(p, name) XFM_REQUIRE((p) != nullptr, "%s: null argument struct", name)
@@ -276,5 +277,17 @@ int xfm_sumsq(const float* x, long n, float* out, float* workspace, void* stream
   XFM_REQUIRE(x && out && workspace, "sumsq: null operand");
   return xfm_sumsq_impl(x, n, out, workspace, ST(stream));
 }
+int xfm_dp_unique_id(void* id) { return xfm_dp_unique_id_impl(id); }
+int xfm_dp_init(const void* id, int rank, int world, void** comm) { return xfm_dp_init_impl(id, rank, world, comm); }
+int xfm_dp_bucket_allreduce(void* comm, void* buf, long n, int dtype, int op, void* stream) {
+  return xfm_dp_bucket_allreduce_impl(comm, buf, n, dtype, op, ST(stream));
+}
+int xfm_dp_allgather(void* comm, const void* send, void* recv, long n_per_rank, int dtype, void* stream) {
+  return xfm_dp_allgather_impl(comm, send, recv, n_per_rank, dtype, ST(stream));
+}
+int xfm_dp_broadcast(void* comm, void* buf, long n, int dtype, int root, void* stream) {
+  return xfm_dp_broadcast_impl(comm, buf, n, dtype, root, ST(stream));
+}
+int xfm_dp_finalize(void* comm) { return xfm_dp_finalize_impl(comm); }
 
 }  // extern "C"
