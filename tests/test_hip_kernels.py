@@ -1266,7 +1266,7 @@ def test_short_attention_backward_delta_from_output(B, H, S, use_bias, monkeypat
     _close(got["1"][0], got["0"][0], 1e-2, "dqkv, the two forms")
 
 
-@pytest.mark.parametrize("mode", ["0", "3"])   # XFM_ATTN_VIT_BWD: 0 = split dQ + dK/dV kernels (default), 3 = single-pass kernel (13 tiles)
+@pytest.mark.parametrize("mode", ["0", "3", "4"])   # XFM_ATTN_VIT_BWD: 0 = split dQ + dK/dV kernels (default), 3 = single-pass kernel (13 tiles), 4 = single pass + the block-walking bias-gradient kernel
 @pytest.mark.parametrize("tiled", [True, False])
 @pytest.mark.parametrize("B,H,S,use_bias", [
     (2, 12, 197, True),     # the 224-px ViT (13 tiles: the seventh key-owner wave holds 5 keys, the last query pair is one tile)
@@ -1281,7 +1281,7 @@ def test_vit_attention_fused_forward_backward(B, H, S, use_bias, tiled, mode, mo
     """The batch-walking ViT kernels (csrc/attention_vit.hip: one workgroup per (batch entry, head) problem at a time; forward with the
     whole score row and the head's bias rows in registers; opt-in single-pass backward with S / dP computed once for dQ, dK, dV and the
     bias gradient) against fp32 math (beit2.py:126-166).  The single-pass backward defines delta_i = dO_i . O_i with the bf16 O."""
-    if mode == "3" and ((use_bias and not tiled) or (S + 15) // 16 != 13):
+    if mode in ("3", "4") and ((use_bias and not tiled) or (S + 15) // 16 != 13):
         pytest.skip("the single-pass backward takes 13-tile sequences and the tiled bias only")
     monkeypatch.setenv("XFM_ATTN_VIT_BWD", mode)   # (the single-pass backward kernels are opt-in; the library reads the switch per call)
     Fx = _fx()
@@ -1317,7 +1317,7 @@ def test_vit_attention_fused_forward_backward(B, H, S, use_bias, tiled, mode, mo
     _close(dqkv[:, :D], qr.grad, 2e-2, "dq")
     _close(dqkv[:, D:2 * D], kr.grad, 2e-2, "dk")
     _close(dqkv[:, 2 * D:], vr.grad, 2e-2, "dv")
-    if mode == "3":   # (the split kernels' delta is the two-pass sum_j P_ij dP_ij)
+    if mode in ("3", "4"):   # (the split kernels' delta is the two-pass sum_j P_ij dP_ij)
         want_delta = (dout.float() * o.float()).view(B, S, H, 64).sum(-1).permute(0, 2, 1)
         _close(delta[:, :, :S], want_delta, 1e-3, "delta")
     if use_bias:

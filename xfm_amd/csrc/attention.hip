@@ -2240,6 +2240,14 @@ int xfm_attn_bwd_impl(const AttnArgs& a_in, hipStream_t st) {
     else hipLaunchKernelGGL(xattn_dkv_kernel<false>, dim3(kblocks, a.H, a.n_groups), dim3(knw * 64), dkv_lds, st, a);
     return xfm_check_launch("xattn_dkv");
   }
+  if (attn_vit_split_dbias(a)) {
+    AttnArgs a2 = a;
+    a2.dbias = nullptr;
+    a2.dbias_ws = nullptr;
+    rc = launch_attn_bwd_vit3(a2, st);
+    if (rc != XFM_OK) return rc;
+    return launch_attn_dbias_blocks(a, st);
+  }
   if (attn_vit3_shape(a)) return launch_attn_bwd_vit3(a, st);
   // long dense unmasked problems (577 / 901 image tokens): attention_long.hip.  The dK/dV kernel reads the transposed bias copy;
   // without one that half stays on the general kernel.

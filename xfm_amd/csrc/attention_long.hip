@@ -594,7 +594,19 @@ static bool attn_long_shape(const AttnArgs& a) {
          // the bias-gradient kernel writes every column of a plane row: the row must end inside the last 128-key block
          (a.dbias == nullptr || (a.bias != nullptr && a.bias_ld <= (long)cdiv(a.Sk, 128) * 128 && ((uintptr_t)a.dbias % 16) == 0));
 }
+// XFM_ATTN_VIT_BWD=4 (experiment): the single-pass backward WITHOUT its bias-gradient sums (they are what spills it) + this file's
+// block-walking bias-gradient kernel on the delta it wrote
+static bool attn_vit_split_dbias(const AttnArgs& a) {
+  const char* e = getenv("XFM_ATTN_VIT_BWD");
+  return e != nullptr && atoi(e) == 4 && a.dbias != nullptr && attn_vit3_shape(a) && a.bias_ld % 4 == 0 && a.bias_ld <= (long)cdiv(a.Sk, 128) * 128 &&
+         ((uintptr_t)a.dbias % 16) == 0 && ((uintptr_t)a.bias % 16) == 0;
+}
 long xfm_attn_bwd_workspace_impl(const AttnArgs& a) {
+  if (attn_vit_split_dbias(a)) {
+    const int blocks = cdiv(a.Sq, 128) * cdiv(a.Sk, 128) * a.H;
+    const int slices = dbias_long_slices(blocks, a.B, (long)a.H * a.Sq * a.bias_ld * 4);
+    return slices > 1 ? (long)slices * a.H * a.Sq * a.bias_ld * 4 : 0;
+  }
   if (a.dbias == nullptr || a.Sk <= 64 * ATTN_RES_MAX) return 0;
   if (attn_long_shape(a)) {
     const int blocks = cdiv(a.Sq, 128) * cdiv(a.Sk, 128) * a.H;
@@ -609,6 +621,7 @@ static void long_attr(K kernel, int bytes) { (void)hipFuncSetAttribute(reinterpr
 // the accumulator-layout bias copies (xfm_bias_tile) serve square problems
 static bool long_tiled(const AttnArgs& a, const float* tiles) { return a.bias != nullptr && tiles != nullptr && a.Sq == a.Sk && ((uintptr_t)tiles % 16) == 0; }
 
+static int launch_attn_dbias_blocks(const AttnArgs& a, hipStream_t st);
 static int launch_attn_bwd_long_dq(const AttnArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -626,7 +639,17 @@ static int launch_attn_bwd_long_dq(const AttnArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((attn_bwd_dq_long_kernel<false, false>), grid, blk, lds_b, st, a, qblocks);
   int rc = xfm_check_launch("attn_bwd_dq_long");
   if (rc != XFM_OK || a.dbias == nullptr) return rc;
-  // bias gradient (reads the delta the kernel above wrote): blocks of 128 x 128, the batch in `slices`
+  return launch_attn_dbias_blocks(a, st);
+}
+
+// bias gradient (reads the delta a dQ kernel wrote): blocks of 128 x 128, the batch in `slices`
+static int launch_attn_dbias_blocks(const AttnArgs& a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    long_attr(attn_dbias_long_kernel<true>, 2 * LD_STAGE);
+    attr_set = true;
+  }
+  int rc;
   const int qb = cdiv(a.Sq, 128), kb = cdiv(a.Sk, 128);
   const long per_entry = (long)a.H * a.Sq * a.bias_ld;
   int slices = dbias_long_slices(qb * kb * a.H, a.B, per_entry * 4);

@@ -1,6 +1,7 @@
 """Raw (non-autograd) tensor-level wrappers over the C ABI.  Device tensors in, kernels enqueued on torch's current
 stream.  PyTorch is used here only for memory, streams and shapes."""
 import ctypes
+import os
 
 import torch
 
@@ -456,7 +457,7 @@ def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, 
     a.dk, a.dk_rs = dk.data_ptr(), dk.stride(0)
     a.dv, a.dv_rs = dv.data_ptr(), dv.stride(0)
     a.delta, a.dbias = delta.data_ptr(), _ptr(dbias)
-    if dbias is not None and Sk > 256 and phase != 2:
+    if dbias is not None and phase != 2 and (Sk > 256 or os.environ.get("XFM_ATTN_VIT_BWD") == "4"):
         # long sequences (the 577 / 901 tokens of the 384 / 480 px ViT): the library says how much scratch the bias gradient wants --
         # a few MB of per-slice planes for the batch-walking kernel of dense unmasked problems, the [B, H, Sq, ld] per-entry dS of the
         # general kernels otherwise (xfm_attn_bwd_workspace)
