@@ -275,6 +275,56 @@ def test_gradient_norm_shares_taken_inside_backward_equal_the_pass_after_it(monk
     assert A._EARLY_NORM
 
 
+def test_repeated_step_reproduces_every_matrix_gradient_bit_for_bit():
+    """The same training-mode step three times in one process (same batch, every counter-based draw rewound: dropout seeds, the drop-path
+    draw; fixed masks and negatives): every 2-D Linear / patch-embedding weight gradient -- all the GEMM weight-gradient paths, grouped
+    and deferred launches included -- comes back BIT FOR BIT, and the four losses too.  The remaining tensors (bias / LayerNorm /
+    layer-scale column sums folded by float atomics, the relative-position tables, embeddings, cls / mask token, temp) agree to
+    float-atomics noise, 1e-6 of their norm (tools/bit_repro.py lists them at the headline shape)."""
+    from xfm_amd import xroberta as XR
+    z, meta = load("pretrain_small")
+    m, wrapped, opt, acc = _build(meta)
+    m.train()
+    B = meta["B"]
+    b = {k: v.cuda() for k, v in syn.pretrain_batch(B, seed=411).items()}
+    masks = syn.mim_block_mask(B, 14, 75, seed=411)
+    arena = m._arena
+    snaps, losses = [], []
+    for rep in range(3):
+        XR._seed_counter[0] = 0
+        torch.manual_seed(7)
+        torch.cuda.manual_seed_all(7)
+        out = wrapped(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"], masked_pos=b["masked_pos"],
+                      masked_ids=b["masked_ids"], ret_mim_loss=True, data_source="image", ids_mask=masks,
+                      neg_idx=([(i + 1) % B for i in range(B)], [(i + 2) % B for i in range(B)]))
+        acc.backward_step(out["loss_itc"] + out["loss_itm"] + out["loss_mlm"] + out["loss_mim"], opt)
+        acc.grads_ready()
+        torch.cuda.synchronize()
+        snaps.append(arena.grad.clone())
+        losses.append([float(out[k].detach()) for k in ("loss_itc", "loss_itm", "loss_mlm", "loss_mim")])
+        m.zero_grad()
+        acc.grads_ready()
+    assert losses[1] == losses[0] and losses[2] == losses[0], losses
+    matrices = exact = 0
+    for p in arena.params:
+        name = arena.names[id(p)]
+        o, n = arena.offsets[id(p)]
+        x = snaps[0][o:o + n]
+        if float(x.abs().max()) == 0.0:
+            continue
+        is_matrix = p.dim() >= 2 and name.endswith(".weight") and "embeddings" not in name and "relative_position" not in name
+        for r in (1, 2):
+            y = snaps[r][o:o + n]
+            if is_matrix:
+                assert torch.equal(x, y), f"{name}: repetition {r} differs"
+            else:
+                assert float((x.double() - y.double()).norm()) <= 1e-6 * float(x.double().norm()), name
+        matrices += int(is_matrix)
+        exact += int(torch.equal(x, snaps[1][o:o + n]) and torch.equal(x, snaps[2][o:o + n]))
+    print(f"{matrices} matrix gradients bit-identical over three repetitions; {exact} of {len(arena.params)} tensors in all")
+    assert matrices >= 60
+
+
 def test_collectives_through_rccl_in_a_group_of_one():
     """The N > 1 branches on hardware before a multi-GPU node is available: a process group of ONE rank on backend 'nccl' (= RCCL)
     with FORCE_COLLECTIVES, three pre-training steps (tests/nccl_w1_worker.py).  The live-set agreement, the arena broadcast, the
