@@ -161,11 +161,12 @@ typedef struct {
 
 /* out[s][c] += sum over the nblocks rows of partial[s][.][c], s < nset: the deferred second half of xfm_layernorm_bwd. */
 typedef struct xfm_reduce_item_s {
-  const float* partial;    /* [nset][nblocks][D] */
+  const float* partial;    /* [nset][nblocks][D]; scratch the reduce may overwrite (an item split over row groups parks the groups' sums in
+                              it and adds them in group order: no float atomics between the groups, bit-reproducible sums) */
   float* out[4];           /* NULL = skip the set */
   int nblocks, D, nset, reserved;
 } xfm_reduce_item;
-/* n items (HOST array) in launches of up to 56; same sums and the same atomics-at-the-end form as the per-call reduce. */
+/* n items (HOST array) in launches of up to 56; the same sums, in the same order, as the per-call reduce. */
 int xfm_reduce_sets_batch(int n, const xfm_reduce_item* items, void* stream);
 
 int xfm_layernorm_fwd(const xfm_ln_fwd_args* a, int D, int mode, void* stream);

@@ -377,11 +377,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
 }
 
 // out[s][c] += sum_b partial[s][b][c]   (each set s has its own destination pointer; null = skip)
-// grid (D/64, sets, row groups): a block folds its group's partial rows (64 columns x 4 row-slices, LDS folds the slices) and
-// adds the 64 sums with fp32 atomics -- a few thousand atomics per call, but every CU takes part (a (D/64) x sets grid alone
-// leaves 200 of the 256 CUs idle while ~48 blocks crawl through up to 9 MB of partials).
+// grid (D/64, sets, row groups): a block folds its group's partial rows (64 columns x 4 row-slices, LDS folds the slices); every CU
+// takes part (a (D/64) x sets grid alone leaves 200 of the 256 CUs idle while ~48 blocks crawl through up to 9 MB of partials).
+// With more than one row group the groups' sums are NOT added with float atomics (the order of the eight adds moved the last bits of
+// every LayerNorm / layer-scale / output-bias gradient from run to run): a group parks its sum in the first partial row of its own
+// range -- rows and columns no other block reads -- and reduce_sets_fold_kernel adds the groups in group order.  `partial` is scratch
+// the caller hands over: it is clobbered.
 #define REDUCE_SETS_GROUPS 8
-struct ReduceSets { const float* partial; float* out[4]; int nblocks; int D; };
+struct ReduceSets { float* partial; float* out[4]; int nblocks; int D; };
 __global__ __launch_bounds__(256) void reduce_sets_kernel(ReduceSets r) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -410,13 +413,36 @@ __global__ __launch_bounds__(256) void reduce_sets_kernel(ReduceSets r) {
   if (sl == 0 && c < r.D && r.out[s] != nullptr && b0 < b1) {
     const float v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
     if (gridDim.z == 1) r.out[s][c] += v;
-    else atomicAdd(r.out[s] + c, v);
+    else r.partial[((long)s * r.nblocks + b0) * r.D + c] = v;   // (every read of this column of this group happened before the barrier)
   }
 }
+// second half for `groups` > 1: out[s][c] += the groups' parked sums, in group order.  grid (D/256, sets)
+__global__ __launch_bounds__(256) void reduce_sets_fold_kernel(ReduceSets r, int groups) {
+  const int c = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+  if (c >= r.D || r.out[s] == nullptr) return;
+  const int per = (r.nblocks + groups - 1) / groups;
+  float v = 0.f;
+  for (int g = 0; g < groups; ++g) {
+    const int b0 = g * per;
+    if (b0 < r.nblocks) v += r.partial[((long)s * r.nblocks + b0) * r.D + c];
+  }
+  r.out[s][c] += v;
+}
 static int reduce_sets_groups(int nblocks) { return nblocks >= 64 * REDUCE_SETS_GROUPS ? REDUCE_SETS_GROUPS : 1; }
+static int launch_reduce_sets(const ReduceSets& r, int nset, hipStream_t st, const char* what) {
+  const int groups = reduce_sets_groups(r.nblocks);
+  hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(r.D, 64), nset, groups), dim3(256), 0, st, r);
+  int rc = xfm_check_launch(what);
+  if (rc != XFM_OK || groups == 1) return rc;
+  hipLaunchKernelGGL(reduce_sets_fold_kernel, dim3(cdiv(r.D, 256), nset), dim3(256), 0, st, r, groups);
+  return xfm_check_launch(what);
+}
 
 // The same fold for a TABLE of deferred reduces (xfm_reduce_sets_batch): grid (max D / 64, 4 sets, items x REDUCE_SETS_GROUPS); an item
-// with few partial rows leaves most of its row groups empty.  One launch for the 36 LayerNorm backwards of a 12-layer tower.
+// with few partial rows leaves most of its row groups empty.  One launch for the 36 LayerNorm backwards of a 12-layer tower, and a
+// second, small one (reduce_sets_batch_fold_kernel) when some item was split over row groups: group order, no float atomics between
+// the groups.  The one atomic add per item and column that remains is there because two items of a table may name the same
+// destination (a gradient shared by two LayerNorms): two commuting adds onto a zeroed gradient, still order-independent.
 #define REDUCE_BATCH_MAX 56
 struct ReduceBatch { int n; xfm_reduce_item it[REDUCE_BATCH_MAX]; };
 __global__ __launch_bounds__(256) void reduce_sets_batch_kernel(ReduceBatch tb) {
@@ -451,8 +477,22 @@ __global__ __launch_bounds__(256) void reduce_sets_batch_kernel(ReduceBatch tb) 
   __syncthreads();
   if (sl == 0 && c < r.D && out != nullptr && b0 < b1) {
     const float v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-    atomicAdd(out + c, v);   // (always: two items of one table may name the same destination -- a gradient shared by two LayerNorms)
+    if (groups == 1) atomicAdd(out + c, v);
+    else const_cast<float*>(r.partial)[((long)s * r.nblocks + b0) * r.D + c] = v;   // parked for the fold (see reduce_sets_kernel)
   }
+}
+// grid (max D / 256, 4 sets, items): the items that were split over row groups
+__global__ __launch_bounds__(256) void reduce_sets_batch_fold_kernel(ReduceBatch tb) {
+  const int c = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+  const xfm_reduce_item& r = tb.it[blockIdx.z];
+  if (r.nblocks < 64 * REDUCE_SETS_GROUPS || c >= r.D || s >= r.nset || r.out[s] == nullptr) return;
+  const int per = (r.nblocks + REDUCE_SETS_GROUPS - 1) / REDUCE_SETS_GROUPS;
+  float v = 0.f;
+  for (int g = 0; g < REDUCE_SETS_GROUPS; ++g) {
+    const int b0 = g * per;
+    if (b0 < r.nblocks) v += r.partial[((long)s * r.nblocks + b0) * r.D + c];
+  }
+  atomicAdd(r.out[s] + c, v);
 }
 int xfm_reduce_sets_batch_impl(int n, const xfm_reduce_item* items, hipStream_t st) {
   XFM_REQUIRE(n >= 0 && (n == 0 || items != nullptr), "reduce_sets_batch: bad arguments");
@@ -467,8 +507,15 @@ int xfm_reduce_sets_batch_impl(int n, const xfm_reduce_item* items, hipStream_t 
       dmax = tb.it[i].D > dmax ? tb.it[i].D : dmax;
     }
     hipLaunchKernelGGL(reduce_sets_batch_kernel, dim3(cdiv(dmax, 64), 4, tb.n * REDUCE_SETS_GROUPS), dim3(256), 0, st, tb);
-    const int rc = xfm_check_launch("reduce_sets_batch");
+    int rc = xfm_check_launch("reduce_sets_batch");
     if (rc != XFM_OK) return rc;
+    bool split = false;
+    for (int i = 0; i < tb.n; ++i) split = split || tb.it[i].nblocks >= 64 * REDUCE_SETS_GROUPS;
+    if (split) {
+      hipLaunchKernelGGL(reduce_sets_batch_fold_kernel, dim3(cdiv(dmax, 256), 4, tb.n), dim3(256), 0, st, tb);
+      rc = xfm_check_launch("reduce_sets_batch_fold");
+      if (rc != XFM_OK) return rc;
+    }
   }
   return XFM_OK;
 }
@@ -583,8 +630,7 @@ int xfm_ln_bwd_impl(LnBwd p, int D, int mode, float* dgamma, float* dbeta, float
     return XFM_OK;
   }
   ReduceSets r{workspace, {dgamma, dbeta, dbias, dls}, grid, D};
-  hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(D, 64), nset, reduce_sets_groups(grid)), dim3(256), 0, st, r);
-  return xfm_check_launch("ln_bwd_reduce");
+  return launch_reduce_sets(r, nset, st, "ln_bwd_reduce");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -628,6 +674,5 @@ int xfm_colsum_impl(const void* y, long ldy, int M, int N, float* out, float* wo
   int rc = xfm_check_launch("colsum");
   if (rc != XFM_OK) return rc;
   ReduceSets r{workspace, {out, nullptr, nullptr, nullptr}, by, N};
-  hipLaunchKernelGGL(reduce_sets_kernel, dim3(cdiv(N, 64), 1, reduce_sets_groups(by)), dim3(256), 0, st, r);
-  return xfm_check_launch("colsum_reduce");
+  return launch_reduce_sets(r, 1, st, "colsum_reduce");
 }
