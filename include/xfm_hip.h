@@ -28,7 +28,7 @@ extern "C" {
 #define XFM_E_LAUNCH (-2)
 #define XFM_E_UNSUPPORTED (-3)
 
-#define XFM_ABI_VERSION 8
+#define XFM_ABI_VERSION 9
 
 const char* xfm_last_error(void);
 int xfm_abi_version(void);
@@ -308,6 +308,9 @@ typedef struct {
                          unpadded rows); -1 skips the token (padding).  mean / rstd / pos_ids stay [B*T]. */
   float* y32;         /* optional fp32 twin of y (same rows): the embedding output enters the encoder's fp32 residual stream un-rounded */
   const float* dy32;  /* optional fp32 gradient added to dy (the residual-branch gradient of the first layer) */
+  float* dz_out;      /* optional fp32 [B*T, D] (bwd): the gradient w.r.t. the embedding sum of every token is STORED here (row b*T+t;
+                         skipped tokens are not written) and dword / dpos are left alone -- the caller scatters it with
+                         xfm_rows_segment_sum in a fixed order instead of one float atomic per element (XFM_DETERMINISTIC) */
 } xfm_embed_args;
 int xfm_embed_ln_fwd(const xfm_embed_args* a, int D, void* stream);
 long xfm_embed_ln_bwd_workspace(int rows, int D);
@@ -319,6 +322,12 @@ int xfm_embed_ln_bwd(const xfm_embed_args* a, int D, float* dgamma, float* dbeta
  * D % 8 == 0); and its adjoint dst32[index[r],:] += src[r,:] (fp32 accumulation, rows with index < 0 are skipped). ------------- */
 int xfm_rows_gather(const xfm_bf16* src, const int* index, int R, int D, xfm_bf16* dst, void* stream);
 int xfm_rows_scatter_add(const xfm_bf16* src, const int* index, int R, int D, float* dst32, void* stream);
+/* out[key, :] += sum of src[perm[i], :] over the run of positions i with sorted_key[i] == key, rows added in position order, one owner per
+ * run: the scatter-add of an embedding gradient without atomics (nn.Embedding backward, xroberta.py:80-102).  sorted_key int64 [R]
+ * ascending (the caller sorts; perm int64 [R] = the matching row order, a STABLE sort keeps it deterministic); runs with key < 0 or
+ * key == skip_key are dropped (padding_idx, skipped tokens).  src fp32 [*, D], out fp32 [*, D], D % 4 == 0. */
+int xfm_rows_segment_sum(const float* src, const int64_t* perm, const int64_t* sorted_key, long R, int D, long skip_key, float* out,
+                         void* stream);
 
 /* ---- One whole RobertaLayer per call (xroberta.py:405-473: self-attention block, optional cross-attention block, FFN block, each
  * closed by dropout + residual + LayerNorm), forward and backward.  The kernels are the ones above; what this adds is the launch
@@ -409,7 +418,8 @@ int xfm_rlayer_bwd(const xfm_rlayer_params* p, const xfm_rlayer_io* io, const xf
  *                fwd: lse [4N] (statistics of the rows of logits, then of logits^T; behind them the 2N rows' loss terms),
  *                loss_sum [2], zeroed by the caller: [0] += the loss, summed over the row terms in a fixed order by the block that takes
  *                the last ticket of the integer counter at [1] (bit-reproducible); bwd: dI, dT (fully written) and
- *                dtemp[0] += for the upstream gradient g[0]
+ *                dtemp[0] += for the upstream gradient g[0]; `lse` is the forward's [4N] buffer: the backward parks the N row shares
+ *                of dtemp in its dead upper half and adds them in a fixed order (bit-reproducible)
  *                idx != NULL (int64 [N], the gathered image ids of the retrieval fine-tuning step, xfm.py:705-713): soft labels -- the
  *                positives of row r are the rows with the same id, weight 1 / cnt_r each; fwd writes cnt [N], bwd reads it
  *   hard_neg     per row of the LOCAL batch: softmax(sim / temp) + 1e-5, own entry zeroed, ONE categorical draw (xfm.py:727-744:

@@ -697,6 +697,52 @@ def test_embedding_fp32_twin_and_fp32_gradient():
         _close(got, ref, 2e-4, name)
 
 
+def test_embedding_gradient_ordered_scatter_is_bit_reproducible(monkeypatch):
+    """XFM_DETERMINISTIC=1 (xfm_embed_args.dz_out + xfm_rows_segment_sum): the per-token gradient is stored and added to the word / position
+    tables in sorted runs, one owner per table row and rows in a fixed order -- the same sums as the float-atomic scatter to rounding, the
+    pad row and skipped tokens excluded alike, and bit-identical from call to call (the atomic form is not)."""
+    Fx = _fx()
+    from xfm_amd import synthetic as syn
+    V, D, B, T = 300, 768, 48, 30            # a small vocabulary: long runs of equal ids
+    b = syn.pretrain_batch(B, seed=5, with_image=False, vocab=V)
+    ids = b["text_ids"].cuda()
+    word, pos, typ = _rand((V, D), 0.1, F32, 190), _rand((64, D), 0.1, F32, 191), _rand((1, D), 0.1, F32, 192)
+    w, bb = _rand((D,), 1.0, F32, 193), _rand((D,), 0.3, F32, 194)
+    y, mean, rstd, pos_ids = Fx.embed_ln_fwd(ids, word, pos, typ, w, bb, 1e-5, 1)
+    dy = _rand((B * T, D), seed=195)
+
+    def run():
+        out = [torch.zeros_like(t) for t in (word, pos, typ.view(-1), w, bb)]
+        Fx.embed_ln_bwd(dy, ids, word, pos, typ, w, bb, 1e-5, 1, mean, rstd, pos_ids, *out)
+        torch.cuda.synchronize()
+        return out
+
+    monkeypatch.setenv("XFM_DETERMINISTIC", "0")
+    atomic = run()
+    monkeypatch.setenv("XFM_DETERMINISTIC", "1")
+    first = run()
+    for _ in range(3):
+        again = run()
+        for a_, b_ in zip(first, again):
+            assert torch.equal(a_, b_)
+    for got, ref, name in zip(first, atomic, ("dword", "dpos", "dtype", "dgamma", "dbeta")):
+        _close(got, ref, 1e-5, name)
+    assert float(first[0][1].abs().max()) == 0.0 and float(first[1][1].abs().max()) == 0.0   # the pad rows (id 1) take no gradient
+    # the segment sum on its own against index_add_
+    src = _rand((500, 64), 1.0, F32, 196)
+    keys = torch.randint(-1, 20, (500,), generator=torch.Generator().manual_seed(2)).cuda()
+    skey, perm = torch.sort(keys, stable=True)
+    out = torch.zeros((20, 64), dtype=F32, device="cuda")
+    from xfm_amd import _lib
+    from xfm_amd._lib import check
+    check(_lib.load().xfm_rows_segment_sum(src.data_ptr(), perm.data_ptr(), skey.data_ptr(), 500, 64, 7, out.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream), "rows_segment_sum")
+    keep = (keys >= 0) & (keys != 7)
+    ref = torch.zeros_like(out).index_add_(0, keys[keep], src[keep])
+    _close(out, ref, 1e-6, "segment sum")
+    assert float(out[7].abs().max()) == 0.0
+
+
 def test_cross_entropy_fwd_bwd_ignore_index():
     Fx = _fx()
     R, V, ld = 37, 50265, 50304

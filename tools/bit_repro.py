@@ -1,18 +1,17 @@
 """Which parameter gradients of the headline step are NOT bit-reproducible?
 
-  python tools/bit_repro.py [--reps 4] [--batch 64] [--eval-mode] [--steps 1]
+  [XFM_DETERMINISTIC=1] python tools/bit_repro.py [--reps 4] [--batch 64] [--eval-mode]
 
 One process, the bench's model / optimizer / accelerator at the headline shape (bench.py wl_pretrain), the SAME batch every
 repetition and every counter-based random draw rewound (dropout seeds, MIM mask draws, hard-negative draws, the drop-path draw on the
 device generator).  Each repetition zeroes the gradient arena, runs forward + backward and snapshots the arena; repetition r is compared
 with repetition 0 parameter by parameter, bit for bit.  A tensor that differs was summed in an order the hardware chose (float atomics,
-a split reduction whose last writer is decided by arrival): the table names it, so the kernel can be found.  With --steps S > 1 every
-repetition restores the parameters and optimizer state and runs S full steps (Adam amplifies a one-ulp gradient difference into the
-parameters), comparing the PARAMETER arena at the end.
+a split reduction whose last writer is decided by arrival): the table names it, so the kernel can be found.  XFM_DETERMINISTIC=1 switches
+the remaining float-atomic reductions to their ordered forms: the list must then be empty.  (Several STEPS, Adam included, across cold
+processes: XFM_DETERMINISTIC=1 python tools/cold_probe.py --runs 5 --steps 3 --tol 1e-13.)
 
 Prints a table and one JSON line `BIT_REPRO {...}`; exit code 1 when anything differs."""
 import argparse
-import copy
 import json
 import os
 import sys
@@ -27,7 +26,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--eval-mode", action="store_true")
     ap.add_argument("--padded-rows", action="store_true")
     a = ap.parse_args()
@@ -43,8 +41,6 @@ def main():
     wrapped, opt, _ = acc.set_up(model, opt, None, 0, 1, 0)
     model.train(not a.eval_mode)
     arena = model._arena
-    params0 = arena.data.clone()
-    opt0 = copy.deepcopy(opt.state_dict()) if a.steps > 1 else None
     gen = model.vision_encoder.generator
 
     def rewind():
@@ -56,22 +52,15 @@ def main():
     snaps, losses = [], []
     for r in range(a.reps):
         rewind()
-        if a.steps > 1:
-            arena.data.copy_(params0)
-            opt.load_state_dict(copy.deepcopy(opt0))
-        for s in range(a.steps):
-            total, parts = forward(wrapped, 0)
-            acc.backward_step(total, opt)
-            if a.steps > 1:
-                acc.optimizer_step(opt, model)
+        total, parts = forward(wrapped, 0)
+        acc.backward_step(total, opt)
         acc.grads_ready()
         torch.cuda.synchronize()
-        snaps.append((arena.data if a.steps > 1 else arena.grad).clone())
-        losses.append({k: float(v) for k, v in parts.items()})
-        if a.steps == 1:
-            model.zero_grad()
-            acc.grads_ready()
-    what = "parameters after %d steps" % a.steps if a.steps > 1 else "gradients"
+        snaps.append(arena.grad.clone())
+        losses.append({k: float(v.detach()) for k, v in parts.items()})
+        model.zero_grad()
+        acc.grads_ready()
+    what = "gradients"
     odd = {}
     for r in range(1, a.reps):
         if losses[r] != losses[0]:
@@ -91,6 +80,7 @@ def main():
         worst = max(rows, key=lambda t: t[1])
         print(f"  {name}: differs in {len(rows)} of {a.reps - 1} repetitions; worst rel-L2 {worst[1]:.2e}, {worst[2]} of {worst[3]} entries")
     print("BIT_REPRO " + json.dumps({"what": what, "reps": a.reps, "batch": a.batch, "train_mode": not a.eval_mode,
+                                     "deterministic_mode": os.environ.get("XFM_DETERMINISTIC", "0") not in ("", "0"),
                                      "tensors": len(arena.params), "not_bit_stable": sorted(odd)}))
     sys.exit(1 if odd else 0)
 

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # XFM_HIP_LIB: A/B a differently built library (kernel experiments); the default is the in-tree build.
 LIB_PATH = os.environ.get("XFM_HIP_LIB") or os.path.join(_HERE, "libxfm_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_void_p, c_int, c_long, c_float, c_u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint32
 
@@ -68,7 +68,7 @@ class EmbedArgs(ctypes.Structure):
                 ("B", c_int), ("T", c_int), ("pad_id", c_int), ("eps", c_float),
                 ("drop_thresh", c_u32), ("drop_scale", c_float), ("seed_lo", c_u32), ("seed_hi", c_u32),
                 ("dy", c_void_p), ("dword", c_void_p), ("dpos", c_void_p), ("partial", c_void_p), ("pos_mode", c_int),
-                ("row_map", c_void_p), ("y32", c_void_p), ("dy32", c_void_p)]
+                ("row_map", c_void_p), ("y32", c_void_p), ("dy32", c_void_p), ("dz_out", c_void_p)]
 
 
 _P, _L, _I, _F, _U = c_void_p, c_long, c_int, c_float, c_u32
@@ -188,6 +188,7 @@ SIGNATURES = {
     "xfm_hard_negatives": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xfm_rows_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "xfm_rows_scatter_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "xfm_rows_segment_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1022,9 +1022,18 @@ __global__ __launch_bounds__(QT * 256) void attn_bwd_dq_short_kernel(AttnArgs a,
     __syncthreads();
     if (wave_active && b_begin < b_end) {
       const int kj = kt0 * 16 + lane;
+      // a.dbias_ws != NULL (XFM_DETERMINISTIC=1): this batch slice's sums go to its own plane [slice][H][Sq][ld] with plain stores,
+      // every column below ld written (zero past the last key), and dbias_reduce_kernel adds the planes in slice order; else one float
+      // atomic per element and slice straight into dbias
+      float* const plane = a.dbias_ws != nullptr ? a.dbias_ws + ((long)zslice * a.H + h) * sq * a.bias_ld : nullptr;
       for (int row = 0; row < 16; ++row) {
         const int q = q0 + row;
-        if (q < sq && lane < nt * 16 && kj < sk) atomicAdd(a.dbias + ((long)h * sq + q) * a.bias_ld + kj, fl[row * 64 + lane]);
+        if (q >= sq || lane >= nt * 16) continue;
+        if (plane != nullptr) {
+          if (kj < a.bias_ld) plane[(long)q * a.bias_ld + kj] = kj < sk ? fl[row * 64 + lane] : 0.f;
+        } else if (kj < sk) {
+          atomicAdd(a.dbias + ((long)h * sq + q) * a.bias_ld + kj, fl[row * 64 + lane]);
+        }
       }
     }
   }
@@ -2206,6 +2215,33 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(dbias + e) = acc;
 }
 
+// the short dense backward pair (attn_bwd_dq_short_kernel / attn_bwd_dkv_short_kernel) takes this problem
+static bool attn_short_dq_ok(const AttnArgs& a) {
+  static const bool short_env = getenv("XFM_ATTN_SHORT_BWD") ? atoi(getenv("XFM_ATTN_SHORT_BWD")) != 0 : true;  // A/B knob
+  return short_env && attn_plain(a) && a.Sk <= 64 * ATTN_RES_MAX && a.q_start == nullptr && a.k_start == nullptr && a.kv_index == nullptr &&
+         (a.bias == nullptr || a.bias_ld >= (long)cdiv(a.Sk, 16) * 16) && (a.dbias == nullptr || a.bias_ld >= a.Sk);
+}
+// its dQ kernel: query groups per (head, batch slice), batch entries per slice; -> number of slices
+static int attn_short_dq_slices(const AttnArgs& a, int& groups, int& nb) {
+  groups = cdiv(cdiv(a.Sq, 16), 3);
+  int z = 256 / (groups * a.H);
+  z = z < 1 ? 1 : (z > a.B ? a.B : z);
+  nb = cdiv(a.B, z);
+  return cdiv(a.B, nb);
+}
+// XFM_DETERMINISTIC=1: the reductions that still end in float atomics by default because the ordered form costs a launch or a pass
+// (the bias gradient of the short attention backward: one plane per batch slice + dbias_reduce_kernel; the embedding gradients) take
+// the ordered form.  Read per call.
+static bool xfm_deterministic() {
+  const char* e = getenv("XFM_DETERMINISTIC");
+  return e != nullptr && atoi(e) != 0;
+}
+// planes for the short dQ kernel's bias gradient: deterministic mode, more than one batch slice, and rows it can cover completely
+static bool attn_short_dbias_planes(const AttnArgs& a) {
+  int groups, nb;
+  return xfm_deterministic() && a.dbias != nullptr && a.bwd_phase != 2 && attn_short_dq_ok(a) && a.bias_ld <= (long)cdiv(a.Sk, 16) * 16 &&
+         attn_short_dq_slices(a, groups, nb) > 1;
+}
 #include "attention_long.hip"
 
 int xfm_attn_bwd_impl(const AttnArgs& a_in, hipStream_t st) {
@@ -2266,10 +2302,8 @@ int xfm_attn_bwd_impl(const AttnArgs& a_in, hipStream_t st) {
   attn_geom(a.Sq, nw, blocks);
   const bool res = attn_resident(a.Sk, nw);
   const bool plain = attn_plain(a);
-  static const bool short_env = getenv("XFM_ATTN_SHORT_BWD") ? atoi(getenv("XFM_ATTN_SHORT_BWD")) != 0 : true;  // A/B knob
-  const bool short_dq = short_env && plain && a.Sk <= 64 * ATTN_RES_MAX && a.q_start == nullptr && a.k_start == nullptr &&
-                        a.kv_index == nullptr && (a.bias == nullptr || a.bias_ld >= (long)cdiv(a.Sk, 16) * 16) &&
-                        (a.dbias == nullptr || a.bias_ld >= a.Sk);
+  const bool short_dq = attn_short_dq_ok(a);
+  float* const short_planes = (a.dbias_ws != nullptr && attn_short_dbias_planes(a)) ? a.dbias_ws : nullptr;
   // the dQ kernel without in-register bias-gradient sums (NKC = 0) runs, and has a workspace to put each entry's dS into
   const bool dbias_via_ws = a.bwd_phase != 2 && !short_dq && !(a.dbias != nullptr && res && plain) && a.dbias != nullptr && a.dbias_ws != nullptr;
   if (!dbias_via_ws) a.dbias_ws = nullptr;
@@ -2289,12 +2323,10 @@ int xfm_attn_bwd_impl(const AttnArgs& a_in, hipStream_t st) {
     }
     // (query groups x heads) workgroups per batch slice; slices so that one round of <= 256 workgroups covers the batch
     // three query tiles (12 waves) per workgroup: four would need 128-VGPR waves (measured: 40 spilled registers) and 161 KB of LDS
-    const int QT = 3;
-    const int groups = cdiv(cdiv(a.Sq, 16), QT);
-    int z = 256 / (groups * a.H);
-    z = z < 1 ? 1 : (z > a.B ? a.B : z);
-    const int nb = cdiv(a.B, z);
-    const dim3 grid(groups * a.H * cdiv(a.B, nb));
+    int groups, nb;
+    const int slices = attn_short_dq_slices(a, groups, nb);
+    const dim3 grid(groups * a.H * slices);
+    a.dbias_ws = short_planes;   // (NULL: float atomics into dbias)
     long long* dbg = nullptr;
     {
       const char* dp = getenv("XFM_ATTN_DBG_PTR");   // (read per launch: tools/attn_timeline.py sets it around the one call it wants a timeline of)
@@ -2343,6 +2375,14 @@ int xfm_attn_bwd_impl(const AttnArgs& a_in, hipStream_t st) {
   if (dbias_via_ws) {
     const long per_entry = (long)a.H * a.Sq * a.bias_ld;
     hipLaunchKernelGGL(dbias_reduce_kernel, dim3(cdiv(per_entry / 4, 256)), dim3(256), 0, st, a.dbias_ws, a.dbias, a.B, per_entry);
+    rc = xfm_check_launch("dbias_reduce");
+    if (rc != XFM_OK) return rc;
+  }
+  if (a.bwd_phase != 2 && short_dq && short_planes != nullptr) {   // the slices' planes, in slice order
+    int groups, nb;
+    const int slices = attn_short_dq_slices(a, groups, nb);
+    const long per_entry = (long)a.H * a.Sq * a.bias_ld;
+    hipLaunchKernelGGL(dbias_reduce_kernel, dim3(cdiv(per_entry / 4, 256)), dim3(256), 0, st, short_planes, a.dbias, slices, per_entry);
     rc = xfm_check_launch("dbias_reduce");
     if (rc != XFM_OK) return rc;
   }

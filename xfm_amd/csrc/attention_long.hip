@@ -607,6 +607,10 @@ long xfm_attn_bwd_workspace_impl(const AttnArgs& a) {
     const int slices = dbias_long_slices(blocks, a.B, (long)a.H * a.Sq * a.bias_ld * 4);
     return slices > 1 ? (long)slices * a.H * a.Sq * a.bias_ld * 4 : 0;
   }
+  if (attn_short_dbias_planes(a)) {   // XFM_DETERMINISTIC: one plane per batch slice of the short dQ kernel
+    int groups, nb;
+    return (long)attn_short_dq_slices(a, groups, nb) * a.H * a.Sq * a.bias_ld * 4;
+  }
   if (a.dbias == nullptr || a.Sk <= 64 * ATTN_RES_MAX) return 0;
   if (attn_long_shape(a)) {
     const int blocks = cdiv(a.Sq, 128) * cdiv(a.Sk, 128) * a.H;

@@ -220,6 +220,11 @@ int xfm_rows_scatter_add(const xfm_bf16* src, const int* index, int R, int D, fl
   XFM_REQUIRE(src && index && dst32, "rows_scatter_add: null operand");
   return xfm_rows_scatter_add_impl(src, index, R, D, dst32, ST(stream));
 }
+int xfm_rows_segment_sum(const float* src, const int64_t* perm, const int64_t* sorted_key, long R, int D, long skip_key, float* out,
+                         void* stream) {
+  XFM_REQUIRE(R == 0 || (src && perm && sorted_key && out), "rows_segment_sum: null operand");
+  return xfm_rows_segment_sum_impl(src, perm, sorted_key, R, D, skip_key, out, ST(stream));
+}
 
 int xfm_rlayer_layout(int R, int B, int T, int D, int H, int FF, int has_cross, int Nenc, int U, int xq_max, int flags,
                       xfm_rlayer_layout_t* out) {

@@ -80,9 +80,11 @@ __global__ __launch_bounds__(256) void vit_tokens_bwd_tok_kernel(const float* __
 }
 
 // dcls += sum_b dx0[b, 0];  dmask_token += sum over masked (b, i) of dx0[b, 1 + i].  One workgroup per slice of batch rows,
-// thread = 4 columns (D <= 1024), row skips are workgroup-uniform; 2 * D atomics per workgroup.
+// thread = 4 columns (D <= 1024), row skips are workgroup-uniform.  The workgroups' sums are PARKED (part[wg][0 / 1][D]: the caller lends
+// the head of dtok, which the token kernel overwrites afterwards) and vit_tokens_bwd_fold_kernel adds them in workgroup order -- the
+// 128 float atomics per element this used to end in moved the last bits of both gradients from run to run.
 __global__ __launch_bounds__(256) void vit_tokens_bwd_vec_kernel(const float* __restrict__ dx0, const uint8_t* __restrict__ mask, int Bx,
-                                                                 int P, int D, float* __restrict__ dcls, float* __restrict__ dmask_token) {
+                                                                 int P, int D, float* __restrict__ part) {
   const int c = threadIdx.x * 4;
   if (c >= D) return;
   f32x4 ac = {0.f, 0.f, 0.f, 0.f}, am = {0.f, 0.f, 0.f, 0.f};
@@ -97,11 +99,20 @@ __global__ __launch_bounds__(256) void vit_tokens_bwd_vec_kernel(const float* __
       am[0] += u[0]; am[1] += u[1]; am[2] += u[2]; am[3] += u[3];
     }
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    atomicAdd(dcls + c + j, ac[j]);
-    if (mask != nullptr) atomicAdd(dmask_token + c + j, am[j]);
+  *reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 2 + 0) * D + c) = ac;
+  *reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 2 + 1) * D + c) = am;
+}
+__global__ __launch_bounds__(256) void vit_tokens_bwd_fold_kernel(const float* __restrict__ part, int nparts, int D, bool masked,
+                                                                  float* __restrict__ dcls, float* __restrict__ dmask_token) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  float a = 0.f, m = 0.f;
+  for (int w = 0; w < nparts; ++w) {
+    a += part[((long)w * 2 + 0) * D + c];
+    if (masked) m += part[((long)w * 2 + 1) * D + c];
   }
+  dcls[c] += a;
+  if (masked) dmask_token[c] += m;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -284,11 +295,19 @@ int xfm_vit_tokens_bwd_impl(const float* dx0, const uint8_t* mask, int Bt, int B
   const long total = (long)Bt * P * (D / 4);
   int grid = cdiv(total, 256);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(vit_tokens_bwd_tok_kernel, dim3(grid), dim3(256), 0, st, dx0, mask, Bt, Bx, P, D, dtok);
-  rc = xfm_check_launch("vit_tokens_bwd");
+  // the cls / mask-token sums first: their per-workgroup parts borrow the head of dtok (Bt * P * D floats, more than 2 * 128 * D
+  // whenever P >= 4 -- checked), which the token kernel then writes in full
+  int nparts = Bx < 128 ? Bx : 128;
+  while ((long)nparts * 2 > (long)Bt * P) nparts >>= 1;
+  XFM_REQUIRE(nparts >= 1, "vit_tokens_bwd: dtok too small to lend the scratch");
+  hipLaunchKernelGGL(vit_tokens_bwd_vec_kernel, dim3(nparts), dim3(256), 0, st, dx0, mask, Bx, P, D, dtok);
+  rc = xfm_check_launch("vit_tokens_bwd_vec");
   if (rc != XFM_OK) return rc;
-  hipLaunchKernelGGL(vit_tokens_bwd_vec_kernel, dim3(Bx < 128 ? Bx : 128), dim3(256), 0, st, dx0, mask, Bx, P, D, dcls, dmask_token);
-  return xfm_check_launch("vit_tokens_bwd_vec");
+  hipLaunchKernelGGL(vit_tokens_bwd_fold_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, dtok, nparts, D, mask != nullptr, dcls, dmask_token);
+  rc = xfm_check_launch("vit_tokens_bwd_fold");
+  if (rc != XFM_OK) return rc;
+  hipLaunchKernelGGL(vit_tokens_bwd_tok_kernel, dim3(grid), dim3(256), 0, st, dx0, mask, Bt, Bx, P, D, dtok);
+  return xfm_check_launch("vit_tokens_bwd");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -423,6 +442,10 @@ __global__ __launch_bounds__(256) void emb_bwd_kernel(EmbArgs p) {
       for (int j = 0; j < 4; ++j) {
         const float dz = rstd * (dy[i][j] * wv[i][j] - c1 - xh[i][j] * c2);
         acc[2][i][j] += dz;
+        if (p.dz_out != nullptr) {   // ordered scatter by the caller (xfm_rows_segment_sum)
+          p.dz_out[(long)row * D + e + j] = dz;
+          continue;
+        }
         // nn.Embedding(padding_idx): the pad row receives no gradient (xroberta.py:80,100-102)
         if (wid != p.pad_id) atomicAdd(p.dword + wid * D + e + j, dz);
         if (p.pos_mode || pid != p.pad_id) atomicAdd(p.dpos + (long)pid * D + e + j, dz);
@@ -663,6 +686,31 @@ int xfm_rows_scatter_add_impl(const bf16* src, const int* index, int R, int D, f
   XFM_REQUIRE(R > 0 && D > 0 && D % 8 == 0, "rows_scatter_add: bad shape R=%d D=%d", R, D);
   hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(cdiv((long)R * (D >> 3), 256)), dim3(256), 0, st, src, index, R, D, dst);
   return xfm_check_launch("rows_scatter_add");
+}
+
+// out[key] += the rows of one run of equal sorted keys, in position order: block i owns the run that STARTS at position i (others exit)
+__global__ __launch_bounds__(256) void rows_segment_sum_kernel(const float* __restrict__ src, const int64_t* __restrict__ perm,
+                                                               const int64_t* __restrict__ key, long R, int D, long skip_key,
+                                                               float* __restrict__ out) {
+  const long i = blockIdx.x;
+  const int64_t k = key[i];
+  if (k < 0 || k == skip_key || (i > 0 && key[i - 1] == k)) return;
+  for (int c = threadIdx.x * 4; c < D; c += 1024) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (long j = i; j < R && key[j] == k; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + perm[j] * D + c);
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    f32x4* dst = reinterpret_cast<f32x4*>(out + k * D + c);
+    *dst = *dst + acc;
+  }
+}
+int xfm_rows_segment_sum_impl(const float* src, const int64_t* perm, const int64_t* key, long R, int D, long skip_key, float* out,
+                              hipStream_t st) {
+  XFM_REQUIRE(R >= 0 && D > 0 && D % 4 == 0, "rows_segment_sum: bad shape R=%ld D=%d", R, D);
+  if (R == 0) return XFM_OK;
+  hipLaunchKernelGGL(rows_segment_sum_kernel, dim3((unsigned)R), dim3(256), 0, st, src, perm, key, R, D, skip_key, out);
+  return xfm_check_launch("rows_segment_sum");
 }
 
 // ---------------------------------------------------------------------------------------------

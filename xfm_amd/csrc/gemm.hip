@@ -1487,6 +1487,14 @@ __device__ __forceinline__ void tn256_bias_out(float* dbias, int n0, const f32x4
       else *d += bacc[h][i];
     }
 }
+// a cut tile's piece: its share of the 256 column sums parked in the piece's slot (tn_group_fixup_kernel adds the pieces in
+// workgroup order: a float atomic per piece moved the last bits of the bias gradient of whichever problem the cut tiles belong to)
+__device__ __forceinline__ void tn256_bias_part(float* part, const f32x4 (&bacc)[2]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 2, wc = w & 3, lr = lane & 15, lg = lane >> 4;
+  if (lr != 0) return;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(part + wr * 128 + h * 64 + wc * 16 + 4 * lg) = bacc[h];
+}
 // partial tile -> workspace slot, one coalesced 16-B store per accumulator register quad (the reduce kernels read the same order)
 __device__ __forceinline__ void tn256_store_partial(float* ws, long slot, const f32x4 (&acc)[8][4]) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1560,6 +1568,7 @@ struct TnGroup {
   int sk_wgs;                // workgroups that share the cut tiles (0: none)
   long sk_iters;             // (total_tiles - full_tiles) * nk
   float* ws;
+  float* ws_bias;            // 256 floats per partial-piece slot, behind the slots' tiles
   TnGroupProb p[TN_GROUP_MAX];
 };
 __host__ __device__ __forceinline__ long tn_sk_bound(long R, int nk, int sk_wgs, int i) {
@@ -1611,7 +1620,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup G) {
     f32x4 acc[8][4], bacc[2];
     tn256_mainloop<true>(sg, smem, acc, bacc);
     if (slot >= 0) {
-      if (sg.do_bias) tn256_bias_out<true>(P.dbias, n0, bacc);
+      if (sg.do_bias) tn256_bias_part(G.ws_bias + slot * 256, bacc);
       tn256_store_partial(G.ws, slot, acc);
     } else {
       if (sg.do_bias) tn256_bias_out<false>(P.dbias, n0, bacc);
@@ -1651,6 +1660,14 @@ __global__ __launch_bounds__(256) void tn_group_fixup_kernel(TnGroup G) {
   const int n = n0 + wr * 128 + nt * 16 + 4 * lg;
 #pragma unroll
   for (int i = 0; i < 4; ++i) P.dW[(long)(n + i) * P.ldw + k] += sum[i];
+  if (blockIdx.x == 0 && P.dbias != nullptr && k0 == 0) {   // the pieces' column sums, same order (256 threads, one column each)
+    float b = 0.f;
+    for (int i = i0; i <= i1; ++i) {
+      const long slot = 2l * i + (tn_sk_bound(R, G.nk, G.sk_wgs, i) >= a ? 0 : 1);
+      b += G.ws_bias[slot * 256 + threadIdx.x];
+    }
+    P.dbias[n0 + threadIdx.x] += b;
+  }
 }
 
 // dW += sum over splits of the partial tiles written by gemm_tn_256_kernel (deterministic: fixed summation order).
@@ -1908,7 +1925,7 @@ long xfm_gemm_tn_group_workspace_impl(int n, const xfm_tn_item* items, int M) {
     int full, sk;
     long R;
     tn_group_plan(tiles, cdiv(M, 64), G, full, sk, R);
-    const long b = sk > 1 ? 2l * sk * 256 * 256 * 4 : 0;
+    const long b = sk > 1 ? 2l * sk * (256 * 256 + 256) * 4 : 0;   // two partial-piece slots per sharing workgroup: tile + column sums
     need = b > need ? b : need;
     tiles = np = 0;
   };
@@ -1943,6 +1960,7 @@ int xfm_gemm_tn_group_impl(int n, const xfm_tn_item* items, int M, float* worksp
   auto flush = [&]() -> int {
     if (g.nprob == 0) return XFM_OK;
     tn_group_plan(g.total_tiles, g.nk, G, g.full_tiles, g.sk_wgs, g.sk_iters);
+    g.ws_bias = g.ws != nullptr ? g.ws + 2l * g.sk_wgs * 256 * 256 : nullptr;
     const int grid = g.full_tiles > 0 ? G : g.sk_wgs;
     hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(grid), dim3(512), smem, st, g);
     int rc = xfm_check_launch("gemm_tn_group");

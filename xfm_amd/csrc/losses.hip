@@ -124,7 +124,9 @@ __global__ __launch_bounds__(256) void itc_bwd_kernel(const float* __restrict__ 
   __syncthreads();
   if (rows) {
     tpart = block_add256(tpart, red);
-    if (threadIdx.x == 0) atomicAdd(dtemp, -tpart * gs * inv_temp);
+    // (the row's share of the temperature gradient is parked behind the statistics -- lse[2N + r], the forward's dead row terms -- and
+    // itc_dtemp_kernel adds the N shares in a fixed order: a float atomic per row made `temp`'s gradient differ from run to run)
+    if (threadIdx.x == 0) const_cast<float*>(lse)[2 * N + r] = -tpart * gs * inv_temp;
   }
   float* out = (rows ? dI : dT) + (long)r * E;
   for (int e = threadIdx.x; e < E; e += 256) {
@@ -236,13 +238,24 @@ int xfm_itc_fwd_impl(const float* I, const float* T, const float* temp, int N, i
   XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((itc_fwd_kernel<EPL>), dim3(2 * N), dim3(256), (N + 4) * sizeof(float), st, I, T, temp, N, E, lse, loss_sum, idx, cnt));
   return xfm_check_launch("itc_fwd");
 }
+__global__ __launch_bounds__(256) void itc_dtemp_kernel(const float* __restrict__ share, int N, float* __restrict__ dtemp) {
+  __shared__ float red[4];
+  float t = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) t += share[j];
+  t = block_add256(t, red);
+  if (threadIdx.x == 0) dtemp[0] += t;
+}
+
 int xfm_itc_bwd_impl(const float* I, const float* T, const float* temp, const float* lse, const float* g, int N, int E, float* dI,
                      float* dT, float* dtemp, const int64_t* idx, const float* cnt, hipStream_t st) {
   int rc = loss_check(N, E);
   if (rc != XFM_OK) return rc;
   XFM_REQUIRE(idx == nullptr || cnt != nullptr, "itc_bwd: idx needs the cnt the forward wrote");
   XFM_EPL_DISPATCH(E, hipLaunchKernelGGL((itc_bwd_kernel<EPL>), dim3(2 * N), dim3(256), (N + 4) * sizeof(float), st, I, T, temp, lse, g, N, E, dI, dT, dtemp, idx, cnt));
-  return xfm_check_launch("itc_bwd");
+  rc = xfm_check_launch("itc_bwd");
+  if (rc != XFM_OK) return rc;
+  hipLaunchKernelGGL(itc_dtemp_kernel, dim3(1), dim3(256), 0, st, lse + 2 * N, N, dtemp);
+  return xfm_check_launch("itc_dtemp");
 }
 int xfm_hard_negatives_impl(const float* I, const float* T, const float* temp, int B, int E, uint64_t seed, int64_t* image_neg,
                             int64_t* text_neg, const int64_t* idx, hipStream_t st) {

@@ -90,6 +90,14 @@ def gemm_nt_ksplit(a, b, n=None, bias=None, out_dtype=BF16):
     return out
 
 
+def deterministic():
+    """XFM_DETERMINISTIC=1: the reductions that by default still end in float atomics because their ordered form costs a launch or a pass
+    take the ordered form (read per call, like the library's own switch): the bias column sums that ride on the M-split weight-gradient
+    GEMMs (here), the bias gradient of the short attention backward (per-slice planes, csrc/attention.hip), the embedding gradients
+    (sorted segment sums, embed_ln_bwd).  Every other reduction of the step is ordered unconditionally (tools/bit_repro.py)."""
+    return os.environ.get("XFM_DETERMINISTIC", "0") not in ("", "0")
+
+
 def gemm_tn(dy, x, dw, n=None, splits=0, dbias=None):
     """dw[N,K] (fp32) += dy[M,N]^T @ x[M,K]; optionally dbias[N] (fp32) += dy.sum(0) in the same pass."""
     _dev(dy)
@@ -98,6 +106,9 @@ def gemm_tn(dy, x, dw, n=None, splits=0, dbias=None):
     M, K = x.shape
     N = dy.shape[1] if n is None else n
     assert dy.shape[0] == M and dw.shape[0] >= N and dw.shape[1] == K, (dy.shape, x.shape, dw.shape)
+    if dbias is not None and deterministic():   # the M-splits of the kernel meet in float atomics on dbias: its own ordered pass instead
+        colsum(dy, dbias, N)
+        dbias = None
     lib = _lib.load()
     need = lib.xfm_gemm_tn_workspace(M, N, K) if splits == 0 else (splits * ((N + 127) // 128) * ((K + 127) // 128) * 65536 if splits > 1 else 0)
     ws = workspace(need, dy.device) if need > 0 else None
@@ -115,6 +126,11 @@ def gemm_tn_batch(dys, xs, dws, dbiases=None):
         assert dy.dtype == BF16 and x.dtype == BF16 and dw.dtype == F32 and dy.shape == (M, N) and x.shape == (M, K)
         assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(-1) == 1 and dw.shape[0] >= N and dw.shape[1] == K
         assert dy.stride(0) == dys[0].stride(0) and x.stride(0) == xs[0].stride(0) and dw.stride(0) == dws[0].stride(0)
+    if dbiases is not None and deterministic():
+        for dy, db in zip(dys, dbiases):
+            if db is not None:
+                colsum(dy, db, N)
+        dbiases = None
     lib = _lib.load()
     need = lib.xfm_gemm_tn_batch_workspace(nb, M, N, K)
     ws = workspace(need, dys[0].device) if need > 0 else None
@@ -457,10 +473,10 @@ def attn_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, scale, bias=None, 
     a.dk, a.dk_rs = dk.data_ptr(), dk.stride(0)
     a.dv, a.dv_rs = dv.data_ptr(), dv.stride(0)
     a.delta, a.dbias = delta.data_ptr(), _ptr(dbias)
-    if dbias is not None and phase != 2 and (Sk > 256 or os.environ.get("XFM_ATTN_VIT_BWD") == "4"):
-        # long sequences (the 577 / 901 tokens of the 384 / 480 px ViT): the library says how much scratch the bias gradient wants --
-        # a few MB of per-slice planes for the batch-walking kernel of dense unmasked problems, the [B, H, Sq, ld] per-entry dS of the
-        # general kernels otherwise (xfm_attn_bwd_workspace)
+    if dbias is not None and phase != 2:
+        # the library says how much scratch the bias gradient wants (xfm_attn_bwd_workspace): long sequences (the 577 / 901 tokens of
+        # the 384 / 480 px ViT) a few MB of per-slice planes for the batch-walking kernel of dense unmasked problems, or the
+        # [B, H, Sq, ld] per-entry dS of the general kernels; short ones nothing, or per-slice planes with XFM_DETERMINISTIC=1
         need = _lib.load().xfm_attn_bwd_workspace(ctypes.byref(a))
         if need > 0:
             a.dbias_ws = workspace(need, q.device).data_ptr()
@@ -612,8 +628,21 @@ def embed_ln_bwd(dy, ids, word, pos, typ, w, b, eps, pad_id, mean, rstd, pos_ids
     a.dy, a.dword, a.dpos, a.dy32 = dy.data_ptr(), dword.data_ptr(), dpos.data_ptr(), _ptr(dy32)
     lib = _lib.load()
     ws = workspace(lib.xfm_embed_ln_bwd_workspace(a.B * a.T, D), dy.device)
+    dz = None
+    if deterministic():   # the per-token gradient is stored and scattered in sorted runs, one owner per embedding row (no float atomics)
+        dz = torch.empty((a.B * a.T, D), dtype=F32, device=dy.device)
+        a.dz_out = dz.data_ptr()
     check(lib.xfm_embed_ln_bwd(ctypes.byref(a), D, _ptr(dgamma), _ptr(dbeta), _ptr(dtype_), ws.data_ptr(), ws.numel() * 4,
                                _stream()), "embed_ln_bwd")
+    if dz is not None:
+        R = a.B * a.T
+        live = None if row_map is None else (row_map.reshape(-1) >= 0)
+        for keys, table, skip in ((ids.reshape(-1).to(torch.int64), dword, pad_id), (pos_ids.reshape(-1).to(torch.int64), dpos, -1 if pos_mode else pad_id)):
+            if live is not None:
+                keys = torch.where(live, keys, torch.full_like(keys, -1))   # tokens the kernel skipped wrote no dz row
+            skey, perm = torch.sort(keys, stable=True)
+            check(lib.xfm_rows_segment_sum(dz.data_ptr(), perm.data_ptr(), skey.data_ptr(), R, D, int(skip), table.data_ptr(), _stream()),
+                  "rows_segment_sum")
 
 
 def rows_gather(src, index, out=None):
@@ -686,6 +715,10 @@ def itc_bwd(image_feat, text_feat, temp, lse, g, idx=None, cnt=None):
     """-> (d image_feat, d text_feat, d temp [1]) for the upstream gradient g (fp32 [1])."""
     N, E = image_feat.shape
     idx = _idx64(idx, N)
+    if lse.untyped_storage().nbytes() < (lse.storage_offset() + 3 * N) * 4:   # (not itc_fwd's [4N] buffer: the backward parks N shares behind 2N)
+        big = torch.empty(4 * N, dtype=F32, device=lse.device)
+        big[:2 * N] = lse[:2 * N]
+        lse = big
     dI, dT = torch.empty_like(image_feat), torch.empty_like(text_feat)
     dtemp = torch.zeros(1, dtype=F32, device=image_feat.device)
     check(_lib.load().xfm_itc_bwd(image_feat.data_ptr(), text_feat.data_ptr(), temp.data_ptr(), lse.data_ptr(), g.data_ptr(), N, E,
