@@ -1306,6 +1306,14 @@ struct Tn256Seg {
   int n0, k0, mbeg, nk;
   bool do_bias;
   int rows;   // RAGGED: rows of this piece that exist (the last K-step of a problem whose M is no multiple of 64 is short)
+  // Progress throttle between the workgroups of ONE XCD (grouped kernel, whole tiles; window = 0: off).  The 32 workgroups of an XCD
+  // walk 32 consecutive tiles, which share their dY / X panels in groups -- 15 panels instead of 64 -- but only while they are within
+  // a few K-steps of each other: a K-step of those panels is 480 KB of the XCD's 4 MB of L2, and left alone the workgroups drift
+  // apart over the 394 K-steps of a tile (27 GB per step beyond L2 against ~7 if every shared panel were read once per XCD).  Every
+  // 4th K-step wave 0 publishes base + K-steps done in row[slot] and holds the workgroup's next barrier back while it is more than
+  // `window` K-steps ahead of the slowest of the row's n workgroups (bounded spin: a workgroup that is not resident yet, or a stale
+  // row, costs at most the bound, never a hang).
+  unsigned* row; int slot, n, window; unsigned prog0;
 };
 __device__ __attribute__((aligned(16))) const unsigned tn_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -1434,6 +1442,20 @@ __device__ __forceinline__ void tn256_mainloop(const Tn256Seg& sg, char* smem, f
     const char* buf = smem + (kt & 1) * BUF;
     const int ph = 4 * kt;
     int last;
+    if (sg.window > 0 && (kt & 3) == 0 && w == 0) {   // (see Tn256Seg)
+      const unsigned mine = sg.prog0 + (unsigned)kt;
+      if (lane == 0) __hip_atomic_store(sg.row + sg.slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spin = 0; spin < 3000; ++spin) {
+        unsigned v = lane < sg.n ? __hip_atomic_load(sg.row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          const unsigned o = (unsigned)__shfl_xor((int)v, off, 64);
+          v = o < v ? o : v;
+        }
+        if (mine <= v + (unsigned)sg.window) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
     // ---- P0: (a0, b0)
     issue(ph + 5);
     read_a(buf + 0 * UNIT);
@@ -1569,6 +1591,9 @@ struct TnGroup {
   long sk_iters;             // (total_tiles - full_tiles) * nk
   float* ws;
   float* ws_bias;            // 256 floats per partial-piece slot, behind the slots' tiles
+  unsigned* prog;            // progress rows of the XCDs (8 x 64 words; Tn256Seg::row), epoch << 20 | K-steps done
+  unsigned epoch;
+  int window;                // 0: no throttle
   TnGroupProb p[TN_GROUP_MAX];
 };
 __host__ __device__ __forceinline__ long tn_sk_bound(long R, int nk, int sk_wgs, int i) {
@@ -1590,6 +1615,15 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup G) {
   }
   const long sk_a = sk_pos;
   bool first = true;
+  int tiles_done = 0;
+  bool left = false;
+  auto leave_rounds = [&]() {
+    if (G.window > 0 && !left && threadIdx.x == 0) {
+      const int per_xcd = nwg >> 3;
+      __hip_atomic_store(G.prog + (wg / per_xcd) * 64 + wg % per_xcd, (G.epoch << 20) + 0xFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    left = true;
+  };
   for (;;) {   // (everything that steers this loop is a function of blockIdx: uniform over the workgroup)
     int tile, it0, it1;
     long slot = -1;   // >= 0: partial piece
@@ -1609,6 +1643,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup G) {
     } else {
       break;
     }
+    if (tile >= G.full_tiles) leave_rounds();   // (past its whole tiles: nobody waits for this workgroup any more)
     if (!first) __syncthreads();   // the previous piece's LDS reads are over before this one's staging lands
     first = false;
     int pi = 0;
@@ -1616,9 +1651,18 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup G) {
     const TnGroupProb& P = G.p[pi];
     const int tl = tile - (pi > 0 ? G.p[pi - 1].tile_end : 0);
     const int n0 = (tl / P.tiles_k) * 256, k0 = (tl % P.tiles_k) * 256;
-    const Tn256Seg sg{P.dY, P.X, P.ldy, P.ldx, n0, k0, it0 * 64, it1 - it0, P.dbias != nullptr && k0 == 0, G.M - it0 * 64};
+    Tn256Seg sg{P.dY, P.X, P.ldy, P.ldx, n0, k0, it0 * 64, it1 - it0, P.dbias != nullptr && k0 == 0, G.M - it0 * 64, nullptr, 0, 0, 0, 0u};
+    if (G.window > 0 && slot < 0 && it0 == 0 && it1 == G.nk && tile < G.full_tiles) {   // a whole tile of the data-parallel rounds
+      const int per_xcd = nwg >> 3;
+      sg.row = G.prog + (wg / per_xcd) * 64;
+      sg.slot = wg % per_xcd;
+      sg.n = per_xcd < 64 ? per_xcd : 64;
+      sg.window = G.window;
+      sg.prog0 = (G.epoch << 20) + (unsigned)(tiles_done * G.nk);
+    }
     f32x4 acc[8][4], bacc[2];
     tn256_mainloop<true>(sg, smem, acc, bacc);
+    if (sg.window > 0) ++tiles_done;
     if (slot >= 0) {
       if (sg.do_bias) tn256_bias_part(G.ws_bias + slot * 256, bacc);
       tn256_store_partial(G.ws, slot, acc);
@@ -1627,6 +1671,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup G) {
       tn256_add_out<false>(P.dW, P.ldw, n0, k0, acc);
     }
   }
+  leave_rounds();
 }
 
 // the cut tiles: dW += the pieces in workgroup order.  grid (64, cut tiles): one thread per accumulator quad, as tn_reduce_kernel.
@@ -1915,6 +1960,7 @@ static void tn_group_plan(int tiles, int nk, int G, int& full, int& sk_wgs, long
     if (sk_wgs < 1) sk_wgs = 1;
   }
 }
+#define TN_PROG_BYTES 2048   // 8 XCDs x 64 progress words (TnGroup::prog), at the END of the caller's workspace
 long xfm_gemm_tn_group_workspace_impl(int n, const xfm_tn_item* items, int M) {
   if (n <= 0 || items == nullptr || M <= 0) return 0;
   const int G = tn_group_cus();
@@ -1925,7 +1971,7 @@ long xfm_gemm_tn_group_workspace_impl(int n, const xfm_tn_item* items, int M) {
     int full, sk;
     long R;
     tn_group_plan(tiles, cdiv(M, 64), G, full, sk, R);
-    const long b = sk > 1 ? 2l * sk * (256 * 256 + 256) * 4 : 0;   // two partial-piece slots per sharing workgroup: tile + column sums
+    const long b = (sk > 1 ? 2l * sk * (256 * 256 + 256) * 4 : 0) + TN_PROG_BYTES;   // two partial-piece slots per sharing workgroup (tile + column sums) + the progress rows
     need = b > need ? b : need;
     tiles = np = 0;
   };
@@ -1962,6 +2008,16 @@ int xfm_gemm_tn_group_impl(int n, const xfm_tn_item* items, int M, float* worksp
     tn_group_plan(g.total_tiles, g.nk, G, g.full_tiles, g.sk_wgs, g.sk_iters);
     g.ws_bias = g.ws != nullptr ? g.ws + 2l * g.sk_wgs * 256 * 256 : nullptr;
     const int grid = g.full_tiles > 0 ? G : g.sk_wgs;
+    // progress throttle of the data-parallel rounds (XFM_TN_SYNC_WINDOW K-steps; 0 = off): needs whole rounds, 8 equal XCD shares and
+    // the progress rows at the end of the workspace
+    static const int window_env = getenv("XFM_TN_SYNC_WINDOW") ? atoi(getenv("XFM_TN_SYNC_WINDOW")) : 0;
+    static unsigned epoch = 0;
+    g.window = 0;
+    if (window_env > 0 && g.full_tiles >= grid && grid % 8 == 0 && grid / 8 <= 64 && workspace != nullptr && workspace_bytes >= TN_PROG_BYTES) {
+      g.window = window_env;
+      g.prog = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + (workspace_bytes - TN_PROG_BYTES) / 16 * 16);
+      g.epoch = (++epoch) & 0xFFFu;
+    }
     hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(grid), dim3(512), smem, st, g);
     int rc = xfm_check_launch("gemm_tn_group");
     if (rc == XFM_OK && g.sk_wgs > 1) {
