@@ -79,40 +79,29 @@ __global__ __launch_bounds__(256) void vit_tokens_bwd_tok_kernel(const float* __
   }
 }
 
-// dcls += sum_b dx0[b, 0];  dmask_token += sum over masked (b, i) of dx0[b, 1 + i].  One workgroup per slice of batch rows,
-// thread = 4 columns (D <= 1024), row skips are workgroup-uniform.  The workgroups' sums are PARKED (part[wg][0 / 1][D]: the caller lends
-// the head of dtok, which the token kernel overwrites afterwards) and vit_tokens_bwd_fold_kernel adds them in workgroup order -- the
-// 128 float atomics per element this used to end in moved the last bits of both gradients from run to run.
+// dcls += sum_b dx0[b, 0];  dmask_token += sum over masked (b, i) of dx0[b, 1 + i].  One workgroup per (batch row, chunk of the patches),
+// thread = 4 columns (D <= 1024), row skips are workgroup-uniform.  The workgroups' sums are PARKED -- part[set][wg][D], the layout of
+// the LayerNorm column-sum partials, in the head of dtok, which the token kernel overwrites afterwards -- and folded by reduce_sets in
+// workgroup order: the 128 float atomics per element this used to end in moved the last bits of both gradients from run to run (and
+// 128 workgroups walking 196 patches each took 103 us at the end of the ViT's backward chain; 4 chunks per row: a quarter of that).
 __global__ __launch_bounds__(256) void vit_tokens_bwd_vec_kernel(const float* __restrict__ dx0, const uint8_t* __restrict__ mask, int Bx,
-                                                                 int P, int D, float* __restrict__ part) {
+                                                                 int P, int D, int chunks, float* __restrict__ part) {
   const int c = threadIdx.x * 4;
   if (c >= D) return;
+  const int np = Bx * chunks, b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+  const int per = (P + chunks - 1) / chunks, i0 = ch * per, i1 = i0 + per < P ? i0 + per : P;
+  const float* base = dx0 + (long)b * (P + 1) * D + c;
   f32x4 ac = {0.f, 0.f, 0.f, 0.f}, am = {0.f, 0.f, 0.f, 0.f};
-  for (int b = blockIdx.x; b < Bx; b += gridDim.x) {
-    const float* base = dx0 + (long)b * (P + 1) * D + c;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(base);
-    ac[0] += v[0]; ac[1] += v[1]; ac[2] += v[2]; ac[3] += v[3];
-    if (mask == nullptr) continue;
-    for (int i = 0; i < P; ++i) {
+  if (ch == 0) ac = *reinterpret_cast<const f32x4*>(base);
+  if (mask != nullptr) {
+    for (int i = i0; i < i1; ++i) {
       if (!mask[(long)b * P + i]) continue;
       const f32x4 u = *reinterpret_cast<const f32x4*>(base + (long)(1 + i) * D);
       am[0] += u[0]; am[1] += u[1]; am[2] += u[2]; am[3] += u[3];
     }
   }
-  *reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 2 + 0) * D + c) = ac;
-  *reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 2 + 1) * D + c) = am;
-}
-__global__ __launch_bounds__(256) void vit_tokens_bwd_fold_kernel(const float* __restrict__ part, int nparts, int D, bool masked,
-                                                                  float* __restrict__ dcls, float* __restrict__ dmask_token) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= D) return;
-  float a = 0.f, m = 0.f;
-  for (int w = 0; w < nparts; ++w) {
-    a += part[((long)w * 2 + 0) * D + c];
-    if (masked) m += part[((long)w * 2 + 1) * D + c];
-  }
-  dcls[c] += a;
-  if (masked) dmask_token[c] += m;
+  *reinterpret_cast<f32x4*>(part + ((long)0 * np + blockIdx.x) * D + c) = ac;
+  *reinterpret_cast<f32x4*>(part + ((long)1 * np + blockIdx.x) * D + c) = am;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -295,16 +284,16 @@ int xfm_vit_tokens_bwd_impl(const float* dx0, const uint8_t* mask, int Bt, int B
   const long total = (long)Bt * P * (D / 4);
   int grid = cdiv(total, 256);
   if (grid > 8192) grid = 8192;
-  // the cls / mask-token sums first: their per-workgroup parts borrow the head of dtok (Bt * P * D floats, more than 2 * 128 * D
-  // whenever P >= 4 -- checked), which the token kernel then writes in full
-  int nparts = Bx < 128 ? Bx : 128;
-  while ((long)nparts * 2 > (long)Bt * P) nparts >>= 1;
-  XFM_REQUIRE(nparts >= 1, "vit_tokens_bwd: dtok too small to lend the scratch");
-  hipLaunchKernelGGL(vit_tokens_bwd_vec_kernel, dim3(nparts), dim3(256), 0, st, dx0, mask, Bx, P, D, dtok);
+  // the cls / mask-token sums first: their per-workgroup parts borrow the head of dtok (Bt * P * D floats), which the token kernel then
+  // writes in full
+  int chunks = 4;
+  while (chunks > 1 && (long)Bx * chunks * 2 > (long)Bt * P) chunks >>= 1;
+  XFM_REQUIRE((long)Bx * chunks * 2 <= (long)Bt * P, "vit_tokens_bwd: dtok too small to lend the scratch");
+  hipLaunchKernelGGL(vit_tokens_bwd_vec_kernel, dim3(Bx * chunks), dim3(256), 0, st, dx0, mask, Bx, P, D, chunks, dtok);
   rc = xfm_check_launch("vit_tokens_bwd_vec");
   if (rc != XFM_OK) return rc;
-  hipLaunchKernelGGL(vit_tokens_bwd_fold_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, dtok, nparts, D, mask != nullptr, dcls, dmask_token);
-  rc = xfm_check_launch("vit_tokens_bwd_fold");
+  ReduceSets rs{dtok, {dcls, mask != nullptr ? dmask_token : nullptr, nullptr, nullptr}, Bx * chunks, D};
+  rc = launch_reduce_sets(rs, 2, st, "vit_tokens_bwd_fold");
   if (rc != XFM_OK) return rc;
   hipLaunchKernelGGL(vit_tokens_bwd_tok_kernel, dim3(grid), dim3(256), 0, st, dx0, mask, Bt, Bx, P, D, dtok);
   return xfm_check_launch("vit_tokens_bwd");

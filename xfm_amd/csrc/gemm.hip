@@ -1318,7 +1318,7 @@ struct Tn256Seg {
 __device__ __attribute__((aligned(16))) const unsigned tn_zero16[4] = {0u, 0u, 0u, 0u};
 
 // RAGGED: rows at or past sg.rows are staged as zeros (their lanes point the direct-to-LDS load at a 16-byte zero constant).
-template <bool RAGGED>
+template <bool RAGGED, bool SYNC = false>
 __device__ __forceinline__ void tn256_mainloop(const Tn256Seg& sg, char* smem, f32x4 (&acc)[8][4], f32x4 (&bacc)[2]) {
   constexpr int UNIT = 64 * 256, BUF = 4 * UNIT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1442,7 +1442,7 @@ __device__ __forceinline__ void tn256_mainloop(const Tn256Seg& sg, char* smem, f
     const char* buf = smem + (kt & 1) * BUF;
     const int ph = 4 * kt;
     int last;
-    if (sg.window > 0 && (kt & 3) == 0 && w == 0) {   // (see Tn256Seg)
+    if (SYNC && sg.window > 0 && (kt & 3) == 0 && w == 0) {   // (see Tn256Seg; compiled into the throttled build only)
       const unsigned mine = sg.prog0 + (unsigned)kt;
       if (lane == 0) __hip_atomic_store(sg.row + sg.slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int spin = 0; spin < 3000; ++spin) {
@@ -1604,6 +1604,8 @@ __host__ __device__ __forceinline__ long tn_sk_bound(long R, int nk, int sk_wgs,
   return raw;
 }
 
+// SYNC: the build with the XCD progress throttle (XFM_TN_SYNC_WINDOW; the default build carries none of its registers)
+template <bool SYNC>
 __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wg = xcd_remap(blockIdx.x, gridDim.x), nwg = gridDim.x;
@@ -1618,7 +1620,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup G) {
   int tiles_done = 0;
   bool left = false;
   auto leave_rounds = [&]() {
-    if (G.window > 0 && !left && threadIdx.x == 0) {
+    if (SYNC && G.window > 0 && !left && threadIdx.x == 0) {
       const int per_xcd = nwg >> 3;
       __hip_atomic_store(G.prog + (wg / per_xcd) * 64 + wg % per_xcd, (G.epoch << 20) + 0xFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1652,7 +1654,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup G) {
     const int tl = tile - (pi > 0 ? G.p[pi - 1].tile_end : 0);
     const int n0 = (tl / P.tiles_k) * 256, k0 = (tl % P.tiles_k) * 256;
     Tn256Seg sg{P.dY, P.X, P.ldy, P.ldx, n0, k0, it0 * 64, it1 - it0, P.dbias != nullptr && k0 == 0, G.M - it0 * 64, nullptr, 0, 0, 0, 0u};
-    if (G.window > 0 && slot < 0 && it0 == 0 && it1 == G.nk && tile < G.full_tiles) {   // a whole tile of the data-parallel rounds
+    if (SYNC && G.window > 0 && slot < 0 && it0 == 0 && it1 == G.nk && tile < G.full_tiles) {   // a whole tile of the data-parallel rounds
       const int per_xcd = nwg >> 3;
       sg.row = G.prog + (wg / per_xcd) * 64;
       sg.slot = wg % per_xcd;
@@ -1661,8 +1663,8 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup G) {
       sg.prog0 = (G.epoch << 20) + (unsigned)(tiles_done * G.nk);
     }
     f32x4 acc[8][4], bacc[2];
-    tn256_mainloop<true>(sg, smem, acc, bacc);
-    if (sg.window > 0) ++tiles_done;
+    tn256_mainloop<true, SYNC>(sg, smem, acc, bacc);
+    if (SYNC && sg.window > 0) ++tiles_done;
     if (slot >= 0) {
       if (sg.do_bias) tn256_bias_part(G.ws_bias + slot * 256, bacc);
       tn256_store_partial(G.ws, slot, acc);
@@ -1996,7 +1998,8 @@ int xfm_gemm_tn_group_impl(int n, const xfm_tn_item* items, int M, float* worksp
   static bool attr_set = false;
   const size_t smem = 2 * 4 * 64 * 256;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   TnGroup g{};
@@ -2018,7 +2021,8 @@ int xfm_gemm_tn_group_impl(int n, const xfm_tn_item* items, int M, float* worksp
       g.prog = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + (workspace_bytes - TN_PROG_BYTES) / 16 * 16);
       g.epoch = (++epoch) & 0xFFFu;
     }
-    hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(grid), dim3(512), smem, st, g);
+    if (g.window > 0) hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(grid), dim3(512), smem, st, g);
+    else hipLaunchKernelGGL(gemm_tn_group_kernel<false>, dim3(grid), dim3(512), smem, st, g);
     int rc = xfm_check_launch("gemm_tn_group");
     if (rc == XFM_OK && g.sk_wgs > 1) {
       hipLaunchKernelGGL(tn_group_fixup_kernel, dim3(64, g.total_tiles - g.full_tiles), dim3(256), 0, st, g);
