@@ -112,10 +112,13 @@ def test_register_bound_kernels_keep_their_budgets():
         if "attn_bwd_dq_short_kernel" in name or "attn_bwd_dkv_short_kernel" in name:
             seen += 1
             assert u["vgprs"] <= 168 and u["spill"] == 0 and u["scratch"] == 0, (name, u)
+        if "gemm_tn_group_kernelILb0E" in name:   # the grouped weight-gradient kernel's default build (the throttled build spills 5 registers)
+            seen += 1
+            assert u["vgprs"] <= 256 and u["spill"] == 0 and u["scratch"] == 0, (name, u)
         if "attn_fwd_vit_kernelILb1ELi13ELb1E" in name:   # <bias, 13 tiles, tiled bias>: the pre-training step's instantiation
             seen += 1
             assert u["scratch"] <= 16, (name, u)
-    assert seen >= 26, sorted(use)[:20]
+    assert seen >= 27, sorted(use)[:20]
 
 
 def test_persistent_gemm_epilogue_issues_the_stores_its_wait_counts_assume():
