@@ -79,7 +79,9 @@ def main():
             continue
         worst = max(rows, key=lambda t: t[1])
         print(f"  {name}: differs in {len(rows)} of {a.reps - 1} repetitions; worst rel-L2 {worst[1]:.2e}, {worst[2]} of {worst[3]} entries")
-    print("BIT_REPRO " + json.dumps({"what": what, "reps": a.reps, "batch": a.batch, "train_mode": not a.eval_mode,
+    import hashlib
+    digest = hashlib.sha1(snaps[0].cpu().numpy().tobytes()).hexdigest()   # (across PROCESSES: compare this between runs)
+    print("BIT_REPRO " + json.dumps({"what": what, "reps": a.reps, "batch": a.batch, "train_mode": not a.eval_mode, "grad_arena_sha1": digest,
                                      "deterministic_mode": os.environ.get("XFM_DETERMINISTIC", "0") not in ("", "0"),
                                      "tensors": len(arena.params), "not_bit_stable": sorted(odd)}))
     sys.exit(1 if odd else 0)
